@@ -1,0 +1,151 @@
+#!/usr/bin/env python
+"""bench.py -- candidate tensors/sec of the v3 inference hot path on MI355X.
+
+A "step" is one pass of the hot path (conv1..conv3 + pools, fc4, fc5, four heads) over one
+batch of 65 536 synthetic [33,4,4] pileup tensors that are already resident in HBM
+(BASELINE.json configs[1]: "v3 inference, 4M synthetic tensors, batch 65536, 1 MI355X";
+64 steps = the 4 194 304-tensor set).  With --gpus N every rank runs the same number of
+steps on its own shard (candidates are independent: no data-path collective) and the value
+is the whole-job rate.  One JSON line is printed by rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BATCH = 65536
+FLOP_EXACT = {"full": 6768960, "slim": 2583264}
+# algorithmic FLOP per candidate of each kernel stage (exact, padding taps excluded)
+STAGE_FLOP = {
+    "full": [2 * 25344, 2 * 350208, 2 * 1400832, 2 * 1548288, 2 * 56448, 2 * 3360],
+    "slim": [2 * 33 * 48 * 8, 2 * (33 * 3 - 2) * 12 * 8 * 16, 2 * (33 * 5 - 6) * 12 * 16 * 32, 2 * 4224 * 36, 2 * 36 * 18,
+             2 * (36 * 4 + 18 * 12)],
+}
+STAGE_NAMES = ["conv1+pool1", "conv2+pool2", "conv3+pool3", "fc4", "fc5", "heads"]
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md (f32-in MFMA = vector rate)
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(arch, P, x_sample, target_s=12.0):
+    """The oracle (C restatement, OpenMP) timed on this box's host cores on a bounded sample."""
+    from oracle import cv_oracle as O
+    cores = os.cpu_count() or 1
+    probe = x_sample[:256]
+    t0 = time.time(); O.predict(arch, P, probe, nthreads=cores); dt = time.time() - t0
+    rate = probe.shape[0] / max(dt, 1e-6)
+    n = int(min(x_sample.shape[0], max(1024, rate * target_s)))
+    t0 = time.time(); out = O.predict(arch, P, x_sample[:n], nthreads=cores); dt = time.time() - t0
+    return {"value": n / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
+            "sample": "%d candidates of the first batch, oracle/cv_oracle.c, %d OpenMP threads, %.1f s"
+                      % (n, cores, dt)}, out, n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--arch", default="full", choices=["full", "slim"])
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import common
+    from oracle import cv_oracle as O
+    from clairvoyante_amd import clairvoyante_v3, clairvoyante_v3_slim, parallel, synth, _lib
+
+    rank, ws, local = parallel.init_from_env()
+    if ws != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, ws), file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    m = clairvoyante_v3.Clairvoyante() if args.arch == "full" else clairvoyante_v3_slim.Clairvoyante()
+    P = common.bench_params(O, args.arch)          # identical seeded weights on every rank
+    m.setParameters(P)
+
+    # synthetic pileup tensors, generated straight into HBM (seed = 20260927 + rank)
+    nbuf = max(1, min(args.steps, 64))
+    batches = [synth.make_candidates(args.batch, seed=synth.BASE_SEED + rank + 1000 * b, device=dev)
+               for b in range(nbuf)]
+    out = torch.empty((args.batch, 16), dtype=torch.float32, device=dev)
+
+    def barrier():
+        if ws > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        m.predict_device(batches[i % nbuf], out)
+    torch.cuda.synchronize()
+    m.setOption("profile", 1)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        m.predict_device(batches[i % nbuf], out)
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    m.setOption("profile", 0)
+    ms = (ctypes.c_double * 6)(); cnt = (ctypes.c_int64 * 6)()
+    _lib.check(m._lib.cv_kernel_times(m._h, ms, cnt))
+    if ws > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total = args.steps * args.batch * ws
+        value = total / dt
+        chunk = ctypes.c_int64(); _lib.check(m._lib.cv_get_option(m._h, b"chunk", ctypes.byref(chunk)))
+        per_launch = min(args.batch, chunk.value)
+        stages = []
+        for s in range(6):
+            if cnt[s] == 0:
+                continue
+            avg_ms = ms[s] / cnt[s]
+            tf = STAGE_FLOP[args.arch][s] * per_launch / (avg_ms * 1e-3) / 1e12
+            stages.append({"kernel": STAGE_NAMES[s], "avg_ms": avg_ms, "launches": int(cnt[s]), "tflops": tf,
+                           "share": ms[s] / max(sum(ms), 1e-12)})
+        dom = max(stages, key=lambda r: r["avg_ms"]) if stages else None
+        roof = None
+        if dom:
+            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                    "avg_launch_ms": dom["avg_ms"], "candidates_per_launch": per_launch,
+                    "whole_path_tflops": value / ws * FLOP_EXACT[args.arch] / 1e12,
+                    "whole_path_frac": value / ws * FLOP_EXACT[args.arch] / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                    "hbm_frac_compulsory": value / ws * 2176 / 1e9 / PEAK_HBM_GBS}
+        line = {"metric": "candidate tensors/sec", "value": value, "unit": "candidates/s", "n_gpus": ws,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic",
+                "config": {"workload": "v3 %s inference, synthetic [33,4,4] pileup tensors resident in HBM, "
+                                       "batch %d x %d steps per GPU" % (args.arch, args.batch, args.steps),
+                           "arch": args.arch, "batch": args.batch, "parallelism": "shard%d" % ws},
+                "roofline": roof, "kernels": stages}
+        if not args.no_cpu:
+            xs = batches[0][:16384].cpu().numpy()
+            cb, ref, n = cpu_baseline(args.arch, P, xs)
+            got = m.predict_device(batches[0][:n].contiguous()).cpu().numpy()
+            line["cpu_baseline"] = cb
+            line["parity"] = {"n": n, "argmax_match_per_head": common.argmax_match(got, ref),
+                              "max_abs_dprob": float(np.abs(got - ref).max()),
+                              "bitwise_equal_frac": common.bitwise_frac(got, ref)}
+        print(json.dumps(line), flush=True)
+    m.close()
+    if ws > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""ctypes binding of the C ABI declared in include/clairvoyante_amd.h.
+
+The library is required: there is deliberately no fallback implementation.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libclairvoyante_hip.so")
+
+NUM_PARAMS = 18
+NUM_OUT = 16
+
+
+class CvArch(ctypes.Structure):
+    _fields_ = [("kh", ctypes.c_int32 * 3), ("cout", ctypes.c_int32 * 3), ("pool", ctypes.c_int32 * 3),
+                ("fc4", ctypes.c_int32), ("fc5", ctypes.c_int32)]
+
+
+class CvError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_SIGS = {
+    "cv_last_error": (ctypes.c_char_p, []),
+    "cv_create": (ctypes.c_int, [ctypes.POINTER(CvArch), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "cv_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "cv_param_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
+                                     ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)]),
+    "cv_param_buffer": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
+                                       ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "cv_set_param": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64,
+                                    ctypes.c_void_p]),
+    "cv_get_param": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64,
+                                    ctypes.c_void_p]),
+    "cv_params_changed": (ctypes.c_int, [ctypes.c_void_p]),
+    "cv_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                  ctypes.c_void_p]),
+    "cv_call_postproc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "cv_get_activation": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+                                         ctypes.c_void_p]),
+    "cv_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
+    "cv_get_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
+    "cv_kernel_times": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                                       ctypes.POINTER(ctypes.c_int64)]),
+    "cv_loss": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                               ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]),
+    "cv_grad": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                               ctypes.c_float, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64,
+                               ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]),
+    "cv_grad_buffer": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
+                                      ctypes.POINTER(ctypes.c_int64)]),
+    "cv_apply_adam": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_int64,
+                                     ctypes.c_void_p]),
+    "cv_flat_copy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                    ctypes.c_void_p]),
+    "cv_adam_buffers": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
+                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]),
+}
+
+EXPORTS = sorted(_SIGS)
+
+
+def load():
+    """dlopen the HIP library (built by clairvoyante_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CvError("%s is missing: build it with `python -m clairvoyante_amd.build` "
+                      "(hipcc, gfx950); there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)      # AttributeError = a declared entry point is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().cv_last_error()
+        raise CvError(msg.decode("utf-8", "replace") if msg else "clairvoyante_amd call failed")

@@ -1,0 +1,348 @@
+// cv_api.hip -- the C ABI (include/clairvoyante_amd.h): model object, parameter
+// table, chunked forward.  Each entry point cites the reference method it replaces
+// in the header.
+#include "cv_internal.hpp"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+
+static thread_local char g_err[512] = "";
+
+void cv_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *cv_last_error(void) { return g_err; }
+
+// variable names of the reference graph (jupyter_nb/visualization.ipynb:103-120)
+static const char *const kParamNames[CV_NUM_PARAMS] = {
+    "conv1/kernel", "conv1/bias", "conv2/kernel", "conv2/bias", "conv3/kernel", "conv3/bias",
+    "fc4/kernel", "fc4/bias", "fc5/kernel", "fc5/bias",
+    "YBaseChangeSigmoid/kernel", "YBaseChangeSigmoid/bias", "YZygosityFC/kernel", "YZygosityFC/bias",
+    "YVarTypeFC/kernel", "YVarTypeFC/bias", "YIndelLengthFC/kernel", "YIndelLengthFC/bias"};
+
+static int compute_shapes(cv_model *m)
+{
+    const cv_arch &a = m->arch;
+    cv_shapes &s = m->sh;
+    int h = CV_INPUT_H, c = CV_INPUT_C;
+    for (int l = 0; l < 3; l++) {
+        if (a.kh[l] < 1 || a.kh[l] > 7 || a.cout[l] < 1 || a.cout[l] > 64 || a.pool[l] < 1 ||
+            a.pool[l] > h) {
+            cv_set_error("cv_create: unsupported layer %d (kh %d cout %d pool %d)", l + 1, a.kh[l],
+                         a.cout[l], a.pool[l]);
+            return 1;
+        }
+        s.cin[l] = c;
+        s.hc[l] = h;
+        h -= a.pool[l] - 1;
+        s.hp[l] = h;
+        c = a.cout[l];
+        s.ntile[l] = (a.cout[l] + 15) / 16;
+        s.cinb[l] = (s.cin[l] + 15) / 16;
+    }
+    if (a.fc4 < 1 || a.fc4 > 512 || a.fc5 < 1 || a.fc5 > 512) {
+        cv_set_error("cv_create: unsupported fc sizes %d/%d", a.fc4, a.fc5);
+        return 1;
+    }
+    s.flat = h * 4 * c;
+    s.kb4 = h * 4 * s.ntile[2];
+    s.nb4 = (a.fc4 + 15) / 16;
+    s.nb5 = (a.fc5 + 15) / 16;
+    // parameter table
+    int p = 0;
+    auto add = [&](int nd, int64_t d0, int64_t d1, int64_t d2, int64_t d3) {
+        m->pndim[p] = nd;
+        m->pdims[p][0] = d0; m->pdims[p][1] = d1; m->pdims[p][2] = d2; m->pdims[p][3] = d3;
+        int64_t sz = 1;
+        for (int i = 0; i < nd; i++) sz *= m->pdims[p][i];
+        m->psize[p] = sz;
+        p++;
+    };
+    for (int l = 0; l < 3; l++) {
+        add(4, a.kh[l], 4, s.cin[l], a.cout[l]);
+        add(1, a.cout[l], 1, 1, 1);
+    }
+    add(2, s.flat, a.fc4, 1, 1); add(1, a.fc4, 1, 1, 1);
+    add(2, a.fc4, a.fc5, 1, 1);  add(1, a.fc5, 1, 1, 1);
+    add(2, a.fc4, 4, 1, 1);      add(1, 4, 1, 1, 1);
+    add(2, a.fc5, 2, 1, 1);      add(1, 2, 1, 1, 1);
+    add(2, a.fc5, 4, 1, 1);      add(1, 4, 1, 1, 1);
+    add(2, a.fc5, 6, 1, 1);      add(1, 6, 1, 1, 1);
+    m->poff[0] = 0;
+    for (int i = 0; i < CV_NUM_PARAMS; i++) m->poff[i + 1] = m->poff[i] + m->psize[i];
+    return 0;
+}
+
+static int find_param(const char *name)
+{
+    for (int i = 0; i < CV_NUM_PARAMS; i++)
+        if (strcmp(name, kParamNames[i]) == 0) return i;
+    cv_set_error("unknown variable '%s'", name);
+    return -1;
+}
+
+extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
+{
+    if (!arch || !out) { cv_set_error("cv_create: null argument"); return 1; }
+    int ndev = 0;
+    CV_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        cv_set_error("cv_create: device %d not present (%d visible)", device, ndev);
+        return 1;
+    }
+    CV_HIP(hipSetDevice(device));
+    cv_model *m = new (std::nothrow) cv_model();
+    if (!m) { cv_set_error("cv_create: out of host memory"); return 1; }
+    memset(m, 0, sizeof(*m));
+    m->arch = *arch;
+    m->device = device;
+    m->impl = 1;
+    m->chunk = 32768;
+    if (compute_shapes(m)) { delete m; return 1; }
+    const int64_t np = m->poff[CV_NUM_PARAMS];
+    const cv_shapes &s = m->sh;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](float **p, size_t nfloat) {
+        if (e == hipSuccess) e = hipMalloc(p, sizeof(float) * nfloat);
+        if (e == hipSuccess) e = hipMemset(*p, 0, sizeof(float) * nfloat);
+    };
+    alloc(&m->params, np); alloc(&m->grads, np); alloc(&m->adam_m, np); alloc(&m->adam_v, np);
+    alloc(&m->wp_conv1, 4 * 64);
+    for (int l = 1; l < 3; l++) alloc(&m->wp_conv[l], (size_t)s.ntile[l] * arch->kh[l] * 4 * s.cinb[l] * 256);
+    alloc(&m->wp_fc4, (size_t)s.kb4 * s.nb4 * 256);
+    alloc(&m->wp_fc5, (size_t)s.nb4 * s.nb5 * 256);
+    if (e == hipSuccess) e = hipMalloc(&m->loss_dev, sizeof(double) * 8);
+    if (e != hipSuccess) {
+        cv_set_error("cv_create: device allocation failed: %s", hipGetErrorString(e));
+        cv_destroy(m);
+        return 1;
+    }
+    m->packed_dirty = true;
+    *out = m;
+    return 0;
+}
+
+extern "C" int cv_destroy(cv_model *m)
+{
+    if (!m) return 0;
+    hipSetDevice(m->device);
+    float *bufs[] = {m->params, m->grads, m->adam_m, m->adam_v, m->wp_conv1, m->wp_conv[1], m->wp_conv[2],
+                     m->wp_fc4, m->wp_fc5, m->tm_p1, m->tm_p2, m->tm_p3, m->tm_h4, m->tm_h5, m->r_a[0],
+                     m->r_a[1], m->r_a[2], m->r_p[0], m->r_p[1], m->r_p[2], m->r_h4, m->r_h5, m->t_buf};
+    for (float *b : bufs)
+        if (b) hipFree(b);
+    if (m->loss_dev) hipFree(m->loss_dev);
+    cv_prof_free(m);
+    delete m;
+    return 0;
+}
+
+extern "C" int cv_param_info(const cv_model *m, int idx, const char **tf_name, int *ndim, int64_t dims[4])
+{
+    if (!m || idx < 0 || idx >= CV_NUM_PARAMS) { cv_set_error("cv_param_info: bad index %d", idx); return 1; }
+    if (tf_name) *tf_name = kParamNames[idx];
+    if (ndim) *ndim = m->pndim[idx];
+    if (dims) for (int i = 0; i < 4; i++) dims[i] = m->pdims[idx][i];
+    return 0;
+}
+
+extern "C" int cv_param_buffer(cv_model *m, float **flat_dev, int64_t *count, int64_t *offsets)
+{
+    if (!m) { cv_set_error("null model"); return 1; }
+    if (flat_dev) *flat_dev = m->params;
+    if (count) *count = m->poff[CV_NUM_PARAMS];
+    if (offsets) for (int i = 0; i <= CV_NUM_PARAMS; i++) offsets[i] = m->poff[i];
+    return 0;
+}
+
+extern "C" int cv_set_param(cv_model *m, const char *tf_name, const float *src, int64_t count, void *stream)
+{
+    if (!m || !tf_name || !src) { cv_set_error("cv_set_param: null argument"); return 1; }
+    int i = find_param(tf_name);
+    if (i < 0) return 1;
+    if (count != m->psize[i]) {
+        cv_set_error("cv_set_param(%s): got %lld values, variable holds %lld", tf_name, (long long)count,
+                     (long long)m->psize[i]);
+        return 1;
+    }
+    CV_HIP(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    CV_HIP(hipMemcpyAsync(m->params + m->poff[i], src, sizeof(float) * count, hipMemcpyHostToDevice, st));
+    CV_HIP(hipStreamSynchronize(st));
+    m->packed_dirty = true;
+    return 0;
+}
+
+extern "C" int cv_get_param(cv_model *m, const char *tf_name, float *dst, int64_t count, void *stream)
+{
+    if (!m || !tf_name || !dst) { cv_set_error("cv_get_param: null argument"); return 1; }
+    int i = find_param(tf_name);
+    if (i < 0) return 1;
+    if (count != m->psize[i]) {
+        cv_set_error("cv_get_param(%s): asked %lld values, variable holds %lld", tf_name, (long long)count,
+                     (long long)m->psize[i]);
+        return 1;
+    }
+    CV_HIP(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    CV_HIP(hipMemcpyAsync(dst, m->params + m->poff[i], sizeof(float) * count, hipMemcpyDeviceToHost, st));
+    CV_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int cv_params_changed(cv_model *m)
+{
+    if (!m) { cv_set_error("null model"); return 1; }
+    m->packed_dirty = true;
+    return 0;
+}
+
+extern "C" int cv_set_option(cv_model *m, const char *key, int64_t value)
+{
+    if (!m || !key) { cv_set_error("cv_set_option: null argument"); return 1; }
+    if (!strcmp(key, "impl")) {
+        if (value != 0 && value != 1) { cv_set_error("impl must be 0 or 1"); return 1; }
+        m->impl = (int)value;
+        return 0;
+    }
+    if (!strcmp(key, "profile")) { m->profile = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "chunk")) {
+        if (value < 16 || value > (1 << 22)) { cv_set_error("chunk must be in [16, 4194304]"); return 1; }
+        m->chunk = (value + 15) / 16 * 16;
+        return 0;
+    }
+    cv_set_error("unknown option '%s'", key);
+    return 1;
+}
+
+extern "C" int cv_get_option(const cv_model *m, const char *key, int64_t *value)
+{
+    if (!m || !key || !value) { cv_set_error("cv_get_option: null argument"); return 1; }
+    if (!strcmp(key, "impl")) { *value = m->impl; return 0; }
+    if (!strcmp(key, "chunk")) { *value = m->chunk; return 0; }
+    if (!strcmp(key, "profile")) { *value = m->profile; return 0; }
+    cv_set_error("unknown option '%s'", key);
+    return 1;
+}
+
+extern "C" int cv_forward(cv_model *m, const float *x_dev, int64_t n, float *out16_dev, void *stream)
+{
+    if (!m) { cv_set_error("cv_forward: null model"); return 1; }
+    if (n < 0) { cv_set_error("cv_forward: negative batch"); return 1; }
+    if (n == 0) return 0;    // the reference runs predict on an empty final batch (utils_v2.py:56-59)
+    if (!x_dev || !out16_dev) { cv_set_error("cv_forward: null buffer"); return 1; }
+    CV_HIP(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t chunk = m->impl ? m->chunk : (m->chunk < 4096 ? m->chunk : 4096);
+    for (int64_t off = 0; off < n; off += chunk) {
+        int64_t cn = n - off < chunk ? n - off : chunk;
+        const float *xc = x_dev + (size_t)off * (CV_INPUT_H * CV_INPUT_W * CV_INPUT_C);
+        float *oc = out16_dev + (size_t)off * CV_NUM_OUT;
+        int rc = m->impl ? cv_mfma_forward(m, xc, cn, oc, st) : cv_ref_forward(m, xc, cn, oc, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int cv_get_activation(cv_model *m, int layer, float *dst_dev, int64_t n, void *stream)
+{
+    if (!m || !dst_dev) { cv_set_error("cv_get_activation: null argument"); return 1; }
+    if (layer < 1 || layer > 5) { cv_set_error("cv_get_activation: layer %d not in 1..5", layer); return 1; }
+    if (n <= 0 || n > m->last_n) {
+        cv_set_error("cv_get_activation: n=%lld but the last pass held %lld candidates", (long long)n,
+                     (long long)m->last_n);
+        return 1;
+    }
+    CV_HIP(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    const cv_shapes &s = m->sh;
+    const cv_arch &a = m->arch;
+    if (m->last_impl == 0) {
+        const float *src; size_t per;
+        if (layer <= 3) { src = m->r_p[layer - 1]; per = (size_t)s.hp[layer - 1] * 4 * a.cout[layer - 1]; }
+        else if (layer == 4) { src = m->r_h4; per = a.fc4; }
+        else { src = m->r_h5; per = a.fc5; }
+        CV_HIP(hipMemcpyAsync(dst_dev, src, sizeof(float) * per * n, hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
+    if (layer <= 3) {
+        int l = layer - 1;
+        const float *tm = l == 0 ? m->tm_p1 : (l == 1 ? m->tm_p2 : m->tm_p3);
+        int npos = s.hp[l] * 4;
+        return cv_tm_to_natural(tm, npos * s.ntile[l], s.ntile[l] * 16, a.cout[l], npos, n, dst_dev, st);
+    }
+    if (layer == 4) return cv_tm_to_natural(m->tm_h4, s.nb4, s.nb4 * 16, a.fc4, 1, n, dst_dev, st);
+    return cv_tm_to_natural(m->tm_h5, s.nb5, s.nb5 * 16, a.fc5, 1, n, dst_dev, st);
+}
+
+// ---- per-kernel timing ---------------------------------------------------------
+#include <vector>
+struct cv_prof {
+    struct rec { hipEvent_t a, b; int stage; };
+    std::vector<rec> recs;        // events in flight
+    std::vector<hipEvent_t> pool; // recycled events
+    hipEvent_t cur[CV_NUM_STAGES];
+    double ms[CV_NUM_STAGES];
+    int64_t cnt[CV_NUM_STAGES];
+};
+
+static hipEvent_t prof_event(cv_prof *p)
+{
+    if (!p->pool.empty()) { hipEvent_t e = p->pool.back(); p->pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void cv_prof_begin(cv_model *m, int stage, hipStream_t st)
+{
+    if (!m->profile) return;
+    if (!m->prof) { cv_prof *p = new cv_prof(); for (int i = 0; i < CV_NUM_STAGES; i++) { p->ms[i] = 0; p->cnt[i] = 0; } m->prof = p; }
+    cv_prof *p = (cv_prof *)m->prof;
+    p->cur[stage] = prof_event(p);
+    (void)hipEventRecord(p->cur[stage], st);
+}
+
+void cv_prof_end(cv_model *m, int stage, hipStream_t st)
+{
+    if (!m->profile || !m->prof) return;
+    cv_prof *p = (cv_prof *)m->prof;
+    hipEvent_t b = prof_event(p);
+    (void)hipEventRecord(b, st);
+    p->recs.push_back({p->cur[stage], b, stage});
+}
+
+void cv_prof_free(cv_model *m)
+{
+    cv_prof *p = (cv_prof *)m->prof;
+    if (!p) return;
+    for (auto &r : p->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : p->pool) (void)hipEventDestroy(e);
+    delete p;
+    m->prof = nullptr;
+}
+
+extern "C" int cv_kernel_times(cv_model *m, double ms[CV_NUM_STAGES], int64_t launches[CV_NUM_STAGES])
+{
+    if (!m || !ms || !launches) { cv_set_error("cv_kernel_times: null argument"); return 1; }
+    for (int i = 0; i < CV_NUM_STAGES; i++) { ms[i] = 0; launches[i] = 0; }
+    cv_prof *p = (cv_prof *)m->prof;
+    if (!p) return 0;
+    CV_HIP(hipSetDevice(m->device));
+    for (auto &r : p->recs) {
+        CV_HIP(hipEventSynchronize(r.b));
+        float t = 0;
+        CV_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        p->ms[r.stage] += t; p->cnt[r.stage]++;
+        p->pool.push_back(r.a); p->pool.push_back(r.b);
+    }
+    p->recs.clear();
+    for (int i = 0; i < CV_NUM_STAGES; i++) { ms[i] = p->ms[i]; launches[i] = p->cnt[i]; p->ms[i] = 0; p->cnt[i] = 0; }
+    return 0;
+}

@@ -1,0 +1,104 @@
+// cv_internal.hpp -- model object and data layouts shared by the kernels and the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/clairvoyante_amd.h"
+
+// ---------------------------------------------------------------------------
+// Tile-major ("TM") activation layout -- the HBM layout of every intermediate.
+//
+// Candidates are processed in GROUPS of 16 (one MFMA tile column each).  A
+// per-candidate feature vector of K = 16*KB values is stored as KB fragments
+// of 1 KiB:   TM[group][kb][lane][s],  lane = kq*16 + c,  (c = candidate in
+// group, feature k = 16*kb + 4*s + kq).  One wave reads a fragment with ONE
+// fully coalesced 16-byte-per-lane load and the four dwords it gets are
+// exactly the B operands (B[k][j]: lane = j + 16*k) of the four
+// v_mfma_f32_16x16x4_f32 steps that cover features 16*kb .. 16*kb+15 in
+// ascending order.  Kernels compute D = W^T * act^T (rows = output features,
+// columns = candidates); with the weight rows permuted by sigma(i) = 4*(i%4) +
+// i/4 the D registers of a lane are again one TM fragment dword-for-dword, so a
+// layer's output is written with one coalesced 16-byte store per lane and feeds
+// the next layer without any transpose.
+// ---------------------------------------------------------------------------
+__host__ __device__ inline int cv_sigma(int i) { return 4 * (i & 3) + (i >> 2); }
+
+// float offset of (candidate, feature k) in a TM buffer with KB fragments per group
+__host__ __device__ inline size_t cv_tm_index(int64_t cand, int k, int KB)
+{
+    int64_t g = cand >> 4;
+    int c = (int)(cand & 15);
+    int kb = k >> 4, j = k & 15, s = j >> 2, kq = j & 3;
+    return ((size_t)(g * KB + kb) * 64 + (size_t)(kq * 16 + c)) * 4 + s;
+}
+
+struct cv_shapes {
+    int hc[3];    // conv output heights (SAME: == input heights)
+    int hp[3];    // pooled heights
+    int cin[3];   // input channels
+    int ntile[3]; // ceil(cout/16)
+    int cinb[3];  // ceil(cin/16) (layer 0: unused)
+    int flat;     // hp[2]*4*cout[2]
+    int kb4;      // fc4 K fragments = hp[2]*4*ntile[2]
+    int nb4, nb5; // fc4 / fc5 output fragments
+};
+
+struct cv_model {
+    cv_arch arch;
+    cv_shapes sh;
+    int device;
+    int impl;          // 0 plain kernels, 1 MFMA kernels
+    int64_t chunk;     // candidates per internal pass
+    // parameters: flat, TF layouts, table order
+    int64_t psize[CV_NUM_PARAMS];
+    int64_t poff[CV_NUM_PARAMS + 1];
+    int pndim[CV_NUM_PARAMS];
+    int64_t pdims[CV_NUM_PARAMS][4];
+    float *params, *grads, *adam_m, *adam_v;
+    // packed (fragment-major) weights for the MFMA kernels
+    float *wp_conv1;     // [kw][64]
+    float *wp_conv[3];   // [1],[2]: [nt][kh][kw][cb][64][4]
+    float *wp_fc4;       // [kb][nb4][64][4]
+    float *wp_fc5;       // [nb4][nb5][64][4]
+    bool packed_dirty;
+    // workspaces (allocated lazily for `ws_cap` candidates)
+    int64_t ws_cap;      // MFMA path capacity (multiple of 16)
+    float *tm_p1, *tm_p2, *tm_p3, *tm_h4, *tm_h5;
+    int64_t ref_cap;     // plain path capacity
+    float *r_a[3], *r_p[3], *r_h4, *r_h5;
+    int64_t last_n;      // candidates of the last chunk (for cv_get_activation)
+    int last_impl;
+    // training workspaces
+    int64_t tr_cap;
+    float *t_buf;        // one slab, carved by the training code
+    size_t t_bytes;
+    double *loss_dev;    // 8 doubles
+    // optional per-kernel timing (option "profile")
+    int profile;
+    void *prof;          // cv_prof*, owned
+};
+
+// brackets one kernel launch with events when profiling is on (no-ops otherwise)
+void cv_prof_begin(cv_model *m, int stage, hipStream_t st);
+void cv_prof_end(cv_model *m, int stage, hipStream_t st);
+void cv_prof_free(cv_model *m);
+
+void cv_set_error(const char *fmt, ...);
+
+#define CV_HIP(expr)                                                                     \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            cv_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                    \
+        }                                                                                \
+    } while (0)
+
+// kernel launchers (defined in the .hip files)
+int cv_ref_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStream_t st);
+int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStream_t st);
+int cv_pack_weights(cv_model *m, hipStream_t st);
+int cv_launch_heads(cv_model *m, const float *h4, const float *h5, int tm, int64_t n, float *out16,
+                    hipStream_t st);
+int cv_tm_to_natural(const float *tm, int KB, int feat_per_pos_padded, int feat_per_pos, int npos,
+                     int64_t n, float *dst, hipStream_t st);

@@ -1,0 +1,82 @@
+// cv_math.hpp -- device scalar math of the pileup-CNN path (gfx950).
+//
+// Every contraction in this library is one fp32 fused-multiply-add chain in
+// ascending (kh, kw, ci) / ascending-k order, bias added after the chain
+// (v_mfma_f32_16x16x4_f32 is bit-for-bit such a chain), and exp() is the fixed
+// fmaf-only sequence below, so results are a pure function of the inputs --
+// independent of tiling, wave count or GPU count.  Compile with
+// -ffp-contract=off: the only fused operations are the explicit ones.
+//
+// selu follows /root/reference/clairvoyante/selu.py:21-25
+//   scale * where(x >= 0, x, alpha * elu(x)),  elu(x) = exp(x) - 1
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cvm {
+
+__device__ __forceinline__ float bits2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// Cephes-style expf with a fixed operation sequence (<= 2 ulp).
+__device__ __forceinline__ float expf_fixed(float x)
+{
+    if (x != x) return x;
+    if (x > 88.72283905206835f) return __builtin_inff();
+    if (x < -87.33654475055310f) return 0.0f;
+    float z = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(z, -0.693359375f, x);
+    r = __builtin_fmaf(z, 2.12194440e-4f, r);
+    float r2 = r * r;
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float y = __builtin_fmaf(p, r2, r);
+    y = y + 1.0f;
+    int n = (int)z;
+    int n1 = n >> 1, n2 = n - n1;
+    y = y * bits2f((uint32_t)(n1 + 127) << 23);
+    y = y * bits2f((uint32_t)(n2 + 127) << 23);
+    return y;
+}
+
+constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f;
+constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
+
+__device__ __forceinline__ float selu(float x)
+{
+    if (x >= 0.0f) return SELU_SCALE * x;
+    float t = expf_fixed(x) - 1.0f;
+    return SELU_SCALE * (SELU_ALPHA * t);
+}
+
+// d selu / d pre-activation
+__device__ __forceinline__ float selu_grad(float pre)
+{
+    if (pre >= 0.0f) return SELU_SCALE;
+    return SELU_SCALE * (SELU_ALPHA * expf_fixed(pre));
+}
+
+// tf.nn.sigmoid = 1 / (1 + exp(-x))
+__device__ __forceinline__ float sigmoid(float x) { return 1.0f / (1.0f + expf_fixed(-x)); }
+
+// tf.nn.softmax over n <= 6 logits: exp(l - max) / sum, sum in index order
+template <int N>
+__device__ __forceinline__ void softmax(const float (&l)[N], float (&p)[N])
+{
+    float m = l[0];
+#pragma unroll
+    for (int i = 1; i < N; i++) m = fmaxf(m, l[i]);
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        p[i] = expf_fixed(l[i] - m);
+        s = (i == 0) ? p[0] : s + p[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) p[i] = p[i] / s;
+}
+
+}  // namespace cvm

@@ -1,0 +1,137 @@
+// cv_post.hip -- device side of callVar.Output, optimizer step and flat-buffer plumbing.
+#include "cv_internal.hpp"
+
+namespace {
+
+// Device part of callVar.Output (/root/reference/clairvoyante/callVar.py:59-87).
+// One thread per candidate.
+__global__ void call_postproc(const float *__restrict__ x, const float *__restrict__ out16, int64_t n,
+                              int32_t *__restrict__ call, float *__restrict__ qual)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *o = out16 + (size_t)i * 16;
+    // np.argmax: first maximum; np.sort()[::-1]: descending values
+    auto top2 = [](const float *p, int cnt, int &am, float &v1, float &v2) {
+        am = 0; v1 = p[0]; v2 = -__builtin_inff();
+        for (int k = 1; k < cnt; k++) {
+            float v = p[k];
+            if (v > v1) { v2 = v1; v1 = v; am = k; }
+            else if (v > v2) v2 = v;
+        }
+    };
+    int at, az, al; float t1, t2, z1, z2, l1, l2;
+    top2(o + 6, 4, at, t1, t2);
+    top2(o + 4, 2, az, z1, z2);
+    top2(o + 10, 6, al, l1, l2);
+    // base[j].argsort()[::-1] : descending by (value, index) -- the HIGHER index
+    // wins ties (callVar.py:81-83)
+    int b1 = 0, b2 = -1;
+    for (int k = 1; k < 4; k++)
+        if (o[k] >= o[b1]) b1 = k;
+    for (int k = 0; k < 4; k++) {
+        if (k == b1) continue;
+        if (b2 < 0 || o[k] >= o[b2]) b2 = k;
+    }
+    int32_t *c = call + (size_t)i * 8;
+    c[0] = at; c[1] = az; c[2] = al; c[3] = b1; c[4] = b2; c[5] = 0; c[6] = 0; c[7] = 0;
+    // qual operands: fp32 products of the sorted probabilities (callVar.py:69-72)
+    float *q = qual + (size_t)i * 4;
+    q[0] = (t1 * z1) * l1;
+    q[1] = (t2 * z2) * l2;
+    // dp = sum X[16,:,0] + sum X[17,:,1] + sum X[17,:,2] + sum X[16,:,3]  (callVar.py:86-87)
+    const float *xi = x + (size_t)i * (CV_INPUT_H * 16);
+    float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int b = 0; b < 4; b++) {
+        s0 += xi[16 * 16 + b * 4 + 0];
+        s1 += xi[17 * 16 + b * 4 + 1];
+        s2 += xi[17 * 16 + b * 4 + 2];
+        s3 += xi[16 * 16 + b * 4 + 3];
+    }
+    q[2] = ((s0 + s1) + s2) + s3;
+    q[3] = 0.0f;
+}
+
+struct offs_t { int64_t o[CV_NUM_PARAMS + 1]; };
+
+// TF1 AdamOptimizer update (/root/reference/clairvoyante/clairvoyante_v3.py:174) on
+// g + lambda*w for kernels (the l2 term of v3.py:150), g for biases.
+__global__ void adam_kernel(float *__restrict__ w, float *__restrict__ mm, float *__restrict__ vv,
+                            const float *__restrict__ g, offs_t offs, float lr_t, float lambda)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= offs.o[CV_NUM_PARAMS]) return;
+    int p = 0;
+    while (i >= offs.o[p + 1]) p++;
+    float gi = g[i];
+    float wi = w[i];
+    if ((p & 1) == 0) gi = gi + lambda * wi;
+    float m1 = mm[i] + (gi - mm[i]) * (1.0f - 0.9f);
+    float v1 = vv[i] + (gi * gi - vv[i]) * (1.0f - 0.999f);
+    mm[i] = m1; vv[i] = v1;
+    w[i] = wi - (m1 * lr_t) / (sqrtf(v1) + 1e-8f);
+}
+
+}  // namespace
+
+extern "C" int cv_call_postproc(cv_model *m, const float *x_dev, const float *out16_dev, int64_t n,
+                                int32_t *call_dev, float *qual_dev, void *stream)
+{
+    if (!m) { cv_set_error("cv_call_postproc: null model"); return 1; }
+    if (n <= 0) return 0;
+    if (!x_dev || !out16_dev || !call_dev || !qual_dev) { cv_set_error("cv_call_postproc: null buffer"); return 1; }
+    CV_HIP(hipSetDevice(m->device));
+    call_postproc<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x_dev, out16_dev, n, call_dev,
+                                                                               qual_dev);
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int cv_grad_buffer(cv_model *m, float **flat_dev, int64_t *count)
+{
+    if (!m) { cv_set_error("null model"); return 1; }
+    if (flat_dev) *flat_dev = m->grads;
+    if (count) *count = m->poff[CV_NUM_PARAMS];
+    return 0;
+}
+
+extern "C" int cv_adam_buffers(cv_model *m, float **m_dev, float **v_dev, int64_t *count)
+{
+    if (!m) { cv_set_error("null model"); return 1; }
+    if (m_dev) *m_dev = m->adam_m;
+    if (v_dev) *v_dev = m->adam_v;
+    if (count) *count = m->poff[CV_NUM_PARAMS];
+    return 0;
+}
+
+extern "C" int cv_flat_copy(cv_model *m, int which, float *caller_dev, int to_model, void *stream)
+{
+    if (!m || !caller_dev) { cv_set_error("cv_flat_copy: null argument"); return 1; }
+    float *bufs[4] = {m->params, m->grads, m->adam_m, m->adam_v};
+    if (which < 0 || which > 3) { cv_set_error("cv_flat_copy: which=%d not in 0..3", which); return 1; }
+    CV_HIP(hipSetDevice(m->device));
+    size_t bytes = sizeof(float) * m->poff[CV_NUM_PARAMS];
+    if (to_model) {
+        CV_HIP(hipMemcpyAsync(bufs[which], caller_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        if (which == 0) m->packed_dirty = true;
+    } else {
+        CV_HIP(hipMemcpyAsync(caller_dev, bufs[which], bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return 0;
+}
+
+extern "C" int cv_apply_adam(cv_model *m, float lr, float lambda, int64_t t, void *stream)
+{
+    if (!m) { cv_set_error("null model"); return 1; }
+    if (t < 1) { cv_set_error("cv_apply_adam: step count t must be >= 1"); return 1; }
+    CV_HIP(hipSetDevice(m->device));
+    offs_t offs;
+    for (int i = 0; i <= CV_NUM_PARAMS; i++) offs.o[i] = m->poff[i];
+    double lr_t = (double)lr * sqrt(1.0 - pow(0.999, (double)t)) / (1.0 - pow(0.9, (double)t));
+    int64_t n = m->poff[CV_NUM_PARAMS];
+    adam_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(m->params, m->adam_m, m->adam_v,
+                                                                             m->grads, offs, (float)lr_t, lambda);
+    CV_HIP(hipGetLastError());
+    m->packed_dirty = true;
+    return 0;
+}

@@ -1,0 +1,475 @@
+// cv_train.hip -- loss, backward and dropout of the training step (plain kernels).
+//
+// Replaces the session.run((loss, training_op, ...)) of train / trainNoRT and
+// session.run(loss) of getLoss / getLossNoRT
+// (/root/reference/clairvoyante/clairvoyante_v3.py:183-227):
+//   loss (v3.py:140-151)  = sum (sigmoid - y)^2 + sum -y*log_softmax(logits) x3
+//                           + lambda * sum_{kernels} sum(w^2)/2      -- SUMS over the batch
+//   alpha-dropout on fc4 (selu.py:34-69): keep mask from a counter-based hash of
+//   (seed, step, candidate, unit) -- the reference's stream is unseeded TF state, so
+//   only the distribution can match.
+// Activations use the reference's natural layouts; gradients accumulate into the flat
+// buffer (cv_grad_buffer) with float atomics across batch slices.
+#include "cv_internal.hpp"
+#include "cv_math.hpp"
+
+namespace {
+
+inline unsigned nblk(int64_t total, int bs) { return (unsigned)((total + bs - 1) / bs); }
+
+__device__ __forceinline__ uint32_t hash_u32(uint64_t a)
+{
+    // splitmix64 finaliser
+    a += 0x9E3779B97F4A7C15ull;
+    a = (a ^ (a >> 30)) * 0xBF58476D1CE4E5B9ull;
+    a = (a ^ (a >> 27)) * 0x94D2049BB133111Bull;
+    a = a ^ (a >> 31);
+    return (uint32_t)(a >> 32);
+}
+
+// ---- forward pieces ------------------------------------------------------------
+__global__ void t_conv_pre(const float *__restrict__ in, const float *__restrict__ w,
+                           const float *__restrict__ bias, float *__restrict__ pre, int64_t n, int H,
+                           int cin, int kh, int cout)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * H * 4 * cout) return;
+    int co = (int)(t % cout);
+    int64_t r = t / cout;
+    int wo = (int)(r % 4); r /= 4;
+    int h = (int)(r % H);
+    int64_t i = r / H;
+    const int padt = (kh - 1) / 2;
+    const float *xi = in + (size_t)i * H * 4 * cin;
+    float acc = 0.0f;
+    for (int a = 0; a < kh; a++) {
+        int hi = h + a - padt;
+        if (hi < 0 || hi >= H) continue;
+        for (int b = 0; b < 4; b++) {
+            int wi = wo + b - 1;
+            if (wi < 0 || wi >= 4) continue;
+            const float *xr = xi + ((size_t)hi * 4 + wi) * cin;
+            const float *wr = w + ((size_t)(a * 4 + b) * cin) * cout + co;
+            for (int ci = 0; ci < cin; ci++) acc = __builtin_fmaf(xr[ci], wr[(size_t)ci * cout], acc);
+        }
+    }
+    pre[t] = acc + bias[co];
+}
+
+// pooled = max over the window of selu(pre)
+__global__ void t_pool_selu(const float *__restrict__ pre, float *__restrict__ out, int64_t n, int H, int c,
+                            int p)
+{
+    int Ho = H - p + 1, row = 4 * c;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * Ho * row) return;
+    int e = (int)(t % row);
+    int64_t r = t / row;
+    int h = (int)(r % Ho);
+    int64_t i = r / Ho;
+    const float *b = pre + ((size_t)i * H + h) * row + e;
+    float m = b[0];
+    for (int d = 1; d < p; d++) m = fmaxf(m, b[(size_t)d * row]);
+    out[t] = cvm::selu(m);     // selu is monotone: max(selu(x)) == selu(max(x))
+}
+
+__global__ void t_dense_pre(const float *__restrict__ x, const float *__restrict__ w,
+                            const float *__restrict__ bias, float *__restrict__ y, int64_t n, int K, int N)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * N) return;
+    int j = (int)(t % N);
+    int64_t i = t / N;
+    const float *xi = x + (size_t)i * K;
+    float acc = 0.0f;
+    for (int k = 0; k < K; k++) acc = __builtin_fmaf(xi[k], w[(size_t)k * N + j], acc);
+    y[t] = acc + bias[j];
+}
+
+// d4 = alpha-dropout(selu(fc4pre)); mask stored as a*keep (0 when dropped)
+__global__ void t_fc4_act(const float *__restrict__ pre, float *__restrict__ d4, float *__restrict__ amask,
+                          int64_t n, int N, float rate, uint64_t seed, uint64_t step, int64_t cand0)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * N) return;
+    float v = cvm::selu(pre[t]);
+    if (rate > 0.0f) {
+        const float ap = -1.7580993408473766f;
+        float q = 1.0f - rate;
+        float a = sqrtf(1.0f / (q * ((1.0f - q) * (ap * ap) + 1.0f)));
+        float b = 0.0f - a * ((1.0f - q) * ap);
+        uint64_t ctr = (seed * 0x9E3779B97F4A7C15ull) ^ (step << 40) ^ (uint64_t)(cand0 * N + t);
+        float u = (float)(hash_u32(ctr) >> 8) * (1.0f / 16777216.0f);   // [0,1)
+        float keep = floorf(q + u);                                     // selu.py:53-56
+        v = a * (v * keep + ap * (1.0f - keep)) + b;
+        amask[t] = a * keep;
+    } else {
+        amask[t] = 1.0f;
+    }
+    d4[t] = v;
+}
+
+__global__ void t_selu_act(const float *__restrict__ pre, float *__restrict__ act, int64_t total)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < total) act[t] = cvm::selu(pre[t]);
+}
+
+// heads: pre-activations, outputs, losses and d loss / d head-pre-activation.
+// 16 candidates x 16 outputs per block.
+__global__ __launch_bounds__(256) void t_heads(
+    const float *__restrict__ d4, const float *__restrict__ h5, int K4, int K5,
+    const float *__restrict__ wb, const float *__restrict__ bb, const float *__restrict__ wz,
+    const float *__restrict__ bz, const float *__restrict__ wt, const float *__restrict__ bt,
+    const float *__restrict__ wl, const float *__restrict__ bl, const float *__restrict__ y, int64_t n,
+    float *__restrict__ ghpre, double *__restrict__ loss)
+{
+    __shared__ float pre[16][17];
+    __shared__ double part[4];
+    int c = threadIdx.x >> 4, j = threadIdx.x & 15;
+    if (threadIdx.x < 4) part[threadIdx.x] = 0.0;
+    int64_t cand = (int64_t)blockIdx.x * 16 + c;
+    int64_t cl = cand < n ? cand : n - 1;
+    const float *w; const float *b; int idx, nh, K; const float *src;
+    if (j < 4)       { w = wb; b = bb; idx = j;      nh = 4; K = K4; src = d4; }
+    else if (j < 6)  { w = wz; b = bz; idx = j - 4;  nh = 2; K = K5; src = h5; }
+    else if (j < 10) { w = wt; b = bt; idx = j - 6;  nh = 4; K = K5; src = h5; }
+    else             { w = wl; b = bl; idx = j - 10; nh = 6; K = K5; src = h5; }
+    float acc = 0.0f;
+    const float *xi = src + (size_t)cl * K;
+    for (int k = 0; k < K; k++) acc = __builtin_fmaf(xi[k], w[(size_t)k * nh + idx], acc);
+    pre[c][j] = acc + b[idx];
+    __syncthreads();
+    if (cand < n && j < 4) {
+        const float *yi = y + (size_t)cand * 16;
+        float *g = ghpre ? ghpre + (size_t)cand * 16 : nullptr;
+        double l = 0.0;
+        if (j == 0) {
+            for (int k = 0; k < 4; k++) {
+                float s = cvm::sigmoid(pre[c][k]);
+                float d = s - yi[k];
+                l += (double)d * d;
+                if (g) g[k] = 2.0f * d * s * (1.0f - s);
+            }
+        } else {
+            const int off = j == 1 ? 4 : (j == 2 ? 6 : 10);
+            const int cnt = j == 1 ? 2 : (j == 2 ? 4 : 6);
+            float lg[6], p[6];
+            float mx = -__builtin_inff();
+            for (int k = 0; k < cnt; k++) { lg[k] = cvm::selu(pre[c][off + k]) + 1e-10f; mx = fmaxf(mx, lg[k]); }
+            float se = 0.0f, ysum = 0.0f;
+            for (int k = 0; k < cnt; k++) { p[k] = cvm::expf_fixed(lg[k] - mx); se += p[k]; ysum += yi[off + k]; }
+            float lse = mx + logf(se);
+            for (int k = 0; k < cnt; k++) {
+                l += -(double)yi[off + k] * (double)(lg[k] - lse);
+                if (g) g[off + k] = (p[k] / se * ysum - yi[off + k]) * cvm::selu_grad(pre[c][off + k]);
+            }
+        }
+        atomicAdd(&part[j], l);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(&loss[threadIdx.x], part[threadIdx.x]);
+}
+
+__global__ void t_l2(const float *__restrict__ w, int64_t count, double *__restrict__ out)
+{
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        s += (double)w[i] * (double)w[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, sh[0] * 0.5);
+}
+
+// ---- backward pieces -------------------------------------------------------------
+// dW[k][j] += sum_n x[n][k] * g[n][j] ; db[j] += sum_n g[n][j] (row k == K)
+// grid: (ceil((K+1)*N / 256), nslices); each slice covers a range of n.
+__global__ void b_dense_wgrad(const float *__restrict__ x, int ldx, const float *__restrict__ g, int ldg,
+                              int64_t n, int K, int N, float *__restrict__ dw, float *__restrict__ db)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)(K + 1) * N) return;
+    int j = (int)(t % N);
+    int k = (int)(t / N);
+    int64_t per = (n + gridDim.y - 1) / gridDim.y;
+    int64_t n0 = per * blockIdx.y, n1 = n0 + per < n ? n0 + per : n;
+    float acc = 0.0f;
+    if (k < K) {
+        for (int64_t i = n0; i < n1; i++) acc = __builtin_fmaf(x[(size_t)i * ldx + k], g[(size_t)i * ldg + j], acc);
+        atomicAdd(&dw[(size_t)k * N + j], acc);
+    } else {
+        for (int64_t i = n0; i < n1; i++) acc += g[(size_t)i * ldg + j];
+        atomicAdd(&db[j], acc);
+    }
+}
+
+// gx[n][k] (+)= sum_j g[n][j] * w[k][j]
+__global__ void b_dense_dgrad(const float *__restrict__ g, int ldg, const float *__restrict__ w, int64_t n,
+                              int K, int N, float *__restrict__ gx, int accumulate)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * K) return;
+    int k = (int)(t % K);
+    int64_t i = t / K;
+    const float *gi = g + (size_t)i * ldg;
+    const float *wr = w + (size_t)k * N;
+    float acc = 0.0f;
+    for (int j = 0; j < N; j++) acc = __builtin_fmaf(gi[j], wr[j], acc);
+    gx[t] = accumulate ? gx[t] + acc : acc;
+}
+
+// g_pre = g_act * selu'(pre) (optionally * amask for the dropout layer)
+__global__ void b_selu(const float *__restrict__ gact, const float *__restrict__ pre,
+                       const float *__restrict__ amask, float *__restrict__ gpre, int64_t total)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    float g = gact[t];
+    if (amask) g *= amask[t];
+    gpre[t] = g * cvm::selu_grad(pre[t]);
+}
+
+// max-pool backward (route to the first maximum of each window) fused with selu':
+// gpre[n][h][e] = selu'(pre) * sum_{ho: argmax(window ho) == h} gpool[n][ho][e]
+__global__ void b_pool_selu(const float *__restrict__ gpool, const float *__restrict__ pre,
+                            float *__restrict__ gpre, int64_t n, int H, int c, int p)
+{
+    int Ho = H - p + 1, row = 4 * c;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * H * row) return;
+    int e = (int)(t % row);
+    int64_t r = t / row;
+    int h = (int)(r % H);
+    int64_t i = r / H;
+    const float *b = pre + (size_t)i * H * row + e;
+    float me = b[(size_t)h * row];
+    float acc = 0.0f;
+    for (int ho = h - p + 1; ho <= h; ho++) {
+        if (ho < 0 || ho >= Ho) continue;
+        bool win = true;
+        for (int d = 0; d < p; d++) {
+            float v = b[(size_t)(ho + d) * row];
+            int hh = ho + d;
+            if (hh < h ? v >= me : v > me) { win = false; break; }   // first maximum wins
+        }
+        if (win) acc += gpool[((size_t)i * Ho + ho) * row + e];
+    }
+    gpre[t] = acc * cvm::selu_grad(me);
+}
+
+// conv weight / bias gradient: one thread per (kh,kw,ci,co) [+ cout bias threads],
+// blockIdx.y slices the batch.
+__global__ void b_conv_wgrad(const float *__restrict__ in, const float *__restrict__ gpre, int64_t n, int H,
+                             int cin, int kh, int cout, float *__restrict__ dw, float *__restrict__ db)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t nw = (int64_t)kh * 4 * cin * cout;
+    if (t >= nw + cout) return;
+    int64_t per = (n + gridDim.y - 1) / gridDim.y;
+    int64_t n0 = per * blockIdx.y, n1 = n0 + per < n ? n0 + per : n;
+    const int padt = (kh - 1) / 2;
+    float acc = 0.0f;
+    if (t < nw) {
+        int co = (int)(t % cout);
+        int64_t r = t / cout;
+        int ci = (int)(r % cin); r /= cin;
+        int b = (int)(r % 4);
+        int a = (int)(r / 4);
+        for (int64_t i = n0; i < n1; i++) {
+            const float *xi = in + (size_t)i * H * 4 * cin;
+            const float *gi = gpre + (size_t)i * H * 4 * cout;
+            for (int h = 0; h < H; h++) {
+                int hi = h + a - padt;
+                if (hi < 0 || hi >= H) continue;
+                for (int wo = 0; wo < 4; wo++) {
+                    int wi = wo + b - 1;
+                    if (wi < 0 || wi >= 4) continue;
+                    acc = __builtin_fmaf(xi[((size_t)hi * 4 + wi) * cin + ci], gi[((size_t)h * 4 + wo) * cout + co], acc);
+                }
+            }
+        }
+        atomicAdd(&dw[t], acc);
+    } else {
+        int co = (int)(t - nw);
+        for (int64_t i = n0; i < n1; i++) {
+            const float *gi = gpre + (size_t)i * H * 4 * cout;
+            for (int e = 0; e < H * 4; e++) acc += gi[(size_t)e * cout + co];
+        }
+        atomicAdd(&db[co], acc);
+    }
+}
+
+// conv input gradient: gin[n][hi][wi][ci] = sum_{kh,kw,co} gpre[n][hi-kh+pad][wi-kw+1][co] * w[kh][kw][ci][co]
+__global__ void b_conv_dgrad(const float *__restrict__ gpre, const float *__restrict__ w, int64_t n, int H,
+                             int cin, int kh, int cout, float *__restrict__ gin)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * H * 4 * cin) return;
+    int ci = (int)(t % cin);
+    int64_t r = t / cin;
+    int wi = (int)(r % 4); r /= 4;
+    int hi = (int)(r % H);
+    int64_t i = r / H;
+    const int padt = (kh - 1) / 2;
+    const float *gi = gpre + (size_t)i * H * 4 * cout;
+    float acc = 0.0f;
+    for (int a = 0; a < kh; a++) {
+        int h = hi - a + padt;
+        if (h < 0 || h >= H) continue;
+        for (int b = 0; b < 4; b++) {
+            int wo = wi - b + 1;
+            if (wo < 0 || wo >= 4) continue;
+            const float *gr = gi + ((size_t)h * 4 + wo) * cout;
+            const float *wr = w + (((size_t)a * 4 + b) * cin + ci) * cout;
+            for (int co = 0; co < cout; co++) acc = __builtin_fmaf(gr[co], wr[co], acc);
+        }
+    }
+    gin[t] = acc;
+}
+
+struct slab {
+    float *base; size_t used, cap;
+    float *take(size_t nfloat) { float *p = base + used; used += (nfloat + 63) / 64 * 64; return used <= cap ? p : nullptr; }
+};
+
+}  // namespace
+
+static size_t train_floats_per_cand(const cv_model *m)
+{
+    const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
+    size_t f = 0;
+    for (int l = 0; l < 3; l++) {
+        f += 2 * (size_t)s.hc[l] * 4 * a.cout[l];   // pre, gpre
+        f += 2 * (size_t)s.hp[l] * 4 * a.cout[l];   // pooled, gpooled
+    }
+    f += 5 * (size_t)a.fc4 + 4 * (size_t)a.fc5 + 32;
+    return f + 64 * 24;
+}
+
+// forward (+ optional backward) of one slice of the batch
+static int train_slice(cv_model *m, const float *x, const float *y, int64_t n, int64_t cand0, bool backward,
+                       float drop4, uint64_t seed, uint64_t step, hipStream_t st)
+{
+    const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
+    const float *P = m->params; float *G = m->grads; const int64_t *o = m->poff;
+    slab sb{m->t_buf, 0, m->t_bytes / sizeof(float)};
+    float *pre[3], *pool[3], *gpre[3], *gpool[3];
+    for (int l = 0; l < 3; l++) {
+        pre[l] = sb.take((size_t)n * s.hc[l] * 4 * a.cout[l]);
+        pool[l] = sb.take((size_t)n * s.hp[l] * 4 * a.cout[l]);
+        gpre[l] = sb.take((size_t)n * s.hc[l] * 4 * a.cout[l]);
+        gpool[l] = sb.take((size_t)n * s.hp[l] * 4 * a.cout[l]);
+    }
+    float *fc4pre = sb.take((size_t)n * a.fc4), *d4 = sb.take((size_t)n * a.fc4), *amask = sb.take((size_t)n * a.fc4);
+    float *gd4 = sb.take((size_t)n * a.fc4), *gfc4pre = sb.take((size_t)n * a.fc4);
+    float *fc5pre = sb.take((size_t)n * a.fc5), *h5 = sb.take((size_t)n * a.fc5);
+    float *gh5 = sb.take((size_t)n * a.fc5), *gfc5pre = sb.take((size_t)n * a.fc5);
+    float *ghpre = sb.take((size_t)n * 16);
+    if (!ghpre) { cv_set_error("training workspace too small"); return 1; }
+    // ---- forward
+    const float *in = x;
+    for (int l = 0; l < 3; l++) {
+        int H = s.hc[l], C = a.cout[l];
+        t_conv_pre<<<nblk(n * H * 4 * C, 256), 256, 0, st>>>(in, P + o[2 * l], P + o[2 * l + 1], pre[l], n, H,
+                                                            s.cin[l], a.kh[l], C);
+        t_pool_selu<<<nblk(n * s.hp[l] * 4 * C, 256), 256, 0, st>>>(pre[l], pool[l], n, H, C, a.pool[l]);
+        in = pool[l];
+    }
+    t_dense_pre<<<nblk(n * a.fc4, 256), 256, 0, st>>>(pool[2], P + o[6], P + o[7], fc4pre, n, s.flat, a.fc4);
+    t_fc4_act<<<nblk(n * a.fc4, 256), 256, 0, st>>>(fc4pre, d4, amask, n, a.fc4, backward ? drop4 : 0.0f, seed,
+                                                    step, cand0);
+    t_dense_pre<<<nblk(n * a.fc5, 256), 256, 0, st>>>(d4, P + o[8], P + o[9], fc5pre, n, a.fc4, a.fc5);
+    t_selu_act<<<nblk(n * a.fc5, 256), 256, 0, st>>>(fc5pre, h5, n * a.fc5);
+    t_heads<<<nblk(n, 16), 256, 0, st>>>(d4, h5, a.fc4, a.fc5, P + o[10], P + o[11], P + o[12], P + o[13],
+                                         P + o[14], P + o[15], P + o[16], P + o[17], y, n,
+                                         backward ? ghpre : nullptr, m->loss_dev);
+    CV_HIP(hipGetLastError());
+    if (!backward) return 0;
+    // ---- backward
+    const int NS = 32;   // batch slices for the weight-gradient reductions
+    // heads: columns of ghpre: 0..3 base (input d4), 4..5 / 6..9 / 10..15 (input h5)
+    b_dense_wgrad<<<dim3(nblk((a.fc4 + 1) * 4, 256), NS), 256, 0, st>>>(d4, a.fc4, ghpre + 0, 16, n, a.fc4, 4, G + o[10], G + o[11]);
+    b_dense_wgrad<<<dim3(nblk((a.fc5 + 1) * 2, 256), NS), 256, 0, st>>>(h5, a.fc5, ghpre + 4, 16, n, a.fc5, 2, G + o[12], G + o[13]);
+    b_dense_wgrad<<<dim3(nblk((a.fc5 + 1) * 4, 256), NS), 256, 0, st>>>(h5, a.fc5, ghpre + 6, 16, n, a.fc5, 4, G + o[14], G + o[15]);
+    b_dense_wgrad<<<dim3(nblk((a.fc5 + 1) * 6, 256), NS), 256, 0, st>>>(h5, a.fc5, ghpre + 10, 16, n, a.fc5, 6, G + o[16], G + o[17]);
+    b_dense_dgrad<<<nblk(n * a.fc4, 256), 256, 0, st>>>(ghpre + 0, 16, P + o[10], n, a.fc4, 4, gd4, 0);
+    b_dense_dgrad<<<nblk(n * a.fc5, 256), 256, 0, st>>>(ghpre + 4, 16, P + o[12], n, a.fc5, 2, gh5, 0);
+    b_dense_dgrad<<<nblk(n * a.fc5, 256), 256, 0, st>>>(ghpre + 6, 16, P + o[14], n, a.fc5, 4, gh5, 1);
+    b_dense_dgrad<<<nblk(n * a.fc5, 256), 256, 0, st>>>(ghpre + 10, 16, P + o[16], n, a.fc5, 6, gh5, 1);
+    // fc5
+    b_selu<<<nblk(n * a.fc5, 256), 256, 0, st>>>(gh5, fc5pre, nullptr, gfc5pre, n * a.fc5);
+    b_dense_wgrad<<<dim3(nblk((int64_t)(a.fc4 + 1) * a.fc5, 256), NS), 256, 0, st>>>(d4, a.fc4, gfc5pre, a.fc5, n, a.fc4, a.fc5, G + o[8], G + o[9]);
+    b_dense_dgrad<<<nblk(n * a.fc4, 256), 256, 0, st>>>(gfc5pre, a.fc5, P + o[8], n, a.fc4, a.fc5, gd4, 1);
+    // dropout4 + selu'
+    b_selu<<<nblk(n * a.fc4, 256), 256, 0, st>>>(gd4, fc4pre, amask, gfc4pre, n * a.fc4);
+    // fc4
+    b_dense_wgrad<<<dim3(nblk((int64_t)(s.flat + 1) * a.fc4, 256), 8), 256, 0, st>>>(pool[2], s.flat, gfc4pre, a.fc4, n, s.flat, a.fc4, G + o[6], G + o[7]);
+    b_dense_dgrad<<<nblk(n * s.flat, 256), 256, 0, st>>>(gfc4pre, a.fc4, P + o[6], n, s.flat, a.fc4, gpool[2], 0);
+    // conv stack
+    for (int l = 2; l >= 0; l--) {
+        int H = s.hc[l], C = a.cout[l];
+        b_pool_selu<<<nblk(n * H * 4 * C, 256), 256, 0, st>>>(gpool[l], pre[l], gpre[l], n, H, C, a.pool[l]);
+        const float *lin = l == 0 ? x : pool[l - 1];
+        int64_t nw = (int64_t)a.kh[l] * 4 * s.cin[l] * C + C;
+        b_conv_wgrad<<<dim3(nblk(nw, 64), 64), 64, 0, st>>>(lin, gpre[l], n, H, s.cin[l], a.kh[l], C, G + o[2 * l], G + o[2 * l + 1]);
+        if (l > 0)
+            b_conv_dgrad<<<nblk(n * H * 4 * s.cin[l], 256), 256, 0, st>>>(gpre[l], P + o[2 * l], n, H, s.cin[l], a.kh[l], C, gpool[l - 1]);
+    }
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
+static int train_pass(cv_model *m, const float *x, const float *y, int64_t n, bool backward, float drop4,
+                      float lambda, uint64_t seed, uint64_t step, double *losses_host, hipStream_t st)
+{
+    if (!m) { cv_set_error("null model"); return 1; }
+    if (n < 0) { cv_set_error("negative batch"); return 1; }
+    if (n > 0 && (!x || !y)) { cv_set_error("null buffer"); return 1; }
+    if (drop4 < 0.0f || drop4 >= 1.0f) { cv_set_error("dropout rate must be in [0,1)"); return 1; }
+    CV_HIP(hipSetDevice(m->device));
+    const int64_t slice = 2048;
+    const size_t need = train_floats_per_cand(m) * (size_t)(n < slice ? (n > 0 ? n : 1) : slice) * sizeof(float);
+    if (m->t_bytes < need) {
+        if (m->t_buf) CV_HIP(hipFree(m->t_buf));
+        m->t_buf = nullptr; m->t_bytes = 0;
+        CV_HIP(hipMalloc(&m->t_buf, need));
+        m->t_bytes = need;
+    }
+    CV_HIP(hipMemsetAsync(m->loss_dev, 0, sizeof(double) * 8, st));
+    if (backward) CV_HIP(hipMemsetAsync(m->grads, 0, sizeof(float) * m->poff[CV_NUM_PARAMS], st));
+    for (int64_t off = 0; off < n; off += slice) {
+        int64_t cn = n - off < slice ? n - off : slice;
+        if (train_slice(m, x + (size_t)off * (CV_INPUT_H * 16), y + (size_t)off * 16, cn, off, backward, drop4,
+                        seed, step, st))
+            return 1;
+    }
+    if (lambda != 0.0f)
+        for (int p = 0; p < CV_NUM_PARAMS; p += 2)
+            t_l2<<<64, 256, 0, st>>>(m->params + m->poff[p], m->psize[p], m->loss_dev + 4);
+    double h[8];
+    CV_HIP(hipMemcpyAsync(h, m->loss_dev, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
+    CV_HIP(hipStreamSynchronize(st));
+    if (losses_host) {
+        for (int k = 0; k < 4; k++) losses_host[k] = h[k];
+        losses_host[4] = h[4] * (double)lambda;
+        losses_host[5] = h[0] + h[1] + h[2] + h[3] + losses_host[4];
+    }
+    return 0;
+}
+
+extern "C" int cv_loss(cv_model *m, const float *x_dev, const float *y_dev, int64_t n, double *losses_host,
+                       void *stream)
+{
+    return train_pass(m, x_dev, y_dev, n, false, 0.0f, 0.0f, 0, 0, losses_host, (hipStream_t)stream);
+}
+
+extern "C" int cv_grad(cv_model *m, const float *x_dev, const float *y_dev, int64_t n, float drop4,
+                       float lambda, uint64_t seed, uint64_t step, double *losses_host, void *stream)
+{
+    return train_pass(m, x_dev, y_dev, n, true, drop4, lambda, seed, step, losses_host, (hipStream_t)stream);
+}

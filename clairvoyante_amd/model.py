@@ -1,0 +1,305 @@
+"""Host-side mirror of the reference model object.
+
+`Clairvoyante` keeps the exact method / attribute surface of
+/root/reference/clairvoyante/clairvoyante_v3.py:5-284 (identical in
+clairvoyante_v3_slim.py) so that the reference's drivers (`callVar.py`, `train.py`,
+`evaluate.py`) work unchanged against it; every method that was one
+`tf.Session.run` is one call into the HIP library (include/clairvoyante_amd.h).
+PyTorch is used for device memory, streams and `torch.distributed` only.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import param
+
+PARAM_NAMES = [
+    "conv1/kernel", "conv1/bias", "conv2/kernel", "conv2/bias", "conv3/kernel", "conv3/bias",
+    "fc4/kernel", "fc4/bias", "fc5/kernel", "fc5/bias",
+    "YBaseChangeSigmoid/kernel", "YBaseChangeSigmoid/bias",
+    "YZygosityFC/kernel", "YZygosityFC/bias",
+    "YVarTypeFC/kernel", "YVarTypeFC/bias",
+    "YIndelLengthFC/kernel", "YIndelLengthFC/bias",
+]
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.CvError("clairvoyante_amd needs an AMD GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback")
+
+
+class Clairvoyante(object):
+    """Drop-in for clairvoyante_v3.Clairvoyante (v3.py:7-29): same constructor
+    keywords, same defaults; `pollSize*` = None / (1,1) means "no pooling layer"
+    (the slim topology)."""
+
+    def __init__(self, inputShape=(2 * param.flankingBaseNum + 1, 4, param.matrixNum),
+                 outputShape1=(4,), outputShape2=(2,), outputShape3=(4,), outputShape4=(6,),
+                 kernelSize1=(1, 4), kernelSize2=(2, 4), kernelSize3=(3, 4),
+                 pollSize1=(5, 1), pollSize2=(4, 1), pollSize3=(3, 1),
+                 numFeature1=16, numFeature2=32, numFeature3=48,
+                 hiddenLayerUnits4=336, hiddenLayerUnits5=168,
+                 initialLearningRate=param.initialLearningRate, learningRateDecay=param.learningRateDecay,
+                 dropoutRateFC4=param.dropoutRateFC4, dropoutRateFC5=param.dropoutRateFC5,
+                 l2RegularizationLambda=param.l2RegularizationLambda,
+                 l2RegularizationLambdaDecay=param.l2RegularizationLambdaDecay,
+                 device=None):
+        if tuple(inputShape) != (33, 4, 4) or (tuple(outputShape1), tuple(outputShape2),
+                                               tuple(outputShape3), tuple(outputShape4)) != ((4,), (2,), (4,), (6,)):
+            raise ValueError("input [33,4,4] and heads 4/2/4/6 are fixed by the tensor format")
+        for ks in (kernelSize1, kernelSize2, kernelSize3):
+            if ks[1] != 4:
+                raise ValueError("kernel width must be 4 (one tap per base)")
+        if dropoutRateFC5 != 0.0:
+            raise ValueError("dropoutRateFC5 other than 0.0 is not supported (reference default, param.py:25)")
+        self.inputShape = inputShape
+        self.outputShape1 = outputShape1; self.outputShape2 = outputShape2
+        self.outputShape3 = outputShape3; self.outputShape4 = outputShape4
+        self.kernelSize1 = kernelSize1; self.kernelSize2 = kernelSize2; self.kernelSize3 = kernelSize3
+        self.pollSize1 = pollSize1; self.pollSize2 = pollSize2; self.pollSize3 = pollSize3
+        self.numFeature1 = numFeature1; self.numFeature2 = numFeature2; self.numFeature3 = numFeature3
+        self.hiddenLayerUnits4 = hiddenLayerUnits4; self.hiddenLayerUnits5 = hiddenLayerUnits5
+        self.learningRateVal = initialLearningRate; self.learningRateDecay = learningRateDecay
+        self.dropoutRateFC4Val = dropoutRateFC4; self.dropoutRateFC5Val = dropoutRateFC5
+        self.l2RegularizationLambdaVal = l2RegularizationLambda
+        self.l2RegularizationLambdaDecay = l2RegularizationLambdaDecay
+        self.trainLossRTVal = None; self.trainSummaryRTVal = None; self.getLossLossRTVal = None
+        self.predictBaseRTVal = None; self.predictZygosityRTVal = None
+        self.predictVarTypeRTVal = None; self.predictIndelLengthRTVal = None
+
+        _require_gpu()
+        self._lib = _lib.load()
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", int(device))
+        arch = _lib.CvArch()
+        arch.kh[:] = [kernelSize1[0], kernelSize2[0], kernelSize3[0]]
+        arch.cout[:] = [numFeature1, numFeature2, numFeature3]
+        arch.pool[:] = [1 if p is None else p[0] for p in (pollSize1, pollSize2, pollSize3)]
+        arch.fc4, arch.fc5 = hiddenLayerUnits4, hiddenLayerUnits5
+        self._arch = arch
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.cv_create(ctypes.byref(arch), self.device.index, ctypes.byref(h)))
+        self._h = h
+        self._shapes = {}
+        for i in range(_lib.NUM_PARAMS):
+            name = ctypes.c_char_p()
+            nd = ctypes.c_int()
+            dims = (ctypes.c_int64 * 4)()
+            _lib.check(self._lib.cv_param_info(self._h, i, ctypes.byref(name), ctypes.byref(nd), dims))
+            self._shapes[name.value.decode()] = tuple(int(d) for d in dims[:nd.value])
+        self.numParameters = int(sum(int(np.prod(s)) for s in self._shapes.values()))
+        self._adam_t = 0           # optimizer step count (beta*_power in the checkpoint)
+        self._train_step = 0       # counter for the dropout stream
+        self._dropout_seed = int.from_bytes(os.urandom(8), "little")   # reference is unseeded (selu.py:55)
+        self._seed_rng = np.random.RandomState()
+
+    # ---- helpers --------------------------------------------------------------
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _to_dev(self, a, last):
+        if torch.is_tensor(a):
+            t = a.to(device=self.device, dtype=torch.float32).contiguous()
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+        return t.reshape((-1,) + last)
+
+    def setOption(self, key, value):
+        _lib.check(self._lib.cv_set_option(self._h, key.encode(), int(value)))
+
+    def paramShapes(self):
+        return dict(self._shapes)
+
+    def setParameter(self, name, value):
+        v = np.ascontiguousarray(value, dtype=np.float32)
+        if tuple(v.shape) != self._shapes[name]:
+            raise ValueError("%s: shape %s, expected %s" % (name, v.shape, self._shapes[name]))
+        _lib.check(self._lib.cv_set_param(self._h, name.encode(), v.ctypes.data_as(ctypes.c_void_p),
+                                          v.size, self._stream()))
+
+    def getParameter(self, name):
+        v = np.empty(self._shapes[name], dtype=np.float32)
+        _lib.check(self._lib.cv_get_param(self._h, name.encode(), v.ctypes.data_as(ctypes.c_void_p),
+                                          v.size, self._stream()))
+        return v
+
+    def setParameters(self, params):
+        for n in PARAM_NAMES:
+            self.setParameter(n, params[n])
+
+    def getParameters(self):
+        return {n: self.getParameter(n) for n in PARAM_NAMES}
+
+    # ---- reference surface ------------------------------------------------------
+    def init(self):
+        """tf.global_variables_initializer (v3.py:177): variance_scaling_initializer(
+        factor=2.0, FAN_IN, uniform=False) = truncated normal, sigma sqrt(1.3*2/fan_in)
+        cut at 2 sigma, for conv/fc4/fc5 (v3.py:57); glorot_uniform for the heads
+        (tf.layers.dense default, v3.py:125-135); zero biases; zero Adam slots."""
+        rng = self._seed_rng
+        for name, shp in self._shapes.items():
+            if name.endswith("bias"):
+                v = np.zeros(shp, dtype=np.float32)
+            else:
+                fan_in = int(np.prod(shp[:-1])); fan_out = shp[-1]
+                if name.startswith("Y"):
+                    lim = np.sqrt(6.0 / (fan_in + fan_out))
+                    v = rng.uniform(-lim, lim, shp).astype(np.float32)
+                else:
+                    std = np.sqrt(1.3 * 2.0 / fan_in)
+                    t = rng.standard_normal(shp)
+                    bad = np.abs(t) > 2.0
+                    while bad.any():
+                        t[bad] = rng.standard_normal(int(bad.sum()))
+                        bad = np.abs(t) > 2.0
+                    v = (t * std).astype(np.float32)
+            self.setParameter(name, v)
+        self._zero_adam()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.cv_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def predict_device(self, x_dev, out16=None):
+        """Fast path: x_dev [n,33,4,4] fp32 on this GPU -> out16 [n,16] device tensor
+        (no host copies, asynchronous on the current stream)."""
+        n = x_dev.shape[0]
+        if out16 is None:
+            out16 = torch.empty((n, _lib.NUM_OUT), dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.cv_forward(self._h, ctypes.c_void_p(x_dev.data_ptr()), n,
+                                        ctypes.c_void_p(out16.data_ptr()), self._stream()))
+        return out16
+
+    def _predict_host(self, XArray):
+        with torch.cuda.device(self.device):
+            x = self._to_dev(XArray, (33, 4, 4))
+            out = self.predict_device(x).cpu().numpy()
+        return (np.ascontiguousarray(out[:, 0:4]), np.ascontiguousarray(out[:, 4:6]),
+                np.ascontiguousarray(out[:, 6:10]), np.ascontiguousarray(out[:, 10:16]))
+
+    def predict(self, XArray):
+        """v3.py:257-267 -> (base [n,4], zygosity [n,2], varType [n,4], indelLength [n,6])"""
+        return self._predict_host(XArray)
+
+    def predictNoRT(self, XArray):
+        """v3.py:269-280: results land in predict*RTVal (called from a worker thread)."""
+        self.predictBaseRTVal = None; self.predictZygosityRTVal = None
+        self.predictVarTypeRTVal = None; self.predictIndelLengthRTVal = None
+        (self.predictBaseRTVal, self.predictZygosityRTVal,
+         self.predictVarTypeRTVal, self.predictIndelLengthRTVal) = self._predict_host(XArray)
+
+    def getActivation(self, layer, n):
+        """Intermediate of the last pass in the reference's layout (debug / parity)."""
+        a = self._arch
+        hp = [33 - (a.pool[0] - 1)]
+        hp.append(hp[0] - (a.pool[1] - 1)); hp.append(hp[1] - (a.pool[2] - 1))
+        shp = {1: (n, hp[0], 4, a.cout[0]), 2: (n, hp[1], 4, a.cout[1]), 3: (n, hp[2], 4, a.cout[2]),
+               4: (n, a.fc4), 5: (n, a.fc5)}[layer]
+        dst = torch.empty(shp, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.cv_get_activation(self._h, layer, ctypes.c_void_p(dst.data_ptr()), n,
+                                               self._stream()))
+        return dst
+
+    # ---- training ---------------------------------------------------------------
+    def _flat(self, which):
+        """Copy of a flat device buffer as a torch tensor view-able by torch.distributed."""
+        raise NotImplementedError
+
+    def _zero_adam(self):
+        mp = ctypes.c_void_p(); vp = ctypes.c_void_p(); cnt = ctypes.c_int64()
+        _lib.check(self._lib.cv_adam_buffers(self._h, ctypes.byref(mp), ctypes.byref(vp), ctypes.byref(cnt)))
+        self._adam_t = 0
+
+    def _losses(self, fn, *args):
+        losses = (ctypes.c_double * 6)()
+        _lib.check(fn(*args, losses, self._stream()))
+        return list(losses)
+
+    def _loss_only(self, batchX, batchY):
+        with torch.cuda.device(self.device):
+            x = self._to_dev(batchX, (33, 4, 4)); y = self._to_dev(batchY, (16,))
+            l = self._losses(self._lib.cv_loss, self._h, ctypes.c_void_p(x.data_ptr()),
+                             ctypes.c_void_p(y.data_ptr()), x.shape[0])
+        return np.float32(l[5])
+
+    def _train_step_impl(self, batchX, batchY):
+        from . import parallel
+        with torch.cuda.device(self.device):
+            x = self._to_dev(batchX, (33, 4, 4)); y = self._to_dev(batchY, (16,))
+            self._train_step += 1
+            l = self._losses(self._lib.cv_grad, self._h, ctypes.c_void_p(x.data_ptr()),
+                             ctypes.c_void_p(y.data_ptr()), x.shape[0],
+                             ctypes.c_float(self.dropoutRateFC4Val),
+                             ctypes.c_float(self.l2RegularizationLambdaVal),
+                             ctypes.c_uint64(self._dropout_seed & 0xFFFFFFFFFFFFFFFF),
+                             ctypes.c_uint64(self._train_step))
+            l = parallel.allreduce_gradients(self, l)
+            self._adam_t += 1
+            _lib.check(self._lib.cv_apply_adam(self._h, ctypes.c_float(self.learningRateVal),
+                                               ctypes.c_float(self.l2RegularizationLambdaVal),
+                                               self._adam_t, self._stream()))
+        summary = {"learning_rate": self.learningRateVal, "l2Lambda": self.l2RegularizationLambdaVal,
+                   "loss1": l[0], "loss2": l[1], "loss3": l[2], "loss4": l[3], "lossL2": l[4], "loss": l[5]}
+        return np.float32(l[5]), summary
+
+    def train(self, batchX, batchY):
+        """v3.py:183-193 -> (loss, summary)"""
+        return self._train_step_impl(batchX, batchY)
+
+    def trainNoRT(self, batchX, batchY):
+        """v3.py:195-205"""
+        self.trainLossRTVal = None; self.trainSummaryRTVal = None
+        self.trainLossRTVal, self.trainSummaryRTVal = self._train_step_impl(batchX, batchY)
+
+    def getLoss(self, batchX, batchY):
+        """v3.py:207-216: phase False, dropout 0, lambda 0"""
+        return self._loss_only(batchX, batchY)
+
+    def getLossNoRT(self, batchX, batchY):
+        """v3.py:218-227"""
+        self.getLossLossRTVal = None
+        self.getLossLossRTVal = self._loss_only(batchX, batchY)
+
+    def setLearningRate(self, learningRate=None):
+        """v3.py:229-234"""
+        if learningRate is None:
+            self.learningRateVal = self.learningRateVal * self.learningRateDecay
+        else:
+            self.learningRateVal = learningRate
+        return self.learningRateVal
+
+    def setL2RegularizationLambda(self, l2RegularizationLambda=None):
+        """v3.py:236-241"""
+        if l2RegularizationLambda is None:
+            self.l2RegularizationLambdaVal = self.l2RegularizationLambdaVal * self.l2RegularizationLambdaDecay
+        else:
+            self.l2RegularizationLambdaVal = l2RegularizationLambda
+        return self.l2RegularizationLambdaVal
+
+    def saveParameters(self, fn):
+        """v3.py:243-246 (tf.train.Saver.save): writes fn.index / fn.data-00000-of-00001 /
+        fn.meta in the TensorFlow V2 checkpoint layout."""
+        from . import tf_checkpoint
+        tf_checkpoint.save_model(self, fn)
+
+    def restoreParameters(self, fn):
+        """v3.py:248-251 (tf.train.Saver.restore)"""
+        from . import tf_checkpoint
+        tf_checkpoint.restore_model(self, fn)
+
+    def summaryFileWriter(self, logsPath):
+        """v3.py:253-255: returns an object with add_summary(summary, step)."""
+        from . import summary
+        return summary.ScalarLogWriter(logsPath)

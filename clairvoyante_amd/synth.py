@@ -1,0 +1,109 @@
+"""Deterministic synthetic pileup tensors (the bench / parity workload).
+
+The value semantics follow the producer of the reference's text tensors
+(/root/reference/dataPrepScripts/CreateTensor.py:32-48): per position and base,
+matrix 0 counts reference bases of aligned reads, matrix 1 query bases plus
+inserted bases, matrix 2 reference bases plus deleted bases, matrix 3 query
+bases; the reader then subtracts matrix 0 from matrices 1..3
+(/root/reference/clairvoyante/utils_v2.py:46).  All values are small signed
+integers held in fp32 (CreateTensor.py:24 prints "%0.1f"; --dcov 250).
+
+Generator spec: seed = 20260927 + rank; reference bases uniform;
+depth ~ clip(Poisson(40), 4, 250); class ~ {ref .70, het-SNP .12, hom-SNP .08,
+INS .05, DEL .05}.  Written with torch ops so the same code fills HBM directly
+on an MI355X (bench) or runs on CPU (tests, fixtures).
+"""
+import torch
+
+H, W, C = 33, 4, 4
+CENTER = 16
+BASE_SEED = 20260927
+CLASS_P = (0.70, 0.12, 0.08, 0.05, 0.05)  # ref, het SNP, hom SNP, INS, DEL
+
+
+def _binomial(n, p, gen):
+    # n: float tensor of counts, p: float or tensor -> Binomial(n, p) via torch.binomial
+    pt = p if torch.is_tensor(p) else torch.full_like(n, float(p))
+    return torch.binomial(n, pt, generator=gen)
+
+
+def make_candidates(n, seed=BASE_SEED, device="cpu", return_class=False):
+    """-> X [n,33,4,4] fp32 (matrices 1..3 already minus matrix 0), optionally class ids."""
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed))
+    f32 = torch.float32
+    ref = torch.randint(0, 4, (n, H), generator=gen, device=dev)
+    depth = torch.poisson(torch.full((n,), 40.0, device=dev), generator=gen).clamp_(4, 250)
+    cls = torch.multinomial(torch.tensor(CLASS_P, device=dev), n, replacement=True, generator=gen)
+    onehot_ref = torch.nn.functional.one_hot(ref, 4).to(f32)            # [n,H,4]
+    dp = _binomial(depth[:, None].expand(n, H).contiguous(), 0.95, gen)  # per-position depth
+    m0 = onehot_ref * dp[..., None]
+    # matrix 3: query bases = ref bases minus sequencing errors moved to another base
+    err = _binomial(dp, 0.01, gen)
+    other = (ref + torch.randint(1, 4, (n, H), generator=gen, device=dev)) % 4
+    onehot_other = torch.nn.functional.one_hot(other, 4).to(f32)
+    m3 = onehot_ref * (dp - err)[..., None] + onehot_other * err[..., None]
+    # SNP at the centre: move an alt fraction (0.5 het / 1.0 hom) to the alt base
+    frac = torch.where(cls == 1, 0.5, torch.where(cls == 2, 1.0, 0.0)).to(f32)
+    alt = (ref[:, CENTER] + torch.randint(1, 4, (n,), generator=gen, device=dev)) % 4
+    altc = _binomial(dp[:, CENTER], frac, gen)
+    m3[:, CENTER] = m3[:, CENTER] - onehot_ref[:, CENTER] * torch.minimum(altc, m3[:, CENTER].gather(
+        1, ref[:, CENTER:CENTER + 1]).squeeze(1))[:, None] + torch.nn.functional.one_hot(alt, 4).to(f32) * altc[:, None]
+    m3.clamp_(min=0)
+    # indels: length 1..6 at offsets centre+1.., carried by ~half of the reads
+    ilen = torch.randint(1, 7, (n,), generator=gen, device=dev)
+    pos = torch.arange(H, device=dev)[None, :]
+    span = (pos > CENTER) & (pos <= CENTER + ilen[:, None])
+    carr = _binomial(depth, 0.5, gen)[:, None] * span.to(f32)            # [n,H]
+    ins_base = torch.randint(0, 4, (n, H), generator=gen, device=dev)
+    m1 = m3 + torch.nn.functional.one_hot(ins_base, 4).to(f32) * (carr * (cls == 3)[:, None])[..., None]
+    m2 = m0 + onehot_ref * (carr * (cls == 4)[:, None])[..., None]
+    # sparse alignment noise on the insertion matrix
+    noise = _binomial(torch.ones((n, H, 4), device=dev), 0.02, gen)
+    m1 = m1 + noise
+    x = torch.stack([m0, m1 - m0, m2 - m0, m3 - m0], dim=-1).contiguous()  # [n,H,4,4]
+    if return_class:
+        return x, cls, ref, alt, ilen
+    return x
+
+
+def make_stress(n, seed=BASE_SEED, device="cpu"):
+    """Uniform integers in [-250, 250] (worst-case magnitudes after subtraction)."""
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed) + 7)
+    return torch.randint(-250, 251, (n, H, W, C), generator=gen, device=dev).to(torch.float32)
+
+
+def make_labels(cls, ref, alt, ilen):
+    """16-vector labels with the reference's encoding
+    (/root/reference/clairvoyante/utils_v2.py:90-117,142-147)."""
+    n = cls.shape[0]
+    y = torch.zeros((n, 16), dtype=torch.float32, device=cls.device)
+    r = ref[:, CENTER]
+    idx = torch.arange(n, device=cls.device)
+    isref = cls == 0
+    het = cls == 1
+    hom = cls == 2
+    ins = cls == 3
+    dele = cls == 4
+    # base change
+    y[idx[isref], r[isref]] = 1.0
+    y[idx[het], r[het]] = 0.5
+    y[idx[het], alt[het]] = 0.5
+    y[idx[hom], alt[hom]] = 1.0
+    indel = ins | dele
+    y[idx[indel], r[indel]] = 0.5          # het indel: utils_v2.py:95-96
+    # zygosity: HET(4) for het SNP and (het) indels, HOM(5) for ref and hom SNP
+    y[:, 4] = (het | indel).float()
+    y[:, 5] = (isref | hom).float()
+    # type REF SNP INS DEL
+    y[:, 6] = isref.float()
+    y[:, 7] = (het | hom).float()
+    y[:, 8] = ins.float()
+    y[:, 9] = dele.float()
+    # length 0,1,2,3,4,>4
+    ln = torch.where(indel, ilen.clamp(max=5), torch.zeros_like(ilen))
+    y[idx, 10 + ln] = 1.0
+    return y

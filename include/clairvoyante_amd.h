@@ -1,0 +1,141 @@
+/*
+ * clairvoyante_amd.h -- C ABI of the MI355X-native Clairvoyante v3 pileup-CNN path.
+ *
+ * The reference has no FFI layer: its boundary is the duck-typed Python class
+ * `Clairvoyante` (clairvoyante/clairvoyante_v3.py:5-284, same surface in
+ * clairvoyante_v3_slim.py) whose methods each wrap ONE `tf.Session.run`.  This
+ * header is what a binding for that class would bind instead of TensorFlow: every
+ * entry point below names the reference method / session.run it replaces.
+ * INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - plain C; pointers + sizes only.  `*_dev` pointers are DEVICE (HBM) pointers
+ *     (e.g. torch `tensor.data_ptr()`), `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream).  Work is enqueued on `stream`; calls do not
+ *     synchronise unless stated.
+ *   - tensors use the reference's layouts: X [n,33,4,4] fp32 NHWC
+ *     (position, base ACGT, matrix), already with matrices 1..3 minus matrix 0
+ *     (clairvoyante/utils_v2.py:46); Y [n,16] fp32; parameters in TensorFlow
+ *     layouts (conv HWIO, dense [in,out]) keyed by their checkpoint variable names.
+ *   - every function returns 0 on success, non-zero on error; cv_last_error()
+ *     returns a thread-local message.  No ownership crosses the boundary except
+ *     the opaque handle.
+ *   - a handle is bound to one GPU and may be used from any host thread, one call
+ *     at a time (the reference drives predictNoRT/trainNoRT from a worker thread:
+ *     callVar.py:197-204, train.py:87-109).
+ */
+#ifndef CLAIRVOYANTE_AMD_H
+#define CLAIRVOYANTE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CV_INPUT_H 33      /* 2*flankingBaseNum+1, clairvoyante/param.py:6 */
+#define CV_INPUT_W 4       /* A C G T */
+#define CV_INPUT_C 4       /* matrixNum, clairvoyante/param.py:7 */
+#define CV_NUM_OUT 16      /* base4 | zygosity2 | varType4 | indelLength6 */
+#define CV_NUM_PARAMS 18
+
+/* Constructor arguments of the reference class (clairvoyante_v3.py:7-16).
+ * v3 full: kh {1,2,3} cout {16,32,48} pool {5,4,3} fc4 336 fc5 168
+ * v3 slim: kh {1,3,5} cout {8,16,32}  pool {1,1,1} fc4 36  fc5 18
+ * (clairvoyante_v3_slim.py:9-11; no pooling layers = window 1).              */
+typedef struct cv_arch {
+    int32_t kh[3];      /* kernelSize{1,2,3}[0]; the width is always 4        */
+    int32_t cout[3];    /* numFeature{1,2,3}                                   */
+    int32_t pool[3];    /* pollSize{1,2,3}[0]; 1 = layer absent                */
+    int32_t fc4, fc5;   /* hiddenLayerUnits{4,5}                               */
+} cv_arch;
+
+typedef struct cv_model cv_model;
+
+/* thread-local text of the last failure on the calling thread */
+const char *cv_last_error(void);
+
+/* replaces Clairvoyante.__init__ + _buildGraph + tf.Session (v3.py:7-29):
+ * allocates weights, optimizer slots and workspaces on GPU `device`.          */
+int cv_create(const cv_arch *arch, int device, cv_model **out);
+/* replaces Clairvoyante.close / __del__ (v3.py:180,283) */
+int cv_destroy(cv_model *m);
+
+/* Variable table = tf.trainable_variables() of the reference graph
+ * (jupyter_nb/visualization.ipynb:103-120).  idx in [0, CV_NUM_PARAMS).       */
+int cv_param_info(const cv_model *m, int idx, const char **tf_name, int *ndim, int64_t dims[4]);
+/* Flat fp32 device buffer holding all 18 variables back to back in table order
+ * (TF layouts): what restoreParameters fills and saveParameters reads
+ * (v3.py:243-251), what a data-parallel host all-reduces / broadcasts.
+ * `offsets` (optional) receives CV_NUM_PARAMS+1 float offsets.                 */
+int cv_param_buffer(cv_model *m, float **flat_dev, int64_t *count, int64_t *offsets);
+/* copy one variable in (tf.train.Saver.restore, v3.py:248-251) / out (save).
+ * `src`/`dst` are HOST pointers; synchronous with respect to `stream`.        */
+int cv_set_param(cv_model *m, const char *tf_name, const float *src, int64_t count, void *stream);
+int cv_get_param(cv_model *m, const char *tf_name, float *dst, int64_t count, void *stream);
+/* tell the model the flat buffer was modified externally (repack on next use) */
+int cv_params_changed(cv_model *m);
+
+/* replaces session.run((YBaseChangeSigmoid, YZygositySoftmax, YVarTypeSoftmax,
+ * YIndelLengthSoftmax), phase False) of predict / predictNoRT (v3.py:257-280).
+ * out16_dev [n,16]: columns 0..3 base sigmoid, 4..5 zygosity softmax,
+ * 6..9 variant-type softmax, 10..15 indel-length softmax.  n may be 0.          */
+int cv_forward(cv_model *m, const float *x_dev, int64_t n, float *out16_dev, void *stream);
+
+/* Device-side part of callVar.Output (callVar.py:59-72,81-87): per candidate
+ * argmax of the three softmax heads (lowest index wins ties, np.argmax), the two
+ * best bases of the sigmoid head (highest index wins ties, argsort()[::-1]),
+ * the genotype-quality operands (top-2 products, fp32) and the depth sum `dp`.
+ * call_dev [n,8] int32: varType, zygosity, indelLength, base1, base2, 0,0,0
+ * qual_dev [n,4] fp32 : top1 product, top2 product, dp, 0                       */
+int cv_call_postproc(cv_model *m, const float *x_dev, const float *out16_dev, int64_t n,
+                     int32_t *call_dev, float *qual_dev, void *stream);
+
+/* debug / parity: copy one intermediate of the LAST cv_forward chunk to
+ * dst_dev in the reference's natural layout ([n,h,4,c] NHWC or [n,units]).
+ * layer: 1..3 = pool1..pool3 outputs (for slim: conv outputs), 4 = fc4, 5 = fc5.
+ * Serves what getTensorAndLayerPNG.py:30-37 reaches into m.conv1.. for.         */
+int cv_get_activation(cv_model *m, int layer, float *dst_dev, int64_t n, void *stream);
+
+/* knobs: "impl" (0 = plain one-thread-per-output kernels, 1 = MFMA tile kernels),
+ * "chunk" (candidates per internal pass), "profile" (0/1, see cv_kernel_times).  */
+int cv_set_option(cv_model *m, const char *key, int64_t value);
+int cv_get_option(const cv_model *m, const char *key, int64_t *value);
+
+/* Per-kernel device timing of cv_forward (option "profile" = 1): every kernel launch
+ * is bracketed by hipEventRecord on the launch stream.  cv_kernel_times synchronises,
+ * returns for stage s = 0..CV_NUM_STAGES-1 (conv1, conv2, conv3, fc4, fc5, heads)
+ * the summed milliseconds and launch counts since the last call, and resets them.  */
+#define CV_NUM_STAGES 6
+int cv_kernel_times(cv_model *m, double ms[CV_NUM_STAGES], int64_t launches[CV_NUM_STAGES]);
+
+/* ---- training (replaces the session.run calls of train / trainNoRT /
+ * getLoss / getLossNoRT, v3.py:183-227, and AdamOptimizer, v3.py:174) ---------- */
+
+/* forward loss with phase False, dropout 0, lambda 0 (getLoss, v3.py:207-216).
+ * losses_host[6]: loss1..loss4, lossL2, total -- SUMS over the batch
+ * (v3.py:140-151).  Synchronises `stream`.                                      */
+int cv_loss(cv_model *m, const float *x_dev, const float *y_dev, int64_t n, double *losses_host,
+            void *stream);
+/* forward (phase True: alpha-dropout rate `drop4` on fc4, selu.py:34-69; rate on
+ * fc5 is 0.0 = identity) + backward into the flat gradient buffer (data terms
+ * only, no lambda term).  seed/step select the counter-based dropout stream.
+ * losses_host as above with lossL2 = lambda*sum(w^2)/2.  Synchronises.          */
+int cv_grad(cv_model *m, const float *x_dev, const float *y_dev, int64_t n, float drop4,
+            float lambda, uint64_t seed, uint64_t step, double *losses_host, void *stream);
+/* flat gradient buffer, same order/size as cv_param_buffer (for RCCL all-reduce) */
+int cv_grad_buffer(cv_model *m, float **flat_dev, int64_t *count);
+/* TF1 Adam (beta1 .9, beta2 .999, eps 1e-8, lr_t = lr*sqrt(1-b2^t)/(1-b1^t)) on
+ * grad + lambda*w for non-bias variables (l2 term of v3.py:150); t = 1,2,...     */
+int cv_apply_adam(cv_model *m, float lr, float lambda, int64_t t, void *stream);
+/* optimizer slots m / v (checkpoint variables "<name>/Adam", "<name>/Adam_1")   */
+int cv_adam_buffers(cv_model *m, float **m_dev, float **v_dev, int64_t *count);
+/* device-to-device copy between a caller buffer (e.g. a torch tensor handed to
+ * torch.distributed) and one of the flat buffers: which 0 = parameters,
+ * 1 = gradients, 2 = Adam m, 3 = Adam v; to_model != 0 copies caller -> model.  */
+int cv_flat_copy(cv_model *m, int which, float *caller_dev, int to_model, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLAIRVOYANTE_AMD_H */

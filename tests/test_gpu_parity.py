@@ -1,0 +1,89 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): argmax-exact on all four heads, |dp| <= 1e-4 on the
+probabilities.  The kernels reproduce the oracle's canonical fmaf order, so the tests
+assert a much tighter 2e-6 and report the bitwise-equal fraction.
+"""
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-6
+
+
+def _model(arch):
+    from clairvoyante_amd import clairvoyante_v3, clairvoyante_v3_slim
+    return clairvoyante_v3.Clairvoyante() if arch == "full" else clairvoyante_v3_slim.Clairvoyante()
+
+
+@pytest.fixture(scope="module", params=["full", "slim"])
+def setup(request, oracle):
+    arch = request.param
+    P = common.bench_params(oracle, arch)
+    m = _model(arch)
+    m.setParameters(P)
+    x = common.inputs(1000, stress=24)
+    ref = oracle.forward_all(arch, P, x)
+    yield arch, P, m, x, ref
+    m.close()
+
+
+@pytest.mark.parametrize("impl", [1, 0])
+def test_outputs_match_oracle(setup, impl):
+    arch, P, m, x, ref = setup
+    m.setOption("impl", impl)
+    base, z, t, l = m.predict(x)
+    got = np.concatenate([base, z, t, l], axis=1)
+    assert got.shape == ref["out"].shape
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref["out"]).max() <= TOL
+    assert common.argmax_match(got, ref["out"]) == [1.0, 1.0, 1.0, 1.0]
+
+
+@pytest.mark.parametrize("impl", [1, 0])
+def test_intermediates_match_oracle(setup, impl):
+    import torch
+    arch, P, m, x, ref = setup
+    m.setOption("impl", impl)
+    n = x.shape[0]
+    m.predict_device(torch.from_numpy(x).cuda())
+    for layer, name in ((1, "pool1"), (2, "pool2"), (3, "pool3"), (4, "fc4"), (5, "fc5")):
+        a = m.getActivation(layer, n).cpu().numpy().reshape(n, -1)
+        b = ref[name].reshape(n, -1)
+        scale = max(1.0, float(np.abs(b).max()))
+        assert np.abs(a - b).max() <= 1e-5 * scale, name
+
+
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 33, 1000])
+def test_ragged_batch_sizes(setup, n):
+    arch, P, m, x, ref = setup
+    m.setOption("impl", 1)
+    base, z, t, l = m.predict(x[:n])
+    assert base.shape == (n, 4) and z.shape == (n, 2) and t.shape == (n, 4) and l.shape == (n, 6)
+    if n:
+        got = np.concatenate([base, z, t, l], axis=1)
+        assert np.abs(got - ref["out"][:n]).max() <= TOL
+
+
+def test_chunking_is_invisible(setup):
+    """results do not depend on the internal pass size"""
+    arch, P, m, x, ref = setup
+    m.setOption("impl", 1)
+    m.setOption("chunk", 256)
+    a = np.concatenate(m.predict(x), axis=1)
+    m.setOption("chunk", 32768)
+    b = np.concatenate(m.predict(x), axis=1)
+    assert np.array_equal(a, b)
+
+
+def test_plain_and_tile_kernels_agree_bitwise(setup):
+    arch, P, m, x, ref = setup
+    m.setOption("impl", 0)
+    a = np.concatenate(m.predict(x), axis=1)
+    m.setOption("impl", 1)
+    b = np.concatenate(m.predict(x), axis=1)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
