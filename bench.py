@@ -42,7 +42,7 @@ def cpu_baseline(arch, P, x_sample, target_s=12.0):
     n = int(min(x_sample.shape[0], max(1024, rate * target_s)))
     t0 = time.time(); out = O.predict(arch, P, x_sample[:n], nthreads=cores); dt = time.time() - t0
     return {"value": n / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
-            "sample": "%d candidates of the first batch, oracle/cv_oracle.c, %d OpenMP threads, %.1f s"
+            "sample": "first %d candidates of the timed set, oracle/cv_oracle.c, %d OpenMP threads, %.1f s"
                       % (n, cores, dt)}, out, n
 
 
@@ -133,9 +133,9 @@ def main():
                            "arch": args.arch, "batch": args.batch, "parallelism": "shard%d" % ws},
                 "roofline": roof, "kernels": stages}
         if not args.no_cpu:
-            xs = batches[0][:16384].cpu().numpy()
+            xs = torch.cat([b_ for b_ in batches[:4]])[:262144].cpu().numpy()
             cb, ref, n = cpu_baseline(args.arch, P, xs)
-            got = m.predict_device(batches[0][:n].contiguous()).cpu().numpy()
+            got = m.predict_device(torch.from_numpy(xs[:n]).to(dev)).cpu().numpy()
             line["cpu_baseline"] = cb
             line["parity"] = {"n": n, "argmax_match_per_head": common.argmax_match(got, ref),
                               "max_abs_dprob": float(np.abs(got - ref).max()),
