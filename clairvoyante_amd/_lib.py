@@ -59,6 +59,13 @@ _SIGS = {
                                     ctypes.c_void_p]),
     "cv_adam_buffers": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
                                        ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]),
+    "cv_parse_tensor_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
+                                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "cv_blosc_nbytes": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64]),
+    "cv_blosc_decompress": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]),
+    "cv_blosc_compress_lz4": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
+                                             ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
 }
 
 EXPORTS = sorted(_SIGS)

@@ -1,0 +1,291 @@
+"""Variant-calling driver: same command line, VCF output and function surface as
+/root/reference/clairvoyante/callVar.py (Run :21-47, Output :50-153, PrintVCFHeader
+:156-178, Test :180-216, main :219-262).
+
+    python -m clairvoyante_amd.callVar --chkpnt_fn MODEL --tensor_fn TENSORS.gz --call_fn OUT.vcf
+
+Pipeline (one process per GPU): a reader thread parses text tensors into pinned batches
+(native parser), the GPU runs the network and the per-candidate arg-max / quality / depth
+reductions (cv_call_postproc), and the host formats VCF lines only for the candidates
+that produce one.  `Output()` keeps the reference's signature (host arrays in, text out)
+and is the formatter both paths share.
+"""
+import argparse
+import ctypes
+import logging
+import os
+import sys
+import time
+from math import log
+from queue import Queue
+from threading import Thread
+
+import numpy as np
+
+from . import param
+
+logging.basicConfig(format='%(message)s', level=logging.INFO)
+num2base = dict(zip((0, 1, 2, 3), "ACGT"))
+base2num = dict(zip("ACGT", (0, 1, 2, 3)))
+v2Zygosity2Name = dict(zip((0, 1), ('HET', 'HOM')))
+v2Type2Name = dict(zip((0, 1, 2, 3), ('REF', 'SNP', 'INS', 'DEL')))
+v2Length2Name = dict(zip((0, 1, 2, 3, 4, 5), ('0', '1', '2', '3', '4', '4+')))
+maxVarLength = 5
+inferIndelLengthMinimumAF = 0.125
+_F = param.flankingBaseNum
+
+
+def _top2_products(t, z, l):
+    """fp32 products of the best and second-best probabilities of the three softmax heads
+    (np.sort(x)[::-1][0/1], callVar.py:69-72); evaluated left to right in fp32 like NumPy."""
+    st = -np.sort(-t, axis=1); sz = -np.sort(-z, axis=1); sl = -np.sort(-l, axis=1)
+    p1 = (st[:, 0] * sz[:, 0]) * sl[:, 0]
+    p2 = (st[:, 1] * sz[:, 1]) * sl[:, 1]
+    return p1.astype(np.float32), p2.astype(np.float32)
+
+
+def _qual(p1, p2):
+    """callVar.py:72 with reference-era promotion: fp32 products, then float64."""
+    return int(-4.343 * log((float(p2) + 1e-300) / (float(p1) + 1e-300)))
+
+
+def _depth(X):
+    """dp of callVar.py:86-87 for every candidate (values are integers: exact in fp32)"""
+    return ((X[:, _F, :, 0].sum(1, dtype=np.float32) + X[:, _F + 1, :, 1].sum(1, dtype=np.float32))
+            + X[:, _F + 1, :, 2].sum(1, dtype=np.float32)) + X[:, _F, :, 3].sum(1, dtype=np.float32)
+
+
+def _format_record(args, x, pos, varType, varZygosity, varLength, base1, base2, qual, dp):
+    """One VCF line (or None when dp == 0) from per-candidate decisions; x is the candidate's
+    [33,4,4] tensor.  Allele / length inference of callVar.py:88-153."""
+    if dp == 0:
+        return None
+    chromosome, coordination, refSeq = pos.split(":")
+    coordination = int(coordination)
+    info = []
+    inferred = 0
+    refBase = refSeq[_F]
+    if varType == 1 or varType == 0:
+        b1 = num2base[base1]; b2 = num2base[base2]
+        altBase = refBase if varType == 0 else (b1 if b1 != refBase else b2)
+        af = x[_F, base2num[altBase], 3] / dp
+    elif varType == 2:
+        if varLength == 0:
+            varLength = 1
+        af = x[_F + 1, :, 1].sum(dtype=np.float32) / dp
+        ins = ""
+        if varLength != maxVarLength:
+            for k in range(_F + 1, _F + varLength + 1):
+                ins += num2base[int(np.argmax(x[k, :, 1]))]
+        else:
+            for k in range(_F + 1, 2 * _F + 1):
+                if k < (_F + maxVarLength) or x[k, :, 1].sum(dtype=np.float32) >= inferIndelLengthMinimumAF * x[k, :, 0].sum(dtype=np.float32):
+                    inferred += 1
+                    ins += num2base[int(np.argmax(x[k, :, 1]))]
+                else:
+                    break
+        if inferred >= _F:
+            altBase = "<INS>"
+            info.append("SVTYPE=INS")
+        else:
+            altBase = refBase + ins
+    else:
+        if varLength == 0:
+            varLength = 1
+        af = x[_F + 1, :, 2].sum(dtype=np.float32) / dp
+        if varLength == maxVarLength:
+            for k in range(_F + 1, 2 * _F + 1):
+                if k < (_F + maxVarLength) or x[k, :, 2].sum(dtype=np.float32) >= inferIndelLengthMinimumAF * x[k, :, 0].sum(dtype=np.float32):
+                    inferred += 1
+                else:
+                    break
+        if inferred >= _F:
+            altBase = "<DEL>"
+            info.append("SVTYPE=DEL")
+        elif varLength != maxVarLength:
+            refBase = refSeq[_F:_F + varLength + 1]
+            altBase = refSeq[_F]
+        else:
+            refBase = refSeq[_F:_F + inferred + 1]
+            altBase = refSeq[_F]
+    if 0 < inferred < _F:
+        info.append("LENGUESS=%d" % inferred)
+    infoStr = ";".join(info) if info else "."
+    if varType == 0:
+        gt = "0/0"
+    else:
+        gt = "0/1" if varZygosity == 0 else "1/1"
+    filt = "."
+    if args.qual is not None:
+        filt = "PASS" if qual >= args.qual else "LowQual"
+    return "%s\t%d\t.\t%s\t%s\t%d\t%s\t%s\tGT:GQ:DP:AF\t%s:%d:%d:%.4f" % (
+        chromosome, coordination, refBase, altBase, qual, filt, infoStr, gt, qual, dp, af)
+
+
+def Output(args, call_fh, num, XBatch, posBatch, base, z, t, l):
+    """callVar.py:50-153: writes the VCF records of one batch given host arrays."""
+    if num != len(base):
+        sys.exit("Inconsistent shape between input tensor and output predictions %d/%d" % (num, len(base)))
+    if num == 0:
+        return
+    X = np.asarray(XBatch, dtype=np.float32)
+    base = np.asarray(base); z = np.asarray(z); t = np.asarray(t); l = np.asarray(l)
+    varType = np.argmax(t, axis=1)
+    keep = np.arange(num) if args.showRef else np.nonzero(varType != 0)[0]
+    if keep.size == 0:
+        return
+    varZyg = np.argmax(z, axis=1)
+    varLen = np.argmax(l, axis=1)
+    p1, p2 = _top2_products(t[keep], z[keep], l[keep])
+    # argsort()[::-1]: descending, the higher index first among equal values (callVar.py:81)
+    order = np.argsort(base[keep], axis=1, kind="stable")[:, ::-1]
+    dp = _depth(X[keep])
+    lines = []
+    for i, j in enumerate(keep):
+        rec = _format_record(args, X[j], posBatch[j], int(varType[j]), int(varZyg[j]), int(varLen[j]),
+                             int(order[i, 0]), int(order[i, 1]), _qual(p1[i], p2[i]), dp[i])
+        if rec is not None:
+            lines.append(rec)
+    if lines:
+        call_fh.write("\n".join(lines) + "\n")
+
+
+def PrintVCFHeader(args, call_fh):
+    """callVar.py:156-178"""
+    hdr = ['##fileformat=VCFv4.1',
+           '##FILTER=<ID=PASS,Description="All filters passed">',
+           '##FILTER=<ID=LowQual,Description="Confidence in this variant being real is below calling threshold.">',
+           '##ALT=<ID=DEL,Description="Deletion">',
+           '##ALT=<ID=INS,Description="Insertion of novel sequence">',
+           '##INFO=<ID=SVTYPE,Number=1,Type=String,Description="Type of structural variant">',
+           '##INFO=<ID=LENGUESS,Number=.,Type=Integer,Description="Best guess of the indel length">',
+           '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
+           '##FORMAT=<ID=GQ,Number=1,Type=Integer,Description="Genotype Quality">',
+           '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="Read Depth">',
+           '##FORMAT=<ID=AF,Number=1,Type=Float,Description="Estimated allele frequency in the range (0,1)">']
+    if args.ref_fn is not None:
+        with open(args.ref_fn + ".fai") as fai_fp:
+            for line in fai_fp:
+                fields = line.strip().split("\t")
+                hdr.append("##contig=<ID=%s,length=%d>" % (fields[0], int(fields[1])))
+    hdr.append('#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s' % (args.sampleName))
+    call_fh.write("\n".join(hdr) + "\n")
+
+
+def OutputFromDevice(args, call_fh, num, XBatch, posBatch, call, qual):
+    """Formatter of the GPU path: `call` [n,8] int32 and `qual` [n,4] fp32 come from
+    cv_call_postproc (arg-maxes, two best bases, the fp32 top-2 products, dp)."""
+    if num == 0:
+        return
+    keep = np.arange(num) if args.showRef else np.nonzero(call[:, 0] != 0)[0]
+    lines = []
+    for j in keep:
+        rec = _format_record(args, XBatch[j], posBatch[j], int(call[j, 0]), int(call[j, 1]), int(call[j, 2]),
+                             int(call[j, 3]), int(call[j, 4]), _qual(qual[j, 0], qual[j, 1]), qual[j, 2])
+        if rec is not None:
+            lines.append(rec)
+    if lines:
+        call_fh.write("\n".join(lines) + "\n")
+
+
+def Run(args):
+    """callVar.py:21-47"""
+    logging.info("Loading model ...")
+    from . import utils_v2 as utils
+    utils.SetupEnv()
+    if args.v2:
+        sys.exit("Clairvoyante v2 topologies are not part of this build (v3 / v3 slim only)")
+    if args.slim:
+        from . import clairvoyante_v3_slim as cv
+    else:
+        from . import clairvoyante_v3 as cv
+    if args.threads is None:
+        if args.tensor_fn == "PIPE":
+            param.NUM_THREADS = 4
+    else:
+        param.NUM_THREADS = args.threads
+    m = cv.Clairvoyante()
+    m.init()
+    m.restoreParameters(os.path.abspath(args.chkpnt_fn))
+    Test(args, m, utils)
+
+
+def Test(args, m, utils):
+    """callVar.py:180-216 re-cut for the GPU: reader thread (parse) || GPU (predict + per-
+    candidate reductions) || writer (format); batches stay in order, so the VCF is the
+    reference's record for record."""
+    import torch
+    from . import _lib
+    call_fh = open(args.call_fn, "w")
+    PrintVCFHeader(args, call_fh)
+    logging.info("Calling variants ...")
+    predictStart = time.time()
+    batch = getattr(args, "batch_size", None) or max(param.predictBatchSize, 16384)
+    q_in = Queue(maxsize=4)
+
+    def reader():
+        try:
+            for item in utils.GetTensor(args.tensor_fn, batch):
+                q_in.put(item)
+        except BaseException as e:   # surfaced on the consumer side (the reference loses it)
+            q_in.put(e)
+        q_in.put(None)
+
+    rt = Thread(target=reader, daemon=True)
+    rt.start()
+    lib = m._lib
+    pending = None                   # (num, X, pos, call_dev, qual_dev, event)
+    with torch.cuda.device(m.device):
+        while True:
+            item = q_in.get()
+            if isinstance(item, BaseException):
+                raise item
+            nxt = None
+            if item is not None:
+                end, num, X, pos = item
+                if num > 0:
+                    xd = torch.from_numpy(X).to(m.device, non_blocking=True)
+                    out = m.predict_device(xd)
+                    call = torch.empty((num, 8), dtype=torch.int32, device=m.device)
+                    qual = torch.empty((num, 4), dtype=torch.float32, device=m.device)
+                    _lib.check(lib.cv_call_postproc(m._h, ctypes.c_void_p(xd.data_ptr()),
+                                                    ctypes.c_void_p(out.data_ptr()), num,
+                                                    ctypes.c_void_p(call.data_ptr()),
+                                                    ctypes.c_void_p(qual.data_ptr()), m._stream()))
+                    nxt = (num, X, pos, call, qual)
+            if pending is not None:      # format batch k while the GPU works on batch k+1
+                pnum, pX, ppos, pcall, pqual = pending
+                OutputFromDevice(args, call_fh, pnum, pX, ppos, pcall.cpu().numpy(), pqual.cpu().numpy())
+            pending = nxt
+            if item is None:
+                break
+    call_fh.close()
+    logging.info("Total time elapsed: %.2f s" % (time.time() - predictStart))
+
+
+def main():
+    parser = argparse.ArgumentParser(
+        description="Call variants using a trained Clairvoyante model and tensors of candididate variants")
+    parser.add_argument('--tensor_fn', type=str, default="PIPE", help="Tensor input, use PIPE for standard input")
+    parser.add_argument('--chkpnt_fn', type=str, default=None, help="Input a checkpoint for testing or continue training")
+    parser.add_argument('--call_fn', type=str, default=None, help="Output variant predictions")
+    parser.add_argument('--qual', type=int, default=None,
+                        help="If set, variant with equal or higher quality will be marked PASS, or LowQual otherwise, optional")
+    parser.add_argument('--sampleName', type=str, default="SAMPLE", help="Define the sample name to be shown in the VCF file")
+    parser.add_argument('--showRef', type=param.str2bool, nargs='?', const=True, default=False, help="Show reference calls, optional")
+    parser.add_argument('--ref_fn', type=str, default=None,
+                        help="Reference fasta file input, optional, print contig tags in the VCF header if set")
+    parser.add_argument('--threads', type=int, default=None, help="Number of threads, optional")
+    parser.add_argument('--v3', type=param.str2bool, nargs='?', const=True, default=True, help="Use Clairvoyante version 3")
+    parser.add_argument('--v2', type=param.str2bool, nargs='?', const=True, default=False, help="Use Clairvoyante version 2")
+    parser.add_argument('--slim', type=param.str2bool, nargs='?', const=True, default=False,
+                        help="Train using the slim version of Clairvoyante, optional")
+    args = parser.parse_args()
+    if len(sys.argv[1:]) == 0:
+        parser.print_help()
+        sys.exit(1)
+    Run(args)
+
+
+if __name__ == "__main__":
+    main()

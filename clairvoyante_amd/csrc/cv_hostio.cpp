@@ -1,0 +1,296 @@
+// cv_hostio.cpp -- host-side data plane of the hot path (no GPU code):
+//   * cv_parse_tensor_text: the text-tensor reader of utils_v2.GetTensor
+//     (/root/reference/clairvoyante/utils_v2.py:20-59; producer format
+//     /root/reference/dataPrepScripts/CreateTensor.py:24,56):  one candidate per line,
+//     "<ctg> <pos> <refSeq33> " + 528 numbers, value index = 16*offset + 4*base + matrix.
+//     The reference tokenises each row in CPython; this is a single pass over the bytes.
+//   * cv_blosc_decompress: c-blosc 1.x chunk decoder (LZ4 / LZ4HC streams, byte shuffle,
+//     split blocks, memcpy'd chunks) for the 500-item blocks of the .bin training file
+//     (utils_v2.py:159-207, tensor2Bin.py:24-28).  c-blosc is a third-party dependency of
+//     the reference (python-blosc, requirements.txt:3, unpinned, not vendored); the decoder
+//     follows its published chunk format (16-byte header, bstarts table, per-split
+//     length-prefixed streams) and the LZ4 block format.
+//   * cv_blosc_compress_lz4: writer of the same container (greedy LZ4, byte shuffle).
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "../../include/clairvoyante_amd.h"
+
+void cv_set_error(const char *fmt, ...);
+
+namespace {
+
+inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+
+// Fast path for the "%0.1f"-style decimals CreateTensor writes; anything else goes to strtod.
+inline bool parse_number(const char *&p, const char *end, float &out)
+{
+    const char *s = p;
+    bool neg = false;
+    if (s < end && (*s == '-' || *s == '+')) { neg = *s == '-'; s++; }
+    if (s >= end || ((*s < '0' || *s > '9') && *s != '.')) return false;
+    uint64_t ip = 0; int nd = 0;
+    while (s < end && *s >= '0' && *s <= '9' && nd < 15) { ip = ip * 10 + (uint64_t)(*s - '0'); s++; nd++; }
+    uint64_t fp = 0; int fd = 0;
+    bool simple = true;
+    if (s < end && *s == '.') {
+        s++;
+        while (s < end && *s >= '0' && *s <= '9' && fd < 6) { fp = fp * 10 + (uint64_t)(*s - '0'); s++; fd++; }
+    }
+    if (s < end && !is_space(*s) && *s != '\n') simple = false;   // exponent, long mantissa, inf/nan ...
+    if (nd == 0 && fd == 0) simple = false;
+    if (!simple) {
+        char tmp[64]; size_t n = 0;
+        const char *q = p;
+        while (q < end && !is_space(*q) && *q != '\n' && n + 1 < sizeof(tmp)) tmp[n++] = *q++;
+        tmp[n] = 0;
+        char *ep = nullptr;
+        double v = strtod(tmp, &ep);
+        if (ep == tmp || *ep != 0) return false;
+        out = (float)v; p = q;
+        return true;
+    }
+    static const double p10[7] = {1, 10, 100, 1000, 10000, 100000, 1000000};
+    double v = (double)ip;
+    if (fd) v += (double)fp / p10[fd];      // exact for the one-decimal values of the format
+    out = (float)(neg ? -v : v);
+    p = s;
+    return true;
+}
+
+}  // namespace
+
+// Parses complete lines from buf[0..len).  For every accepted row r (centre base of the
+// upper-cased refSeq in ACGT, utils_v2.py:38-40) writes 528 floats to x_out (matrices 1..3
+// minus matrix 0, utils_v2.py:45-46) and 6 int64 to meta_out: byte offsets/lengths of ctg,
+// pos, seq inside buf.  Stops after max_rows rows or at the last complete line.
+// *consumed = bytes eaten (whole lines only), *nrows = accepted rows, *nbad = malformed rows.
+extern "C" int cv_parse_tensor_text(const char *buf, int64_t len, int64_t max_rows, float *x_out,
+                                    int64_t *meta_out, int64_t *consumed, int64_t *nrows, int64_t *nbad)
+{
+    if (!buf || !x_out || !meta_out || !consumed || !nrows) { cv_set_error("cv_parse_tensor_text: null argument"); return 1; }
+    const int NV = CV_INPUT_H * CV_INPUT_W * CV_INPUT_C;
+    int64_t rows = 0, bad = 0;
+    const char *p = buf, *end = buf + len;
+    const char *line_start = p;
+    while (rows < max_rows) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        if (!nl) break;
+        const char *q = p;
+        line_start = p;
+        p = nl + 1;
+        // three string tokens
+        const char *tok[3]; int64_t tl[3]; int nt = 0;
+        while (nt < 3) {
+            while (q < nl && is_space(*q)) q++;
+            if (q >= nl) break;
+            tok[nt] = q;
+            while (q < nl && !is_space(*q)) q++;
+            tl[nt] = q - tok[nt];
+            nt++;
+        }
+        if (nt == 0) continue;                       // blank line
+        float *xr = x_out + (size_t)rows * NV;
+        bool ok = nt == 3;
+        int nv = 0;
+        while (ok) {
+            while (q < nl && is_space(*q)) q++;
+            if (q >= nl) break;
+            if (nv >= NV) { ok = false; break; }
+            if (!parse_number(q, nl, xr[nv])) { ok = false; break; }
+            nv++;
+        }
+        if (!ok || nv != NV) { bad++; continue; }     // the reference prints "UnpackATensorRecord Failure"
+        if (tl[2] <= CV_INPUT_H / 2) continue;
+        char c = tok[2][CV_INPUT_H / 2];
+        if (c >= 'a' && c <= 'z') c = (char)(c - 32);
+        if (c != 'A' && c != 'C' && c != 'G' && c != 'T') continue;
+        for (int e = 0; e < NV; e += 4) { float m0 = xr[e]; xr[e + 1] -= m0; xr[e + 2] -= m0; xr[e + 3] -= m0; }
+        int64_t *mr = meta_out + rows * 6;
+        for (int k = 0; k < 3; k++) { mr[2 * k] = tok[k] - buf; mr[2 * k + 1] = tl[k]; }
+        rows++;
+    }
+    (void)line_start;
+    *consumed = p - buf;
+    *nrows = rows;
+    if (nbad) *nbad = bad;
+    return 0;
+}
+
+// ---- c-blosc 1.x container ------------------------------------------------------------
+namespace {
+
+int lz4_decompress(const uint8_t *src, int srclen, uint8_t *dst, int dstcap)
+{
+    const uint8_t *ip = src, *iend = src + srclen;
+    uint8_t *op = dst, *oend = dst + dstcap;
+    while (ip < iend) {
+        unsigned token = *ip++;
+        size_t lit = token >> 4;
+        if (lit == 15) { unsigned b; do { if (ip >= iend) return -1; b = *ip++; lit += b; } while (b == 255); }
+        if ((size_t)(iend - ip) < lit || (size_t)(oend - op) < lit) return -1;
+        memcpy(op, ip, lit); op += lit; ip += lit;
+        if (ip >= iend) break;                       // last sequence has no match
+        if (iend - ip < 2) return -1;
+        size_t off = ip[0] | ((size_t)ip[1] << 8); ip += 2;
+        if (off == 0 || (size_t)(op - dst) < off) return -1;
+        size_t ml = token & 15;
+        if (ml == 15) { unsigned b; do { if (ip >= iend) return -1; b = *ip++; ml += b; } while (b == 255); }
+        ml += 4;
+        if ((size_t)(oend - op) < ml) return -1;
+        const uint8_t *m = op - off;
+        for (size_t i = 0; i < ml; i++) op[i] = m[i];  // overlapping copies are the point
+        op += ml;
+    }
+    return (int)(op - dst);
+}
+
+// greedy single-pass LZ4 block compressor (hash of 4 bytes); returns size or -1 if dst too small
+int lz4_compress(const uint8_t *src, int n, uint8_t *dst, int cap)
+{
+    const int HB = 13;
+    int table[1 << HB];
+    for (int i = 0; i < (1 << HB); i++) table[i] = -1;
+    int ip = 0, anchor = 0, op = 0;
+    auto emit = [&](int litlen, int mlen, int off) -> bool {
+        int need = 1 + litlen + litlen / 255 + 1 + (mlen >= 0 ? 2 + (mlen - 4) / 255 + 1 : 0);
+        if (op + need > cap) return false;
+        int tok = op++;
+        int l = litlen;
+        if (l >= 15) { dst[tok] = 15 << 4; l -= 15; while (l >= 255) { dst[op++] = 255; l -= 255; } dst[op++] = (uint8_t)l; }
+        else dst[tok] = (uint8_t)(l << 4);
+        memcpy(dst + op, src + anchor, (size_t)litlen); op += litlen;
+        if (mlen >= 0) {
+            dst[op++] = (uint8_t)(off & 255); dst[op++] = (uint8_t)(off >> 8);
+            int m = mlen - 4;
+            if (m >= 15) { dst[tok] |= 15; m -= 15; while (m >= 255) { dst[op++] = 255; m -= 255; } dst[op++] = (uint8_t)m; }
+            else dst[tok] |= (uint8_t)m;
+        }
+        return true;
+    };
+    const int mflimit = n - 12;      // LZ4 end-of-block rules: last 5 bytes literals, last match >= 12 from end
+    while (ip < mflimit) {
+        uint32_t v; memcpy(&v, src + ip, 4);
+        uint32_t h = (v * 2654435761u) >> (32 - HB);
+        int cand = table[h];
+        table[h] = ip;
+        uint32_t cv = 0;
+        if (cand >= 0) memcpy(&cv, src + cand, 4);
+        if (cand >= 0 && ip - cand < 65536 && cv == v) {
+            int ml = 4;
+            const int maxml = n - 5 - ip;
+            while (ml < maxml && src[cand + ml] == src[ip + ml]) ml++;
+            if (!emit(ip - anchor, ml, ip - cand)) return -1;
+            ip += ml; anchor = ip;
+        } else ip++;
+    }
+    if (!emit(n - anchor, -1, 0)) return -1;
+    return op;
+}
+
+void shuffle_bytes(const uint8_t *src, uint8_t *dst, int n, int ts)
+{
+    int ne = n / ts;
+    for (int j = 0; j < ts; j++)
+        for (int i = 0; i < ne; i++) dst[j * ne + i] = src[i * ts + j];
+    memcpy(dst + (size_t)ne * ts, src + (size_t)ne * ts, (size_t)(n - ne * ts));
+}
+
+void unshuffle_bytes(const uint8_t *src, uint8_t *dst, int n, int ts)
+{
+    int ne = n / ts;
+    for (int i = 0; i < ne; i++)
+        for (int j = 0; j < ts; j++) dst[i * ts + j] = src[j * ne + i];
+    memcpy(dst + (size_t)ne * ts, src + (size_t)ne * ts, (size_t)(n - ne * ts));
+}
+
+inline int32_t rd32(const uint8_t *p) { return (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)); }
+inline void wr32(uint8_t *p, int32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+
+}  // namespace
+
+// uncompressed size recorded in a blosc chunk header (or -1)
+extern "C" int64_t cv_blosc_nbytes(const uint8_t *chunk, int64_t clen)
+{
+    if (!chunk || clen < 16) return -1;
+    return (int64_t)(uint32_t)rd32(chunk + 4);
+}
+
+extern "C" int cv_blosc_decompress(const uint8_t *chunk, int64_t clen, uint8_t *dst, int64_t dstcap)
+{
+    if (!chunk || !dst || clen < 16) { cv_set_error("blosc: truncated chunk"); return 1; }
+    const int flags = chunk[2], typesize = chunk[3] ? chunk[3] : 1;
+    const int32_t nbytes = rd32(chunk + 4), blocksize = rd32(chunk + 8), cbytes = rd32(chunk + 12);
+    if (chunk[0] != 2) { cv_set_error("blosc: unsupported format version %d", chunk[0]); return 1; }
+    if (nbytes < 0 || dstcap < nbytes || cbytes > clen || blocksize <= 0) { cv_set_error("blosc: bad header"); return 1; }
+    if (nbytes == 0) return 0;
+    if (flags & 0x2) {                                  // memcpy'd
+        if (clen < 16 + (int64_t)nbytes) { cv_set_error("blosc: truncated memcpy chunk"); return 1; }
+        memcpy(dst, chunk + 16, (size_t)nbytes);
+        return 0;
+    }
+    if (flags & 0x4) { cv_set_error("blosc: bit-shuffle is not supported"); return 1; }
+    const int codec = (flags & 0xe0) >> 5;
+    if (codec != 1) { cv_set_error("blosc: compressor format %d not supported (the .bin files use lz4hc)", codec); return 1; }
+    const bool doshuffle = (flags & 0x1) && typesize > 1;
+    const bool dont_split = (flags & 0x10) != 0;
+    const int nblocks = (nbytes + blocksize - 1) / blocksize;
+    if (16 + 4 * (int64_t)nblocks > clen) { cv_set_error("blosc: truncated bstarts"); return 1; }
+    uint8_t *tmp = doshuffle ? (uint8_t *)malloc((size_t)blocksize) : nullptr;
+    int rc = 0;
+    for (int b = 0; b < nblocks && !rc; b++) {
+        int bsize = blocksize;
+        bool leftover = false;
+        if (b == nblocks - 1 && nbytes % blocksize) { bsize = nbytes % blocksize; leftover = true; }
+        int nsplits = 1;
+        if (!dont_split && typesize <= 16 && blocksize / typesize >= 128 && !leftover) nsplits = typesize;
+        const int neblock = bsize / nsplits;
+        int64_t ip = rd32(chunk + 16 + 4 * b);
+        uint8_t *out = doshuffle ? tmp : dst + (size_t)b * blocksize;
+        for (int s = 0; s < nsplits; s++) {
+            if (ip + 4 > clen) { rc = 1; break; }
+            int32_t cb = rd32(chunk + ip); ip += 4;
+            if (cb < 0 || ip + cb > clen) { rc = 1; break; }
+            if (cb == neblock) memcpy(out + (size_t)s * neblock, chunk + ip, (size_t)cb);
+            else if (lz4_decompress(chunk + ip, cb, out + (size_t)s * neblock, neblock) != neblock) { rc = 1; break; }
+            ip += cb;
+        }
+        if (!rc && doshuffle) unshuffle_bytes(tmp, dst + (size_t)b * blocksize, bsize, typesize);
+    }
+    free(tmp);
+    if (rc) cv_set_error("blosc: corrupt LZ4 stream");
+    return rc;
+}
+
+// Writes one chunk (single block, no split, byte shuffle when typesize > 1, LZ4 stream,
+// compressor tag lz4).  dstcap >= n + 32.  Returns the chunk size in *clen.
+extern "C" int cv_blosc_compress_lz4(const uint8_t *src, int64_t n, int typesize, uint8_t *dst, int64_t dstcap,
+                                     int64_t *clen)
+{
+    if (!src || !dst || !clen || n < 0 || n > 0x7fffff00) { cv_set_error("blosc: bad compress arguments"); return 1; }
+    if (dstcap < n + 32) { cv_set_error("blosc: destination too small"); return 1; }
+    if (typesize < 1 || typesize > 255) typesize = 1;
+    const bool sh = typesize > 1 && n >= typesize;
+    dst[0] = 2; dst[1] = 1; dst[3] = (uint8_t)typesize;
+    wr32(dst + 4, (int32_t)n); wr32(dst + 8, (int32_t)(n > 0 ? n : 1));
+    int flags = (1 << 5) | 0x10 | (sh ? 1 : 0);
+    int64_t total = -1;
+    if (n >= 64) {
+        uint8_t *tmp = sh ? (uint8_t *)malloc((size_t)n) : nullptr;
+        if (sh) shuffle_bytes(src, tmp, (int)n, typesize);
+        wr32(dst + 16, 20);
+        int c = lz4_compress(sh ? tmp : src, (int)n, dst + 24, (int)(n - 1));
+        if (c > 0) { wr32(dst + 20, c); total = 24 + c; }
+        free(tmp);
+    }
+    if (total < 0) {                                   // incompressible / tiny: memcpy'd chunk
+        flags = (1 << 5) | 0x10 | 0x2;
+        memcpy(dst + 16, src, (size_t)n);
+        total = 16 + n;
+    }
+    dst[2] = (uint8_t)flags;
+    wr32(dst + 12, (int32_t)total);
+    *clen = total;
+    return 0;
+}

@@ -1,0 +1,311 @@
+"""Data plane of the hot path: same functions, arguments and return values as
+/root/reference/clairvoyante/utils_v2.py (SetupEnv :14, GetTensor :23-59,
+GetTrainingArray :62-186, DecompressArray :189-207), with the per-row tokenising and
+the blosc codec done in native code (csrc/cv_hostio.cpp) instead of CPython / python-blosc.
+"""
+import ctypes
+import gc
+import gzip
+import io
+import os
+import pickle
+import random
+import shlex
+import subprocess
+import sys
+
+import numpy as np
+
+from . import _lib
+from . import param
+
+base2num = dict(zip("ACGT", (0, 1, 2, 3)))
+_NV = (2 * param.flankingBaseNum + 1) * 4 * param.matrixNum
+
+
+def SetupEnv():
+    """utils_v2.py:14-18 (CXX / TF log level / blosc threads have no meaning here)."""
+    os.environ["CXX"] = "g++"
+    gc.enable()
+
+
+class PosBatch(object):
+    """The `pos` list of a GetTensor batch ("chrom:coord:seq", utils_v2.py:41), built lazily:
+    at GPU rates only the few candidates that become VCF records ever need their string."""
+
+    def __init__(self, buf, meta):
+        self._buf = buf
+        self._meta = meta
+
+    def __len__(self):
+        return self._meta.shape[0]
+
+    def __getitem__(self, j):
+        if isinstance(j, slice):
+            return [self[i] for i in range(*j.indices(len(self)))]
+        m = self._meta[j]
+        b = self._buf
+        return (b[m[0]:m[0] + m[1]] + b":" + b[m[2]:m[2] + m[3]] + b":" + b[m[4]:m[4] + m[5]].upper()).decode("ascii")
+
+    def __iter__(self):
+        for j in range(len(self)):
+            yield self[j]
+
+
+def _open_tensor_stream(tensor_fn):
+    if tensor_fn != "PIPE":
+        f = subprocess.Popen(shlex.split("gzip -fdc %s" % (tensor_fn)), stdout=subprocess.PIPE, bufsize=8388608)
+        return f, f.stdout
+    return None, sys.stdin.buffer
+
+
+def GetTensor(tensor_fn, num, log=True):
+    """Generator over batches of `num` candidates: yields (endFlag, c, X, pos) exactly like
+    utils_v2.py:23-59 -- X [c,33,4,4] fp32 with matrices 1..3 minus matrix 0, rows whose
+    centre base is not ACGT dropped, a final (possibly empty) batch with endFlag 1."""
+    lib = _lib.load()
+    proc, fo = _open_tensor_stream(tensor_fn)
+    total = 0
+    pending = b""
+    rows = np.empty((num, _NV), dtype=np.float32)
+    meta = np.empty((num, 6), dtype=np.int64)
+    c = 0
+    bufs = []          # (bytes, meta rows) pieces of the batch being filled
+    consumed = ctypes.c_int64(); nrows = ctypes.c_int64(); nbad = ctypes.c_int64()
+    eof = False
+    while True:
+        chunk = fo.read(1 << 24) if not eof else b""
+        if not chunk:
+            eof = True
+            if pending and not pending.endswith(b"\n"):
+                pending += b"\n"
+        data = pending + chunk
+        off = 0
+        while off < len(data):
+            view = data[off:]
+            _lib.check(lib.cv_parse_tensor_text(view, len(view), num - c,
+                                                rows[c:].ctypes.data_as(ctypes.c_void_p),
+                                                meta[c:].ctypes.data_as(ctypes.c_void_p),
+                                                ctypes.byref(consumed), ctypes.byref(nrows), ctypes.byref(nbad)))
+            if nbad.value:
+                print("UnpackATensorRecord Failure (%d malformed rows skipped)" % nbad.value, file=sys.stderr)
+            if nrows.value:
+                bufs.append((view, meta[c:c + nrows.value].copy()))
+            c += nrows.value
+            off += consumed.value
+            if c == num:
+                total += c
+                if log:
+                    print("Processed %d tensors" % total, file=sys.stderr)
+                yield 0, c, rows.reshape((num, 2 * param.flankingBaseNum + 1, 4, param.matrixNum)), _join_pos(bufs)
+                rows = np.empty((num, _NV), dtype=np.float32)
+                meta = np.empty((num, 6), dtype=np.int64)
+                c = 0
+                bufs = []
+            elif consumed.value == 0:
+                break
+        pending = data[off:]
+        if eof:
+            break
+    if proc is not None:
+        fo.close()
+        proc.wait()
+    total += c
+    if log:
+        print("Processed %d tensors" % total, file=sys.stderr)
+    yield 1, c, rows[:c].reshape((c, 2 * param.flankingBaseNum + 1, 4, param.matrixNum)), _join_pos(bufs)
+
+
+def _join_pos(bufs):
+    if len(bufs) == 1:
+        return PosBatch(bufs[0][0], bufs[0][1])
+    out = []
+    for b, m in bufs:
+        out += list(PosBatch(b, m))
+    return out
+
+
+# ---- blosc container (python-blosc pack_array / unpack_array equivalents) ---------------
+def blosc_decompress(chunk):
+    lib = _lib.load()
+    n = lib.cv_blosc_nbytes(chunk, len(chunk))
+    if n < 0:
+        raise _lib.CvError("blosc: truncated chunk")
+    out = ctypes.create_string_buffer(max(int(n), 1))
+    _lib.check(lib.cv_blosc_decompress(chunk, len(chunk), out, n))
+    return out.raw[:n]
+
+
+def blosc_compress(data, typesize):
+    lib = _lib.load()
+    out = ctypes.create_string_buffer(len(data) + 64)
+    clen = ctypes.c_int64()
+    _lib.check(lib.cv_blosc_compress_lz4(data, len(data), int(typesize), out, len(out), ctypes.byref(clen)))
+    return out.raw[:clen.value]
+
+
+def pack_array(arr):
+    """blosc.pack_array: compress(pickle.dumps(array, HIGHEST_PROTOCOL), typesize=itemsize)"""
+    return blosc_compress(pickle.dumps(arr, pickle.HIGHEST_PROTOCOL), arr.itemsize)
+
+
+def unpack_array(chunk):
+    """blosc.unpack_array; accepts blocks pickled by Python 2 (latin1 / bytes payloads)."""
+    if isinstance(chunk, str):
+        chunk = chunk.encode("latin1")
+    raw = blosc_decompress(bytes(chunk))
+    try:
+        return pickle.loads(raw)
+    except (UnicodeDecodeError, ValueError):
+        return pickle.loads(raw, encoding="latin1")
+
+
+def LoadBin(bin_fn):
+    """The four back-to-back pickles of tensor2Bin.py:24-28 (also files written by Python 2)."""
+    with open(bin_fn, "rb") as fh:
+        try:
+            objs = [pickle.load(fh) for _ in range(4)]
+        except (UnicodeDecodeError, ValueError):
+            fh.seek(0)
+            objs = [pickle.load(fh, encoding="bytes") for _ in range(4)]
+    return objs[0], objs[1], objs[2], objs[3]
+
+
+def _label(row):
+    """16-vector label of one truth row `ctg pos ref alt gt1 gt2` (utils_v2.py:90-119):
+    base A,C,G,T | HET,HOM | REF,SNP,INS,DEL | length 0,1,2,3,4,>4"""
+    ref, alt, g1, g2 = row[2], row[3], row[4], row[5]
+    v = [0.0] * 16
+    snp_like = len(ref) == 1 and len(alt) == 1
+    if g1 == "0" and g2 == "1":
+        if snp_like:
+            v[base2num[ref[0]]] = 0.5
+            v[base2num[alt[0]]] = 0.5
+        else:
+            v[base2num[ref[0]]] = 0.5
+        v[4] = 1.0
+    elif g1 == "1" and g2 == "1":
+        if snp_like:
+            v[base2num[alt[0]]] = 1
+        v[5] = 1.0
+    if len(ref) > 1 and len(alt) == 1:
+        v[9] = 1.0
+    elif len(alt) > 1 and len(ref) == 1:
+        v[8] = 1.0
+    else:
+        v[7] = 1.0
+    d = abs(len(ref) - len(alt))
+    v[15 if d > 4 else 10 + d] = 1.0
+    return v
+
+
+class _Intervals(object):
+    """Point-stabbing over the BED intervals of one contig (the reference uses
+    intervaltree.IntervalTree.addi(begin, end) / search(pos), half-open [begin, end))."""
+
+    def __init__(self):
+        self.iv = []
+        self._sorted = None
+
+    def addi(self, b, e):
+        self.iv.append((b, e))
+        self._sorted = None
+
+    def hit(self, p):
+        if self._sorted is None:
+            iv = sorted(self.iv)
+            self._b = np.array([x[0] for x in iv], dtype=np.int64)
+            # running maximum of the ends lets one bisect answer "any interval covers p"
+            self._emax = np.maximum.accumulate(np.array([x[1] for x in iv], dtype=np.int64)) if iv else np.array([], dtype=np.int64)
+            self._sorted = True
+        k = int(np.searchsorted(self._b, p, side="right"))
+        return k > 0 and self._emax[k - 1] > p
+
+
+def _gz_lines(fn):
+    f = subprocess.Popen(shlex.split("gzip -fdc %s" % (fn)), stdout=subprocess.PIPE, bufsize=8388608)
+    for row in io.TextIOWrapper(f.stdout, encoding="ascii", errors="replace"):
+        yield row
+    f.stdout.close()
+    f.wait()
+
+
+def GetTrainingArray(tensor_fn, var_fn, bed_fn, shuffle=True):
+    """utils_v2.py:62-186 -> (total, XArrayCompressed, YArrayCompressed, posArrayCompressed):
+    blocks of param.bloscBlockSize items; X fp32 [k,33,4,4] (matrix-0-subtracted), Y float64
+    [k,16], pos string array; a trailing (possibly empty) block is always appended."""
+    tree = {}
+    if bed_fn is not None:
+        for row in _gz_lines(bed_fn):
+            row = row.split()
+            if not row:
+                continue
+            t = tree.setdefault(row[0], _Intervals())
+            begin = int(row[1]); end = int(row[2]) - 1
+            if end == begin:
+                end += 1
+            t.addi(begin, end)
+    Y = {}
+    if var_fn is not None:
+        for row in _gz_lines(var_fn):
+            row = row.split()
+            if not row:
+                continue
+            ctg = row[0]; pos = int(row[1])
+            if bed_fn is not None and not tree[ctg].hit(pos):
+                continue
+            Y[ctg + ":" + str(pos)] = _label(row)
+    X = {}
+    total = 0
+    for end, c, xb, posb in GetTensor(tensor_fn, 4096, log=False):
+        for j in range(c):
+            chrom, coord, seq = posb[j].split(":")
+            if bed_fn is not None:
+                if chrom not in tree or not tree[chrom].hit(int(coord)):
+                    continue
+            key = chrom + ":" + coord
+            X[key] = np.copy(xb[j])
+            if key not in Y:
+                v = [0.0] * 16
+                v[5] = 1.0; v[6] = 1.0; v[10] = 1.0          # HOM, REF, length 0
+                v[base2num[seq[param.flankingBaseNum]]] = 1.0
+                Y[key] = v
+            total += 1
+            if total % 100000 == 0:
+                print("Processed %d tensors" % total, file=sys.stderr)
+    allPos = sorted(X.keys())
+    if shuffle:
+        random.shuffle(allPos)
+    XC, YC, PC = [], [], []
+    bs = param.bloscBlockSize
+    for s in range(0, len(allPos), bs):
+        keys = allPos[s:s + bs]
+        if len(keys) < bs:
+            break
+        XC.append(pack_array(np.array([X[k] for k in keys])))
+        YC.append(pack_array(np.array([Y[k] for k in keys])))
+        PC.append(pack_array(np.array(keys)))
+    keys = allPos[len(allPos) // bs * bs:]
+    XC.append(pack_array(np.array([X[k] for k in keys])))
+    YC.append(pack_array(np.array([Y[k] for k in keys])))
+    PC.append(pack_array(np.array(keys)))
+    return len(allPos), XC, YC, PC
+
+
+def DecompressArray(array, start, num, maximum):
+    """utils_v2.py:189-207 -> (items [start, start+num) clipped at maximum, count, endFlag)."""
+    endFlag = 0
+    if start + num >= maximum:
+        num = maximum - start
+        endFlag = 1
+    bs = param.bloscBlockSize
+    leftEnd = start % bs
+    first = int(start / bs)
+    last = int((start + num - 1) / bs)
+    parts = [unpack_array(array[first])]
+    for i in range(first + 1, last + 1):
+        parts.append(unpack_array(array[i]))
+    out = np.concatenate(parts[:])
+    if leftEnd != 0 or num % bs != 0:
+        out = out[leftEnd:(leftEnd + num)]
+    return out, num, endFlag

@@ -135,6 +135,27 @@ int cv_adam_buffers(cv_model *m, float **m_dev, float **v_dev, int64_t *count);
  * 1 = gradients, 2 = Adam m, 3 = Adam v; to_model != 0 copies caller -> model.  */
 int cv_flat_copy(cv_model *m, int which, float *caller_dev, int to_model, void *stream);
 
+/* ---- host data plane (no GPU work) ------------------------------------------------ */
+
+/* Text-tensor reader = the per-row work of utils_v2.GetTensor (utils_v2.py:20-21,33-46;
+ * writer dataPrepScripts/CreateTensor.py:24,56).  Parses whole lines
+ * "<ctg> <pos> <refSeq33> <528 numbers>" from buf[0,len): rows whose centre base is not
+ * A/C/G/T are dropped (utils_v2.py:38-40); x_out[row][528] receives the values with
+ * matrices 1..3 minus matrix 0 (utils_v2.py:45-46); meta_out[row][6] = byte offset and
+ * length of ctg, pos, seq inside buf.  Stops after max_rows rows or the last complete
+ * line; *consumed = bytes eaten, *nrows = rows written, *nbad = malformed rows skipped.  */
+int cv_parse_tensor_text(const char *buf, int64_t len, int64_t max_rows, float *x_out,
+                         int64_t *meta_out, int64_t *consumed, int64_t *nrows, int64_t *nbad);
+
+/* c-blosc 1.x chunk codec for the 500-item blocks of the `.bin` training file
+ * (utils_v2.py:159-186 blosc.pack_array(cname='lz4hc'), :189-207 blosc.unpack_array;
+ * tensor2Bin.py:24-28).  Decoder: LZ4/LZ4HC streams, byte shuffle, split blocks, memcpy'd
+ * chunks.  Encoder: one LZ4 block with byte shuffle (readable by c-blosc).              */
+int64_t cv_blosc_nbytes(const uint8_t *chunk, int64_t clen);
+int cv_blosc_decompress(const uint8_t *chunk, int64_t clen, uint8_t *dst, int64_t dstcap);
+int cv_blosc_compress_lz4(const uint8_t *src, int64_t n, int typesize, uint8_t *dst, int64_t dstcap,
+                          int64_t *clen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,64 @@
+"""The C-ABI shared library loads on a CPU-only box and exports every entry point that
+include/clairvoyante_amd.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "clairvoyante_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_is_plain_c(tmp_path):
+    c = tmp_path / "t.c"
+    c.write_text('#include "clairvoyante_amd.h"\nint main(void){cv_arch a; (void)a; return CV_NUM_PARAMS == 18 ? 0 : 1;}\n')
+    import subprocess
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(c),
+                           "-o", str(tmp_path / "t.o")])
+
+
+def test_library_exports_every_declared_symbol():
+    from clairvoyante_amd import _lib, build
+    build.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "missing export %s" % n
+    # the ctypes binding covers the same set
+    assert sorted(_lib.EXPORTS) == names
+    _lib.load()
+
+
+def test_error_reporting_without_gpu():
+    """bad arguments fail with a message instead of crashing"""
+    from clairvoyante_amd import _lib
+    lib = _lib.load()
+    assert lib.cv_set_option(None, b"impl", 1) != 0
+    assert b"null" in lib.cv_last_error()
+    h = ctypes.c_void_p()
+    arch = _lib.CvArch()
+    arch.kh[:] = [1, 2, 3]; arch.cout[:] = [16, 32, 48]; arch.pool[:] = [5, 4, 3]; arch.fc4, arch.fc5 = 336, 168
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.cv_create(ctypes.byref(arch), 0, ctypes.byref(h)) != 0     # no device: loud failure
+        assert len(lib.cv_last_error()) > 0
+        with pytest.raises(_lib.CvError):
+            from clairvoyante_amd import clairvoyante_v3
+            clairvoyante_v3.Clairvoyante()
+
+
+def test_product_does_not_import_the_oracle():
+    """oracle/ is test infrastructure: nothing under clairvoyante_amd/ may reference it"""
+    pkg = os.path.join(ROOT, "clairvoyante_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                txt = open(os.path.join(dp, fn), errors="replace").read()
+                assert "cv_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn

@@ -1,0 +1,120 @@
+"""Host logic of the hot path against golden vectors produced by the REFERENCE ITSELF
+(tests/golden/make_golden_ref.py: /root/reference/clairvoyante/{callVar,utils_v2}.py imported
+through 2to3 in the build container).  CPU only; calls the native host code through the C ABI."""
+import io
+import os
+import pickle
+import random
+import types
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _args(showRef, qual, ref_fn, sample):
+    return types.SimpleNamespace(v2=False, v3=True, showRef=showRef, qual=qual, ref_fn=ref_fn, sampleName=sample)
+
+
+@pytest.mark.parametrize("tag,showRef,qual,ref,sample", [
+    ("a", False, None, None, "SAMPLE"), ("b", True, 20, os.path.join(G, "mini.fa"), "HG001"),
+    ("c", False, 150, None, "SAMPLE")])
+def test_output_matches_reference_vcf(tag, showRef, qual, ref, sample):
+    from clairvoyante_amd import callVar
+    d = np.load(os.path.join(G, "output_cases.npz"))
+    X = d["X"].astype(np.float32); pos = [str(s) for s in d["pos"]]
+    args = _args(showRef, qual, ref, sample)
+    fh = io.StringIO()
+    callVar.PrintVCFHeader(args, fh)
+    n = X.shape[0]
+    for s in range(0, n, 100):
+        e = min(n, s + 100)
+        callVar.Output(args, fh, e - s, X[s:e], pos[s:e], d["base"][s:e], d["z"][s:e], d["t"][s:e], d["l"][s:e])
+    want = open(os.path.join(G, "output_%s.vcf" % tag)).read()
+    got = fh.getvalue()
+    assert got.splitlines() == want.splitlines()
+
+
+def test_output_rejects_inconsistent_batch():
+    from clairvoyante_amd import callVar
+    d = np.load(os.path.join(G, "output_cases.npz"))
+    with pytest.raises(SystemExit):
+        callVar.Output(_args(False, None, None, "S"), io.StringIO(), 5, d["X"][:5].astype(np.float32),
+                       list(d["pos"][:5]), d["base"][:4], d["z"][:4], d["t"][:4], d["l"][:4])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_gettensor_matches_reference(tag):
+    from clairvoyante_amd import utils_v2
+    d = np.load(os.path.join(G, "gettensor_%s.npz" % tag))
+    ends, nums, Xs, poss = [], [], [], []
+    for end, c, x, pos in utils_v2.GetTensor(os.path.join(G, "gettensor_%s.txt.gz" % tag), int(d["num"]), log=False):
+        assert x.shape == (c, 33, 4, 4) and x.dtype == np.float32 and len(pos) == c
+        ends.append(end); nums.append(c); Xs.append(np.array(x)); poss += list(pos)
+    assert ends == list(d["ends"]) and nums == list(d["nums"])
+    assert np.array_equal(np.concatenate(Xs), d["X"])
+    assert poss == [str(s) for s in d["pos"]]
+
+
+def test_gettensor_odd_batch_sizes():
+    """batch boundaries anywhere in the stream give the same rows"""
+    from clairvoyante_amd import utils_v2
+    d = np.load(os.path.join(G, "gettensor_a.npz"))
+    for num in (1, 7, 43, 44, 1000):
+        Xs, poss, ends = [], [], []
+        for end, c, x, pos in utils_v2.GetTensor(os.path.join(G, "gettensor_a.txt.gz"), num, log=False):
+            Xs.append(np.array(x)); poss += list(pos); ends.append(end)
+        assert ends[-1] == 1 and sum(ends) == 1
+        assert np.array_equal(np.concatenate(Xs), d["X"]) and poss == [str(s) for s in d["pos"]]
+
+
+def test_training_array_matches_reference():
+    from clairvoyante_amd import utils_v2
+    d = np.load(os.path.join(G, "trainarray.npz"))
+    random.seed(1234)       # same seed as the generator: the reference shuffles with `random`
+    total, XC, YC, PC = utils_v2.GetTrainingArray(os.path.join(G, "trainarray_tensor.txt.gz"),
+                                                 os.path.join(G, "trainarray_var.txt.gz"),
+                                                 os.path.join(G, "trainarray.bed.gz"))
+    assert total == int(d["total"]) and len(XC) == len(YC) == len(PC) == int(d["nblocks"])
+    X, n, e = utils_v2.DecompressArray(XC, 0, total, total)
+    Y, _, _ = utils_v2.DecompressArray(YC, 0, total, total)
+    P, _, _ = utils_v2.DecompressArray(PC, 0, total, total)
+    assert (n, e) == (total, 1)
+    assert X.dtype == np.float32 and np.array_equal(X, d["X"])
+    assert Y.dtype == np.float64 and np.array_equal(Y, d["Y"])
+    assert [str(s) for s in P] == [str(s) for s in d["pos"]]
+
+
+@pytest.mark.parametrize("fn", ["mini.bin", "mini_py2proto.bin"])
+def test_bin_file_blocks_written_by_c_blosc(fn):
+    """`.bin` = 4 pickles (tensor2Bin.py:24-28); blocks here were packed by the real c-blosc"""
+    from clairvoyante_amd import utils_v2
+    d = np.load(os.path.join(G, "trainarray.npz"))
+    total, XC, YC, PC = utils_v2.LoadBin(os.path.join(G, fn))
+    assert total == int(d["total"])
+    X, _, _ = utils_v2.DecompressArray(XC, 0, total, total)
+    Y, _, _ = utils_v2.DecompressArray(YC, 0, total, total)
+    assert np.array_equal(X, d["X"]) and np.array_equal(Y, d["Y"])
+    dc = np.load(os.path.join(G, "decompress.npz"))
+    k = 0
+    while "m%d" % k in dc:
+        st, nm, mx, nn, ef = [int(v) for v in dc["m%d" % k]]
+        a, n2, e2 = utils_v2.DecompressArray(XC, st, nm, mx)
+        assert (n2, e2) == (nn, ef) and np.array_equal(np.asarray(a, dtype=np.float32), dc["x%d" % k])
+        k += 1
+    assert k >= 10
+
+
+def test_blosc_roundtrip_and_edge_sizes():
+    from clairvoyante_amd import utils_v2
+    rng = np.random.RandomState(3)
+    for n, ts in ((0, 4), (1, 4), (63, 4), (64, 4), (1000, 8), (4096, 4), (100003, 4), (5000, 1), (7777, 44)):
+        raw = (rng.randint(0, 4, n).astype(np.uint8) * rng.randint(0, 2, n).astype(np.uint8)).tobytes()
+        c = utils_v2.blosc_compress(raw, ts)
+        assert utils_v2.blosc_decompress(c) == raw
+        noise = rng.bytes(n)
+        assert utils_v2.blosc_decompress(utils_v2.blosc_compress(noise, ts)) == noise
+    a = rng.standard_normal((500, 33, 4, 4)).astype(np.float32).round()
+    assert np.array_equal(utils_v2.unpack_array(utils_v2.pack_array(a)), a)
+    assert len(utils_v2.pack_array(a)) < a.nbytes // 2

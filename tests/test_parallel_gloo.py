@@ -1,0 +1,64 @@
+"""world_size-2 `gloo` tests of the N>1 path on CPU: contiguous candidate shards need no
+collective for inference; training = one all-reduce(SUM) of the flat gradient per step."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_ranges_cover_everything():
+    from clairvoyante_amd import parallel
+    for total in (0, 1, 7, 8, 9, 40000000, 4194304 + 3):
+        for ws in (1, 2, 3, 8):
+            spans = [parallel.shard_range(total, r, ws) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, ws, port, tmp):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws),
+                      LOCAL_RANK=str(rank))
+    from clairvoyante_amd import parallel, synth
+    from oracle import cv_oracle as O
+    import common
+    r, w, _ = parallel.init_from_env(backend="gloo")
+    assert (r, w) == (rank, ws)
+    arch = "slim"
+    P = common.bench_params(O, arch)
+    n = 22
+    xt, cls, rf, alt, il = synth.make_candidates(n, seed=4, return_class=True)
+    y = synth.make_labels(cls, rf, alt, il).numpy(); x = xt.numpy()
+    lo, hi = parallel.shard_range(n, rank, ws)
+    # inference shard: rank-local, concatenation in rank order == the unsharded result
+    out = O.predict(arch, P, x[lo:hi])
+    gathered = [None] * ws
+    dist.all_gather_object(gathered, out)
+    full = O.predict(arch, P, x)
+    assert np.array_equal(np.concatenate(gathered), full)
+    # training: shard gradients (data terms), all-reduce SUM, add lambda*w once
+    lam = 0.01
+    l_sh, parts, g_sh = O.loss_grad(arch, P, x[lo:hi], y[lo:hi], lam=0.0)
+    flat = torch.from_numpy(np.concatenate([g_sh[k].ravel() for k in O.PARAM_NAMES]))
+    losses = parallel.allreduce_sum_(flat, parts[0:4])
+    l_all, parts_all, g_all = O.loss_grad(arch, P, x, y, lam=lam)
+    ref = np.concatenate([(g_all[k] - (lam * P[k] if "bias" not in k else 0)).ravel() for k in O.PARAM_NAMES])
+    assert np.abs(flat.numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+    assert np.allclose(losses, parts_all[0:4], rtol=1e-6)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
+
+
+def test_two_rank_gloo_shards_and_gradient_allreduce(tmp_path, oracle):
+    port = 29600 + os.getpid() % 300
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
