@@ -66,6 +66,7 @@ _SIGS = {
     "cv_blosc_decompress": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]),
     "cv_blosc_compress_lz4": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
                                              ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
+    "cv_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int64]),
 }
 
 EXPORTS = sorted(_SIGS)

@@ -294,3 +294,50 @@ extern "C" int cv_blosc_compress_lz4(const uint8_t *src, int64_t n, int typesize
     *clen = total;
     return 0;
 }
+
+// ---- CRC32C (Castagnoli) for the TensorFlow checkpoint bundle -------------------------------
+namespace {
+uint32_t crc_table[8][256];
+bool crc_init_done = false;
+void crc_init()
+{
+    for (uint32_t i = 0; i < 256; i++) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0x82f63b78u & (0u - (c & 1)));
+        crc_table[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; i++)
+        for (int t = 1; t < 8; t++) crc_table[t][i] = (crc_table[t - 1][i] >> 8) ^ crc_table[0][crc_table[t - 1][i] & 255];
+    crc_init_done = true;
+}
+__attribute__((target("sse4.2"))) uint32_t crc_hw(uint32_t crc, const uint8_t *p, int64_t n)
+{
+    uint64_t c = crc;
+    while (n >= 8) { uint64_t v; memcpy(&v, p, 8); c = __builtin_ia32_crc32di(c, v); p += 8; n -= 8; }
+    while (n-- > 0) c = __builtin_ia32_crc32qi((uint32_t)c, *p++);
+    return (uint32_t)c;
+}
+uint32_t crc_sw(uint32_t c, const uint8_t *p, int64_t n)
+{
+    if (!crc_init_done) crc_init();
+    while (n >= 8) {
+        uint32_t lo, hi; memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = crc_table[7][lo & 255] ^ crc_table[6][(lo >> 8) & 255] ^ crc_table[5][(lo >> 16) & 255] ^ crc_table[4][lo >> 24] ^
+            crc_table[3][hi & 255] ^ crc_table[2][(hi >> 8) & 255] ^ crc_table[1][(hi >> 16) & 255] ^ crc_table[0][hi >> 24];
+        p += 8; n -= 8;
+    }
+    while (n-- > 0) c = (c >> 8) ^ crc_table[0][(c ^ *p++) & 255];
+    return c;
+}
+}  // namespace
+
+// CRC32C of data, continuing from `crc` (0 to start); unmasked.
+extern "C" uint32_t cv_crc32c(uint32_t crc, const void *data, int64_t n)
+{
+    if (!data || n <= 0) return crc;
+    const uint8_t *p = (const uint8_t *)data;
+    uint32_t c = ~crc;
+    c = __builtin_cpu_supports("sse4.2") ? crc_hw(c, p, n) : crc_sw(c, p, n);
+    return ~c;
+}

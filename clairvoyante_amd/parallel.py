@@ -91,3 +91,14 @@ def broadcast_parameters(model, src=0):
         _lib.check(model._lib.cv_flat_copy(model._h, which, ctypes.c_void_p(b.data_ptr()), 0, st))
         dist.broadcast(b, src=src)
         _lib.check(model._lib.cv_flat_copy(model._h, which, ctypes.c_void_p(b.data_ptr()), 1, st))
+
+
+def allreduce_scalar(value, model=None):
+    """SUM of a python float over the ranks (validation-loss bookkeeping of train.py:118-122)."""
+    rank, ws = world()
+    if ws == 1:
+        return value
+    dev = model.device if model is not None else "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

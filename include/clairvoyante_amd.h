@@ -156,6 +156,10 @@ int cv_blosc_decompress(const uint8_t *chunk, int64_t clen, uint8_t *dst, int64_
 int cv_blosc_compress_lz4(const uint8_t *src, int64_t n, int typesize, uint8_t *dst, int64_t dstcap,
                           int64_t *clen);
 
+/* CRC32C (Castagnoli) of the tensor bytes / table blocks of the TensorFlow V2 checkpoint
+ * bundle written by saveParameters and read by restoreParameters (v3.py:243-251).        */
+uint32_t cv_crc32c(uint32_t crc, const void *data, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,9 @@ inputs and the reference's outputs are stored here (data, not source):
   output_cases.npz + output_*.vcf     callVar.Output / PrintVCFHeader   (callVar.py:50-178)
   gettensor_rows.txt.gz + gettensor.npz   utils_v2.GetTensor            (utils_v2.py:23-59)
   trainarray_*.{txt.gz,npz}           utils_v2.GetTrainingArray labels  (utils_v2.py:62-186)
+  train_schedule.json                 train.TrainAll driven with a recording mock model:
+                                      batch schedule, LR/lambda decay, checkpoint names, logs
+                                      (train.py:37-218)
   decompress.npz + mini.bin           DecompressArray + tensor2Bin layout (utils_v2.py:189-207,
                                       tensor2Bin.py:24-28); blocks packed by the real c-blosc
                                       (/opt/conda/lib/libblosc.so) through a shim that follows
@@ -40,7 +43,7 @@ REF = "/root/reference/clairvoyante"
 
 def prepare_reference():
     tmp = tempfile.mkdtemp(prefix="cv_ref23_")
-    for f in ("callVar.py", "utils_v2.py", "param.py", "tensor2Bin.py"):
+    for f in ("callVar.py", "utils_v2.py", "param.py", "tensor2Bin.py", "train.py"):
         shutil.copy(os.path.join(REF, f), tmp)
     subprocess.check_call(["/opt/conda/bin/2to3", "-nw"] + [os.path.join(tmp, f) for f in os.listdir(tmp)],
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -49,6 +52,9 @@ def prepare_reference():
     src = open(up).read().replace("stdout=subprocess.PIPE, bufsize=8388608)",
                                   "stdout=subprocess.PIPE, bufsize=8388608, universal_newlines=True)")
     open(up, "w").write(src)
+    tp = os.path.join(tmp, "train.py")      # np.int was removed from NumPy 1.24 (reference era: alias of int)
+    tsrc = open(tp).read().replace("dtype=np.int )", "dtype=int)").replace("dtype=np.int)", "dtype=int)")
+    open(tp, "w").write(tsrc)
     # shim modules the image lacks (python-blosc) / changed API (intervaltree 3: search -> at)
     blosc = types.ModuleType("blosc")
     lib = ctypes.CDLL("/opt/conda/lib/libblosc.so.1")
@@ -262,6 +268,81 @@ def gen_trainarray(utils, param):
     np.savez_compressed(os.path.join(HERE, "decompress.npz"), **outs)
 
 
+class MockModel(object):
+    """records what train.TrainAll asks of the model object (train.py:37-218)"""
+
+    def __init__(self, script):
+        self.calls = []
+        self.script = list(script)
+        self.lr = None; self.lam = None
+        self.trainLossRTVal = None; self.trainSummaryRTVal = None; self.getLossLossRTVal = None
+
+    def _tag(self, X):
+        return [int(X[0, 0]) if len(X) else -1, int(len(X))]
+
+    def trainNoRT(self, X, Y):
+        self.calls.append(["train"] + self._tag(X)); self.trainLossRTVal = float(len(X)); self.trainSummaryRTVal = None
+
+    def getLossNoRT(self, X, Y):
+        self.calls.append(["val"] + self._tag(X)); self.getLossLossRTVal = 0.0
+
+    def getLoss(self, X, Y):
+        self.calls.append(["val_sync"] + self._tag(X)); return self.script.pop(0)
+
+    def predict(self, X):
+        self.calls.append(["predict"] + self._tag(X))
+        n = len(X); i = X[:, 0].astype(np.int64)
+        oh = lambda k, v: np.eye(k, dtype=np.float32)[v % k]
+        return oh(4, i), oh(2, i // 3), oh(4, i // 5), oh(6, i // 7)
+
+    def setLearningRate(self, v=None):
+        self.lr = self.lr * 0.1 if v is None else v; self.calls.append(["lr", self.lr]); return self.lr
+
+    def setL2RegularizationLambda(self, v=None):
+        self.lam = self.lam * 0.1 if v is None else v; self.calls.append(["lambda", self.lam]); return self.lam
+
+    def saveParameters(self, fn):
+        self.calls.append(["save", os.path.basename(fn)])
+
+
+def gen_train_schedule(train, utils):
+    import json
+    import logging
+    out = {}
+    for tag, total, chk in (("a", 23456, None), ("b", 30000, None), ("c", 1234, "model-000041")):
+        idx = np.arange(total)
+        rng = np.random.RandomState(5)
+        ylab = np.zeros((total, 16)); ylab[idx, rng.randint(0, 4, total)] = 1; ylab[idx, 4 + rng.randint(0, 2, total)] = 1
+        ylab[idx, 6 + rng.randint(0, 4, total)] = 1; ylab[idx, 10 + rng.randint(0, 6, total)] = 1
+        XC, YC = [], []
+        import blosc
+        for s in range(0, total + 1, 500):          # trailing (possibly empty) block like utils_v2.py:181
+            XC.append(blosc.pack_array(idx[s:s + 500].reshape(-1, 1).astype(np.float32), cname="lz4hc"))
+            YC.append(blosc.pack_array(ylab[s:s + 500], cname="lz4hc"))
+        script = [10, 9, 8, 7, 6, 5, 4, 3, 4, 3, 4, 3, 4, 2, 2, 9, 9, 9, 1, 2, 1, 2, 1, 2, 1, 2, 1, 2, 1, 2, 1, 2, 1]
+        m = MockModel(script)
+        binfn = os.path.join(tempfile.gettempdir(), "cv_sched_%s.bin" % tag)
+        with open(binfn, "wb") as fh:
+            pickle.dump(total, fh); pickle.dump(XC, fh); pickle.dump(YC, fh); pickle.dump([], fh)
+        args = types.SimpleNamespace(bin_fn=binfn, tensor_fn=None, var_fn=None, bed_fn=None, chkpnt_fn=chk,
+                                     learning_rate=1e-3, lambd=1e-3, ochk_prefix="/tmp/out/model", olog_dir=None,
+                                     v2=False, v3=True, slim=False)
+        logs = []
+
+        class H(logging.Handler):
+            def emit(self, rec):
+                msg = rec.getMessage()
+                if "time elapsed" not in msg:
+                    logs.append(msg)
+        h = H(); logging.getLogger().addHandler(h)
+        train.TrainAll(args, m, utils)
+        logging.getLogger().removeHandler(h)
+        os.remove(binfn)
+        out[tag] = {"total": total, "chkpnt_fn": chk, "script": script, "calls": m.calls, "logs": logs}
+        print("train schedule %s: %d calls, %d log lines" % (tag, len(m.calls), len(logs)))
+    json.dump(out, open(os.path.join(HERE, "train_schedule.json"), "w"))
+
+
 def main():
     tmp = prepare_reference()
     try:
@@ -272,6 +353,8 @@ def main():
         gen_output(callVar, param)
         gen_gettensor(utils)
         gen_trainarray(utils, param)
+        train = importlib.import_module("train")
+        gen_train_schedule(train, utils)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
