@@ -112,8 +112,10 @@ def test_gradients_and_adam_match_oracle(oracle, arch):
         gref = g_or[name] - (lam * P[name] if "bias" not in name else 0)     # data terms only
         assert np.abs(g - gref).max() <= 2e-5 * np.abs(gref).max() + 1e-7, name
         w = P[name].copy().ravel(); mm = np.zeros_like(w); vv = np.zeros_like(w)
-        oracle.adam_step(w, mm, vv, np.ascontiguousarray(g_or[name].ravel()), 1e-3, 1)
-        assert np.abs(m.getParameter(name).ravel() - w).max() <= 2e-6, name
+        # the optimizer kernel on ITS OWN gradient (+ lambda*w for kernels): TF1 Adam, step 1
+        gfull = (g + (lam * P[name] if "bias" not in name else 0)).astype(np.float32)
+        oracle.adam_step(w, mm, vv, np.ascontiguousarray(gfull.ravel()), 1e-3, 1)
+        assert np.abs(m.getParameter(name).ravel() - w).max() <= 1e-6, name
     m.close()
 
 
