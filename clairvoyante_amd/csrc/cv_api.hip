@@ -115,8 +115,11 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     alloc(&m->params, np); alloc(&m->grads, np); alloc(&m->adam_m, np); alloc(&m->adam_v, np);
     alloc(&m->wp_conv1, 4 * 64);
     for (int l = 1; l < 3; l++) alloc(&m->wp_conv[l], (size_t)s.ntile[l] * arch->kh[l] * 4 * s.cinb[l] * 256);
-    alloc(&m->wp_fc4, (size_t)s.kb4 * s.nb4 * 256);
-    alloc(&m->wp_fc5, (size_t)s.nb4 * s.nb5 * 256);
+    alloc(&m->wp_fc4, (size_t)s.kb4 * ((s.nb4 + 3) / 4 * 4) * 256);   // fragments padded to the wave count
+    alloc(&m->wp_fc5, (size_t)s.nb4 * ((s.nb5 + 3) / 4 * 4) * 256);
+    alloc(&m->wp_heads0, (size_t)s.nb4 * 256);
+    alloc(&m->wp_heads1, (size_t)s.nb5 * 256);
+    m->variant = 3;
     if (e == hipSuccess) e = hipMalloc(&m->loss_dev, sizeof(double) * 8);
     if (e != hipSuccess) {
         cv_set_error("cv_create: device allocation failed: %s", hipGetErrorString(e));
@@ -133,7 +136,7 @@ extern "C" int cv_destroy(cv_model *m)
     if (!m) return 0;
     hipSetDevice(m->device);
     float *bufs[] = {m->params, m->grads, m->adam_m, m->adam_v, m->wp_conv1, m->wp_conv[1], m->wp_conv[2],
-                     m->wp_fc4, m->wp_fc5, m->tm_p1, m->tm_p2, m->tm_p3, m->tm_h4, m->tm_h5, m->r_a[0],
+                     m->wp_fc4, m->wp_fc5, m->wp_heads0, m->wp_heads1, m->tm_p1, m->tm_p2, m->tm_p3, m->tm_h4, m->tm_h5, m->r_a[0],
                      m->r_a[1], m->r_a[2], m->r_p[0], m->r_p[1], m->r_p[2], m->r_h4, m->r_h5, m->t_buf};
     for (float *b : bufs)
         if (b) hipFree(b);
@@ -212,6 +215,7 @@ extern "C" int cv_set_option(cv_model *m, const char *key, int64_t value)
         return 0;
     }
     if (!strcmp(key, "profile")) { m->profile = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "variant")) { m->variant = (int)value; return 0; }
     if (!strcmp(key, "chunk")) {
         if (value < 16 || value > (1 << 22)) { cv_set_error("chunk must be in [16, 4194304]"); return 1; }
         m->chunk = (value + 15) / 16 * 16;
@@ -227,6 +231,7 @@ extern "C" int cv_get_option(const cv_model *m, const char *key, int64_t *value)
     if (!strcmp(key, "impl")) { *value = m->impl; return 0; }
     if (!strcmp(key, "chunk")) { *value = m->chunk; return 0; }
     if (!strcmp(key, "profile")) { *value = m->profile; return 0; }
+    if (!strcmp(key, "variant")) { *value = m->variant; return 0; }
     cv_set_error("unknown option '%s'", key);
     return 1;
 }

@@ -86,16 +86,17 @@ __global__ void pack_conv(const float *__restrict__ w, float *__restrict__ wp, i
     wp[t] = (ci < cin && co < cout) ? w[(((size_t)kh * 4 + kw) * cin + ci) * cout + co] : 0.0f;
 }
 
-// dense [K][N] -> [kb][ob][lane][s];  input feature k = 16*kb + 4*s + kq
-__global__ void pack_dense(const float *__restrict__ w, float *__restrict__ wp, int K, int N, int KB, int NB)
+// dense [K][N] -> [kb][ob][lane][s];  input feature k = 16*kb + 4*s + kq.  NBP >= ceil(N/16)
+// fragments per k step (pad fragments are zero: see dense_tm)
+__global__ void pack_dense(const float *__restrict__ w, float *__restrict__ wp, int K, int N, int KB, int NBP)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t total = (int64_t)KB * NB * 256;
+    int64_t total = (int64_t)KB * NBP * 256;
     if (t >= total) return;
     int s = (int)(t & 3), lane = (int)((t >> 2) & 63);
     int64_t frag = t >> 8;
-    int ob = (int)(frag % NB);
-    int kb = (int)(frag / NB);
+    int ob = (int)(frag % NBP);
+    int kb = (int)(frag / NBP);
     int i = lane & 15, kq = lane >> 4;
     int k = 16 * kb + 4 * s + kq, o = 16 * ob + cv_sigma(i);
     wp[t] = (k < K && o < N) ? w[(size_t)k * N + o] : 0.0f;
@@ -180,16 +181,102 @@ __global__ __launch_bounds__(256) void conv1_tm(const float *__restrict__ x, int
 }
 
 // ---------------------------------------------------------------------------
-// generic conv (k(KH,4), CINB*16 -> NT*16 channels) + SELU + max-pool(POOL,1),
-// TM -> TM.  One wave per (group, output tile nt); weights of the whole layer
-// sit in LDS (loaded once per workgroup).  Per position and wave:
-// KH*4*CINB ds_read_b128 feed KH*12*CINB*4 MFMA steps.
+// generic conv (k(KH,4), CINB*16 -> NT*16 channels) + SELU + max-pool(POOL,1) -> TM.
+// One wave per (group, output tile nt); weights of the whole layer sit in LDS (loaded
+// once per workgroup).  Per position and wave: KH*4*CINB ds_read_b128 feed
+// KH*12*CINB*4 MFMA steps.
+// Input rows come from a row source:
+//   FRONT == 0: a TM buffer (one coalesced 16-byte load per fragment), or
+//   FRONT  > 0: the raw pileup tensor X [n,33,4,4] pushed through conv1 k(1,4) + SELU +
+//               max-pool(FRONT,1) on the fly (12 extra MFMA steps per position), so the
+//               first layer never round-trips through HBM (CINB must be 1, HIN = 34-FRONT).
 // ---------------------------------------------------------------------------
-template <int KH, int CINB, int NT, int POOL, int HIN>
-__global__ __launch_bounds__(256) void conv_tm(const f4 *__restrict__ in_tm, const f4 *__restrict__ wp,
-                                                const float *__restrict__ bias, int cout,
-                                                f4 *__restrict__ out_tm, int G)
+template <int FRONT>
+struct front_source {
+    static constexpr int NP = FRONT > 1 ? FRONT - 1 : 1;
+    const float *xp;       // lane (c, ci = q): &X[cand][0][0][ci]
+    float A[4];            // conv1 weight fragments, one MFMA step per kw
+    f4 b4;
+    f4 cw[NP][4];          // previous conv1 rows (after SELU) of the pooling window
+    float xc[4], xn[4];    // current / prefetched input row
+    int hx;                // next conv1 row
+
+    __device__ __forceinline__ void load_x(float (&dst)[4], int h)
+    {
+        if (h < CV_INPUT_H) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) dst[w] = xp[h * 16 + w * 4];
+        }
+    }
+    __device__ __forceinline__ void conv1_row(f4 (&v)[4])
+    {
+        f4 acc[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) acc[w] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kw = 0; kw < 4; kw++)
+#pragma unroll
+            for (int wo = 0; wo < 4; wo++) {
+                const int wi = wo + kw - 1;
+                if (wi < 0 || wi > 3) continue;
+                acc[wo] = mfma4(A[kw], xc[wi], acc[wo]);
+            }
+#pragma unroll
+        for (int w = 0; w < 4; w++) v[w] = selu4(acc[w] + b4);
+#pragma unroll
+        for (int w = 0; w < 4; w++) xc[w] = xn[w];
+        hx++;
+        load_x(xn, hx + 1);
+    }
+    __device__ __forceinline__ void init(const float *x, int64_t cand, int q, const float *wp1,
+                                         const float *bias1, int cout1, int lane)
+    {
+        xp = x + (size_t)cand * (CV_INPUT_H * 16) + q;
+#pragma unroll
+        for (int kw = 0; kw < 4; kw++) A[kw] = wp1[kw * 64 + lane];
+        b4 = load_bias4(bias1, 0, q, cout1);
+        hx = 0;
+        load_x(xc, 0);
+        load_x(xn, 1);
+        if constexpr (FRONT > 1) {
+#pragma unroll
+            for (int j = 0; j < FRONT - 1; j++) conv1_row(cw[j]);
+        }
+    }
+    // next pooled conv1 row (rows are requested in ascending order)
+    __device__ __forceinline__ void next(f4 (&row)[4][1])
+    {
+        f4 v[4];
+        conv1_row(v);
+        if constexpr (FRONT > 1) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                f4 o = v[w];
+#pragma unroll
+                for (int j = 0; j < FRONT - 1; j++) o = max4(o, cw[j][w]);
+                row[w][0] = o;
+            }
+#pragma unroll
+            for (int j = 0; j + 1 < FRONT - 1; j++)
+#pragma unroll
+                for (int w = 0; w < 4; w++) cw[j][w] = cw[j + 1][w];
+#pragma unroll
+            for (int w = 0; w < 4; w++) cw[FRONT - 2][w] = v[w];
+        } else {
+#pragma unroll
+            for (int w = 0; w < 4; w++) row[w][0] = v[w];
+        }
+    }
+};
+
+template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT>
+__global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, const float *__restrict__ x,
+                                                   int64_t n, const float *__restrict__ wp1,
+                                                   const float *__restrict__ bias1, int cout1,
+                                                   const f4 *__restrict__ wp, const float *__restrict__ bias,
+                                                   int cout, f4 *__restrict__ out_tm, int G)
 {
+    static_assert(FRONT == 0 || CINB == 1, "the fused first layer feeds one 16-channel fragment");
     extern __shared__ __attribute__((aligned(16))) f4 ldsw[];
     constexpr int PADT = (KH - 1) / 2;
     constexpr int HOUT = HIN - POOL + 1;
@@ -206,6 +293,23 @@ __global__ __launch_bounds__(256) void conv_tm(const f4 *__restrict__ in_tm, con
     const f4 *wl = ldsw + (size_t)nt * (KH * 4 * CINB * 64) + lane;
     f4 *op = out_tm + (size_t)g * (HOUT * 4 * NT * 64) + (size_t)nt * 64 + lane;
 
+    front_source<FRONT> fs;
+    if constexpr (FRONT > 0) {
+        int64_t cand = (int64_t)g * 16 + (lane & 15);
+        if (cand >= n) cand = n - 1;
+        fs.init(x, cand, q, wp1, bias1, cout1, lane);
+    }
+    auto fetch_row = [&](int hr, f4 (&row)[4][CINB]) {     // rows are requested in ascending order
+        if constexpr (FRONT > 0) {
+            fs.next(row);
+        } else {
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+#pragma unroll
+                for (int cb = 0; cb < CINB; cb++) row[w][cb] = inp[(size_t)((hr * 4 + w) * CINB + cb) * 64];
+        }
+    };
+
     f4 win[KH][4][CINB];   // win[kh] = input row h + kh - PADT
     f4 nxt[4][CINB];
     f4 pw[POOL > 1 ? POOL - 1 : 1][4];
@@ -218,13 +322,17 @@ __global__ __launch_bounds__(256) void conv_tm(const f4 *__restrict__ in_tm, con
 #pragma unroll
     for (int j = 0; j < KH; j++) {
         const int hr = j - PADT;
+        f4 tmp[4][CINB];
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int cb = 0; cb < CINB; cb++) tmp[w][cb] = zero;
+        if (hr >= 0 && hr < HIN) fetch_row(hr, tmp);
 #pragma unroll
         for (int w = 0; w < 4; w++)
 #pragma unroll
             for (int cb = 0; cb < CINB; cb++) {
-                f4 v = zero;
-                if (hr >= 0 && hr < HIN) v = inp[(size_t)((hr * 4 + w) * CINB + cb) * 64];
-                if (j < KH - 1) win[j][w][cb] = v; else nxt[w][cb] = v;
+                if (j < KH - 1) win[j][w][cb] = tmp[w][cb]; else nxt[w][cb] = tmp[w][cb];
             }
     }
 #pragma unroll 1
@@ -233,14 +341,9 @@ __global__ __launch_bounds__(256) void conv_tm(const f4 *__restrict__ in_tm, con
         for (int w = 0; w < 4; w++)
 #pragma unroll
             for (int cb = 0; cb < CINB; cb++) win[KH - 1][w][cb] = nxt[w][cb];
-        {   // prefetch the row the next position needs
+        {   // fetch / produce the row the next position needs
             const int hr = h + 1 + (KH - 1) - PADT;
-            if (hr < HIN) {
-#pragma unroll
-                for (int w = 0; w < 4; w++)
-#pragma unroll
-                    for (int cb = 0; cb < CINB; cb++) nxt[w][cb] = inp[(size_t)((hr * 4 + w) * CINB + cb) * 64];
-            }
+            if (hr < HIN) fetch_row(hr, nxt);
         }
         f4 acc[4];
 #pragma unroll
@@ -300,55 +403,185 @@ __global__ __launch_bounds__(256) void conv_tm(const f4 *__restrict__ in_tm, con
 }
 
 // ---------------------------------------------------------------------------
+// heads (v3.py:124-138): one wave per group of 16 candidates.
+//   tile 0 (input fc4 side, K = NB4*16): rows 0..3  = base logits -> sigmoid
+//   tile 1 (input fc5,      K = NB5*16): rows 0..1  = zygosity, rows 4..7 = variant type,
+//                                        rows 8..13 = indel length -> softmax(selu(.)+1e-10)
+// Rows are NOT sigma-permuted (identity), so lane (c, q) holds rows 4q..4q+3 of candidate c:
+// q=0: base[0..3] and zyg[0..1];  q=1: type[0..3];  q=2: len[0..3];  q=3: len[4..5].
+// The 6-way softmax spans lanes c+32 / c+48; its sum is formed in index order
+// ((((e0+e1)+e2)+e3)+e4)+e5 by passing the partial sum across.
+// ---------------------------------------------------------------------------
+__global__ void pack_heads(const float *__restrict__ wb, const float *__restrict__ wz,
+                           const float *__restrict__ wt, const float *__restrict__ wl, int K4, int K5,
+                           int NB4, int NB5, float *__restrict__ wp0, float *__restrict__ wp1)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int tot0 = NB4 * 256, tot1 = NB5 * 256;
+    if (t < tot0) {
+        int s = t & 3, lane = (t >> 2) & 63, kb = t >> 8;
+        int i = lane & 15, kq = lane >> 4, k = 16 * kb + 4 * s + kq;
+        wp0[t] = (i < 4 && k < K4) ? wb[(size_t)k * 4 + i] : 0.0f;
+    } else if (t < tot0 + tot1) {
+        int u = t - tot0;
+        int s = u & 3, lane = (u >> 2) & 63, kb = u >> 8;
+        int i = lane & 15, kq = lane >> 4, k = 16 * kb + 4 * s + kq;
+        float v = 0.0f;
+        if (k < K5) {
+            if (i < 2) v = wz[(size_t)k * 2 + i];
+            else if (i >= 4 && i < 8) v = wt[(size_t)k * 4 + (i - 4)];
+            else if (i >= 8 && i < 14) v = wl[(size_t)k * 6 + (i - 8)];
+        }
+        wp1[u] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void heads_tm(const f4 *__restrict__ h4, const f4 *__restrict__ h5, int NB4,
+                                                 int NB5, const f4 *__restrict__ wp0, const f4 *__restrict__ wp1,
+                                                 const float *__restrict__ bb, const float *__restrict__ bz,
+                                                 const float *__restrict__ bt, const float *__restrict__ bl,
+                                                 int64_t n, float *__restrict__ out16, int G)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const int c = lane & 15, q = lane >> 4;
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 a0 = zero, a1 = zero;
+    const f4 *p4 = h4 + (size_t)g * NB4 * 64 + lane;
+    const f4 *p5 = h5 + (size_t)g * NB5 * 64 + lane;
+#pragma unroll 3
+    for (int kb = 0; kb < NB4; kb++) {
+        const f4 B = p4[(size_t)kb * 64];
+        const f4 A = wp0[(size_t)kb * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 4; s++) a0 = mfma4(A[s], B[s], a0);
+    }
+#pragma unroll 3
+    for (int kb = 0; kb < NB5; kb++) {
+        const f4 B = p5[(size_t)kb * 64];
+        const f4 A = wp1[(size_t)kb * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 4; s++) a1 = mfma4(A[s], B[s], a1);
+    }
+    // biases of this lane's rows
+    f4 bias1 = zero;
+    if (q == 0) { bias1[0] = bz[0]; bias1[1] = bz[1]; }
+    else if (q == 1) { bias1[0] = bt[0]; bias1[1] = bt[1]; bias1[2] = bt[2]; bias1[3] = bt[3]; }
+    else if (q == 2) { bias1[0] = bl[0]; bias1[1] = bl[1]; bias1[2] = bl[2]; bias1[3] = bl[3]; }
+    else { bias1[0] = bl[4]; bias1[1] = bl[5]; }
+    f4 lg;
+#pragma unroll
+    for (int r = 0; r < 4; r++) lg[r] = cvm::selu(a1[r] + bias1[r]) + 1e-10f;
+    const int64_t cand = (int64_t)g * 16 + c;
+    float *o = out16 + (size_t)cand * 16;
+    // 6-way softmax across lanes q=2 (len0..3) and q=3 (len4..5)
+    float m_loc = q == 3 ? fmaxf(lg[0], lg[1]) : fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+    float m_oth = __shfl_xor(m_loc, 16);
+    const float m6 = fmaxf(m_loc, m_oth);
+    if (q == 0) {
+        if (cand < n) {
+            float4 b;
+            b.x = cvm::sigmoid(a0[0] + bb[0]); b.y = cvm::sigmoid(a0[1] + bb[1]);
+            b.z = cvm::sigmoid(a0[2] + bb[2]); b.w = cvm::sigmoid(a0[3] + bb[3]);
+            *reinterpret_cast<float4 *>(o) = b;
+            float l2[2] = {lg[0], lg[1]}, p2[2];
+            cvm::softmax<2>(l2, p2);
+            o[4] = p2[0]; o[5] = p2[1];
+        }
+    } else if (q == 1) {
+        if (cand < n) {
+            float l4[4] = {lg[0], lg[1], lg[2], lg[3]}, p4v[4];
+            cvm::softmax<4>(l4, p4v);
+            o[6] = p4v[0]; o[7] = p4v[1]; o[8] = p4v[2]; o[9] = p4v[3];
+        }
+    }
+    // all lanes take part in the exchange below (shuffles need the full wave)
+    float e[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) e[r] = cvm::expf_fixed(lg[r] - m6);
+    float s03 = ((e[0] + e[1]) + e[2]) + e[3];              // meaningful on q == 2
+    float s03_from2 = __shfl_xor(s03, 16);                  // q == 3 receives q == 2's partial sum
+    float tot = (s03_from2 + e[0]) + e[1];                  // meaningful on q == 3
+    float tot_from3 = __shfl_xor(tot, 16);                  // q == 2 receives the total
+    if (cand < n) {
+        if (q == 2) {
+            o[10] = e[0] / tot_from3; o[11] = e[1] / tot_from3; o[12] = e[2] / tot_from3; o[13] = e[3] / tot_from3;
+        } else if (q == 3) {
+            o[14] = e[0] / tot; o[15] = e[1] / tot;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // dense (KB*16 -> NB*16) + bias + SELU, TM -> TM.  One wave per group of 16
 // candidates holds all NB accumulator tiles; the workgroup streams the packed
 // weight matrix through a 3-stage LDS ring (one barrier per 16-deep k step),
 // each wave streams its own activation fragments straight from HBM/L2.
 // ---------------------------------------------------------------------------
 template <int NB, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void dense_tm(const f4 *__restrict__ in_tm, int KB,
+__global__ __launch_bounds__(WAVES * 64, 2) void dense_tm(const f4 *__restrict__ in_tm, int KB,
                                                         const f4 *__restrict__ wp,
                                                         const float *__restrict__ bias, int nout,
                                                         f4 *__restrict__ out_tm, int G)
 {
+    // The packed weight matrix holds NBP = roundup(NB, WAVES) fragments per k step (the pad
+    // fragments are zero and never multiplied), so every thread stages exactly PER 16-byte
+    // pieces per step: no conditional loads in the loop, which lets the waits sit at the
+    // LDS writes (after the MFMAs) instead of right behind the load issue.
     extern __shared__ __attribute__((aligned(16))) f4 ring[];
-    constexpr int T = WAVES * 64;
-    constexpr int STAGE = NB * 64;               // f4 per stage
-    constexpr int PER = (STAGE + T - 1) / T;
+    constexpr int NBP = (NB + WAVES - 1) / WAVES * WAVES;
+    constexpr int STAGE = NBP * 64;              // f4 per stage
+    constexpr int PER = NBP / WAVES;             // fragments each wave stages per k step
     const int tid = threadIdx.x, lane = tid & 63;
-    const int g = blockIdx.x * WAVES + (tid >> 6);
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x * WAVES + wid;
     const int gl = g < G ? g : G - 1;
     const f4 *bp = in_tm + (size_t)gl * KB * 64 + lane;
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
     f4 acc[NB];
 #pragma unroll
     for (int ob = 0; ob < NB; ob++) acc[ob] = zero;
-    f4 st[PER];
-    auto load_stage = [&](int kb) {
+    // global -> LDS DMA (global_load_lds_dwordx4): a wave moves one 1 KiB fragment per
+    // instruction, destination = wave-uniform LDS base (M0) + lane*16 = the fragment layout
+    // itself.  Issued from inline asm so that hipcc does not fence every following ds_read
+    // behind it (it cannot tell the ring slots apart); completion is waited for explicitly
+    // (vmcnt) before the barrier that publishes the slot.
+    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) f4 *)ring;
+    auto stage_async = [&](int kb, int slot) {
 #pragma unroll
         for (int p = 0; p < PER; p++) {
-            const int idx = tid + p * T;
-            if (idx < STAGE) st[p] = wp[(size_t)kb * STAGE + idx];
+            const f4 *gp = wp + ((size_t)kb * NBP + wid * PER + p) * 64 + lane;
+            const unsigned ldst = ring_base + (unsigned)((slot * NBP + wid * PER + p) * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gp), "s"(ldst) : "memory");
         }
     };
-    auto write_stage = [&](int slot) {
-#pragma unroll
-        for (int p = 0; p < PER; p++) {
-            const int idx = tid + p * T;
-            if (idx < STAGE) ring[slot * STAGE + idx] = st[p];
-        }
+    // The activation fragments are loaded from asm as well: with no compiler-visible VMEM in
+    // the loop hipcc emits no vmcnt waits of its own (its counted waits would also drain the
+    // DMA pieces queued behind them); every VMEM completion is the explicit wait below.
+    auto load_frag = [&](const f4 *ptr) {
+        f4 v;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+        return v;
     };
-    load_stage(0);
-    write_stage(0);
-    if (KB > 1) { load_stage(1); write_stage(1); }
+    stage_async(0, 0);
+    stage_async(KB > 1 ? 1 : 0, 1);
+    f4 B = load_frag(bp);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(B) : : "memory");
     __syncthreads();
-    f4 B = bp[0];
     int slot = 0;
 #pragma unroll 1
     for (int kb = 0; kb < KB; kb++) {
-        if (kb + 2 < KB) load_stage(kb + 2);
-        f4 Bn = zero;
-        if (kb + 1 < KB) Bn = bp[(size_t)(kb + 1) * 64];
+        // stage kb+2 and activation fragment kb+1 (indices clamped: the surplus loads of the
+        // last two steps re-read valid data and land in ring slots nobody reads again)
+        const int ks = kb + 2 < KB ? kb + 2 : KB - 1;
+        const int kn = kb + 1 < KB ? kb + 1 : KB - 1;
+        int wslot = slot + 2; if (wslot >= 3) wslot -= 3;
+        f4 Bn = load_frag(bp + (size_t)kn * 64);
+        stage_async(ks, wslot);          // slot (kb+2)%3 was last read in step kb-1 (barrier passed)
         const f4 *wl = ring + slot * STAGE + lane;
 #pragma unroll
         for (int ob = 0; ob < NB; ob += 3) {
@@ -362,9 +595,9 @@ __global__ __launch_bounds__(WAVES * 64) void dense_tm(const f4 *__restrict__ in
                 for (int j = 0; j < 3; j++)
                     if (ob + j < NB) acc[ob + j] = mfma4(A[j][s], B[s], acc[ob + j]);
         }
-        int wslot = slot + 2; if (wslot >= 3) wslot -= 3;
-        if (kb + 2 < KB) write_stage(wslot);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);                  // keep the MFMAs above the wait
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(Bn) : : "memory");   // this wave's DMA pieces and Bn have landed
+        __syncthreads();                                    // every wave's pieces have: slot is readable
         B = Bn;
         slot = slot + 1 == 3 ? 0 : slot + 1;
     }
@@ -388,15 +621,15 @@ int set_lds(K kernel, size_t bytes)
     return 0;
 }
 
-template <int KH, int CINB, int NT, int POOL, int HIN>
-int launch_conv(const float *in, const float *wp, const float *bias, int cout, float *out, int G,
-                hipStream_t st)
+template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT>
+int launch_conv(const float *in, const float *x, int64_t n, const float *wp1, const float *bias1, int cout1,
+                const float *wp, const float *bias, int cout, float *out, int G, hipStream_t st)
 {
-    auto k = conv_tm<KH, CINB, NT, POOL, HIN>;
+    auto k = conv_tm<KH, CINB, NT, POOL, HIN, FRONT>;
     size_t lds = (size_t)NT * KH * 4 * CINB * 1024;
     if (set_lds(k, lds)) return 1;
     unsigned grid = nblk((int64_t)G * NT, 4);
-    k<<<grid, 256, lds, st>>>((const f4 *)in, (const f4 *)wp, bias, cout, (f4 *)out, G);
+    k<<<grid, 256, lds, st>>>((const f4 *)in, x, n, wp1, bias1, cout1, (const f4 *)wp, bias, cout, (f4 *)out, G);
     CV_HIP(hipGetLastError());
     return 0;
 }
@@ -407,7 +640,7 @@ int launch_dense(const float *in, int KB, const float *wp, const float *bias, in
 {
     constexpr int WAVES = 4;
     auto k = dense_tm<NB, WAVES>;
-    size_t lds = (size_t)3 * NB * 1024;
+    size_t lds = (size_t)3 * ((NB + WAVES - 1) / WAVES * WAVES) * 1024;
     if (set_lds(k, lds)) return 1;
     k<<<nblk(G, WAVES), WAVES * 64, lds, st>>>((const f4 *)in, KB, (const f4 *)wp, bias, nout, (f4 *)out, G);
     CV_HIP(hipGetLastError());
@@ -436,11 +669,15 @@ int cv_pack_weights(cv_model *m, hipStream_t st)
                                                   m->arch.cout[l], s.cinb[l], s.ntile[l]);
     }
     {
-        int64_t tot = (int64_t)s.kb4 * s.nb4 * 256;
-        pack_dense<<<nblk(tot, 256), 256, 0, st>>>(P + o[6], m->wp_fc4, s.flat, m->arch.fc4, s.kb4, s.nb4);
-        tot = (int64_t)s.nb4 * s.nb5 * 256;
-        pack_dense<<<nblk(tot, 256), 256, 0, st>>>(P + o[8], m->wp_fc5, m->arch.fc4, m->arch.fc5, s.nb4, s.nb5);
+        const int nbp4 = (s.nb4 + 3) / 4 * 4, nbp5 = (s.nb5 + 3) / 4 * 4;   // launch_dense: WAVES = 4
+        int64_t tot = (int64_t)s.kb4 * nbp4 * 256;
+        pack_dense<<<nblk(tot, 256), 256, 0, st>>>(P + o[6], m->wp_fc4, s.flat, m->arch.fc4, s.kb4, nbp4);
+        tot = (int64_t)s.nb4 * nbp5 * 256;
+        pack_dense<<<nblk(tot, 256), 256, 0, st>>>(P + o[8], m->wp_fc5, m->arch.fc4, m->arch.fc5, s.nb4, nbp5);
     }
+    pack_heads<<<nblk((int64_t)(s.nb4 + s.nb5) * 256, 256), 256, 0, st>>>(P + o[10], P + o[12], P + o[14], P + o[16],
+                                                                          m->arch.fc4, m->arch.fc5, s.nb4, s.nb5,
+                                                                          m->wp_heads0, m->wp_heads1);
     CV_HIP(hipGetLastError());
     m->packed_dirty = false;
     return 0;
@@ -479,15 +716,23 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
     const int G = (int)((n + 15) / 16);
     const cv_shapes &s = m->sh;
     int rc = 0;
+    const bool fuse_front = (m->variant & 1) != 0;
+    const float *W1 = m->wp_conv1, *B1 = P + o[1];
     if (full) {
-        cv_prof_begin(m, 0, st);
-        conv1_tm<5><<<nblk(G, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)m->tm_p1, G);
-        cv_prof_end(m, 0, st);
-        cv_prof_begin(m, 1, st);
-        rc |= launch_conv<2, 1, 2, 4, 29>(m->tm_p1, m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
-        cv_prof_end(m, 1, st);
+        if (fuse_front) {
+            cv_prof_begin(m, 1, st);
+            rc |= launch_conv<2, 1, 2, 4, 29, 5>(nullptr, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
+            cv_prof_end(m, 1, st);
+        } else {
+            cv_prof_begin(m, 0, st);
+            conv1_tm<5><<<nblk(G, 4), 256, 0, st>>>(x, n, W1, B1, a.cout[0], (f4 *)m->tm_p1, G);
+            cv_prof_end(m, 0, st);
+            cv_prof_begin(m, 1, st);
+            rc |= launch_conv<2, 1, 2, 4, 29, 0>(m->tm_p1, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
+            cv_prof_end(m, 1, st);
+        }
         cv_prof_begin(m, 2, st);
-        rc |= launch_conv<3, 2, 3, 3, 26>(m->tm_p2, m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st);
+        rc |= launch_conv<3, 2, 3, 3, 26, 0>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st);
         cv_prof_end(m, 2, st);
         cv_prof_begin(m, 3, st);
         rc |= launch_dense<21>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
@@ -496,14 +741,20 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         rc |= launch_dense<11>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st);
         cv_prof_end(m, 4, st);
     } else {
-        cv_prof_begin(m, 0, st);
-        conv1_tm<1><<<nblk(G, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)m->tm_p1, G);
-        cv_prof_end(m, 0, st);
-        cv_prof_begin(m, 1, st);
-        rc |= launch_conv<3, 1, 1, 1, 33>(m->tm_p1, m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
-        cv_prof_end(m, 1, st);
+        if (fuse_front) {
+            cv_prof_begin(m, 1, st);
+            rc |= launch_conv<3, 1, 1, 1, 33, 1>(nullptr, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
+            cv_prof_end(m, 1, st);
+        } else {
+            cv_prof_begin(m, 0, st);
+            conv1_tm<1><<<nblk(G, 4), 256, 0, st>>>(x, n, W1, B1, a.cout[0], (f4 *)m->tm_p1, G);
+            cv_prof_end(m, 0, st);
+            cv_prof_begin(m, 1, st);
+            rc |= launch_conv<3, 1, 1, 1, 33, 0>(m->tm_p1, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
+            cv_prof_end(m, 1, st);
+        }
         cv_prof_begin(m, 2, st);
-        rc |= launch_conv<5, 1, 2, 1, 33>(m->tm_p2, m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st);
+        rc |= launch_conv<5, 1, 2, 1, 33, 0>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st);
         cv_prof_end(m, 2, st);
         cv_prof_begin(m, 3, st);
         rc |= launch_dense<3>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
@@ -517,7 +768,15 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
     m->last_n = n;
     m->last_impl = 1;
     cv_prof_begin(m, 5, st);
-    rc = cv_launch_heads(m, m->tm_h4, m->tm_h5, 1, n, out16, st);
+    if (m->variant & 2) {
+        heads_tm<<<nblk(G, 4), 256, 0, st>>>((const f4 *)m->tm_h4, (const f4 *)m->tm_h5, s.nb4, s.nb5,
+                                            (const f4 *)m->wp_heads0, (const f4 *)m->wp_heads1, P + o[11], P + o[13],
+                                            P + o[15], P + o[17], n, out16, G);
+        rc = 0;
+    } else {
+        rc = cv_launch_heads(m, m->tm_h4, m->tm_h5, 1, n, out16, st);
+    }
     cv_prof_end(m, 5, st);
+    CV_HIP(hipGetLastError());
     return rc;
 }

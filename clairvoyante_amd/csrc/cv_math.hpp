@@ -45,11 +45,34 @@ __device__ __forceinline__ float expf_fixed(float x)
 constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f;
 constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
 
+// Branch-free form of the same operation sequence (a wave never diverges on the sign of
+// an activation): bitwise identical to `x >= 0 ? SCALE*x : SCALE*(ALPHA*(expf_fixed(x)-1))`
+// for every finite or NaN x.
 __device__ __forceinline__ float selu(float x)
 {
-    if (x >= 0.0f) return SELU_SCALE * x;
-    float t = expf_fixed(x) - 1.0f;
-    return SELU_SCALE * (SELU_ALPHA * t);
+    const float xn = fminf(x, 0.0f);
+    const float xc = fmaxf(xn, -87.33654475055310f);
+    float z = __builtin_rintf(xc * 1.44269504088896341f);
+    float r = __builtin_fmaf(z, -0.693359375f, xc);
+    r = __builtin_fmaf(z, 2.12194440e-4f, r);
+    float r2 = r * r;
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float y = __builtin_fmaf(p, r2, r);
+    y = y + 1.0f;
+    int n = (int)z;
+    int n1 = n >> 1, n2 = n - n1;
+    y = y * bits2f((uint32_t)(n1 + 127) << 23);
+    y = y * bits2f((uint32_t)(n2 + 127) << 23);
+    y = xn < -87.33654475055310f ? 0.0f : y;            // flush below FLT_MIN (as expf_fixed)
+    const float neg = SELU_SCALE * (SELU_ALPHA * (y - 1.0f));
+    const float pos = SELU_SCALE * x;
+    float out = x >= 0.0f ? pos : neg;
+    return x != x ? x : out;
 }
 
 // d selu / d pre-activation
