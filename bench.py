@@ -22,12 +22,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 BATCH = 65536
 FLOP_EXACT = {"full": 6768960, "slim": 2583264}
 # algorithmic FLOP per candidate of each kernel stage (exact, padding taps excluded)
-STAGE_FLOP = {
+STAGE_FLOP = {   # 2 x exact MACs (SAME-padding taps excluded) of conv1, conv2, conv3, fc4, fc5, heads
     "full": [2 * 25344, 2 * 350208, 2 * 1400832, 2 * 1548288, 2 * 56448, 2 * 3360],
-    "slim": [2 * 33 * 48 * 8, 2 * (33 * 3 - 2) * 12 * 8 * 16, 2 * (33 * 5 - 6) * 12 * 16 * 32, 2 * 4224 * 36, 2 * 36 * 18,
-             2 * (36 * 4 + 18 * 12)],
+    "slim": [2 * 12672, 2 * 148992, 2 * 976896, 2 * 152064, 2 * 648, 2 * 360],
 }
-STAGE_NAMES = ["conv1+pool1", "conv2+pool2", "conv3+pool3", "fc4", "fc5", "heads"]
+STAGE_NAMES = ["conv1+pool1", "conv1+pool1+conv2+pool2 (fused)", "conv3+pool3", "fc4", "fc5", "heads"]
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md (f32-in MFMA = vector rate)
 PEAK_HBM_GBS = 8000.0
 
@@ -112,14 +111,23 @@ def main():
             if cnt[s] == 0:
                 continue
             avg_ms = ms[s] / cnt[s]
-            tf = STAGE_FLOP[args.arch][s] * per_launch / (avg_ms * 1e-3) / 1e12
+            flop = STAGE_FLOP[args.arch][s] + (STAGE_FLOP[args.arch][0] if (s == 1 and cnt[0] == 0) else 0)
+            tf = flop * per_launch / (avg_ms * 1e-3) / 1e12
             stages.append({"kernel": STAGE_NAMES[s], "avg_ms": avg_ms, "launches": int(cnt[s]), "tflops": tf,
                            "share": ms[s] / max(sum(ms), 1e-12)})
         dom = max(stages, key=lambda r: r["avg_ms"]) if stages else None
+        traffic = None
+        try:   # HBM bytes per launch of that kernel from the separate rocprofv3 --pmc passes (profiles/)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            ent = tj.get(args.arch, {}).get(dom["kernel"]) if dom else None
+            if ent and ent.get("candidates_per_launch") == per_launch:
+                traffic = ent["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roof = None
         if dom:
             roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                     "avg_launch_ms": dom["avg_ms"], "candidates_per_launch": per_launch,
                     "whole_path_tflops": value / ws * FLOP_EXACT[args.arch] / 1e12,
                     "whole_path_frac": value / ws * FLOP_EXACT[args.arch] / 1e12 / PEAK_FP32_MFMA_TFLOPS,

@@ -20,6 +20,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = os.environ.get("CV_EXTRA_FLAGS", "").split()       # development: e.g. -DCV_SETPRIO
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     headers.append(os.path.join(HERE, "..", "include", "clairvoyante_amd.h"))
     objs = []
@@ -31,7 +32,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [hipcc] + FLAGS + [] + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((cmd, subprocess.Popen(cmd)))

@@ -103,7 +103,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     m->arch = *arch;
     m->device = device;
     m->impl = 1;
-    m->chunk = 32768;
+    m->chunk = 65536;
     if (compute_shapes(m)) { delete m; return 1; }
     const int64_t np = m->poff[CV_NUM_PARAMS];
     const cv_shapes &s = m->sh;
@@ -119,7 +119,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     alloc(&m->wp_fc5, (size_t)s.nb4 * ((s.nb5 + 3) / 4 * 4) * 256);
     alloc(&m->wp_heads0, (size_t)s.nb4 * 256);
     alloc(&m->wp_heads1, (size_t)s.nb5 * 256);
-    m->variant = 3;
+    m->variant = 7;
     if (e == hipSuccess) e = hipMalloc(&m->loss_dev, sizeof(double) * 8);
     if (e != hipSuccess) {
         cv_set_error("cv_create: device allocation failed: %s", hipGetErrorString(e));

@@ -112,10 +112,16 @@ __global__ __launch_bounds__(256) void conv1_tm(const float *__restrict__ x, int
                                                  const float *__restrict__ bias, int cout,
                                                  f4 *__restrict__ out_tm, int G)
 {
-    constexpr int HIN = CV_INPUT_H, HOUT = HIN - POOL + 1;
+    // The layer has almost no arithmetic (12 MFMA steps per position) and a long dependent
+    // chain per position (load -> MFMA -> SELU -> pool -> store), so it is latency-bound:
+    // SPLIT waves share a group, each producing a contiguous range of pooled rows (and
+    // recomputing the POOL-1 conv rows of overlap) -- 4x the waves in flight.
+    constexpr int HIN = CV_INPUT_H, HOUT = HIN - POOL + 1, SPLIT = 4;
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int g = wv / SPLIT, part = wv % SPLIT;
     if (g >= G) return;
+    const int r0 = (HOUT * part) / SPLIT, r1 = (HOUT * (part + 1)) / SPLIT;   // pooled rows [r0, r1)
     const int c = lane & 15, q = lane >> 4;
     int64_t cand = (int64_t)g * 16 + c;
     if (cand >= n) cand = n - 1;
@@ -131,13 +137,15 @@ __global__ __launch_bounds__(256) void conv1_tm(const float *__restrict__ x, int
         for (int w = 0; w < 4; w++) pw[j][w] = (f4){0.f, 0.f, 0.f, 0.f};
     float xw[4], xn[4];
 #pragma unroll
-    for (int w = 0; w < 4; w++) xw[w] = xp[w * 4];
+    for (int w = 0; w < 4; w++) xw[w] = xp[r0 * 16 + w * 4];
     f4 *op = out_tm + (size_t)g * HOUT * 4 * 64 + lane;
+    const int hend = r1 + POOL - 1;          // conv rows r0 .. r1+POOL-2
 #pragma unroll 1
-    for (int h = 0; h < HIN; h++) {
-        if (h + 1 < HIN) {
+    for (int h = r0; h < hend; h++) {
+        {
+            const int hn = h + 1 < hend ? h + 1 : h;
 #pragma unroll
-            for (int w = 0; w < 4; w++) xn[w] = xp[(h + 1) * 16 + w * 4];
+            for (int w = 0; w < 4; w++) xn[w] = xp[hn * 16 + w * 4];
         }
         f4 acc[4];
 #pragma unroll
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256) void conv1_tm(const float *__restrict__ x, int
                 for (int w = 0; w < 4; w++) pw[j][w] = pw[j + 1][w];
 #pragma unroll
             for (int w = 0; w < 4; w++) pw[POOL - 2][w] = v[w];
-            if (h >= POOL - 1) {
+            if (h - r0 >= POOL - 1) {
 #pragma unroll
                 for (int w = 0; w < 4; w++) op[(size_t)((h - (POOL - 1)) * 4 + w) * 64] = o[w];
             }
@@ -343,11 +351,18 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
             for (int cb = 0; cb < CINB; cb++) win[KH - 1][w][cb] = nxt[w][cb];
         {   // fetch / produce the row the next position needs
             const int hr = h + 1 + (KH - 1) - PADT;
+#if defined(CV_ABL) && (CV_ABL & 2)
+            (void)hr;                                          // ablation: no row fetch
+#else
             if (hr < HIN) fetch_row(hr, nxt);
+#endif
         }
         f4 acc[4];
 #pragma unroll
         for (int w = 0; w < 4; w++) acc[w] = zero;
+#ifdef CV_SETPRIO
+        __builtin_amdgcn_s_setprio(1);     // the wave in its MFMA phase outranks the one in its epilogue
+#endif
 #pragma unroll
         for (int kh = 0; kh < KH; kh++) {
             const int hr = h + kh - PADT;
@@ -368,9 +383,17 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
                     }
             }
         }
+#ifdef CV_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         f4 v[4];
+#if defined(CV_ABL) && (CV_ABL & 1)
+#pragma unroll
+        for (int w = 0; w < 4; w++) v[w] = acc[w] + b4;      // ablation: no SELU
+#else
 #pragma unroll
         for (int w = 0; w < 4; w++) v[w] = selu4(acc[w] + b4);
+#endif
         if constexpr (POOL > 1) {
             f4 o[4];
 #pragma unroll
@@ -520,7 +543,7 @@ __global__ __launch_bounds__(256) void heads_tm(const f4 *__restrict__ h4, const
 // each wave streams its own activation fragments straight from HBM/L2.
 // ---------------------------------------------------------------------------
 template <int NB, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 2) void dense_tm(const f4 *__restrict__ in_tm, int KB,
+__global__ __launch_bounds__(WAVES * 64, WAVES / 2) void dense_tm(const f4 *__restrict__ in_tm, int KB,
                                                         const f4 *__restrict__ wp,
                                                         const float *__restrict__ bias, int nout,
                                                         f4 *__restrict__ out_tm, int G)
@@ -596,8 +619,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void dense_tm(const f4 *__restrict__
                     if (ob + j < NB) acc[ob + j] = mfma4(A[j][s], B[s], acc[ob + j]);
         }
         __builtin_amdgcn_sched_barrier(0);                  // keep the MFMAs above the wait
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(Bn) : : "memory");   // this wave's DMA pieces and Bn have landed
-        __syncthreads();                                    // every wave's pieces have: slot is readable
+        // Counted wait: leave THIS step's PER DMA pieces (stage kb+2, first read two steps from
+        // now) in flight; everything older -- Bn and the pieces of stage kb+1 issued one step
+        // ago -- has landed.  The barrier then publishes stage kb+1 to the whole workgroup.
+        if constexpr (PER == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(Bn) : : "memory");
+        else if constexpr (PER == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(Bn) : : "memory");
+        else if constexpr (PER == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(Bn) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(Bn) : : "memory");
+        __syncthreads();
         B = Bn;
         slot = slot + 1 == 3 ? 0 : slot + 1;
     }
@@ -634,11 +663,10 @@ int launch_conv(const float *in, const float *x, int64_t n, const float *wp1, co
     return 0;
 }
 
-template <int NB>
+template <int NB, int WAVES>
 int launch_dense(const float *in, int KB, const float *wp, const float *bias, int nout, float *out, int G,
                  hipStream_t st)
 {
-    constexpr int WAVES = 4;
     auto k = dense_tm<NB, WAVES>;
     size_t lds = (size_t)3 * ((NB + WAVES - 1) / WAVES * WAVES) * 1024;
     if (set_lds(k, lds)) return 1;
@@ -725,7 +753,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             cv_prof_end(m, 1, st);
         } else {
             cv_prof_begin(m, 0, st);
-            conv1_tm<5><<<nblk(G, 4), 256, 0, st>>>(x, n, W1, B1, a.cout[0], (f4 *)m->tm_p1, G);
+            conv1_tm<5><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, W1, B1, a.cout[0], (f4 *)m->tm_p1, G);
             cv_prof_end(m, 0, st);
             cv_prof_begin(m, 1, st);
             rc |= launch_conv<2, 1, 2, 4, 29, 0>(m->tm_p1, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
@@ -735,10 +763,11 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         rc |= launch_conv<3, 2, 3, 3, 26, 0>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st);
         cv_prof_end(m, 2, st);
         cv_prof_begin(m, 3, st);
-        rc |= launch_dense<21>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
+        if (m->variant & 4) rc |= launch_dense<21, 8>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
+        else rc |= launch_dense<21, 4>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
         cv_prof_end(m, 3, st);
         cv_prof_begin(m, 4, st);
-        rc |= launch_dense<11>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st);
+        rc |= launch_dense<11, 4>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st);
         cv_prof_end(m, 4, st);
     } else {
         if (fuse_front) {
@@ -747,7 +776,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             cv_prof_end(m, 1, st);
         } else {
             cv_prof_begin(m, 0, st);
-            conv1_tm<1><<<nblk(G, 4), 256, 0, st>>>(x, n, W1, B1, a.cout[0], (f4 *)m->tm_p1, G);
+            conv1_tm<1><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, W1, B1, a.cout[0], (f4 *)m->tm_p1, G);
             cv_prof_end(m, 0, st);
             cv_prof_begin(m, 1, st);
             rc |= launch_conv<3, 1, 1, 1, 33, 0>(m->tm_p1, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
@@ -757,10 +786,10 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         rc |= launch_conv<5, 1, 2, 1, 33, 0>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st);
         cv_prof_end(m, 2, st);
         cv_prof_begin(m, 3, st);
-        rc |= launch_dense<3>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
+        rc |= launch_dense<3, 4>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
         cv_prof_end(m, 3, st);
         cv_prof_begin(m, 4, st);
-        rc |= launch_dense<2>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st);
+        rc |= launch_dense<2, 4>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st);
         cv_prof_end(m, 4, st);
     }
     if (rc) return 1;

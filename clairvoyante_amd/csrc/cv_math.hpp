@@ -47,11 +47,13 @@ constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
 
 // Branch-free form of the same operation sequence (a wave never diverges on the sign of
 // an activation): bitwise identical to `x >= 0 ? SCALE*x : SCALE*(ALPHA*(expf_fixed(x)-1))`
-// for every finite or NaN x.
+// for every x.  Notes: (i) the argument is clamped at the flush threshold instead of
+// flushing exp to 0 -- below it exp(x) <= 1.2e-38 and exp(x) - 1 rounds to -1 either way;
+// (ii) the final select is `x < 0 ? neg : pos`, which also routes NaN (and -0) to pos.
 __device__ __forceinline__ float selu(float x)
 {
-    const float xn = fminf(x, 0.0f);
-    const float xc = fmaxf(xn, -87.33654475055310f);
+    // clamp to [flush threshold, 0] (one v_med3_f32); for x > 0 the exp branch is unused
+    const float xc = __builtin_amdgcn_fmed3f(x, -87.33654475055310f, 0.0f);
     float z = __builtin_rintf(xc * 1.44269504088896341f);
     float r = __builtin_fmaf(z, -0.693359375f, xc);
     r = __builtin_fmaf(z, 2.12194440e-4f, r);
@@ -64,15 +66,12 @@ __device__ __forceinline__ float selu(float x)
     p = __builtin_fmaf(p, r, 5.0000001201e-1f);
     float y = __builtin_fmaf(p, r2, r);
     y = y + 1.0f;
-    int n = (int)z;
-    int n1 = n >> 1, n2 = n - n1;
-    y = y * bits2f((uint32_t)(n1 + 127) << 23);
-    y = y * bits2f((uint32_t)(n2 + 127) << 23);
-    y = xn < -87.33654475055310f ? 0.0f : y;            // flush below FLT_MIN (as expf_fixed)
+    // y * 2^n: n in [-126, 0] here and y in [0.70, 1.42), the product is a normal number, so
+    // one v_ldexp_f32 equals expf_fixed's two exact power-of-two multiplications bit for bit
+    y = __builtin_ldexpf(y, (int)z);
     const float neg = SELU_SCALE * (SELU_ALPHA * (y - 1.0f));
     const float pos = SELU_SCALE * x;
-    float out = x >= 0.0f ? pos : neg;
-    return x != x ? x : out;
+    return x < 0.0f ? neg : pos;
 }
 
 // d selu / d pre-activation
