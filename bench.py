@@ -35,7 +35,7 @@ def cpu_baseline(arch, P, x_sample, target_s=12.0):
     """The oracle (C restatement, OpenMP) timed on this box's host cores on a bounded sample."""
     from oracle import cv_oracle as O
     cores = os.cpu_count() or 1
-    probe = x_sample[:256]
+    probe = x_sample[:8192]
     t0 = time.time(); O.predict(arch, P, probe, nthreads=cores); dt = time.time() - t0
     rate = probe.shape[0] / max(dt, 1e-6)
     n = int(min(x_sample.shape[0], max(1024, rate * target_s)))

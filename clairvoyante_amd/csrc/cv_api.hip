@@ -276,6 +276,11 @@ extern "C" int cv_get_activation(cv_model *m, int layer, float *dst_dev, int64_t
         CV_HIP(hipMemcpyAsync(dst_dev, src, sizeof(float) * per * n, hipMemcpyDeviceToDevice, st));
         return 0;
     }
+    if (layer == 1 && m->last_impl == 1 && (m->last_variant & 1)) {
+        cv_set_error("layer 1 is not materialised while the first layer is fused into the conv2 kernel "
+                     "(option variant bit 0); clear the bit to inspect it");
+        return 1;
+    }
     if (layer <= 3) {
         int l = layer - 1;
         const float *tm = l == 0 ? m->tm_p1 : (l == 1 ? m->tm_p2 : m->tm_p3);

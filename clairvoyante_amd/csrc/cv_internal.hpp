@@ -71,6 +71,7 @@ struct cv_model {
     float *r_a[3], *r_p[3], *r_h4, *r_h5;
     int64_t last_n;      // candidates of the last chunk (for cv_get_activation)
     int last_impl;
+    int last_variant;
     // training workspaces
     int64_t tr_cap;
     float *t_buf;        // one slab, carved by the training code

@@ -796,6 +796,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
     CV_HIP(hipGetLastError());
     m->last_n = n;
     m->last_impl = 1;
+    m->last_variant = m->variant;
     cv_prof_begin(m, 5, st);
     if (m->variant & 2) {
         heads_tm<<<nblk(G, 4), 256, 0, st>>>((const f4 *)m->tm_h4, (const f4 *)m->tm_h5, s.nb4, s.nb5,
