@@ -21,10 +21,15 @@ def world():
     return 0, 1
 
 
+def _active():
+    """collectives run when there is more than one rank (or when forced, to test them at N=1)"""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or bool(os.environ.get("CV_FORCE_DIST")))
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* (torchrun)."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws <= 1:
+    if ws <= 1 and not os.environ.get("CV_FORCE_DIST"):     # CV_FORCE_DIST: exercise the collective path at N=1
         return 0, 1, 0
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -48,8 +53,7 @@ def shard_range(total, rank, world_size):
 
 def allreduce_sum_(flat, losses=None):
     """In-place SUM all-reduce of a flat tensor (+ optional list of python floats)."""
-    rank, ws = world()
-    if ws == 1:
+    if not _active():
         return losses
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if losses is not None:
@@ -62,8 +66,7 @@ def allreduce_sum_(flat, losses=None):
 def allreduce_gradients(model, losses):
     """Gradient exchange of one optimizer step.  losses = [l1,l2,l3,l4,lL2,total] of this
     rank's shard; returns the global-batch values (lL2 is identical on all ranks)."""
-    rank, ws = world()
-    if ws == 1:
+    if not _active():
         return losses
     from . import _lib
     n = model.numParameters
@@ -80,8 +83,7 @@ def allreduce_gradients(model, losses):
 
 def broadcast_parameters(model, src=0):
     """Replicate rank `src`'s weights and optimizer slots (done once after init/restore)."""
-    rank, ws = world()
-    if ws == 1:
+    if not _active():
         return
     from . import _lib
     n = model.numParameters
@@ -95,8 +97,7 @@ def broadcast_parameters(model, src=0):
 
 def allreduce_scalar(value, model=None):
     """SUM of a python float over the ranks (validation-loss bookkeeping of train.py:118-122)."""
-    rank, ws = world()
-    if ws == 1:
+    if not _active():
         return value
     dev = model.device if model is not None else "cpu"
     t = torch.tensor([value], dtype=torch.float64, device=dev)
