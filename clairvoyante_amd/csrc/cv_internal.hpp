@@ -60,6 +60,8 @@ struct cv_model {
     float *wp_conv[3];   // [1],[2]: [nt][kh][kw][cb][64][4]
     float *wp_fc4;       // [kb][nb4][64][4]
     float *wp_fc5;       // [nb4][nb5][64][4]
+    float *wpd_conv[3];  // data-gradient weights of conv2 / conv3 (pack_conv_dgrad)
+    float *wpd_fc4;      // data-gradient weights of fc4 [slab][jb][24][64][4]
     float *wp_heads0;    // [nb4][64][4]  base head (rows 0..3)
     float *wp_heads1;    // [nb5][64][4]  zygosity / type / length heads
     int variant;         // bit 0: first layer fused into conv2; bit 1: MFMA heads kernel; bit 2: 8-wave fc4 workgroups
@@ -104,5 +106,15 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
 int cv_pack_weights(cv_model *m, hipStream_t st);
 int cv_launch_heads(cv_model *m, const float *h4, const float *h5, int tm, int64_t n, float *out16,
                     hipStream_t st);
+bool cv_tile_supported(const cv_model *m);
+int cv_pack_train_weights(cv_model *m, hipStream_t st);
+int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float *a1, float *p2, float *a2,
+                        float *p3, float *a3, hipStream_t st);
+int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm, int64_t n, hipStream_t st);
+int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
+int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
+int cv_natural_to_tm(const float *nat, int KB, int FPP, int FP, int npos, int64_t n, float *tm, hipStream_t st);
+int cv_dropout_tm(cv_model *m, const float *h4, float *d4, float *amask, int64_t n, float rate, uint64_t seed,
+                  uint64_t step, int64_t cand0, hipStream_t st);
 int cv_tm_to_natural(const float *tm, int KB, int feat_per_pos_padded, int feat_per_pos, int npos,
                      int64_t n, float *dst, hipStream_t st);

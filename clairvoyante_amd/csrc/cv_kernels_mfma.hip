@@ -102,15 +102,105 @@ __global__ void pack_dense(const float *__restrict__ w, float *__restrict__ wp, 
     wp[t] = (k < K && o < N) ? w[(size_t)k * N + o] : 0.0f;
 }
 
+// data-gradient weights of a dense layer: out feature = original input k, in feature =
+// original output j; fragments [slab][jb][ob_in_slab][lane][s] (slabs of NBS output fragments)
+__global__ void pack_dense_dgrad(const float *__restrict__ w, float *__restrict__ wp, int K, int N, int JB,
+                                 int NBS, int NSLAB)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)NSLAB * JB * NBS * 256;
+    if (t >= total) return;
+    int s = (int)(t & 3), lane = (int)((t >> 2) & 63);
+    int64_t frag = t >> 8;
+    int obs = (int)(frag % NBS); frag /= NBS;
+    int jb = (int)(frag % JB);
+    int slab = (int)(frag / JB);
+    int i = lane & 15, kq = lane >> 4;
+    int j = 16 * jb + 4 * s + kq;                       // contraction index = original output unit
+    int k = 16 * (slab * NBS + obs) + cv_sigma(i);      // result feature = original input unit
+    wp[t] = (j < N && k < K) ? w[(size_t)k * N + j] : 0.0f;
+}
+
+// data-gradient weights of a conv layer (see conv_tm MODE 2): flipped taps, channels swapped
+//   Wd[nt'][kh'][kw'][cb'][lane][s] = W[KH-1-kh'][3-kw'][ci = 16 nt' + sigma(i)][co = 16 cb' + 4 s + kq]
+__global__ void pack_conv_dgrad(const float *__restrict__ w, float *__restrict__ wp, int KH, int cin, int cout,
+                                int COB, int CIT)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)CIT * KH * 4 * COB * 256;
+    if (t >= total) return;
+    int s = (int)(t & 3), lane = (int)((t >> 2) & 63);
+    int frag = (int)(t >> 8);
+    int cb = frag % COB; frag /= COB;
+    int kw = frag % 4; frag /= 4;
+    int kh = frag % KH;
+    int nt = frag / KH;
+    int i = lane & 15, kq = lane >> 4;
+    int co = 16 * cb + 4 * s + kq, ci = 16 * nt + cv_sigma(i);
+    wp[t] = (ci < cin && co < cout) ? w[(((size_t)(KH - 1 - kh) * 4 + (3 - kw)) * cin + ci) * cout + co] : 0.0f;
+}
+
+// natural [n][npos][FP] -> TM (KB = npos*FPP/16 fragments per group); padding features and the
+// candidates beyond n in the last group are written as zeros
+__global__ void natural_to_tm(const float *__restrict__ nat, int KB, int FPP, int FP, int npos, int64_t n,
+                              int64_t G, float *__restrict__ tm)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= G * KB * 256) return;
+    int s = (int)(t & 3), lane = (int)((t >> 2) & 63);
+    int64_t frag = t >> 8;
+    int kb = (int)(frag % KB);
+    int64_t g = frag / KB;
+    int c = lane & 15, kq = lane >> 4;
+    int k = 16 * kb + 4 * s + kq;
+    int pos = k / FPP, f = k % FPP;
+    int64_t cand = g * 16 + c;
+    tm[t] = (cand < n && f < FP) ? nat[((size_t)cand * npos + pos) * FP + f] : 0.0f;
+}
+
+// alpha-dropout on fc4 in TM layout (selu.py:34-69): d4 = a*(h4*keep + alpha'*(1-keep)) + b;
+// amask = a*keep is kept for the backward pass.  Counter-based stream of (seed, step, cand, unit).
+__global__ void dropout_tm(const float *__restrict__ h4, float *__restrict__ d4, float *__restrict__ amask,
+                           int NB, int nunits, int64_t G, float rate, uint64_t seed, uint64_t step, int64_t cand0)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= G * NB * 256) return;
+    int s = (int)(t & 3), lane = (int)((t >> 2) & 63);
+    int64_t frag = t >> 8;
+    int ob = (int)(frag % NB);
+    int64_t g = frag / NB;
+    int c = lane & 15, kq = lane >> 4;
+    int unit = 16 * ob + 4 * s + kq;
+    float v = h4[t], mk = 1.0f;
+    if (unit >= nunits) { v = 0.0f; mk = 0.0f; }
+    else if (rate > 0.0f) {
+        const float ap = -1.7580993408473766f;
+        float q = 1.0f - rate;
+        float a = sqrtf(1.0f / (q * ((1.0f - q) * (ap * ap) + 1.0f)));
+        float b = 0.0f - a * ((1.0f - q) * ap);
+        uint64_t ctr = (seed * 0x9E3779B97F4A7C15ull) ^ (step << 40) ^ (uint64_t)((cand0 + g * 16 + c) * nunits + unit);
+        ctr += 0x9E3779B97F4A7C15ull;
+        ctr = (ctr ^ (ctr >> 30)) * 0xBF58476D1CE4E5B9ull;
+        ctr = (ctr ^ (ctr >> 27)) * 0x94D2049BB133111Bull;
+        ctr = ctr ^ (ctr >> 31);
+        float u = (float)((uint32_t)(ctr >> 32) >> 8) * (1.0f / 16777216.0f);
+        float keep = floorf(q + u);
+        v = a * (v * keep + ap * (1.0f - keep)) + b;
+        mk = a * keep;
+    }
+    d4[t] = v;
+    amask[t] = mk;
+}
+
 // ---------------------------------------------------------------------------
 // conv1 (k(1,4), cin 4) + SELU + max-pool(POOL,1): raw X [n,33,4,4] -> TM
 // One wave per group of 16 candidates; per position 12 MFMA steps (K = 4 each).
 // ---------------------------------------------------------------------------
-template <int POOL>
+template <int POOL, bool SAVE = false>
 __global__ __launch_bounds__(256) void conv1_tm(const float *__restrict__ x, int64_t n,
                                                  const float *__restrict__ wp1,
                                                  const float *__restrict__ bias, int cout,
-                                                 f4 *__restrict__ out_tm, int G)
+                                                 f4 *__restrict__ out_tm, int G, f4 *__restrict__ act_tm = nullptr)
 {
     // The layer has almost no arithmetic (12 MFMA steps per position) and a long dependent
     // chain per position (load -> MFMA -> SELU -> pool -> store), so it is latency-bound:
@@ -161,6 +251,11 @@ __global__ __launch_bounds__(256) void conv1_tm(const float *__restrict__ x, int
         f4 v[4];
 #pragma unroll
         for (int w = 0; w < 4; w++) v[w] = selu4(acc[w] + b4);
+        if constexpr (SAVE) {     // rows shared by two parts are written twice with identical values
+            f4 *ap = act_tm + (size_t)g * HIN * 4 * 64 + lane;
+#pragma unroll
+            for (int w = 0; w < 4; w++) ap[(size_t)(h * 4 + w) * 64] = v[w];
+        }
         if constexpr (POOL > 1) {
             f4 o[4];
 #pragma unroll
@@ -277,16 +372,24 @@ struct front_source {
     }
 };
 
-template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT>
+// MODE 0: inference forward.  MODE 1: training forward -- additionally stores the SELU
+// outputs BEFORE pooling (act_tm, [g][HIN*4*NT] fragments) that the backward pass routes the
+// pooling gradient with.  MODE 2: data-gradient pass -- the same kernel run as the transposed
+// convolution  gIn[h][w][ci] = sum g[h-kh+pt][w-kw+1][co] W[kh][kw][ci][co]  on flipped,
+// in/out-swapped packed weights (pack_conv_dgrad): padding 2 left / 1 right and
+// KH-1-(KH-1)/2 on top, no bias, no activation, no pooling.
+template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, const float *__restrict__ x,
                                                    int64_t n, const float *__restrict__ wp1,
                                                    const float *__restrict__ bias1, int cout1,
                                                    const f4 *__restrict__ wp, const float *__restrict__ bias,
-                                                   int cout, f4 *__restrict__ out_tm, int G)
+                                                   int cout, f4 *__restrict__ out_tm, f4 *__restrict__ act_tm, int G)
 {
     static_assert(FRONT == 0 || CINB == 1, "the fused first layer feeds one 16-channel fragment");
+    static_assert(MODE != 2 || (POOL == 1 && FRONT == 0), "the data-gradient pass has no pooling / first layer");
     extern __shared__ __attribute__((aligned(16))) f4 ldsw[];
-    constexpr int PADT = (KH - 1) / 2;
+    constexpr int PADT = MODE == 2 ? KH - 1 - (KH - 1) / 2 : (KH - 1) / 2;
+    constexpr int PADL = MODE == 2 ? 2 : 1;
     constexpr int HOUT = HIN - POOL + 1;
     constexpr int NFRAG = NT * KH * 4 * CINB;
     for (int i = threadIdx.x; i < NFRAG * 64; i += 256) ldsw[i] = wp[i];
@@ -296,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
     const int g = wv / NT, nt = wv % NT;
     if (g >= G) return;
     const int q = lane >> 4;
-    const f4 b4 = load_bias4(bias, nt, q, cout);
+    const f4 b4 = MODE == 2 ? (f4){0.f, 0.f, 0.f, 0.f} : load_bias4(bias, nt, q, cout);
     const f4 *inp = in_tm + (size_t)g * (HIN * 4 * CINB * 64) + lane;
     const f4 *wl = ldsw + (size_t)nt * (KH * 4 * CINB * 64) + lane;
     f4 *op = out_tm + (size_t)g * (HOUT * 4 * NT * 64) + (size_t)nt * 64 + lane;
@@ -376,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
                         for (int s = 0; s < 4; s++)
 #pragma unroll
                             for (int wo = 0; wo < 4; wo++) {
-                                const int wi = wo + kw - 1;
+                                const int wi = wo + kw - PADL;
                                 if (wi < 0 || wi > 3) continue;
                                 acc[wo] = mfma4(A[s], win[kh][wi][cb][s], acc[wo]);
                             }
@@ -387,13 +490,23 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
         __builtin_amdgcn_s_setprio(0);
 #endif
         f4 v[4];
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) v[w] = acc[w];
+        } else {
 #if defined(CV_ABL) && (CV_ABL & 1)
 #pragma unroll
-        for (int w = 0; w < 4; w++) v[w] = acc[w] + b4;      // ablation: no SELU
+            for (int w = 0; w < 4; w++) v[w] = acc[w] + b4;      // ablation: no SELU
 #else
 #pragma unroll
-        for (int w = 0; w < 4; w++) v[w] = selu4(acc[w] + b4);
+            for (int w = 0; w < 4; w++) v[w] = selu4(acc[w] + b4);
 #endif
+        }
+        if constexpr (MODE == 1) {
+            f4 *ap = act_tm + (size_t)g * (HIN * 4 * NT * 64) + (size_t)nt * 64 + lane;
+#pragma unroll
+            for (int w = 0; w < 4; w++) ap[(size_t)(h * 4 + w) * (NT * 64)] = v[w];
+        }
         if constexpr (POOL > 1) {
             f4 o[4];
 #pragma unroll
@@ -542,11 +655,14 @@ __global__ __launch_bounds__(256) void heads_tm(const f4 *__restrict__ h4, const
 // weight matrix through a 3-stage LDS ring (one barrier per 16-deep k step),
 // each wave streams its own activation fragments straight from HBM/L2.
 // ---------------------------------------------------------------------------
-template <int NB, int WAVES>
+// EPI 0: + bias, SELU (forward layer).  EPI 1: raw accumulators (data-gradient pass: the same
+// kernel on transposed packed weights; blockIdx.y selects a slab of NB output fragments of a
+// wider result with NBT fragments per group).
+template <int NB, int WAVES, int EPI = 0>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 2) void dense_tm(const f4 *__restrict__ in_tm, int KB,
-                                                        const f4 *__restrict__ wp,
+                                                        const f4 *__restrict__ wp_all,
                                                         const float *__restrict__ bias, int nout,
-                                                        f4 *__restrict__ out_tm, int G)
+                                                        f4 *__restrict__ out_tm, int G, int NBT = NB)
 {
     // The packed weight matrix holds NBP = roundup(NB, WAVES) fragments per k step (the pad
     // fragments are zero and never multiplied), so every thread stages exactly PER 16-byte
@@ -556,6 +672,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 2) void dense_tm(const f4 *__re
     constexpr int NBP = (NB + WAVES - 1) / WAVES * WAVES;
     constexpr int STAGE = NBP * 64;              // f4 per stage
     constexpr int PER = NBP / WAVES;             // fragments each wave stages per k step
+    const f4 *wp = wp_all + (size_t)blockIdx.y * KB * STAGE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.x * WAVES + wid;
@@ -632,11 +749,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 2) void dense_tm(const f4 *__re
     }
     if (g >= G) return;
     const int q = lane >> 4;
-    f4 *op = out_tm + (size_t)g * NB * 64 + lane;
+    f4 *op = out_tm + ((size_t)g * NBT + (size_t)blockIdx.y * NB) * 64 + lane;
 #pragma unroll
     for (int ob = 0; ob < NB; ob++) {
-        const f4 b4 = load_bias4(bias, ob, q, nout);
-        op[ob * 64] = selu4(acc[ob] + b4);
+        if constexpr (EPI == 0) {
+            const f4 b4 = load_bias4(bias, ob, q, nout);
+            op[ob * 64] = selu4(acc[ob] + b4);
+        } else {
+            op[ob * 64] = acc[ob];
+        }
     }
 }
 
@@ -650,27 +771,30 @@ int set_lds(K kernel, size_t bytes)
     return 0;
 }
 
-template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT>
+template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT, int MODE = 0>
 int launch_conv(const float *in, const float *x, int64_t n, const float *wp1, const float *bias1, int cout1,
-                const float *wp, const float *bias, int cout, float *out, int G, hipStream_t st)
+                const float *wp, const float *bias, int cout, float *out, int G, hipStream_t st,
+                float *act = nullptr)
 {
-    auto k = conv_tm<KH, CINB, NT, POOL, HIN, FRONT>;
+    auto k = conv_tm<KH, CINB, NT, POOL, HIN, FRONT, MODE>;
     size_t lds = (size_t)NT * KH * 4 * CINB * 1024;
     if (set_lds(k, lds)) return 1;
     unsigned grid = nblk((int64_t)G * NT, 4);
-    k<<<grid, 256, lds, st>>>((const f4 *)in, x, n, wp1, bias1, cout1, (const f4 *)wp, bias, cout, (f4 *)out, G);
+    k<<<grid, 256, lds, st>>>((const f4 *)in, x, n, wp1, bias1, cout1, (const f4 *)wp, bias, cout, (f4 *)out,
+                              (f4 *)act, G);
     CV_HIP(hipGetLastError());
     return 0;
 }
 
-template <int NB, int WAVES>
+template <int NB, int WAVES, int EPI = 0>
 int launch_dense(const float *in, int KB, const float *wp, const float *bias, int nout, float *out, int G,
-                 hipStream_t st)
+                 hipStream_t st, int slabs = 1)
 {
-    auto k = dense_tm<NB, WAVES>;
+    auto k = dense_tm<NB, WAVES, EPI>;
     size_t lds = (size_t)3 * ((NB + WAVES - 1) / WAVES * WAVES) * 1024;
     if (set_lds(k, lds)) return 1;
-    k<<<nblk(G, WAVES), WAVES * 64, lds, st>>>((const f4 *)in, KB, (const f4 *)wp, bias, nout, (f4 *)out, G);
+    k<<<dim3(nblk(G, WAVES), slabs), WAVES * 64, lds, st>>>((const f4 *)in, KB, (const f4 *)wp, bias, nout,
+                                                            (f4 *)out, G, NB * slabs);
     CV_HIP(hipGetLastError());
     return 0;
 }
@@ -809,4 +933,107 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
     cv_prof_end(m, 5, st);
     CV_HIP(hipGetLastError());
     return rc;
+}
+
+// ---------------------------------------------------------------------------
+// tile-kernel entry points of the training step (cv_train.hip)
+// ---------------------------------------------------------------------------
+static bool is_full(const cv_arch &a) { return arch_is(a, 1, 2, 3, 16, 32, 48, 5, 4, 3, 336, 168); }
+static bool is_slim(const cv_arch &a) { return arch_is(a, 1, 3, 5, 8, 16, 32, 1, 1, 1, 36, 18); }
+
+bool cv_tile_supported(const cv_model *m) { return is_full(m->arch) || is_slim(m->arch); }
+
+int cv_pack_train_weights(cv_model *m, hipStream_t st)
+{
+    const float *P = m->params;
+    const int64_t *o = m->poff;
+    const cv_shapes &s = m->sh;
+    const cv_arch &a = m->arch;
+    for (int l = 1; l < 3; l++) {
+        int64_t tot = (int64_t)s.cinb[l] * a.kh[l] * 4 * s.ntile[l] * 256;
+        pack_conv_dgrad<<<nblk(tot, 256), 256, 0, st>>>(P + o[2 * l], m->wpd_conv[l], a.kh[l], s.cin[l], a.cout[l],
+                                                        s.ntile[l], s.cinb[l]);
+    }
+    int64_t tot = (int64_t)(s.kb4 / 24) * s.nb4 * 24 * 256;
+    pack_dense_dgrad<<<nblk(tot, 256), 256, 0, st>>>(P + o[6], m->wpd_fc4, s.flat, a.fc4, s.nb4, 24, s.kb4 / 24);
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
+// conv1..conv3 (+pools) with the pre-pool activations kept; buffers are TM
+int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float *a1, float *p2, float *a2,
+                        float *p3, float *a3, hipStream_t st)
+{
+    const cv_arch &a = m->arch;
+    const float *P = m->params;
+    const int64_t *o = m->poff;
+    const int G = (int)((n + 15) / 16);
+    int rc = 0;
+    if (is_full(a)) {
+        conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (f4 *)a1);
+        rc |= launch_conv<2, 1, 2, 4, 29, 0, 1>(p1, x, n, nullptr, nullptr, 0, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
+        rc |= launch_conv<3, 2, 3, 3, 26, 0, 1>(p2, x, n, nullptr, nullptr, 0, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
+    } else {
+        conv1_tm<1, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (f4 *)a1);
+        rc |= launch_conv<3, 1, 1, 1, 33, 0, 1>(p1, x, n, nullptr, nullptr, 0, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
+        rc |= launch_conv<5, 1, 2, 1, 33, 0, 1>(p2, x, n, nullptr, nullptr, 0, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
+    }
+    CV_HIP(hipGetLastError());
+    return rc;
+}
+
+int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm, int64_t n, hipStream_t st)
+{
+    const cv_arch &a = m->arch;
+    const float *P = m->params;
+    const int64_t *o = m->poff;
+    const cv_shapes &s = m->sh;
+    const int G = (int)((n + 15) / 16);
+    if (is_full(a)) {
+        if (layer == 4) return launch_dense<21, 8>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);
+        return launch_dense<11, 4>(in_tm, s.nb4, m->wp_fc5, P + o[9], a.fc5, out_tm, G, st);
+    }
+    if (layer == 4) return launch_dense<3, 4>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);
+    return launch_dense<2, 4>(in_tm, s.nb4, m->wp_fc5, P + o[9], a.fc5, out_tm, G, st);
+}
+
+// gF[k] = sum_j g4pre[j] W4[k][j]  (input TM with nb4 fragments, output TM with kb4 fragments)
+int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st)
+{
+    const cv_shapes &s = m->sh;
+    const int G = (int)((n + 15) / 16);
+    return launch_dense<24, 8, 1>(g_tm, s.nb4, m->wpd_fc4, nullptr, 0, gin_tm, G, st, s.kb4 / 24);
+}
+
+// layer 1 = conv2, 2 = conv3: gradient w.r.t. the layer input from the pre-activation gradient
+int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st)
+{
+    const cv_arch &a = m->arch;
+    const int G = (int)((n + 15) / 16);
+    const float *W = m->wpd_conv[layer];
+    if (is_full(a)) {
+        if (layer == 2) return launch_conv<3, 3, 2, 1, 26, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
+        return launch_conv<2, 2, 1, 1, 29, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
+    }
+    if (layer == 2) return launch_conv<5, 2, 1, 1, 33, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
+    return launch_conv<3, 1, 1, 1, 33, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
+}
+
+int cv_natural_to_tm(const float *nat, int KB, int FPP, int FP, int npos, int64_t n, float *tm, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    int64_t G = (n + 15) / 16;
+    natural_to_tm<<<nblk(G * KB * 256, 256), 256, 0, st>>>(nat, KB, FPP, FP, npos, n, G, tm);
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
+int cv_dropout_tm(cv_model *m, const float *h4, float *d4, float *amask, int64_t n, float rate, uint64_t seed,
+                  uint64_t step, int64_t cand0, hipStream_t st)
+{
+    int64_t G = (n + 15) / 16;
+    dropout_tm<<<nblk(G * m->sh.nb4 * 256, 256), 256, 0, st>>>(h4, d4, amask, m->sh.nb4, m->arch.fc4, G, rate, seed,
+                                                              step, cand0);
+    CV_HIP(hipGetLastError());
+    return 0;
 }

@@ -8,8 +8,12 @@
 //   alpha-dropout on fc4 (selu.py:34-69): keep mask from a counter-based hash of
 //   (seed, step, candidate, unit) -- the reference's stream is unseeded TF state, so
 //   only the distribution can match.
-// Activations use the reference's natural layouts; gradients accumulate into the flat
-// buffer (cv_grad_buffer) with float atomics across batch slices.
+// The forward pass and the data-gradient GEMMs (fc4, conv3, conv2) run on the MFMA tile
+// kernels (cv_kernels_mfma.hip: conv_tm MODE 1/2, dense_tm EPI 1); the element-wise steps
+// (SELU', pool routing, dropout) and the weight-gradient reductions are plain kernels on
+// natural-layout copies for now.  Gradients accumulate into the flat buffer
+// (cv_grad_buffer) with float atomics across batch slices.  Architectures the tile kernels
+// do not cover fall back to the all-plain path (train_slice_plain).
 #include "cv_internal.hpp"
 #include "cv_math.hpp"
 
@@ -223,6 +227,52 @@ __global__ void b_dense_dgrad(const float *__restrict__ g, int ldg, const float 
     gx[t] = accumulate ? gx[t] + acc : acc;
 }
 
+// d selu / d pre-activation expressed through the layer OUTPUT y = selu(pre):
+//   pre >= 0  <=>  y >= 0 : SCALE ;   pre < 0 : SCALE*ALPHA*exp(pre) = y + SCALE*ALPHA
+__device__ __forceinline__ float selu_grad_from_out(float y)
+{
+    return y >= 0.0f ? cvm::SELU_SCALE : y + cvm::SELU_SCALE * cvm::SELU_ALPHA;
+}
+
+// g_pre = g_act * selu'(.) from the activation (optionally * amask for the dropout layer)
+__global__ void b_selu_act(const float *__restrict__ gact, const float *__restrict__ act,
+                           const float *__restrict__ amask, float *__restrict__ gpre, int64_t total)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    float g = gact[t];
+    if (amask) g *= amask[t];
+    gpre[t] = g * selu_grad_from_out(act[t]);
+}
+
+// max-pool backward on the saved SELU outputs (monotone in the pre-activation, so the first
+// maximum is the same element) fused with selu'
+__global__ void b_pool_selu_act(const float *__restrict__ gpool, const float *__restrict__ act,
+                                float *__restrict__ gpre, int64_t n, int H, int c, int p)
+{
+    int Ho = H - p + 1, row = 4 * c;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * H * row) return;
+    int e = (int)(t % row);
+    int64_t r = t / row;
+    int h = (int)(r % H);
+    int64_t i = r / H;
+    const float *b = act + (size_t)i * H * row + e;
+    float me = b[(size_t)h * row];
+    float acc = 0.0f;
+    for (int ho = h - p + 1; ho <= h; ho++) {
+        if (ho < 0 || ho >= Ho) continue;
+        bool win = true;
+        for (int d = 0; d < p; d++) {
+            float v = b[(size_t)(ho + d) * row];
+            int hh = ho + d;
+            if (hh < h ? v >= me : v > me) { win = false; break; }
+        }
+        if (win) acc += gpool[((size_t)i * Ho + ho) * row + e];
+    }
+    gpre[t] = acc * selu_grad_from_out(me);
+}
+
 // g_pre = g_act * selu'(pre) (optionally * amask for the dropout layer)
 __global__ void b_selu(const float *__restrict__ gact, const float *__restrict__ pre,
                        const float *__restrict__ amask, float *__restrict__ gpre, int64_t total)
@@ -348,11 +398,15 @@ static size_t train_floats_per_cand(const cv_model *m)
         f += 2 * (size_t)s.hp[l] * 4 * a.cout[l];   // pooled, gpooled
     }
     f += 5 * (size_t)a.fc4 + 4 * (size_t)a.fc5 + 32;
-    return f + 64 * 24;
+    // tile path: TM copies of activations, pre-pool activations and three gradient maps,
+    // padded channel counts, plus the dense TM buffers
+    for (int l = 0; l < 3; l++) f += (size_t)(2 * s.hc[l] + 2 * s.hp[l]) * 4 * s.ntile[l] * 16;
+    f += 6 * (size_t)s.nb4 * 16 + 2 * (size_t)s.nb5 * 16;
+    return f + 64 * 48;
 }
 
-// forward (+ optional backward) of one slice of the batch
-static int train_slice(cv_model *m, const float *x, const float *y, int64_t n, int64_t cand0, bool backward,
+// forward (+ optional backward) of one slice of the batch: all-plain path
+static int train_slice_plain(cv_model *m, const float *x, const float *y, int64_t n, int64_t cand0, bool backward,
                        float drop4, uint64_t seed, uint64_t step, hipStream_t st)
 {
     const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
@@ -424,6 +478,106 @@ static int train_slice(cv_model *m, const float *x, const float *y, int64_t n, i
     return 0;
 }
 
+
+// forward (+ optional backward) of one slice of the batch on the tile kernels
+static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t n, int64_t cand0, bool backward,
+                            float drop4, uint64_t seed, uint64_t step, hipStream_t st)
+{
+    const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
+    const float *P = m->params; float *G = m->grads; const int64_t *o = m->poff;
+    const int64_t np = (n + 15) / 16 * 16;             // TM buffers hold whole groups
+    slab sb{m->t_buf, 0, m->t_bytes / sizeof(float)};
+    // TM (tile-major) buffers
+    size_t fp[3], fa[3];                               // floats per candidate: pooled / pre-pool
+    for (int l = 0; l < 3; l++) { fp[l] = (size_t)s.hp[l] * 4 * s.ntile[l] * 16; fa[l] = (size_t)s.hc[l] * 4 * s.ntile[l] * 16; }
+    float *tp[3], *ta[3];
+    for (int l = 0; l < 3; l++) { tp[l] = sb.take(np * fp[l]); ta[l] = sb.take(np * fa[l]); }
+    float *th4 = sb.take(np * s.nb4 * 16), *td4 = sb.take(np * s.nb4 * 16), *tmask = sb.take(np * s.nb4 * 16);
+    float *th5 = sb.take(np * s.nb5 * 16);
+    // natural copies / gradients
+    float *act[3], *pool[3], *gpre[3], *gpool[3];
+    for (int l = 0; l < 3; l++) {
+        act[l] = sb.take((size_t)n * s.hc[l] * 4 * a.cout[l]);
+        pool[l] = sb.take((size_t)n * s.hp[l] * 4 * a.cout[l]);
+        gpre[l] = sb.take((size_t)n * s.hc[l] * 4 * a.cout[l]);
+        gpool[l] = sb.take((size_t)n * s.hp[l] * 4 * a.cout[l]);
+    }
+    float *h4 = sb.take((size_t)n * a.fc4), *d4 = sb.take((size_t)n * a.fc4), *amask = sb.take((size_t)n * a.fc4);
+    float *gd4 = sb.take((size_t)n * a.fc4), *gfc4pre = sb.take((size_t)n * a.fc4);
+    float *h5 = sb.take((size_t)n * a.fc5), *gh5 = sb.take((size_t)n * a.fc5), *gfc5pre = sb.take((size_t)n * a.fc5);
+    float *ghpre = sb.take((size_t)n * 16);
+    // TM gradients for the tile data-gradient passes
+    float *tg4 = sb.take(np * s.nb4 * 16);
+    float *tgpre[3] = {nullptr, sb.take(np * fa[1]), sb.take(np * fa[2])};
+    float *tgin[3] = {sb.take(np * fp[0]), sb.take(np * fp[1]), sb.take(np * fp[2])};   // grads of pool1, pool2, pool3
+    if (!tgin[2]) { cv_set_error("training workspace too small"); return 1; }
+    // ---- forward on the tile kernels
+    if (m->packed_dirty && cv_pack_weights(m, st)) return 1;
+    if (cv_tile_train_convs(m, x, n, tp[0], ta[0], tp[1], ta[1], tp[2], ta[2], st)) return 1;
+    if (cv_tile_dense_fwd(m, 4, tp[2], th4, n, st)) return 1;
+    if (cv_dropout_tm(m, th4, td4, tmask, n, backward ? drop4 : 0.0f, seed, step, cand0, st)) return 1;
+    if (cv_tile_dense_fwd(m, 5, td4, th5, n, st)) return 1;
+    cv_tm_to_natural(td4, s.nb4, s.nb4 * 16, a.fc4, 1, n, d4, st);
+    cv_tm_to_natural(th5, s.nb5, s.nb5 * 16, a.fc5, 1, n, h5, st);
+    t_heads<<<nblk(n, 16), 256, 0, st>>>(d4, h5, a.fc4, a.fc5, P + o[10], P + o[11], P + o[12], P + o[13],
+                                         P + o[14], P + o[15], P + o[16], P + o[17], y, n,
+                                         backward ? ghpre : nullptr, m->loss_dev);
+    CV_HIP(hipGetLastError());
+    if (!backward) return 0;
+    // natural copies the plain backward kernels read
+    cv_tm_to_natural(th4, s.nb4, s.nb4 * 16, a.fc4, 1, n, h4, st);
+    cv_tm_to_natural(tmask, s.nb4, s.nb4 * 16, a.fc4, 1, n, amask, st);
+    for (int l = 0; l < 3; l++) {
+        cv_tm_to_natural(ta[l], s.hc[l] * 4 * s.ntile[l], s.ntile[l] * 16, a.cout[l], s.hc[l] * 4, n, act[l], st);
+        cv_tm_to_natural(tp[l], s.hp[l] * 4 * s.ntile[l], s.ntile[l] * 16, a.cout[l], s.hp[l] * 4, n, pool[l], st);
+    }
+    if (cv_pack_train_weights(m, st)) return 1;
+    // ---- backward
+    const int NS = 32;
+    b_dense_wgrad<<<dim3(nblk((a.fc4 + 1) * 4, 256), NS), 256, 0, st>>>(d4, a.fc4, ghpre + 0, 16, n, a.fc4, 4, G + o[10], G + o[11]);
+    b_dense_wgrad<<<dim3(nblk((a.fc5 + 1) * 2, 256), NS), 256, 0, st>>>(h5, a.fc5, ghpre + 4, 16, n, a.fc5, 2, G + o[12], G + o[13]);
+    b_dense_wgrad<<<dim3(nblk((a.fc5 + 1) * 4, 256), NS), 256, 0, st>>>(h5, a.fc5, ghpre + 6, 16, n, a.fc5, 4, G + o[14], G + o[15]);
+    b_dense_wgrad<<<dim3(nblk((a.fc5 + 1) * 6, 256), NS), 256, 0, st>>>(h5, a.fc5, ghpre + 10, 16, n, a.fc5, 6, G + o[16], G + o[17]);
+    b_dense_dgrad<<<nblk(n * a.fc4, 256), 256, 0, st>>>(ghpre + 0, 16, P + o[10], n, a.fc4, 4, gd4, 0);
+    b_dense_dgrad<<<nblk(n * a.fc5, 256), 256, 0, st>>>(ghpre + 4, 16, P + o[12], n, a.fc5, 2, gh5, 0);
+    b_dense_dgrad<<<nblk(n * a.fc5, 256), 256, 0, st>>>(ghpre + 6, 16, P + o[14], n, a.fc5, 4, gh5, 1);
+    b_dense_dgrad<<<nblk(n * a.fc5, 256), 256, 0, st>>>(ghpre + 10, 16, P + o[16], n, a.fc5, 6, gh5, 1);
+    // fc5
+    b_selu_act<<<nblk(n * a.fc5, 256), 256, 0, st>>>(gh5, h5, nullptr, gfc5pre, n * a.fc5);
+    b_dense_wgrad<<<dim3(nblk((int64_t)(a.fc4 + 1) * a.fc5, 256), NS), 256, 0, st>>>(d4, a.fc4, gfc5pre, a.fc5, n, a.fc4, a.fc5, G + o[8], G + o[9]);
+    b_dense_dgrad<<<nblk(n * a.fc4, 256), 256, 0, st>>>(gfc5pre, a.fc5, P + o[8], n, a.fc4, a.fc5, gd4, 1);
+    // dropout4 + selu' (h4 is the SELU output before dropout)
+    b_selu_act<<<nblk(n * a.fc4, 256), 256, 0, st>>>(gd4, h4, amask, gfc4pre, n * a.fc4);
+    // fc4: weight gradient plain, data gradient on the tile kernel
+    b_dense_wgrad<<<dim3(nblk((int64_t)(s.flat + 1) * a.fc4, 256), 8), 256, 0, st>>>(pool[2], s.flat, gfc4pre, a.fc4, n, s.flat, a.fc4, G + o[6], G + o[7]);
+    cv_natural_to_tm(gfc4pre, s.nb4, s.nb4 * 16, a.fc4, 1, n, tg4, st);
+    if (cv_tile_fc4_dgrad(m, tg4, tgin[2], n, st)) return 1;
+    cv_tm_to_natural(tgin[2], s.hp[2] * 4 * s.ntile[2], s.ntile[2] * 16, a.cout[2], s.hp[2] * 4, n, gpool[2], st);
+    // conv stack
+    for (int l = 2; l >= 0; l--) {
+        int H = s.hc[l], C = a.cout[l];
+        b_pool_selu_act<<<nblk(n * H * 4 * C, 256), 256, 0, st>>>(gpool[l], act[l], gpre[l], n, H, C, a.pool[l]);
+        const float *lin = l == 0 ? x : pool[l - 1];
+        int64_t nw = (int64_t)a.kh[l] * 4 * s.cin[l] * C + C;
+        b_conv_wgrad<<<dim3(nblk(nw, 64), 64), 64, 0, st>>>(lin, gpre[l], n, H, s.cin[l], a.kh[l], C, G + o[2 * l], G + o[2 * l + 1]);
+        if (l > 0) {
+            cv_natural_to_tm(gpre[l], H * 4 * s.ntile[l], s.ntile[l] * 16, C, H * 4, n, tgpre[l], st);
+            if (cv_tile_conv_dgrad(m, l, tgpre[l], tgin[l - 1], n, st)) return 1;
+            cv_tm_to_natural(tgin[l - 1], s.hp[l - 1] * 4 * s.ntile[l - 1], s.ntile[l - 1] * 16, a.cout[l - 1],
+                             s.hp[l - 1] * 4, n, gpool[l - 1], st);
+        }
+    }
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
+static int train_slice(cv_model *m, const float *x, const float *y, int64_t n, int64_t cand0, bool backward,
+                       float drop4, uint64_t seed, uint64_t step, hipStream_t st)
+{
+    if (m->impl == 1 && cv_tile_supported(m)) return train_slice_tile(m, x, y, n, cand0, backward, drop4, seed, step, st);
+    return train_slice_plain(m, x, y, n, cand0, backward, drop4, seed, step, st);
+}
+
 static int train_pass(cv_model *m, const float *x, const float *y, int64_t n, bool backward, float drop4,
                       float lambda, uint64_t seed, uint64_t step, double *losses_host, hipStream_t st)
 {
@@ -433,7 +587,7 @@ static int train_pass(cv_model *m, const float *x, const float *y, int64_t n, bo
     if (drop4 < 0.0f || drop4 >= 1.0f) { cv_set_error("dropout rate must be in [0,1)"); return 1; }
     CV_HIP(hipSetDevice(m->device));
     const int64_t slice = 2048;
-    const size_t need = train_floats_per_cand(m) * (size_t)(n < slice ? (n > 0 ? n : 1) : slice) * sizeof(float);
+    const size_t need = train_floats_per_cand(m) * (size_t)((n < slice ? (n > 0 ? n : 1) : slice) + 16) * sizeof(float);
     if (m->t_bytes < need) {
         if (m->t_buf) CV_HIP(hipFree(m->t_buf));
         m->t_buf = nullptr; m->t_bytes = 0;
