@@ -936,6 +936,191 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
 }
 
 // ---------------------------------------------------------------------------
+// weight gradients: contraction over CANDIDATES on the matrix cores.
+//
+// A TM fragment has the candidate as the tile column.  For dW = X^T . G both operands need
+// the candidate as the MFMA k index instead, i.e. the 16x16 transpose of the fragment
+// ("CM" fragment: lane (f, rg) register t = value(feature f, candidate 4*rg + t)).  The
+// transpose itself is done by the matrix core: feeding TM register s as the A operand and
+// the constant 0/1 matrix B_s[k][j] = (j == 4s + k) accumulates D[c][f] = value(c, f) in four
+// steps -- exact (products with 1.0 and 0.0 only).  CM fragments of the layer input (A operand)
+// and of the pre-activation gradient (B operand) then give  dW[i][j] += sum_c X[c][i] G[c][j]
+// with four MFMA steps per 16 candidates; partial sums over candidate ranges are combined
+// with float atomics (the order of a training reduction is not part of the parity contract).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tm_to_cm(const f4 *__restrict__ tm, f4 *__restrict__ cm, int64_t nfrag)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, k = lane >> 4;
+    float Bc[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) Bc[s] = (j == 4 * s + k) ? 1.0f : 0.0f;
+    int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t fr = wv; fr < nfrag; fr += stride) {
+        const f4 v = tm[fr * 64 + lane];
+        f4 d = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; s++) d = mfma4(v[s], Bc[s], d);
+        cm[fr * 64 + lane] = d;
+    }
+}
+
+// dense layer: dW[k][j] += sum_cand X[cand][k] G[cand][j], db[j] += sum_cand G[cand][j].
+// Workgroup = 8 waves = 16 input fragments (two per wave) x all NJB output fragments; the
+// G fragments of a group are staged once per workgroup in a double-buffered LDS slot.
+// grid = (ceil(KB/16), group splits).
+template <int NJB>
+__global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_cm, int KB,
+                                                       const f4 *__restrict__ g_cm, int G, int K, int N,
+                                                       float *__restrict__ dw, float *__restrict__ db)
+{
+    __shared__ __attribute__((aligned(16))) f4 gl[2][NJB * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int kb0 = blockIdx.x * 16 + wid * 2;
+    const int per = (G + gridDim.y - 1) / gridDim.y;
+    const int g0 = blockIdx.y * per, g1 = g0 + per < G ? g0 + per : G;
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 acc[2][NJB];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int jb = 0; jb < NJB; jb++) acc[a][jb] = zero;
+    const bool v0 = kb0 < KB, v1 = kb0 + 1 < KB;
+    if (g0 < g1) {
+        for (int i = tid; i < NJB * 64; i += 512) gl[0][i] = g_cm[(size_t)g0 * NJB * 64 + i];
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int g = g0; g < g1; g++) {
+        if (g + 1 < g1) {
+            for (int i = tid; i < NJB * 64; i += 512) gl[buf ^ 1][i] = g_cm[(size_t)(g + 1) * NJB * 64 + i];
+        }
+        f4 X0 = zero, X1 = zero;
+        if (v0) X0 = x_cm[((size_t)g * KB + kb0) * 64 + lane];
+        if (v1) X1 = x_cm[((size_t)g * KB + kb0 + 1) * 64 + lane];
+#pragma unroll
+        for (int jb = 0; jb < NJB; jb++) {
+            const f4 B = gl[buf][jb * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                acc[0][jb] = mfma4(X0[t], B[t], acc[0][jb]);
+                acc[1][jb] = mfma4(X1[t], B[t], acc[1][jb]);
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    // scatter-add the tiles: lane (c', q) register r  <->  dW[16 kb + 4q + r][16 jb + c']
+    const int cq = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        const int kb = kb0 + a;
+        if (kb >= KB) continue;
+#pragma unroll
+        for (int jb = 0; jb < NJB; jb++) {
+            const int j = 16 * jb + cq;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int k = 16 * kb + 4 * q + r;
+                if (k < K && j < N) atomicAdd(&dw[(size_t)k * N + j], acc[a][jb][r]);
+            }
+        }
+    }
+    (void)db;      // bias gradients are reduced by the plain kernel b_bias_grad (cv_train.hip)
+}
+
+// conv layer: dW[kh][kw][ci][co] += sum_{cand,h,wo} In[cand][h+kh-PT][wo+kw-1][ci] G[cand][h][wo][co].
+// One wave per (output fragment cob, candidate-range split); it keeps all KH*4*CINB tiles of
+// that cob in registers and streams over groups and positions with a KH-row window of input
+// CM fragments.  grid = (NT, splits), 64 threads.
+template <int KH, int CINB, int NT, int HIN>
+__global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_cm, const f4 *__restrict__ g_cm,
+                                                     int G, int cin, int cout, float *__restrict__ dw)
+{
+    constexpr int PADT = (KH - 1) / 2;
+    const int lane = threadIdx.x;
+    const int cob = blockIdx.x;
+    const int per = (G + gridDim.y - 1) / gridDim.y;
+    const int g0 = blockIdx.y * per, g1 = g0 + per < G ? g0 + per : G;
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 acc[KH][4][CINB];
+#pragma unroll
+    for (int a = 0; a < KH; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int c = 0; c < CINB; c++) acc[a][b][c] = zero;
+    for (int g = g0; g < g1; g++) {
+        const f4 *ip = in_cm + (size_t)g * (HIN * 4 * CINB * 64) + lane;
+        const f4 *gp = g_cm + (size_t)g * (HIN * 4 * NT * 64) + (size_t)cob * 64 + lane;
+        f4 win[KH][4][CINB];     // win[kh] = input row h + kh - PADT
+#pragma unroll
+        for (int j = 0; j < KH; j++) {
+            const int hr = j - PADT;     // rows for h = 0; the last slot is (re)loaded in the loop
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+#pragma unroll
+                for (int cb = 0; cb < CINB; cb++)
+                    win[j][w][cb] = (hr >= 0 && hr < HIN && j < KH - 1) ? ip[(size_t)((hr * 4 + w) * CINB + cb) * 64] : zero;
+        }
+#pragma unroll 1
+        for (int h = 0; h < HIN; h++) {
+            {
+                const int hr = h + KH - 1 - PADT;
+#pragma unroll
+                for (int w = 0; w < 4; w++)
+#pragma unroll
+                    for (int cb = 0; cb < CINB; cb++)
+                        win[KH - 1][w][cb] = hr < HIN ? ip[(size_t)((hr * 4 + w) * CINB + cb) * 64] : zero;
+            }
+            f4 Gr[4];
+#pragma unroll
+            for (int w = 0; w < 4; w++) Gr[w] = gp[(size_t)(h * 4 + w) * (NT * 64)];
+#pragma unroll
+            for (int kh = 0; kh < KH; kh++) {
+                const int hr = h + kh - PADT;
+                if (hr >= 0 && hr < HIN) {
+#pragma unroll
+                    for (int kw = 0; kw < 4; kw++)
+#pragma unroll
+                        for (int wo = 0; wo < 4; wo++) {
+                            const int wi = wo + kw - 1;
+                            if (wi < 0 || wi > 3) continue;
+#pragma unroll
+                            for (int t = 0; t < 4; t++)
+#pragma unroll
+                                for (int cb = 0; cb < CINB; cb++)
+                                    acc[kh][kw][cb] = mfma4(win[kh][wi][cb][t], Gr[wo][t], acc[kh][kw][cb]);
+                        }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j + 1 < KH; j++)
+#pragma unroll
+                for (int w = 0; w < 4; w++)
+#pragma unroll
+                    for (int cb = 0; cb < CINB; cb++) win[j][w][cb] = win[j + 1][w][cb];
+        }
+    }
+    // lane (c', q) register r  <->  dW[kh][kw][ci = 16 cb + 4q + r][co = 16 cob + c']
+    const int cq = lane & 15, q = lane >> 4;
+    const int co = 16 * cob + cq;
+#pragma unroll
+    for (int kh = 0; kh < KH; kh++)
+#pragma unroll
+        for (int kw = 0; kw < 4; kw++)
+#pragma unroll
+            for (int cb = 0; cb < CINB; cb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int ci = 16 * cb + 4 * q + r;
+                    if (ci < cin && co < cout)
+                        atomicAdd(&dw[(((size_t)kh * 4 + kw) * cin + ci) * cout + co], acc[kh][kw][cb][r]);
+                }
+}
+
+// ---------------------------------------------------------------------------
 // tile-kernel entry points of the training step (cv_train.hip)
 // ---------------------------------------------------------------------------
 static bool is_full(const cv_arch &a) { return arch_is(a, 1, 2, 3, 16, 32, 48, 5, 4, 3, 336, 168); }
@@ -1034,6 +1219,55 @@ int cv_dropout_tm(cv_model *m, const float *h4, float *d4, float *amask, int64_t
     int64_t G = (n + 15) / 16;
     dropout_tm<<<nblk(G * m->sh.nb4 * 256, 256), 256, 0, st>>>(h4, d4, amask, m->sh.nb4, m->arch.fc4, G, rate, seed,
                                                               step, cand0);
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
+int cv_tm_to_cm(const float *tm, float *cm, int64_t nfrag, hipStream_t st)
+{
+    if (nfrag <= 0) return 0;
+    unsigned grid = (unsigned)(nfrag / 4 + 1 < 4096 ? nfrag / 4 + 1 : 4096);
+    tm_to_cm<<<grid, 256, 0, st>>>((const f4 *)tm, (f4 *)cm, nfrag);
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
+// layer 4 = fc4 (x = pool3 CM, g = fc4 pre-activation gradient CM), 5 = fc5
+int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_cm, const float *g_cm, int64_t n, hipStream_t st)
+{
+    const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
+    const int G = (int)((n + 15) / 16);
+    float *Gd = m->grads; const int64_t *o = m->poff;
+    const int splits = G >= 64 ? 16 : 1;
+    if (layer == 4) {
+        dim3 grid((s.kb4 + 15) / 16, splits);
+        if (is_full(a)) wgrad_dense_cm<21><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.kb4, (const f4 *)g_cm, G, s.flat, a.fc4, Gd + o[6], nullptr);
+        else wgrad_dense_cm<3><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.kb4, (const f4 *)g_cm, G, s.flat, a.fc4, Gd + o[6], nullptr);
+    } else {
+        dim3 grid((s.nb4 + 15) / 16, splits);
+        if (is_full(a)) wgrad_dense_cm<11><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.nb4, (const f4 *)g_cm, G, a.fc4, a.fc5, Gd + o[8], nullptr);
+        else wgrad_dense_cm<2><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.nb4, (const f4 *)g_cm, G, a.fc4, a.fc5, Gd + o[8], nullptr);
+    }
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
+// layer 1 = conv2 (in = pool1 CM), 2 = conv3 (in = pool2 CM); g = pre-activation gradient CM
+int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_cm, const float *g_cm, int64_t n, hipStream_t st)
+{
+    const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
+    const int G = (int)((n + 15) / 16);
+    float *dw = m->grads + m->poff[2 * layer];
+    const int splits = G < 256 ? (G > 0 ? G : 1) : 256;
+    dim3 grid(s.ntile[layer], splits);
+    const int cin = s.cin[layer], cout = a.cout[layer];
+    if (is_full(a)) {
+        if (layer == 2) wgrad_conv_cm<3, 2, 3, 26><<<grid, 64, 0, st>>>((const f4 *)in_cm, (const f4 *)g_cm, G, cin, cout, dw);
+        else wgrad_conv_cm<2, 1, 2, 29><<<grid, 64, 0, st>>>((const f4 *)in_cm, (const f4 *)g_cm, G, cin, cout, dw);
+    } else {
+        if (layer == 2) wgrad_conv_cm<5, 1, 2, 33><<<grid, 64, 0, st>>>((const f4 *)in_cm, (const f4 *)g_cm, G, cin, cout, dw);
+        else wgrad_conv_cm<3, 1, 1, 33><<<grid, 64, 0, st>>>((const f4 *)in_cm, (const f4 *)g_cm, G, cin, cout, dw);
+    }
     CV_HIP(hipGetLastError());
     return 0;
 }

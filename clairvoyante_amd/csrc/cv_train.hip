@@ -382,6 +382,18 @@ __global__ void b_conv_dgrad(const float *__restrict__ gpre, const float *__rest
     gin[t] = acc;
 }
 
+// db[c] += sum over rows of g[rows][C] (natural layout); blockIdx.y slices the rows
+__global__ void b_bias_grad(const float *__restrict__ g, int64_t rows, int C, float *__restrict__ db)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+    int64_t r0 = per * blockIdx.y, r1 = r0 + per < rows ? r0 + per : rows;
+    float acc = 0.0f;
+    for (int64_t r = r0; r < r1; r++) acc += g[(size_t)r * C + c];
+    atomicAdd(&db[c], acc);
+}
+
 struct slab {
     float *base; size_t used, cap;
     float *take(size_t nfloat) { float *p = base + used; used += (nfloat + 63) / 64 * 64; return used <= cap ? p : nullptr; }
@@ -402,7 +414,10 @@ static size_t train_floats_per_cand(const cv_model *m)
     // padded channel counts, plus the dense TM buffers
     for (int l = 0; l < 3; l++) f += (size_t)(2 * s.hc[l] + 2 * s.hp[l]) * 4 * s.ntile[l] * 16;
     f += 6 * (size_t)s.nb4 * 16 + 2 * (size_t)s.nb5 * 16;
-    return f + 64 * 48;
+    // candidate-major operand copies of the weight-gradient kernels
+    for (int l = 0; l < 3; l++) f += (size_t)(s.hp[l] + s.hc[l]) * 4 * s.ntile[l] * 16;
+    f += 2 * (size_t)s.nb4 * 16 + 2 * (size_t)s.nb5 * 16;
+    return f + 64 * 64;
 }
 
 // forward (+ optional backward) of one slice of the batch: all-plain path
@@ -510,7 +525,13 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     float *tg4 = sb.take(np * s.nb4 * 16);
     float *tgpre[3] = {nullptr, sb.take(np * fa[1]), sb.take(np * fa[2])};
     float *tgin[3] = {sb.take(np * fp[0]), sb.take(np * fp[1]), sb.take(np * fp[2])};   // grads of pool1, pool2, pool3
-    if (!tgin[2]) { cv_set_error("training workspace too small"); return 1; }
+    // candidate-major (CM) operand copies for the weight-gradient kernels
+    float *cp[3] = {sb.take(np * fp[0]), sb.take(np * fp[1]), sb.take(np * fp[2])};
+    float *cd4 = sb.take(np * s.nb4 * 16), *cg4 = sb.take(np * s.nb4 * 16);
+    float *tg5 = sb.take(np * s.nb5 * 16), *cg5 = sb.take(np * s.nb5 * 16);
+    float *cgpre[3] = {nullptr, sb.take(np * fa[1]), sb.take(np * fa[2])};
+    if (!cgpre[2]) { cv_set_error("training workspace too small"); return 1; }
+    const int64_t Gn = np / 16;
     // ---- forward on the tile kernels
     if (m->packed_dirty && cv_pack_weights(m, st)) return 1;
     if (cv_tile_train_convs(m, x, n, tp[0], ta[0], tp[1], ta[1], tp[2], ta[2], st)) return 1;
@@ -544,24 +565,36 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     b_dense_dgrad<<<nblk(n * a.fc5, 256), 256, 0, st>>>(ghpre + 10, 16, P + o[16], n, a.fc5, 6, gh5, 1);
     // fc5
     b_selu_act<<<nblk(n * a.fc5, 256), 256, 0, st>>>(gh5, h5, nullptr, gfc5pre, n * a.fc5);
-    b_dense_wgrad<<<dim3(nblk((int64_t)(a.fc4 + 1) * a.fc5, 256), NS), 256, 0, st>>>(d4, a.fc4, gfc5pre, a.fc5, n, a.fc4, a.fc5, G + o[8], G + o[9]);
+    // fc5 weight gradient on the matrix cores (candidate contraction), bias plain
+    cv_natural_to_tm(gfc5pre, s.nb5, s.nb5 * 16, a.fc5, 1, n, tg5, st);
+    cv_tm_to_cm(td4, cd4, Gn * s.nb4, st);
+    cv_tm_to_cm(tg5, cg5, Gn * s.nb5, st);
+    if (cv_tile_dense_wgrad(m, 5, cd4, cg5, n, st)) return 1;
+    b_bias_grad<<<dim3(nblk(a.fc5, 64), 32), 64, 0, st>>>(gfc5pre, n, a.fc5, G + o[9]);
     b_dense_dgrad<<<nblk(n * a.fc4, 256), 256, 0, st>>>(gfc5pre, a.fc5, P + o[8], n, a.fc4, a.fc5, gd4, 1);
     // dropout4 + selu' (h4 is the SELU output before dropout)
     b_selu_act<<<nblk(n * a.fc4, 256), 256, 0, st>>>(gd4, h4, amask, gfc4pre, n * a.fc4);
-    // fc4: weight gradient plain, data gradient on the tile kernel
-    b_dense_wgrad<<<dim3(nblk((int64_t)(s.flat + 1) * a.fc4, 256), 8), 256, 0, st>>>(pool[2], s.flat, gfc4pre, a.fc4, n, s.flat, a.fc4, G + o[6], G + o[7]);
+    // fc4: weight and data gradients on the tile kernels
     cv_natural_to_tm(gfc4pre, s.nb4, s.nb4 * 16, a.fc4, 1, n, tg4, st);
+    cv_tm_to_cm(tp[2], cp[2], Gn * s.kb4, st);
+    cv_tm_to_cm(tg4, cg4, Gn * s.nb4, st);
+    if (cv_tile_dense_wgrad(m, 4, cp[2], cg4, n, st)) return 1;
+    b_bias_grad<<<dim3(nblk(a.fc4, 64), 32), 64, 0, st>>>(gfc4pre, n, a.fc4, G + o[7]);
     if (cv_tile_fc4_dgrad(m, tg4, tgin[2], n, st)) return 1;
     cv_tm_to_natural(tgin[2], s.hp[2] * 4 * s.ntile[2], s.ntile[2] * 16, a.cout[2], s.hp[2] * 4, n, gpool[2], st);
     // conv stack
     for (int l = 2; l >= 0; l--) {
         int H = s.hc[l], C = a.cout[l];
         b_pool_selu_act<<<nblk(n * H * 4 * C, 256), 256, 0, st>>>(gpool[l], act[l], gpre[l], n, H, C, a.pool[l]);
-        const float *lin = l == 0 ? x : pool[l - 1];
-        int64_t nw = (int64_t)a.kh[l] * 4 * s.cin[l] * C + C;
-        b_conv_wgrad<<<dim3(nblk(nw, 64), 64), 64, 0, st>>>(lin, gpre[l], n, H, s.cin[l], a.kh[l], C, G + o[2 * l], G + o[2 * l + 1]);
-        if (l > 0) {
+        if (l == 0) {        // first layer (K = 16 per tap, 0.7 % of the work): plain reduction on X
+            int64_t nw = (int64_t)a.kh[l] * 4 * s.cin[l] * C + C;
+            b_conv_wgrad<<<dim3(nblk(nw, 64), 64), 64, 0, st>>>(x, gpre[l], n, H, s.cin[l], a.kh[l], C, G + o[0], G + o[1]);
+        } else {
             cv_natural_to_tm(gpre[l], H * 4 * s.ntile[l], s.ntile[l] * 16, C, H * 4, n, tgpre[l], st);
+            cv_tm_to_cm(tgpre[l], cgpre[l], Gn * H * 4 * s.ntile[l], st);
+            cv_tm_to_cm(tp[l - 1], cp[l - 1], Gn * s.hp[l - 1] * 4 * s.ntile[l - 1], st);
+            if (cv_tile_conv_wgrad(m, l, cp[l - 1], cgpre[l], n, st)) return 1;
+            b_bias_grad<<<dim3(nblk(C, 64), 64), 64, 0, st>>>(gpre[l], n * H * 4, C, G + o[2 * l + 1]);
             if (cv_tile_conv_dgrad(m, l, tgpre[l], tgin[l - 1], n, st)) return 1;
             cv_tm_to_natural(tgin[l - 1], s.hp[l - 1] * 4 * s.ntile[l - 1], s.ntile[l - 1] * 16, a.cout[l - 1],
                              s.hp[l - 1] * 4, n, gpool[l - 1], st);
@@ -586,7 +619,7 @@ static int train_pass(cv_model *m, const float *x, const float *y, int64_t n, bo
     if (n > 0 && (!x || !y)) { cv_set_error("null buffer"); return 1; }
     if (drop4 < 0.0f || drop4 >= 1.0f) { cv_set_error("dropout rate must be in [0,1)"); return 1; }
     CV_HIP(hipSetDevice(m->device));
-    const int64_t slice = 2048;
+    const int64_t slice = 16384;        // one pass for train.py's batch of 10 000
     const size_t need = train_floats_per_cand(m) * (size_t)((n < slice ? (n > 0 ? n : 1) : slice) + 16) * sizeof(float);
     if (m->t_bytes < need) {
         if (m->t_buf) CV_HIP(hipFree(m->t_buf));
