@@ -987,6 +987,11 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_c
 #pragma unroll
         for (int jb = 0; jb < NJB; jb++) acc[a][jb] = zero;
     const bool v0 = kb0 < KB, v1 = kb0 + 1 < KB;
+    constexpr int NBS = (NJB + 7) / 8;               // bias: wave w of column 0 sums fragments w, w+8, ..
+    f4 bs[NBS];
+#pragma unroll
+    for (int i = 0; i < NBS; i++) bs[i] = zero;
+    const bool do_bias = blockIdx.x == 0 && db != nullptr;
     if (g0 < g1) {
         for (int i = tid; i < NJB * 64; i += 512) gl[0][i] = g_cm[(size_t)g0 * NJB * 64 + i];
     }
@@ -1007,9 +1012,22 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_c
                 acc[0][jb] = mfma4(X0[t], B[t], acc[0][jb]);
                 acc[1][jb] = mfma4(X1[t], B[t], acc[1][jb]);
             }
+            if (do_bias && (jb & 7) == wid) bs[jb >> 3] += B;
         }
         __syncthreads();
         buf ^= 1;
+    }
+    if (do_bias) {
+        // CM fragment: lane (f, rg) register t = G(feature f, candidate 4 rg + t): sum registers, then lanes rg
+#pragma unroll
+        for (int i = 0; i < NBS; i++) {
+            const int jb = i * 8 + wid;
+            float v = (bs[i][0] + bs[i][1]) + (bs[i][2] + bs[i][3]);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int j = 16 * jb + (lane & 15);
+            if (jb < NJB && lane < 16 && j < N) atomicAdd(&db[j], v);
+        }
     }
     // scatter-add the tiles: lane (c', q) register r  <->  dW[16 kb + 4q + r][16 jb + c']
     const int cq = lane & 15, q = lane >> 4;
@@ -1027,7 +1045,6 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_c
             }
         }
     }
-    (void)db;      // bias gradients are reduced by the plain kernel b_bias_grad (cv_train.hip)
 }
 
 // conv layer: dW[kh][kw][ci][co] += sum_{cand,h,wo} In[cand][h+kh-PT][wo+kw-1][ci] G[cand][h][wo][co].
@@ -1036,7 +1053,8 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_c
 // CM fragments.  grid = (NT, splits), 64 threads.
 template <int KH, int CINB, int NT, int HIN>
 __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_cm, const f4 *__restrict__ g_cm,
-                                                     int G, int cin, int cout, float *__restrict__ dw)
+                                                     int G, int cin, int cout, float *__restrict__ dw,
+                                                     float *__restrict__ db)
 {
     constexpr int PADT = (KH - 1) / 2;
     const int lane = threadIdx.x;
@@ -1051,6 +1069,7 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_cm
         for (int b = 0; b < 4; b++)
 #pragma unroll
             for (int c = 0; c < CINB; c++) acc[a][b][c] = zero;
+    f4 bsum = zero;
     for (int g = g0; g < g1; g++) {
         const f4 *ip = in_cm + (size_t)g * (HIN * 4 * CINB * 64) + lane;
         const f4 *gp = g_cm + (size_t)g * (HIN * 4 * NT * 64) + (size_t)cob * 64 + lane;
@@ -1077,6 +1096,7 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_cm
             f4 Gr[4];
 #pragma unroll
             for (int w = 0; w < 4; w++) Gr[w] = gp[(size_t)(h * 4 + w) * (NT * 64)];
+            bsum += (Gr[0] + Gr[1]) + (Gr[2] + Gr[3]);
 #pragma unroll
             for (int kh = 0; kh < KH; kh++) {
                 const int hr = h + kh - PADT;
@@ -1103,6 +1123,13 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_cm
                     for (int cb = 0; cb < CINB; cb++) win[j][w][cb] = win[j + 1][w][cb];
         }
     }
+    {   // bias gradient: sum of the G fragments over registers (t) and lanes rg
+        float v = (bsum[0] + bsum[1]) + (bsum[2] + bsum[3]);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        const int cb_ = 16 * cob + (lane & 15);
+        if (lane < 16 && cb_ < cout) atomicAdd(&db[cb_], v);
+    }
     // lane (c', q) register r  <->  dW[kh][kw][ci = 16 cb + 4q + r][co = 16 cob + c']
     const int cq = lane & 15, q = lane >> 4;
     const int co = 16 * cob + cq;
@@ -1118,6 +1145,54 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_cm
                     if (ci < cin && co < cout)
                         atomicAdd(&dw[(((size_t)kh * 4 + kw) * cin + ci) * cout + co], acc[kh][kw][cb][r]);
                 }
+}
+
+// first layer (k(1,4), 4 input channels): the 16 (base, matrix) values of a position form ONE
+// fragment, so  T_wo[(wi, ci)][co] += X[h][(wi, ci)] G[h][wo][co]  gives every tap at once:
+// dW[kw][ci][co] = sum_wo T_wo[(wo + kw - 1, ci)][co].  One wave per candidate-range split.
+__global__ __launch_bounds__(64) void wgrad_conv1_cm(const f4 *__restrict__ x_cm, const f4 *__restrict__ g_cm,
+                                                      int G, int cout, float *__restrict__ dw,
+                                                      float *__restrict__ db)
+{
+    constexpr int HIN = CV_INPUT_H;
+    const int lane = threadIdx.x;
+    const int per = (G + gridDim.x - 1) / gridDim.x;
+    const int g0 = blockIdx.x * per, g1 = g0 + per < G ? g0 + per : G;
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 acc[4] = {zero, zero, zero, zero};
+    f4 bsum = zero;
+    for (int g = g0; g < g1; g++) {
+        const f4 *xp = x_cm + (size_t)g * HIN * 64 + lane;
+        const f4 *gp = g_cm + (size_t)g * HIN * 4 * 64 + lane;
+#pragma unroll 3
+        for (int h = 0; h < HIN; h++) {
+            const f4 X = xp[(size_t)h * 64];
+#pragma unroll
+            for (int wo = 0; wo < 4; wo++) {
+                const f4 Gf = gp[(size_t)(h * 4 + wo) * 64];
+                bsum += Gf;
+#pragma unroll
+                for (int t = 0; t < 4; t++) acc[wo] = mfma4(X[t], Gf[t], acc[wo]);
+            }
+        }
+    }
+    {
+        float v = (bsum[0] + bsum[1]) + (bsum[2] + bsum[3]);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16 && lane < cout) atomicAdd(&db[lane], v);
+    }
+    // lane (co, q) register r of T_wo: row i = 4q + r = wi*4 + ci  =>  wi = q, ci = r
+    const int co = lane & 15, wi = lane >> 4;
+    if (co < cout) {
+#pragma unroll
+        for (int wo = 0; wo < 4; wo++) {
+            const int kw = wi - wo + 1;
+            if (kw < 0 || kw > 3) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) atomicAdd(&dw[((size_t)kw * 4 + r) * cout + co], acc[wo][r]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1241,12 +1316,12 @@ int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_cm, const float *
     const int splits = G >= 64 ? 16 : 1;
     if (layer == 4) {
         dim3 grid((s.kb4 + 15) / 16, splits);
-        if (is_full(a)) wgrad_dense_cm<21><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.kb4, (const f4 *)g_cm, G, s.flat, a.fc4, Gd + o[6], nullptr);
-        else wgrad_dense_cm<3><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.kb4, (const f4 *)g_cm, G, s.flat, a.fc4, Gd + o[6], nullptr);
+        if (is_full(a)) wgrad_dense_cm<21><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.kb4, (const f4 *)g_cm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7]);
+        else wgrad_dense_cm<3><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.kb4, (const f4 *)g_cm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7]);
     } else {
         dim3 grid((s.nb4 + 15) / 16, splits);
-        if (is_full(a)) wgrad_dense_cm<11><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.nb4, (const f4 *)g_cm, G, a.fc4, a.fc5, Gd + o[8], nullptr);
-        else wgrad_dense_cm<2><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.nb4, (const f4 *)g_cm, G, a.fc4, a.fc5, Gd + o[8], nullptr);
+        if (is_full(a)) wgrad_dense_cm<11><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.nb4, (const f4 *)g_cm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9]);
+        else wgrad_dense_cm<2><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.nb4, (const f4 *)g_cm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9]);
     }
     CV_HIP(hipGetLastError());
     return 0;
@@ -1258,16 +1333,29 @@ int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_cm, const float *
     const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
     const int G = (int)((n + 15) / 16);
     float *dw = m->grads + m->poff[2 * layer];
+    float *db = m->grads + m->poff[2 * layer + 1];
     const int splits = G < 256 ? (G > 0 ? G : 1) : 256;
     dim3 grid(s.ntile[layer], splits);
     const int cin = s.cin[layer], cout = a.cout[layer];
     if (is_full(a)) {
-        if (layer == 2) wgrad_conv_cm<3, 2, 3, 26><<<grid, 64, 0, st>>>((const f4 *)in_cm, (const f4 *)g_cm, G, cin, cout, dw);
-        else wgrad_conv_cm<2, 1, 2, 29><<<grid, 64, 0, st>>>((const f4 *)in_cm, (const f4 *)g_cm, G, cin, cout, dw);
+        if (layer == 2) wgrad_conv_cm<3, 2, 3, 26><<<grid, 64, 0, st>>>((const f4 *)in_cm, (const f4 *)g_cm, G, cin, cout, dw, db);
+        else wgrad_conv_cm<2, 1, 2, 29><<<grid, 64, 0, st>>>((const f4 *)in_cm, (const f4 *)g_cm, G, cin, cout, dw, db);
     } else {
-        if (layer == 2) wgrad_conv_cm<5, 1, 2, 33><<<grid, 64, 0, st>>>((const f4 *)in_cm, (const f4 *)g_cm, G, cin, cout, dw);
-        else wgrad_conv_cm<3, 1, 1, 33><<<grid, 64, 0, st>>>((const f4 *)in_cm, (const f4 *)g_cm, G, cin, cout, dw);
+        if (layer == 2) wgrad_conv_cm<5, 1, 2, 33><<<grid, 64, 0, st>>>((const f4 *)in_cm, (const f4 *)g_cm, G, cin, cout, dw, db);
+        else wgrad_conv_cm<3, 1, 1, 33><<<grid, 64, 0, st>>>((const f4 *)in_cm, (const f4 *)g_cm, G, cin, cout, dw, db);
     }
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
+// first layer: x_cm = CM fragments of X viewed as [33 positions][16 = base*4 + matrix], g = CM of its
+// pre-activation gradient ([33*4] fragments per group)
+int cv_tile_conv1_wgrad(cv_model *m, const float *x_cm, const float *g_cm, int64_t n, hipStream_t st)
+{
+    const int G = (int)((n + 15) / 16);
+    const int splits = G < 512 ? (G > 0 ? G : 1) : 512;
+    wgrad_conv1_cm<<<splits, 64, 0, st>>>((const f4 *)x_cm, (const f4 *)g_cm, G, m->arch.cout[0], m->grads + m->poff[0],
+                                          m->grads + m->poff[1]);
     CV_HIP(hipGetLastError());
     return 0;
 }

@@ -417,7 +417,8 @@ static size_t train_floats_per_cand(const cv_model *m)
     // candidate-major operand copies of the weight-gradient kernels
     for (int l = 0; l < 3; l++) f += (size_t)(s.hp[l] + s.hc[l]) * 4 * s.ntile[l] * 16;
     f += 2 * (size_t)s.nb4 * 16 + 2 * (size_t)s.nb5 * 16;
-    return f + 64 * 64;
+    f += 2 * 33 * 16 + 2 * (size_t)s.hc[0] * 4 * s.ntile[0] * 16;     // first-layer weight gradient operands
+    return f + 64 * 80;
 }
 
 // forward (+ optional backward) of one slice of the batch: all-plain path
@@ -530,7 +531,9 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     float *cd4 = sb.take(np * s.nb4 * 16), *cg4 = sb.take(np * s.nb4 * 16);
     float *tg5 = sb.take(np * s.nb5 * 16), *cg5 = sb.take(np * s.nb5 * 16);
     float *cgpre[3] = {nullptr, sb.take(np * fa[1]), sb.take(np * fa[2])};
-    if (!cgpre[2]) { cv_set_error("training workspace too small"); return 1; }
+    float *tx = sb.take(np * 33 * 16), *cx = sb.take(np * 33 * 16);
+    float *tgpre0 = sb.take(np * fa[0]), *cgpre0 = sb.take(np * fa[0]);
+    if (!cgpre0) { cv_set_error("training workspace too small"); return 1; }
     const int64_t Gn = np / 16;
     // ---- forward on the tile kernels
     if (m->packed_dirty && cv_pack_weights(m, st)) return 1;
@@ -570,7 +573,6 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     cv_tm_to_cm(td4, cd4, Gn * s.nb4, st);
     cv_tm_to_cm(tg5, cg5, Gn * s.nb5, st);
     if (cv_tile_dense_wgrad(m, 5, cd4, cg5, n, st)) return 1;
-    b_bias_grad<<<dim3(nblk(a.fc5, 64), 32), 64, 0, st>>>(gfc5pre, n, a.fc5, G + o[9]);
     b_dense_dgrad<<<nblk(n * a.fc4, 256), 256, 0, st>>>(gfc5pre, a.fc5, P + o[8], n, a.fc4, a.fc5, gd4, 1);
     // dropout4 + selu' (h4 is the SELU output before dropout)
     b_selu_act<<<nblk(n * a.fc4, 256), 256, 0, st>>>(gd4, h4, amask, gfc4pre, n * a.fc4);
@@ -579,22 +581,23 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     cv_tm_to_cm(tp[2], cp[2], Gn * s.kb4, st);
     cv_tm_to_cm(tg4, cg4, Gn * s.nb4, st);
     if (cv_tile_dense_wgrad(m, 4, cp[2], cg4, n, st)) return 1;
-    b_bias_grad<<<dim3(nblk(a.fc4, 64), 32), 64, 0, st>>>(gfc4pre, n, a.fc4, G + o[7]);
     if (cv_tile_fc4_dgrad(m, tg4, tgin[2], n, st)) return 1;
     cv_tm_to_natural(tgin[2], s.hp[2] * 4 * s.ntile[2], s.ntile[2] * 16, a.cout[2], s.hp[2] * 4, n, gpool[2], st);
     // conv stack
     for (int l = 2; l >= 0; l--) {
         int H = s.hc[l], C = a.cout[l];
         b_pool_selu_act<<<nblk(n * H * 4 * C, 256), 256, 0, st>>>(gpool[l], act[l], gpre[l], n, H, C, a.pool[l]);
-        if (l == 0) {        // first layer (K = 16 per tap, 0.7 % of the work): plain reduction on X
-            int64_t nw = (int64_t)a.kh[l] * 4 * s.cin[l] * C + C;
-            b_conv_wgrad<<<dim3(nblk(nw, 64), 64), 64, 0, st>>>(x, gpre[l], n, H, s.cin[l], a.kh[l], C, G + o[0], G + o[1]);
+        if (l == 0) {        // first layer: X viewed as [33][16] fragments
+            cv_natural_to_tm(x, 33, 16, 16, 33, n, tx, st);
+            cv_tm_to_cm(tx, cx, Gn * 33, st);
+            cv_natural_to_tm(gpre[0], H * 4 * s.ntile[0], s.ntile[0] * 16, C, H * 4, n, tgpre0, st);
+            cv_tm_to_cm(tgpre0, cgpre0, Gn * H * 4 * s.ntile[0], st);
+            if (cv_tile_conv1_wgrad(m, cx, cgpre0, n, st)) return 1;
         } else {
             cv_natural_to_tm(gpre[l], H * 4 * s.ntile[l], s.ntile[l] * 16, C, H * 4, n, tgpre[l], st);
             cv_tm_to_cm(tgpre[l], cgpre[l], Gn * H * 4 * s.ntile[l], st);
             cv_tm_to_cm(tp[l - 1], cp[l - 1], Gn * s.hp[l - 1] * 4 * s.ntile[l - 1], st);
             if (cv_tile_conv_wgrad(m, l, cp[l - 1], cgpre[l], n, st)) return 1;
-            b_bias_grad<<<dim3(nblk(C, 64), 64), 64, 0, st>>>(gpre[l], n * H * 4, C, G + o[2 * l + 1]);
             if (cv_tile_conv_dgrad(m, l, tgpre[l], tgin[l - 1], n, st)) return 1;
             cv_tm_to_natural(tgin[l - 1], s.hp[l - 1] * 4 * s.ntile[l - 1], s.ntile[l - 1] * 16, a.cout[l - 1],
                              s.hp[l - 1] * 4, n, gpool[l - 1], st);
