@@ -80,6 +80,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise CvError("%s is missing: build it with `python -m clairvoyante_amd.build` "
                       "(hipcc, gfx950); there is no CPU fallback" % LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64; it must be the one HIP runtime of the process
+    # (two runtimes = two device contexts and "no ROCm-capable device"), so torch is imported --
+    # and its runtime mapped -- before this library, whose libamdhip64 dependency then
+    # resolves to the copy already loaded.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)      # AttributeError = a declared entry point is not exported
