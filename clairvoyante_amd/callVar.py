@@ -263,25 +263,29 @@ def Test(args, m, utils):
     logging.info("Total time elapsed: %.2f s" % (time.time() - predictStart))
 
 
+_CLI = (   # flag, type, default, help  -- the reference's options and defaults (callVar.py:219-254)
+    ("--tensor_fn", str, "PIPE", "Tensor input, use PIPE for standard input"),
+    ("--chkpnt_fn", str, None, "Input a checkpoint for testing or continue training"),
+    ("--call_fn", str, None, "Output variant predictions"),
+    ("--qual", int, None, "If set, variant with equal or higher quality will be marked PASS, or LowQual otherwise, optional"),
+    ("--sampleName", str, "SAMPLE", "Define the sample name to be shown in the VCF file"),
+    ("--ref_fn", str, None, "Reference fasta file input, optional, print contig tags in the VCF header if set"),
+    ("--threads", int, None, "Number of threads, optional"),
+)
+_SWITCHES = (("--showRef", False, "Show reference calls, optional"), ("--v3", True, "Use Clairvoyante version 3"),
+             ("--v2", False, "Use Clairvoyante version 2"),
+             ("--slim", False, "Train using the slim version of Clairvoyante, optional"))
+
+
 def main():
     parser = argparse.ArgumentParser(
         description="Call variants using a trained Clairvoyante model and tensors of candididate variants")
-    parser.add_argument('--tensor_fn', type=str, default="PIPE", help="Tensor input, use PIPE for standard input")
-    parser.add_argument('--chkpnt_fn', type=str, default=None, help="Input a checkpoint for testing or continue training")
-    parser.add_argument('--call_fn', type=str, default=None, help="Output variant predictions")
-    parser.add_argument('--qual', type=int, default=None,
-                        help="If set, variant with equal or higher quality will be marked PASS, or LowQual otherwise, optional")
-    parser.add_argument('--sampleName', type=str, default="SAMPLE", help="Define the sample name to be shown in the VCF file")
-    parser.add_argument('--showRef', type=param.str2bool, nargs='?', const=True, default=False, help="Show reference calls, optional")
-    parser.add_argument('--ref_fn', type=str, default=None,
-                        help="Reference fasta file input, optional, print contig tags in the VCF header if set")
-    parser.add_argument('--threads', type=int, default=None, help="Number of threads, optional")
-    parser.add_argument('--v3', type=param.str2bool, nargs='?', const=True, default=True, help="Use Clairvoyante version 3")
-    parser.add_argument('--v2', type=param.str2bool, nargs='?', const=True, default=False, help="Use Clairvoyante version 2")
-    parser.add_argument('--slim', type=param.str2bool, nargs='?', const=True, default=False,
-                        help="Train using the slim version of Clairvoyante, optional")
+    for flag, typ, default, text in _CLI:
+        parser.add_argument(flag, type=typ, default=default, help=text)
+    for flag, default, text in _SWITCHES:
+        parser.add_argument(flag, type=param.str2bool, nargs='?', const=True, default=default, help=text)
     args = parser.parse_args()
-    if len(sys.argv[1:]) == 0:
+    if not sys.argv[1:]:
         parser.print_help()
         sys.exit(1)
     Run(args)

@@ -87,129 +87,143 @@ def _shard(a, rank, ws):
     return a[lo:hi]
 
 
+class _BatchStream(object):
+    """The batch sequence of one epoch (train.py:83-107): 10 000-candidate batches up to
+    validationStart (the last one clipped to end exactly there), then batches aligned to multiples of
+    1 000; `last` marks the batch that reaches the end of the data set."""
+
+    def __init__(self, utils, XC, YC, total, validationStart):
+        self.utils, self.XC, self.YC, self.total, self.vstart = utils, XC, YC, total, validationStart
+        self.ptr = 0
+
+    def rewind(self):
+        self.ptr = 0
+
+    def fetch(self, size):
+        X, xn, xe = self.utils.DecompressArray(self.XC, self.ptr, size, self.total)
+        Y, yn, ye = self.utils.DecompressArray(self.YC, self.ptr, size, self.total)
+        if xn != yn or xe != ye:
+            sys.exit("Inconsistency between decompressed arrays: %d/%d" % (xn, yn))
+        start = self.ptr
+        self.ptr += xn
+        return X, Y, start, xn, xe != 0
+
+    def next_size(self):
+        return _next_batch_size(self.ptr, self.vstart)
+
+
+class _Job(Thread):
+    """Worker thread of the in-flight batch (train.py:87-93,109); unlike the reference an exception
+    raised inside it is re-raised by the caller."""
+
+    def __init__(self, fn, X, Y):
+        Thread.__init__(self)
+        self.fn, self.X, self.Y, self.err = fn, X, Y, None
+
+    def run(self):
+        try:
+            self.fn(self.X, self.Y)
+        except BaseException as e:
+            self.err = e
+
+    def finish(self):
+        self.join()
+        if self.err is not None:
+            raise self.err
+
+
 def TrainAll(args, m, utils):
     """train.py:37-218"""
     from . import parallel
     rank, ws = parallel.world()
     logging.info("Loading the training dataset ...")
     if args.bin_fn is not None:
-        total, XArrayCompressed, YArrayCompressed, posArrayCompressed = utils.LoadBin(args.bin_fn) \
-            if hasattr(utils, "LoadBin") else _load_bin(args.bin_fn)
+        total, XC, YC, _posC = utils.LoadBin(args.bin_fn) if hasattr(utils, "LoadBin") else _load_bin(args.bin_fn)
     else:
-        total, XArrayCompressed, YArrayCompressed, posArrayCompressed = \
-            utils.GetTrainingArray(args.tensor_fn, args.var_fn, args.bed_fn)
+        total, XC, YC, _posC = utils.GetTrainingArray(args.tensor_fn, args.var_fn, args.bed_fn)
     logging.info("The size of training dataset: {}".format(total))
 
-    summaryWriter = None
-    if args.olog_dir is not None and rank == 0:
-        summaryWriter = m.summaryFileWriter(args.olog_dir)
+    writer = m.summaryFileWriter(args.olog_dir) if (args.olog_dir is not None and rank == 0) else None
 
     logging.info("Start training ...")
     logging.info("Learning rate: %.2e" % m.setLearningRate(args.learning_rate))
     logging.info("L2 regularization lambda: %.2e" % m.setL2RegularizationLambda(args.lambd))
 
-    validationLosses = []
-    trainingStart = time.time()
+    t_begin = time.time()
     trainingTotal = int(total * param.trainingDatasetPercentage)
     validationStart = trainingTotal + 1
     numValItems = total - validationStart
-    maxLearningRateSwitch = param.maxLearningRateSwitch
+    switches_left = param.maxLearningRateSwitch
+    history = []                     # (validation loss sum, epoch)
+    since_switch = 0
+    epoch = 1 if args.chkpnt_fn is None else int(args.chkpnt_fn[-param.parameterOutputPlaceHolder:]) + 1
+    stream = _BatchStream(utils, XC, YC, total, validationStart)
 
-    def fetch(ptr, size):
-        X, xn, xe = utils.DecompressArray(XArrayCompressed, ptr, size, total)
-        Y, yn, ye = utils.DecompressArray(YArrayCompressed, ptr, size, total)
-        if xn != yn or xe != ye:
-            sys.exit("Inconsistency between decompressed arrays: %d/%d" % (xn, yn))
-        return X, Y, xn, xe
+    def mine(a):
+        return _shard(a, rank, ws)
 
-    class _Job(Thread):
-        """worker thread for the in-flight batch; re-raises in the caller (the reference
-        loses exceptions raised inside its Thread targets)"""
+    def reduced(v):
+        return parallel.allreduce_scalar(float(v), m) if ws > 1 else float(v)
 
-        def __init__(self, fn, X, Y):
-            Thread.__init__(self)
-            self.fn, self.X, self.Y, self.err = fn, X, Y, None
+    while epoch < param.maxEpoch:
+        t_epoch = time.time()
+        train_sum = 0
+        val_sum = 0
+        stream.rewind()
+        X, Y, start, count, last = stream.fetch(param.trainBatchSize)
+        while True:
+            # the batch is trained iff it ends strictly before validationStart (train.py:88-91)
+            training = start + count < validationStart
+            job = _Job(m.trainNoRT if training else m.getLossNoRT, mine(X), mine(Y))
+            job.start()
+            nxt = stream.fetch(stream.next_size())         # decompress while the GPU works
+            job.finish()
+            if training:
+                train_sum += m.trainLossRTVal
+                if writer is not None:
+                    writer.add_summary(m.trainSummaryRTVal, epoch)
+            else:
+                val_sum += reduced(m.getLossLossRTVal)
+            X, Y, start, count, last = nxt
+            if last:
+                break
+        val_sum += reduced(m.getLoss(mine(X), mine(Y)))    # the final batch, synchronously (train.py:122)
+        logging.info(" ".join([str(epoch), "Training loss:", str(train_sum / trainingTotal), "Validation loss: ",
+                               str(val_sum / numValItems)]))
+        logging.info("Epoch time elapsed: %.2f s" % (time.time() - t_epoch))
+        history.append((val_sum, epoch))
+        if args.ochk_prefix is not None and rank == 0:
+            name = "%s-%0*d" % (args.ochk_prefix, param.parameterOutputPlaceHolder, epoch)
+            m.saveParameters(os.path.abspath(name))
+        since_switch += 1
+        if since_switch >= 6 and _zigzag(history):
+            switches_left -= 1
+            if switches_left == 0:
+                break
+            logging.info("New learning rate: %.2e" % m.setLearningRate())
+            logging.info("New L2 regularization lambda: %.2e" % m.setL2RegularizationLambda())
+            since_switch = 0
+        epoch += 1
 
-        def run(self):
-            try:
-                self.fn(_shard(self.X, rank, ws), _shard(self.Y, rank, ws))
-            except BaseException as e:
-                self.err = e
-
-    def val_loss(X, Y):
-        v = float(m.getLoss(_shard(X, rank, ws), _shard(Y, rank, ws)))
-        return parallel.allreduce_scalar(v, m) if ws > 1 else v
-
-    c = 0
-    i = 1 if args.chkpnt_fn is None else int(args.chkpnt_fn[-param.parameterOutputPlaceHolder:]) + 1
-    epochStart = time.time()
-    trainLossSum = 0
-    validationLossSum = 0
-    datasetPtr = 0
-    XBatch, YBatch, XNum, _ = fetch(datasetPtr, param.trainBatchSize)
-    datasetPtr += XNum
-    while i < param.maxEpoch:
-        training = datasetPtr < validationStart
-        job = _Job(m.trainNoRT if training else m.getLossNoRT, XBatch, YBatch)
-        job.start()
-        XBatch2, YBatch2, XNum2, XEndFlag2 = fetch(datasetPtr, _next_batch_size(datasetPtr, validationStart))
-        job.join()
-        if job.err is not None:
-            raise job.err
-        XBatch = XBatch2; YBatch = YBatch2
-        if training:
-            trainLossSum += m.trainLossRTVal
-            if summaryWriter is not None:
-                summaryWriter.add_summary(m.trainSummaryRTVal, i)
-        else:
-            v = float(m.getLossLossRTVal)
-            validationLossSum += parallel.allreduce_scalar(v, m) if ws > 1 else v
-        datasetPtr += XNum2
-
-        if XEndFlag2 != 0:
-            validationLossSum += val_loss(XBatch, YBatch)
-            logging.info(" ".join([str(i), "Training loss:", str(trainLossSum / trainingTotal), "Validation loss: ",
-                                   str(validationLossSum / numValItems)]))
-            logging.info("Epoch time elapsed: %.2f s" % (time.time() - epochStart))
-            validationLosses.append((validationLossSum, i))
-            if args.ochk_prefix is not None and rank == 0:
-                parameterOutputPath = "%s-%%0%dd" % (args.ochk_prefix, param.parameterOutputPlaceHolder)
-                m.saveParameters(os.path.abspath(parameterOutputPath % i))
-            c += 1
-            if c >= 6 and _zigzag(validationLosses):
-                maxLearningRateSwitch -= 1
-                if maxLearningRateSwitch == 0:
-                    break
-                logging.info("New learning rate: %.2e" % m.setLearningRate())
-                logging.info("New L2 regularization lambda: %.2e" % m.setL2RegularizationLambda())
-                c = 0
-            i += 1
-            trainLossSum = 0; validationLossSum = 0; datasetPtr = 0; epochStart = time.time()
-            XBatch, YBatch, XNum, _ = fetch(datasetPtr, param.trainBatchSize)
-            datasetPtr += XNum
-
-    logging.info("Training time elapsed: %.2f s" % (time.time() - trainingStart))
-
-    validationLosses.sort()
-    i = validationLosses[0][1]
-    logging.info("Best validation loss at batch: %d" % i)
+    logging.info("Training time elapsed: %.2f s" % (time.time() - t_begin))
+    history.sort()
+    logging.info("Best validation loss at batch: %d" % history[0][1])
 
     logging.info("Testing on the training and validation dataset ...")
-    predictStart = time.time()
-    predictBatchSize = param.predictBatchSize
-    datasetPtr = 0
-    bases = []; zs = []; ts = []; ls = []
+    t_pred = time.time()
+    step = param.predictBatchSize
+    outs = [[], [], [], []]
+    ptr = 0
     while True:
-        XBatch, _, endFlag = utils.DecompressArray(XArrayCompressed, datasetPtr, predictBatchSize, total)
-        base, z, t, l = m.predict(XBatch)
-        bases.append(base); zs.append(z); ts.append(t); ls.append(l)
-        datasetPtr += predictBatchSize
-        if not (datasetPtr < total) or (endFlag != 0 and datasetPtr > predictBatchSize):
+        Xb, _, endFlag = utils.DecompressArray(XC, ptr, step, total)
+        for acc, o in zip(outs, m.predict(Xb)):
+            acc.append(o)
+        ptr += step
+        if ptr >= total or (endFlag != 0 and ptr > step):
             break
-    bases = np.concatenate(bases[:]); zs = np.concatenate(zs[:]); ts = np.concatenate(ts[:]); ls = np.concatenate(ls[:])
-    logging.info("Prediciton time elapsed: %.2f s" % (time.time() - predictStart))
-
-    YArray, _, _ = utils.DecompressArray(YArrayCompressed, 0, total, total)
+    bases, zs, ts, ls = [np.concatenate(o) for o in outs]
+    logging.info("Prediciton time elapsed: %.2f s" % (time.time() - t_pred))
+    YArray, _, _ = utils.DecompressArray(YC, 0, total, total)
     EvaluateReport(bases, zs, ts, ls, YArray)
 
 
@@ -237,27 +251,29 @@ def _load_bin(fn):
         return pickle.load(fh), pickle.load(fh), pickle.load(fh), pickle.load(fh)
 
 
+_CLI = (   # flag, type, default, help  -- the reference's options and defaults (train.py:221-262)
+    ("--bin_fn", str, None, "Binary tensor input generated by tensor2Bin.py, tensor_fn, var_fn and bed_fn will be ignored"),
+    ("--tensor_fn", str, "vartensors", "Tensor input"),
+    ("--var_fn", str, "truthvars", "Truth variants list input"),
+    ("--bed_fn", str, None, "High confident genome regions input in the BED format"),
+    ("--chkpnt_fn", str, None, "Input a checkpoint for testing or continue training"),
+    ("--learning_rate", float, param.initialLearningRate, "Set the initial learning rate, default: %(default)s"),
+    ("--lambd", float, param.l2RegularizationLambda, "Set the l2 regularization lambda, default: %(default)s"),
+    ("--ochk_prefix", str, None, "Prefix for checkpoint outputs at each learning rate change, optional"),
+    ("--olog_dir", str, None, "Directory for tensorboard log outputs, optional"),
+)
+_SWITCHES = (("--v3", True, "Use Clairvoyante version 3"), ("--v2", False, "Use Clairvoyante version 2"),
+             ("--slim", False, "Train using the slim version of Clairvoyante, optional"))
+
+
 def main():
     parser = argparse.ArgumentParser(description="Train Clairvoyante")
-    parser.add_argument('--bin_fn', type=str, default=None,
-                        help="Binary tensor input generated by tensor2Bin.py, tensor_fn, var_fn and bed_fn will be ignored")
-    parser.add_argument('--tensor_fn', type=str, default="vartensors", help="Tensor input")
-    parser.add_argument('--var_fn', type=str, default="truthvars", help="Truth variants list input")
-    parser.add_argument('--bed_fn', type=str, default=None, help="High confident genome regions input in the BED format")
-    parser.add_argument('--chkpnt_fn', type=str, default=None, help="Input a checkpoint for testing or continue training")
-    parser.add_argument('--learning_rate', type=float, default=param.initialLearningRate,
-                        help="Set the initial learning rate, default: %(default)s")
-    parser.add_argument('--lambd', type=float, default=param.l2RegularizationLambda,
-                        help="Set the l2 regularization lambda, default: %(default)s")
-    parser.add_argument('--ochk_prefix', type=str, default=None,
-                        help="Prefix for checkpoint outputs at each learning rate change, optional")
-    parser.add_argument('--olog_dir', type=str, default=None, help="Directory for tensorboard log outputs, optional")
-    parser.add_argument('--v3', type=param.str2bool, nargs='?', const=True, default=True, help="Use Clairvoyante version 3")
-    parser.add_argument('--v2', type=param.str2bool, nargs='?', const=True, default=False, help="Use Clairvoyante version 2")
-    parser.add_argument('--slim', type=param.str2bool, nargs='?', const=True, default=False,
-                        help="Train using the slim version of Clairvoyante, optional")
+    for flag, typ, default, text in _CLI:
+        parser.add_argument(flag, type=typ, default=default, help=text)
+    for flag, default, text in _SWITCHES:
+        parser.add_argument(flag, type=param.str2bool, nargs='?', const=True, default=default, help=text)
     args = parser.parse_args()
-    if len(sys.argv[1:]) == 0:
+    if not sys.argv[1:]:
         parser.print_help()
         sys.exit(1)
     Run(args)
