@@ -121,7 +121,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     alloc(&m->wpd_fc4, (size_t)((s.kb4 + 23) / 24) * s.nb4 * 24 * 256);
     alloc(&m->wp_heads0, (size_t)s.nb4 * 256);
     alloc(&m->wp_heads1, (size_t)s.nb5 * 256);
-    m->variant = 7;
+    m->variant = 15;
     if (e == hipSuccess) e = hipMalloc(&m->loss_dev, sizeof(double) * 8);
     if (e != hipSuccess) {
         cv_set_error("cv_create: device allocation failed: %s", hipGetErrorString(e));

@@ -64,7 +64,7 @@ struct cv_model {
     float *wpd_fc4;      // data-gradient weights of fc4 [slab][jb][24][64][4]
     float *wp_heads0;    // [nb4][64][4]  base head (rows 0..3)
     float *wp_heads1;    // [nb5][64][4]  zygosity / type / length heads
-    int variant;         // bit 0: first layer fused into conv2; bit 1: MFMA heads kernel; bit 2: 8-wave fc4 workgroups
+    int variant;         // bit 0: first layer fused into conv2; bit 1: MFMA heads kernel; bit 2: 8-wave fc4 workgroups; bit 3: rotating-window conv3
     bool packed_dirty;
     // workspaces (allocated lazily for `ws_cap` candidates)
     int64_t ws_cap;      // MFMA path capacity (multiple of 16)

@@ -19,6 +19,7 @@
 // kh -> (kh-1)/2 on top; taps on padding are skipped (they add an exact zero).
 #include "cv_internal.hpp"
 #include "cv_math.hpp"
+#include <type_traits>
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -539,6 +540,95 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
 }
 
 // ---------------------------------------------------------------------------
+// conv3-class layer, register-lean form (variant bit 3): the KH = 3 row window lives in THREE
+// rotating register slots (the position loop is unrolled by 3 so every slot index is a
+// compile-time constant: no shift copies), the row a position needs next is loaded straight
+// into the slot that just retired and is consumed by the LAST kh of that position (its load
+// overlaps the first two thirds of the MFMA block), and the pooling window is two running
+// maxima.  184 VGPRs (conv_tm: 252).  Three waves per SIMD would need <= 168: hipcc then spills
+// 17 dwords per lane into the loop and the kernel is 27 % slower, so it runs at two (measured
+// -2.4 % on conv3 against conv_tm).  Same arithmetic in the same order: bit-identical results.
+// ---------------------------------------------------------------------------
+template <int CINB, int NT, int HIN, int WAVES, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restrict__ in_tm, const f4 *__restrict__ wp,
+                                                            const float *__restrict__ bias, int cout,
+                                                            f4 *__restrict__ out_tm, int G)
+{
+    constexpr int KH = 3, PADT = 1, POOL = 3, HOUT = HIN - POOL + 1;
+    extern __shared__ __attribute__((aligned(16))) f4 ldsw[];
+    constexpr int NFRAG = NT * KH * 4 * CINB;
+    for (int i = threadIdx.x; i < NFRAG * 64; i += WAVES * 64) ldsw[i] = wp[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const int g = wv / NT, nt = wv % NT;
+    if (g >= G) return;
+    const int q = lane >> 4;
+    const f4 b4 = load_bias4(bias, nt, q, cout);
+    const f4 *inp = in_tm + (size_t)g * (HIN * 4 * CINB * 64) + lane;
+    const f4 *wl = ldsw + (size_t)nt * (KH * 4 * CINB * 64) + lane;
+    f4 *op = out_tm + (size_t)g * (HOUT * 4 * NT * 64) + (size_t)nt * 64 + lane;
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 win[3][4][CINB];          // slot (r + 1) % 3 holds input row r
+    f4 m1[4], m2[4];             // SELU outputs of the previous row / max of the previous two
+#pragma unroll
+    for (int w = 0; w < 4; w++) { m1[w] = zero; m2[w] = zero; }
+    auto load_row = [&](int hr, f4 (&row)[4][CINB]) {
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int cb = 0; cb < CINB; cb++) row[w][cb] = inp[(size_t)((hr * 4 + w) * CINB + cb) * 64];
+    };
+    load_row(0, win[1]);         // row 0 -> slot 1 ; row -1 (slot 0) is padding and never read
+    // one position; R = h % 3 is a compile-time constant so that slot indices are static
+    auto step = [&](auto Rc, int h) {
+        constexpr int R = decltype(Rc)::value;
+        // rows h-1, h, h+1 are in slots R, (R+1)%3, (R+2)%3; fetch row h+1 now, use it last
+        if (h + 1 < HIN) load_row(h + 1, win[(R + 2) % 3]);
+        f4 acc[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) acc[w] = zero;
+#pragma unroll
+        for (int kh = 0; kh < KH; kh++) {
+            const int hr = h + kh - PADT;
+            if (hr >= 0 && hr < HIN) {
+#pragma unroll
+                for (int kw = 0; kw < 4; kw++)
+#pragma unroll
+                    for (int cb = 0; cb < CINB; cb++) {
+                        const f4 A = wl[(size_t)((kh * 4 + kw) * CINB + cb) * 64];
+#pragma unroll
+                        for (int s = 0; s < 4; s++)
+#pragma unroll
+                            for (int wo = 0; wo < 4; wo++) {
+                                const int wi = wo + kw - 1;
+                                if (wi < 0 || wi > 3) continue;
+                                acc[wo] = mfma4(A[s], win[(R + kh) % 3][wi][cb][s], acc[wo]);
+                            }
+                    }
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const f4 v = selu4(acc[w] + b4);
+            const f4 o = max4(m2[w], v);             // max(v[h-2], v[h-1], v[h]); exact, order-free
+            m2[w] = max4(m1[w], v);
+            m1[w] = v;
+            if (h >= POOL - 1) op[(size_t)((h - (POOL - 1)) * 4 + w) * (NT * 64)] = o;
+        }
+    };
+#pragma unroll 1
+    for (int h0 = 0; h0 < HIN; h0 += 3) {
+        step(std::integral_constant<int, 0>{}, h0);
+        __builtin_amdgcn_sched_barrier(0);     // keep the three positions apart: register budget
+        if (h0 + 1 < HIN) step(std::integral_constant<int, 1>{}, h0 + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (h0 + 2 < HIN) step(std::integral_constant<int, 2>{}, h0 + 2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // heads (v3.py:124-138): one wave per group of 16 candidates.
 //   tile 0 (input fc4 side, K = NB4*16): rows 0..3  = base logits -> sigmoid
 //   tile 1 (input fc5,      K = NB5*16): rows 0..1  = zygosity, rows 4..7 = variant type,
@@ -786,6 +876,17 @@ int launch_conv(const float *in, const float *x, int64_t n, const float *wp1, co
     return 0;
 }
 
+template <int CINB, int NT, int HIN, int WAVES, int MINW>
+int launch_conv3_rot(const float *in, const float *wp, const float *bias, int cout, float *out, int G, hipStream_t st)
+{
+    auto k = conv3_rot<CINB, NT, HIN, WAVES, MINW>;
+    size_t lds = (size_t)NT * 3 * 4 * CINB * 1024;
+    if (set_lds(k, lds)) return 1;
+    k<<<nblk((int64_t)G * NT, WAVES), WAVES * 64, lds, st>>>((const f4 *)in, (const f4 *)wp, bias, cout, (f4 *)out, G);
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int NB, int WAVES, int EPI = 0>
 int launch_dense(const float *in, int KB, const float *wp, const float *bias, int nout, float *out, int G,
                  hipStream_t st, int slabs = 1)
@@ -884,7 +985,8 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             cv_prof_end(m, 1, st);
         }
         cv_prof_begin(m, 2, st);
-        rc |= launch_conv<3, 2, 3, 3, 26, 0>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st);
+        if (m->variant & 8) rc |= launch_conv3_rot<2, 3, 26, 4, 2>(m->tm_p2, m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st);
+        else rc |= launch_conv<3, 2, 3, 3, 26, 0>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st);
         cv_prof_end(m, 2, st);
         cv_prof_begin(m, 3, st);
         if (m->variant & 4) rc |= launch_dense<21, 8>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);

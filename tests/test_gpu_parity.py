@@ -44,7 +44,7 @@ def test_outputs_match_oracle(setup, impl):
     assert common.argmax_match(got, ref["out"]) == [1.0, 1.0, 1.0, 1.0]
 
 
-@pytest.mark.parametrize("impl,variant", [(1, 7), (1, 6), (1, 0), (0, 7)])
+@pytest.mark.parametrize("impl,variant", [(1, 15), (1, 6), (1, 0), (0, 15)])
 def test_intermediates_match_oracle(setup, impl, variant):
     import torch
     arch, P, m, x, ref = setup
@@ -52,7 +52,7 @@ def test_intermediates_match_oracle(setup, impl, variant):
     m.setOption("variant", variant)
     n = x.shape[0]
     m.predict_device(torch.from_numpy(x).cuda())
-    m.setOption("variant", 7)
+    m.setOption("variant", 15)
     for layer, name in ((1, "pool1"), (2, "pool2"), (3, "pool3"), (4, "fc4"), (5, "fc5")):
         if layer == 1 and impl == 1 and (variant & 1):
             continue      # with the first layer fused into the conv2 kernel pool1 never reaches HBM
@@ -89,9 +89,9 @@ def test_plain_and_tile_kernels_agree_bitwise(setup):
     m.setOption("impl", 0)
     a = np.concatenate(m.predict(x), axis=1)
     m.setOption("impl", 1)
-    for variant in (0, 1, 2, 4, 7):           # every kernel variant computes the same bits
+    for variant in (0, 1, 2, 4, 7, 8, 15):           # every kernel variant computes the same bits
         m.setOption("variant", variant)
         b = np.concatenate(m.predict(x), axis=1)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), variant
-    m.setOption("variant", 7)
+    m.setOption("variant", 15)
     assert np.array_equal(a.view(np.uint32), ref["out"].view(np.uint32))     # ... the oracle's bits
