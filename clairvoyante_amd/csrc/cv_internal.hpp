@@ -62,6 +62,7 @@ struct cv_model {
     float *wp_fc5;       // [nb4][nb5][64][4]
     float *wpd_conv[3];  // data-gradient weights of conv2 / conv3 (pack_conv_dgrad)
     float *wpd_fc4;      // data-gradient weights of fc4 [slab][jb][24][64][4]
+    float *wpd_fc5;      // data-gradient weights of fc5 [jb][24 | 4][64][4]
     float *wp_heads0;    // [nb4][64][4]  base head (rows 0..3)
     float *wp_heads1;    // [nb5][64][4]  zygosity / type / length heads
     int variant;         // bit 0: first layer fused into conv2; bit 1: MFMA heads kernel; bit 2: 8-wave fc4 workgroups; bit 3: rotating-window conv3
@@ -111,6 +112,7 @@ int cv_pack_train_weights(cv_model *m, hipStream_t st);
 int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float *a1, float *p2, float *a2,
                         float *p3, float *a3, hipStream_t st);
 int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm, int64_t n, hipStream_t st);
+int cv_tile_fc5_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
 int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
 int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
 int cv_tm_to_cm(const float *tm, float *cm, int64_t nfrag, hipStream_t st);

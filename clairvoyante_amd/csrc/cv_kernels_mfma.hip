@@ -1318,6 +1318,11 @@ int cv_pack_train_weights(cv_model *m, hipStream_t st)
     }
     int64_t tot = (int64_t)(s.kb4 / 24) * s.nb4 * 24 * 256;
     pack_dense_dgrad<<<nblk(tot, 256), 256, 0, st>>>(P + o[6], m->wpd_fc4, s.flat, a.fc4, s.nb4, 24, s.kb4 / 24);
+    {   // fc5: one slab; fragment stride = dense_tm's padded count (full: 21 -> 24 with 8 waves, slim: 3 -> 4)
+        const int nbp = is_full(a) ? 24 : 4;
+        tot = (int64_t)s.nb5 * nbp * 256;
+        pack_dense_dgrad<<<nblk(tot, 256), 256, 0, st>>>(P + o[8], m->wpd_fc5, a.fc4, a.fc5, s.nb5, nbp, 1);
+    }
     CV_HIP(hipGetLastError());
     return 0;
 }
@@ -1365,6 +1370,15 @@ int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, 
     const cv_shapes &s = m->sh;
     const int G = (int)((n + 15) / 16);
     return launch_dense<24, 8, 1>(g_tm, s.nb4, m->wpd_fc4, nullptr, 0, gin_tm, G, st, s.kb4 / 24);
+}
+
+// g(d4)[k] = sum_j g5pre[j] W5[k][j]  (input TM with nb5 fragments, output TM with nb4 fragments)
+int cv_tile_fc5_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st)
+{
+    const cv_shapes &s = m->sh;
+    const int G = (int)((n + 15) / 16);
+    if (is_full(m->arch)) return launch_dense<21, 8, 1>(g_tm, s.nb5, m->wpd_fc5, nullptr, 0, gin_tm, G, st);
+    return launch_dense<3, 4, 1>(g_tm, s.nb5, m->wpd_fc5, nullptr, 0, gin_tm, G, st);
 }
 
 // layer 1 = conv2, 2 = conv3: gradient w.r.t. the layer input from the pre-activation gradient

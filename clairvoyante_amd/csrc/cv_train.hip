@@ -394,6 +394,166 @@ __global__ void b_bias_grad(const float *__restrict__ g, int64_t rows, int C, fl
     atomicAdd(&db[c], acc);
 }
 
+// ---- element-wise backward steps directly on tile-major buffers ----------------------------
+typedef float tf4 __attribute__((ext_vector_type(4)));
+
+// g_pre = g_act * (mask) * selu'(act) over a whole TM buffer (padding entries carry zeros)
+__global__ void b_selu_tm(const tf4 *__restrict__ gact, const tf4 *__restrict__ act, const tf4 *__restrict__ mask,
+                          tf4 *__restrict__ gpre, int64_t nf4)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nf4) return;
+    tf4 g = gact[t], a = act[t], r;
+    if (mask) g *= mask[t];
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k] = g[k] * selu_grad_from_out(a[k]);
+    gpre[t] = r;
+}
+
+// max-pool backward + selu' on TM maps: one thread per (group, base*tile, lane) walks the positions.
+// act: H rows, gpool: H-p+1 rows, gpre: H rows; row stride = 4*NT fragments.
+__global__ void b_pool_selu_tm(const tf4 *__restrict__ gpool, const tf4 *__restrict__ act, tf4 *__restrict__ gpre,
+                               int64_t G, int H, int NT, int p)
+{
+    const int cols = 4 * NT * 64;                     // f4 columns per group row
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= G * cols) return;
+    const int col = (int)(t % cols);
+    const int64_t g = t / cols;
+    const int Ho = H - p + 1;
+    const tf4 *a = act + (size_t)g * H * cols + col;
+    const tf4 *gp = gpool + (size_t)g * Ho * cols + col;
+    tf4 *o = gpre + (size_t)g * H * cols + col;
+    for (int h = 0; h < H; h++) {
+        const tf4 me = a[(size_t)h * cols];
+        tf4 acc = (tf4){0.f, 0.f, 0.f, 0.f};
+        for (int ho = h - p + 1; ho <= h; ho++) {
+            if (ho < 0 || ho >= Ho) continue;
+            bool win[4] = {true, true, true, true};
+            for (int d = 0; d < p; d++) {
+                const int hh = ho + d;
+                if (hh == h) continue;
+                const tf4 v = a[(size_t)hh * cols];
+#pragma unroll
+                for (int k = 0; k < 4; k++) win[k] = win[k] && (hh < h ? v[k] < me[k] : v[k] <= me[k]);
+            }
+            const tf4 gv = gp[(size_t)ho * cols];
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] += win[k] ? gv[k] : 0.0f;
+        }
+        tf4 r;
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = acc[k] * selu_grad_from_out(me[k]);
+        o[(size_t)h * cols] = r;
+    }
+}
+
+// heads on TM inputs: same as t_heads with cv_tm_index addressing
+__global__ __launch_bounds__(256) void t_heads_tm(
+    const float *__restrict__ d4, const float *__restrict__ h5, int K4, int K5, int KB4, int KB5,
+    const float *__restrict__ wb, const float *__restrict__ bb, const float *__restrict__ wz,
+    const float *__restrict__ bz, const float *__restrict__ wt, const float *__restrict__ bt,
+    const float *__restrict__ wl, const float *__restrict__ bl, const float *__restrict__ y, int64_t n,
+    float *__restrict__ ghpre, double *__restrict__ loss)
+{
+    __shared__ float pre[16][17];
+    __shared__ double part[4];
+    int c = threadIdx.x >> 4, j = threadIdx.x & 15;
+    if (threadIdx.x < 4) part[threadIdx.x] = 0.0;
+    int64_t cand = (int64_t)blockIdx.x * 16 + c;
+    int64_t cl = cand < n ? cand : n - 1;
+    const float *w; const float *b; int idx, nh, K, KB; const float *src;
+    if (j < 4)       { w = wb; b = bb; idx = j;      nh = 4; K = K4; KB = KB4; src = d4; }
+    else if (j < 6)  { w = wz; b = bz; idx = j - 4;  nh = 2; K = K5; KB = KB5; src = h5; }
+    else if (j < 10) { w = wt; b = bt; idx = j - 6;  nh = 4; K = K5; KB = KB5; src = h5; }
+    else             { w = wl; b = bl; idx = j - 10; nh = 6; K = K5; KB = KB5; src = h5; }
+    float acc = 0.0f;
+    for (int k = 0; k < K; k++) acc = __builtin_fmaf(src[cv_tm_index(cl, k, KB)], w[(size_t)k * nh + idx], acc);
+    pre[c][j] = acc + b[idx];
+    __syncthreads();
+    if (cand < n && j < 4) {
+        const float *yi = y + (size_t)cand * 16;
+        float *g = ghpre ? ghpre + (size_t)cand * 16 : nullptr;
+        double l = 0.0;
+        if (j == 0) {
+            for (int k = 0; k < 4; k++) {
+                float s = cvm::sigmoid(pre[c][k]);
+                float d = s - yi[k];
+                l += (double)d * d;
+                if (g) g[k] = 2.0f * d * s * (1.0f - s);
+            }
+        } else {
+            const int off = j == 1 ? 4 : (j == 2 ? 6 : 10);
+            const int cnt = j == 1 ? 2 : (j == 2 ? 4 : 6);
+            float lg[6], p[6];
+            float mx = -__builtin_inff();
+            for (int k = 0; k < cnt; k++) { lg[k] = cvm::selu(pre[c][off + k]) + 1e-10f; mx = fmaxf(mx, lg[k]); }
+            float se = 0.0f, ysum = 0.0f;
+            for (int k = 0; k < cnt; k++) { p[k] = cvm::expf_fixed(lg[k] - mx); se += p[k]; ysum += yi[off + k]; }
+            float lse = mx + logf(se);
+            for (int k = 0; k < cnt; k++) {
+                l += -(double)yi[off + k] * (double)(lg[k] - lse);
+                if (g) g[off + k] = (p[k] / se * ysum - yi[off + k]) * cvm::selu_grad(pre[c][off + k]);
+            }
+        }
+        atomicAdd(&part[j], l);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(&loss[threadIdx.x], part[threadIdx.x]);
+}
+
+// heads: weight / bias gradients with the layer input read from a TM buffer
+// dW[k][j] += sum_n X[n][k] g[n][j0 + j] ; row k == K is the bias
+__global__ void b_head_wgrad_tm(const float *__restrict__ xtm, int KB, const float *__restrict__ g, int j0, int64_t n,
+                                int K, int N, float *__restrict__ dw, float *__restrict__ db)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)(K + 1) * N) return;
+    int j = (int)(t % N);
+    int k = (int)(t / N);
+    int64_t per = (n + gridDim.y - 1) / gridDim.y;
+    int64_t n0 = per * blockIdx.y, n1 = n0 + per < n ? n0 + per : n;
+    float acc = 0.0f;
+    if (k < K) {
+        for (int64_t i = n0; i < n1; i++) acc = __builtin_fmaf(xtm[cv_tm_index(i, k, KB)], g[(size_t)i * 16 + j0 + j], acc);
+        atomicAdd(&dw[(size_t)k * N + j], acc);
+    } else {
+        for (int64_t i = n0; i < n1; i++) acc += g[(size_t)i * 16 + j0 + j];
+        atomicAdd(&db[j], acc);
+    }
+}
+
+// heads: data gradients written into TM buffers.  mode 0: gh5_tm = sum over the three fc5-side
+// heads (all entries written, padding = 0); mode 1: gd4_tm += base-head contribution.
+__global__ void b_head_dgrad_tm(const float *__restrict__ ghpre, const float *__restrict__ wb,
+                                const float *__restrict__ wz, const float *__restrict__ wt,
+                                const float *__restrict__ wl, int K, int KB, int64_t n, int64_t G, int mode,
+                                float *__restrict__ out_tm)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= G * KB * 256) return;
+    int s = (int)(t & 3), lane = (int)((t >> 2) & 63);
+    int64_t frag = t >> 8;
+    int kb = (int)(frag % KB);
+    int64_t g = frag / KB;
+    int c = lane & 15, kq = lane >> 4;
+    int k = 16 * kb + 4 * s + kq;
+    int64_t cand = g * 16 + c;
+    float acc = 0.0f;
+    if (cand < n && k < K) {
+        const float *gi = ghpre + (size_t)cand * 16;
+        if (mode == 0) {
+            for (int j = 0; j < 2; j++) acc = __builtin_fmaf(gi[4 + j], wz[(size_t)k * 2 + j], acc);
+            for (int j = 0; j < 4; j++) acc = __builtin_fmaf(gi[6 + j], wt[(size_t)k * 4 + j], acc);
+            for (int j = 0; j < 6; j++) acc = __builtin_fmaf(gi[10 + j], wl[(size_t)k * 6 + j], acc);
+        } else {
+            for (int j = 0; j < 4; j++) acc = __builtin_fmaf(gi[j], wb[(size_t)k * 4 + j], acc);
+        }
+    }
+    if (mode == 0) out_tm[t] = acc;
+    else out_tm[t] += acc;
+}
+
 struct slab {
     float *base; size_t used, cap;
     float *take(size_t nfloat) { float *p = base + used; used += (nfloat + 63) / 64 * 64; return used <= cap ? p : nullptr; }
@@ -495,112 +655,83 @@ static int train_slice_plain(cv_model *m, const float *x, const float *y, int64_
 }
 
 
-// forward (+ optional backward) of one slice of the batch on the tile kernels
+// forward (+ optional backward) of one slice of the batch on the tile kernels; every
+// intermediate stays tile-major, the only natural-layout tensors are X, Y and the 16 head
+// gradients per candidate
 static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t n, int64_t cand0, bool backward,
                             float drop4, uint64_t seed, uint64_t step, hipStream_t st)
 {
     const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
     const float *P = m->params; float *G = m->grads; const int64_t *o = m->poff;
     const int64_t np = (n + 15) / 16 * 16;             // TM buffers hold whole groups
+    const int64_t Gn = np / 16;
     slab sb{m->t_buf, 0, m->t_bytes / sizeof(float)};
-    // TM (tile-major) buffers
-    size_t fp[3], fa[3];                               // floats per candidate: pooled / pre-pool
+    size_t fp[3], fa[3];                               // floats per candidate: pooled / pre-pool maps
     for (int l = 0; l < 3; l++) { fp[l] = (size_t)s.hp[l] * 4 * s.ntile[l] * 16; fa[l] = (size_t)s.hc[l] * 4 * s.ntile[l] * 16; }
+    const size_t f4u = (size_t)s.nb4 * 16, f5u = (size_t)s.nb5 * 16;
     float *tp[3], *ta[3];
     for (int l = 0; l < 3; l++) { tp[l] = sb.take(np * fp[l]); ta[l] = sb.take(np * fa[l]); }
-    float *th4 = sb.take(np * s.nb4 * 16), *td4 = sb.take(np * s.nb4 * 16), *tmask = sb.take(np * s.nb4 * 16);
-    float *th5 = sb.take(np * s.nb5 * 16);
-    // natural copies / gradients
-    float *act[3], *pool[3], *gpre[3], *gpool[3];
-    for (int l = 0; l < 3; l++) {
-        act[l] = sb.take((size_t)n * s.hc[l] * 4 * a.cout[l]);
-        pool[l] = sb.take((size_t)n * s.hp[l] * 4 * a.cout[l]);
-        gpre[l] = sb.take((size_t)n * s.hc[l] * 4 * a.cout[l]);
-        gpool[l] = sb.take((size_t)n * s.hp[l] * 4 * a.cout[l]);
-    }
-    float *h4 = sb.take((size_t)n * a.fc4), *d4 = sb.take((size_t)n * a.fc4), *amask = sb.take((size_t)n * a.fc4);
-    float *gd4 = sb.take((size_t)n * a.fc4), *gfc4pre = sb.take((size_t)n * a.fc4);
-    float *h5 = sb.take((size_t)n * a.fc5), *gh5 = sb.take((size_t)n * a.fc5), *gfc5pre = sb.take((size_t)n * a.fc5);
+    float *th4 = sb.take(np * f4u), *td4 = sb.take(np * f4u), *tmask = sb.take(np * f4u), *th5 = sb.take(np * f5u);
     float *ghpre = sb.take((size_t)n * 16);
-    // TM gradients for the tile data-gradient passes
-    float *tg4 = sb.take(np * s.nb4 * 16);
-    float *tgpre[3] = {nullptr, sb.take(np * fa[1]), sb.take(np * fa[2])};
-    float *tgin[3] = {sb.take(np * fp[0]), sb.take(np * fp[1]), sb.take(np * fp[2])};   // grads of pool1, pool2, pool3
-    // candidate-major (CM) operand copies for the weight-gradient kernels
-    float *cp[3] = {sb.take(np * fp[0]), sb.take(np * fp[1]), sb.take(np * fp[2])};
-    float *cd4 = sb.take(np * s.nb4 * 16), *cg4 = sb.take(np * s.nb4 * 16);
-    float *tg5 = sb.take(np * s.nb5 * 16), *cg5 = sb.take(np * s.nb5 * 16);
-    float *cgpre[3] = {nullptr, sb.take(np * fa[1]), sb.take(np * fa[2])};
-    float *tx = sb.take(np * 33 * 16), *cx = sb.take(np * 33 * 16);
-    float *tgpre0 = sb.take(np * fa[0]), *cgpre0 = sb.take(np * fa[0]);
-    if (!cgpre0) { cv_set_error("training workspace too small"); return 1; }
-    const int64_t Gn = np / 16;
-    // ---- forward on the tile kernels
+    if (!ghpre) { cv_set_error("training workspace too small"); return 1; }
+    // ---- forward
     if (m->packed_dirty && cv_pack_weights(m, st)) return 1;
     if (cv_tile_train_convs(m, x, n, tp[0], ta[0], tp[1], ta[1], tp[2], ta[2], st)) return 1;
     if (cv_tile_dense_fwd(m, 4, tp[2], th4, n, st)) return 1;
     if (cv_dropout_tm(m, th4, td4, tmask, n, backward ? drop4 : 0.0f, seed, step, cand0, st)) return 1;
     if (cv_tile_dense_fwd(m, 5, td4, th5, n, st)) return 1;
-    cv_tm_to_natural(td4, s.nb4, s.nb4 * 16, a.fc4, 1, n, d4, st);
-    cv_tm_to_natural(th5, s.nb5, s.nb5 * 16, a.fc5, 1, n, h5, st);
-    t_heads<<<nblk(n, 16), 256, 0, st>>>(d4, h5, a.fc4, a.fc5, P + o[10], P + o[11], P + o[12], P + o[13],
-                                         P + o[14], P + o[15], P + o[16], P + o[17], y, n,
-                                         backward ? ghpre : nullptr, m->loss_dev);
+    t_heads_tm<<<nblk(n, 16), 256, 0, st>>>(td4, th5, a.fc4, a.fc5, s.nb4, s.nb5, P + o[10], P + o[11], P + o[12],
+                                            P + o[13], P + o[14], P + o[15], P + o[16], P + o[17], y, n,
+                                            backward ? ghpre : nullptr, m->loss_dev);
     CV_HIP(hipGetLastError());
     if (!backward) return 0;
-    // natural copies the plain backward kernels read
-    cv_tm_to_natural(th4, s.nb4, s.nb4 * 16, a.fc4, 1, n, h4, st);
-    cv_tm_to_natural(tmask, s.nb4, s.nb4 * 16, a.fc4, 1, n, amask, st);
+    // ---- backward buffers (TM gradients, CM operand copies)
+    float *tg5 = sb.take(np * f5u), *tg5pre = sb.take(np * f5u), *tgd4 = sb.take(np * f4u), *tg4pre = sb.take(np * f4u);
+    float *tgpre[3], *tgin[3], *cgpre[3], *cp[3];
     for (int l = 0; l < 3; l++) {
-        cv_tm_to_natural(ta[l], s.hc[l] * 4 * s.ntile[l], s.ntile[l] * 16, a.cout[l], s.hc[l] * 4, n, act[l], st);
-        cv_tm_to_natural(tp[l], s.hp[l] * 4 * s.ntile[l], s.ntile[l] * 16, a.cout[l], s.hp[l] * 4, n, pool[l], st);
+        tgpre[l] = sb.take(np * fa[l]); tgin[l] = sb.take(np * fp[l]);
+        cgpre[l] = sb.take(np * fa[l]); cp[l] = sb.take(np * fp[l]);
     }
+    float *cd4 = sb.take(np * f4u), *cg4 = sb.take(np * f4u), *cg5 = sb.take(np * f5u);
+    float *tx = sb.take(np * 33 * 16), *cx = sb.take(np * 33 * 16);
+    if (!cx) { cv_set_error("training workspace too small"); return 1; }
     if (cv_pack_train_weights(m, st)) return 1;
-    // ---- backward
     const int NS = 32;
-    b_dense_wgrad<<<dim3(nblk((a.fc4 + 1) * 4, 256), NS), 256, 0, st>>>(d4, a.fc4, ghpre + 0, 16, n, a.fc4, 4, G + o[10], G + o[11]);
-    b_dense_wgrad<<<dim3(nblk((a.fc5 + 1) * 2, 256), NS), 256, 0, st>>>(h5, a.fc5, ghpre + 4, 16, n, a.fc5, 2, G + o[12], G + o[13]);
-    b_dense_wgrad<<<dim3(nblk((a.fc5 + 1) * 4, 256), NS), 256, 0, st>>>(h5, a.fc5, ghpre + 6, 16, n, a.fc5, 4, G + o[14], G + o[15]);
-    b_dense_wgrad<<<dim3(nblk((a.fc5 + 1) * 6, 256), NS), 256, 0, st>>>(h5, a.fc5, ghpre + 10, 16, n, a.fc5, 6, G + o[16], G + o[17]);
-    b_dense_dgrad<<<nblk(n * a.fc4, 256), 256, 0, st>>>(ghpre + 0, 16, P + o[10], n, a.fc4, 4, gd4, 0);
-    b_dense_dgrad<<<nblk(n * a.fc5, 256), 256, 0, st>>>(ghpre + 4, 16, P + o[12], n, a.fc5, 2, gh5, 0);
-    b_dense_dgrad<<<nblk(n * a.fc5, 256), 256, 0, st>>>(ghpre + 6, 16, P + o[14], n, a.fc5, 4, gh5, 1);
-    b_dense_dgrad<<<nblk(n * a.fc5, 256), 256, 0, st>>>(ghpre + 10, 16, P + o[16], n, a.fc5, 6, gh5, 1);
+    // heads: weight gradients (inputs read from TM), data gradients written to TM
+    b_head_wgrad_tm<<<dim3(nblk((a.fc4 + 1) * 4, 256), NS), 256, 0, st>>>(td4, s.nb4, ghpre, 0, n, a.fc4, 4, G + o[10], G + o[11]);
+    b_head_wgrad_tm<<<dim3(nblk((a.fc5 + 1) * 2, 256), NS), 256, 0, st>>>(th5, s.nb5, ghpre, 4, n, a.fc5, 2, G + o[12], G + o[13]);
+    b_head_wgrad_tm<<<dim3(nblk((a.fc5 + 1) * 4, 256), NS), 256, 0, st>>>(th5, s.nb5, ghpre, 6, n, a.fc5, 4, G + o[14], G + o[15]);
+    b_head_wgrad_tm<<<dim3(nblk((a.fc5 + 1) * 6, 256), NS), 256, 0, st>>>(th5, s.nb5, ghpre, 10, n, a.fc5, 6, G + o[16], G + o[17]);
+    b_head_dgrad_tm<<<nblk(Gn * s.nb5 * 256, 256), 256, 0, st>>>(ghpre, P + o[10], P + o[12], P + o[14], P + o[16], a.fc5,
+                                                               s.nb5, n, Gn, 0, tg5);
     // fc5
-    b_selu_act<<<nblk(n * a.fc5, 256), 256, 0, st>>>(gh5, h5, nullptr, gfc5pre, n * a.fc5);
-    // fc5 weight gradient on the matrix cores (candidate contraction), bias plain
-    cv_natural_to_tm(gfc5pre, s.nb5, s.nb5 * 16, a.fc5, 1, n, tg5, st);
+    b_selu_tm<<<nblk(np * f5u / 4, 256), 256, 0, st>>>((const tf4 *)tg5, (const tf4 *)th5, nullptr, (tf4 *)tg5pre, np * f5u / 4);
     cv_tm_to_cm(td4, cd4, Gn * s.nb4, st);
-    cv_tm_to_cm(tg5, cg5, Gn * s.nb5, st);
+    cv_tm_to_cm(tg5pre, cg5, Gn * s.nb5, st);
     if (cv_tile_dense_wgrad(m, 5, cd4, cg5, n, st)) return 1;
-    b_dense_dgrad<<<nblk(n * a.fc4, 256), 256, 0, st>>>(gfc5pre, a.fc5, P + o[8], n, a.fc4, a.fc5, gd4, 1);
+    if (cv_tile_fc5_dgrad(m, tg5pre, tgd4, n, st)) return 1;
+    b_head_dgrad_tm<<<nblk(Gn * s.nb4 * 256, 256), 256, 0, st>>>(ghpre, P + o[10], P + o[12], P + o[14], P + o[16], a.fc4,
+                                                               s.nb4, n, Gn, 1, tgd4);
     // dropout4 + selu' (h4 is the SELU output before dropout)
-    b_selu_act<<<nblk(n * a.fc4, 256), 256, 0, st>>>(gd4, h4, amask, gfc4pre, n * a.fc4);
-    // fc4: weight and data gradients on the tile kernels
-    cv_natural_to_tm(gfc4pre, s.nb4, s.nb4 * 16, a.fc4, 1, n, tg4, st);
+    b_selu_tm<<<nblk(np * f4u / 4, 256), 256, 0, st>>>((const tf4 *)tgd4, (const tf4 *)th4, (const tf4 *)tmask, (tf4 *)tg4pre, np * f4u / 4);
+    // fc4
     cv_tm_to_cm(tp[2], cp[2], Gn * s.kb4, st);
-    cv_tm_to_cm(tg4, cg4, Gn * s.nb4, st);
+    cv_tm_to_cm(tg4pre, cg4, Gn * s.nb4, st);
     if (cv_tile_dense_wgrad(m, 4, cp[2], cg4, n, st)) return 1;
-    if (cv_tile_fc4_dgrad(m, tg4, tgin[2], n, st)) return 1;
-    cv_tm_to_natural(tgin[2], s.hp[2] * 4 * s.ntile[2], s.ntile[2] * 16, a.cout[2], s.hp[2] * 4, n, gpool[2], st);
+    if (cv_tile_fc4_dgrad(m, tg4pre, tgin[2], n, st)) return 1;
     // conv stack
     for (int l = 2; l >= 0; l--) {
-        int H = s.hc[l], C = a.cout[l];
-        b_pool_selu_act<<<nblk(n * H * 4 * C, 256), 256, 0, st>>>(gpool[l], act[l], gpre[l], n, H, C, a.pool[l]);
+        const int H = s.hc[l], NT = s.ntile[l];
+        b_pool_selu_tm<<<nblk(Gn * 4 * NT * 64, 256), 256, 0, st>>>((const tf4 *)tgin[l], (const tf4 *)ta[l], (tf4 *)tgpre[l], Gn, H, NT, a.pool[l]);
+        cv_tm_to_cm(tgpre[l], cgpre[l], Gn * H * 4 * NT, st);
         if (l == 0) {        // first layer: X viewed as [33][16] fragments
             cv_natural_to_tm(x, 33, 16, 16, 33, n, tx, st);
             cv_tm_to_cm(tx, cx, Gn * 33, st);
-            cv_natural_to_tm(gpre[0], H * 4 * s.ntile[0], s.ntile[0] * 16, C, H * 4, n, tgpre0, st);
-            cv_tm_to_cm(tgpre0, cgpre0, Gn * H * 4 * s.ntile[0], st);
-            if (cv_tile_conv1_wgrad(m, cx, cgpre0, n, st)) return 1;
+            if (cv_tile_conv1_wgrad(m, cx, cgpre[0], n, st)) return 1;
         } else {
-            cv_natural_to_tm(gpre[l], H * 4 * s.ntile[l], s.ntile[l] * 16, C, H * 4, n, tgpre[l], st);
-            cv_tm_to_cm(tgpre[l], cgpre[l], Gn * H * 4 * s.ntile[l], st);
             cv_tm_to_cm(tp[l - 1], cp[l - 1], Gn * s.hp[l - 1] * 4 * s.ntile[l - 1], st);
             if (cv_tile_conv_wgrad(m, l, cp[l - 1], cgpre[l], n, st)) return 1;
             if (cv_tile_conv_dgrad(m, l, tgpre[l], tgin[l - 1], n, st)) return 1;
-            cv_tm_to_natural(tgin[l - 1], s.hp[l - 1] * 4 * s.ntile[l - 1], s.ntile[l - 1] * 16, a.cout[l - 1],
-                             s.hp[l - 1] * 4, n, gpool[l - 1], st);
         }
     }
     CV_HIP(hipGetLastError());
