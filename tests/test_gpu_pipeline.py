@@ -160,3 +160,31 @@ def test_train_command_line_on_a_small_bin(oracle, tmp_path, monkeypatch):
     args.chkpnt_fn = "%s-%06d" % (prefix, 3)
     train.Run(args)
     assert os.path.exists("%s-%06d.index" % (prefix, 5)) and not os.path.exists("%s-%06d.index" % (prefix, 6))
+
+
+def test_evaluate_report_on_a_small_bin(oracle, tmp_path, caplog):
+    """evaluate.Run: predictions over a .bin and the confusion-matrix report (evaluate.py:37-107)"""
+    import logging
+    from clairvoyante_amd import evaluate, synth, utils_v2
+    n = 1700
+    xt, cls, rf, alt, il = synth.make_candidates(n, seed=31, return_class=True)
+    y = synth.make_labels(cls, rf, alt, il).numpy().astype(np.float64); x = xt.numpy()
+    XC = [utils_v2.pack_array(x[s:s + 500]) for s in range(0, n + 1, 500)]
+    YC = [utils_v2.pack_array(y[s:s + 500]) for s in range(0, n + 1, 500)]
+    binfn = str(tmp_path / "e.bin")
+    with open(binfn, "wb") as fh:
+        pickle.dump(n, fh); pickle.dump(XC, fh); pickle.dump(YC, fh); pickle.dump([], fh)
+    P = common.bench_params(oracle, "slim")
+    m = _model("slim"); m.setParameters(P)
+    prefix = str(tmp_path / "model"); m.saveParameters(prefix); m.close()
+    args = types.SimpleNamespace(bin_fn=binfn, tensor_fn=None, var_fn=None, bed_fn=None, chkpnt_fn=prefix,
+                                 v2=False, v3=True, slim=True)
+    with caplog.at_level(logging.INFO):
+        evaluate.Run(args)
+    text = caplog.text
+    o = oracle.predict("slim", P, x)
+    order = np.argsort(o[:, 0:4], axis=1, kind="stable")[:, ::-1]
+    truth = np.argmax(y[:, 0:4], axis=1)
+    top1 = int(np.sum(order[:, 0] == truth))
+    assert "Dataset size: %d" % n in text
+    assert "all/top1/top2/top1p/top2p: %d/%d/" % (n, top1) in text

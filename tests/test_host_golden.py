@@ -118,3 +118,21 @@ def test_blosc_roundtrip_and_edge_sizes():
     a = rng.standard_normal((500, 33, 4, 4)).astype(np.float32).round()
     assert np.array_equal(utils_v2.unpack_array(utils_v2.pack_array(a)), a)
     assert len(utils_v2.pack_array(a)) < a.nbytes // 2
+
+
+def test_tensor2bin_writes_the_reference_layout(tmp_path):
+    """tensor2Bin -> .bin -> LoadBin -> DecompressArray reproduces the reference's arrays"""
+    from clairvoyante_amd import tensor2Bin, utils_v2
+    d = np.load(os.path.join(G, "trainarray.npz"))
+    out = str(tmp_path / "t.bin")
+    args = types.SimpleNamespace(tensor_fn=os.path.join(G, "trainarray_tensor.txt.gz"),
+                                 var_fn=os.path.join(G, "trainarray_var.txt.gz"),
+                                 bed_fn=os.path.join(G, "trainarray.bed.gz"), bin_fn=out)
+    random.seed(1234)
+    tensor2Bin.Convert(args, utils_v2)
+    with open(out, "rb") as fh:
+        assert pickle.load(fh) == int(d["total"])          # first pickle is the plain int total
+    total, XC, YC, PC = utils_v2.LoadBin(out)
+    X, _, _ = utils_v2.DecompressArray(XC, 0, total, total)
+    Y, _, _ = utils_v2.DecompressArray(YC, 0, total, total)
+    assert np.array_equal(X, d["X"]) and np.array_equal(Y, d["Y"])
