@@ -32,17 +32,20 @@ PEAK_HBM_GBS = 8000.0
 
 
 def cpu_baseline(arch, P, x_sample, target_s=12.0):
-    """The oracle (C restatement, OpenMP) timed on this box's host cores on a bounded sample."""
+    """The oracle (C restatement, OpenMP) timed on this box's host cores on a bounded sample:
+    whole passes over the sample until ~target_s seconds of CPU work have been done."""
     from oracle import cv_oracle as O
     cores = os.cpu_count() or 1
-    probe = x_sample[:8192]
-    t0 = time.time(); O.predict(arch, P, probe, nthreads=cores); dt = time.time() - t0
-    rate = probe.shape[0] / max(dt, 1e-6)
-    n = int(min(x_sample.shape[0], max(1024, rate * target_s)))
-    t0 = time.time(); out = O.predict(arch, P, x_sample[:n], nthreads=cores); dt = time.time() - t0
-    return {"value": n / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
-            "sample": "first %d candidates of the timed set, oracle/cv_oracle.c, %d OpenMP threads, %.1f s"
-                      % (n, cores, dt)}, out, n
+    O.predict(arch, P, x_sample[:4096], nthreads=cores)            # warm-up (thread pool, page faults)
+    t0 = time.time(); out = O.predict(arch, P, x_sample, nthreads=cores); dt = time.time() - t0
+    passes, total = 1, dt
+    while total < target_s and passes < 64:
+        t0 = time.time(); O.predict(arch, P, x_sample, nthreads=cores); total += time.time() - t0
+        passes += 1
+    n = x_sample.shape[0]
+    return {"value": n * passes / total, "unit": "candidates/s", "cores": cores, "kind": "port",
+            "sample": "%d pass(es) over the first %d candidates of the timed set, oracle/cv_oracle.c, "
+                      "%d OpenMP threads, %.1f s" % (passes, n, cores, total)}, out, n
 
 
 def main():

@@ -12,7 +12,8 @@
  * imported in this image, and the reference ships no tests / golden vectors
  * for this path.  The restatement is pinned instead
  *   (1) against an independently written torch-CPU formulation of the same
- *       graph (tests/golden/make_golden.py, float64 + float32), and
+ *       graph (tests/torch_ref.py; fixtures tests/golden/forward_*.npz written by
+ *       tests/golden/make_golden_forward.py), and
  *   (2) for the host logic (VCF Output, GetTensor, DecompressArray) against
  *       the reference's own Python imported in the build container.
  *
@@ -333,23 +334,83 @@ static void forward_one(const cvo_arch *a, const cvo_layout *L, const float *con
 
 /* ---- public: inference --------------------------------------------------- */
 
+/* dense pre-activation for a block of candidates: the weight row w[k][:] is loaded once per
+ * block instead of once per candidate (fc4 is 6.2 MB); each accumulator is still the canonical
+ * ascending-k fmaf chain, so the result is bit-identical to dense_pre. */
+#define CVO_BLK 8
+static void dense_pre_block(const float *const *xs, int nb, int K, const float *wt, const float *bias, int N,
+                            float *const *ys)
+{
+    float acc[CVO_BLK][512];
+    for (int b = 0; b < nb; b++)
+        for (int n = 0; n < N; n++) acc[b][n] = 0.0f;
+    for (int k = 0; k < K; k++) {
+        const float *wr = wt + (size_t)k * N;
+        for (int b = 0; b < nb; b++) {
+            const float xv = xs[b][k];
+            float *ab = acc[b];
+            for (int n = 0; n < N; n++) ab[n] = __builtin_fmaf(xv, wr[n], ab[n]);
+        }
+    }
+    for (int b = 0; b < nb; b++)
+        for (int n = 0; n < N; n++) ys[b][n] = acc[b][n] + bias[n];
+}
+
 /* out16[n][16] = base(4) | zygosity(2) | type(4) | length(6)  (clairvoyante_v3.py:257-266) */
 void cvo_predict(const cvo_arch *a, const float *const *P, const float *x, int64_t n,
                  float *out16, int nthreads)
 {
     cvo_layout L; cvo_make_layout(a, &L);
+    cvo_shape s; cvo_shapes(a, &s);
+    static const int hn[4] = {4, 2, 4, 6};
+    static const int ho[4] = {0, 4, 6, 10};
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
+    const int64_t nblk = (n + CVO_BLK - 1) / CVO_BLK;
 #pragma omp parallel
     {
-        float *rec = (float *)malloc(sizeof(float) * L.total);
-#pragma omp for schedule(static)
-        for (int64_t i = 0; i < n; i++) {
-            forward_one(a, &L, P, x + (size_t)i * CVO_H * CVO_W * CVO_CIN, rec, NULL, 0.0f);
-            memcpy(out16 + (size_t)i * CVO_NOUT, rec + L.out, sizeof(float) * CVO_NOUT);
+        float *recs = (float *)malloc(sizeof(float) * L.total * CVO_BLK);
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t bi = 0; bi < nblk; bi++) {
+            const int64_t i0 = bi * CVO_BLK;
+            const int nb = (int)(n - i0 < CVO_BLK ? n - i0 : CVO_BLK);
+            const float *xs[CVO_BLK]; float *ys[CVO_BLK];
+            for (int b = 0; b < nb; b++) {          /* conv stack per candidate */
+                float *rec = recs + (size_t)b * L.total;
+                const float *in = x + (size_t)(i0 + b) * CVO_H * CVO_W * CVO_CIN;
+                for (int l = 0; l < 3; l++) {
+                    int cnt = s.hc[l] * CVO_W * a->cout[l];
+                    conv_pre(in, s.hc[l], s.cin[l], P[2 * l], P[2 * l + 1], a->kh[l], a->cout[l], rec + L.pre[l]);
+                    selu_inplace_copy(rec + L.pre[l], rec + L.act[l], cnt);
+                    pool_h(rec + L.act[l], s.hc[l], a->cout[l], a->pool[l], rec + L.pooled[l]);
+                    in = rec + L.pooled[l];
+                }
+            }
+            for (int b = 0; b < nb; b++) { xs[b] = recs + (size_t)b * L.total + L.pooled[2]; ys[b] = recs + (size_t)b * L.total + L.fc4pre; }
+            dense_pre_block(xs, nb, s.flat, P[6], P[7], a->fc4, ys);
+            for (int b = 0; b < nb; b++) {
+                float *rec = recs + (size_t)b * L.total;
+                selu_inplace_copy(rec + L.fc4pre, rec + L.fc4, a->fc4);
+                memcpy(rec + L.d4, rec + L.fc4, sizeof(float) * a->fc4);     /* inference: dropout = identity */
+                xs[b] = rec + L.d4; ys[b] = rec + L.fc5pre;
+            }
+            dense_pre_block(xs, nb, a->fc4, P[8], P[9], a->fc5, ys);
+            for (int b = 0; b < nb; b++) {
+                float *rec = recs + (size_t)b * L.total;
+                float *o = out16 + (size_t)(i0 + b) * CVO_NOUT;
+                selu_inplace_copy(rec + L.fc5pre, rec + L.fc5, a->fc5);
+                dense_pre(rec + L.d4, a->fc4, P[10], P[11], 4, rec + L.hpre[0]);
+                for (int k = 0; k < 4; k++) o[k] = cvo_sigmoid(rec[L.hpre[0] + k]);
+                for (int hd = 1; hd < 4; hd++) {
+                    float lg[6];
+                    dense_pre(rec + L.fc5, a->fc5, P[10 + 2 * hd], P[11 + 2 * hd], hn[hd], rec + L.hpre[hd]);
+                    for (int k = 0; k < hn[hd]; k++) lg[k] = cvo_selu(rec[L.hpre[hd] + k]) + 1e-10f;
+                    cvo_softmax(lg, hn[hd], o + ho[hd]);
+                }
+            }
         }
-        free(rec);
+        free(recs);
     }
 }
 
