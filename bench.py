@@ -31,11 +31,29 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md (f32-in
 PEAK_HBM_GBS = 8000.0
 
 
+def usable_cores():
+    """host threads this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box reports 256 logical CPUs under a 16-CPU quota; oversubscribing it throttles)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(round(float(quota) / float(period)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(round(q / p_))))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(arch, P, x_sample, target_s=12.0):
     """The oracle (C restatement, OpenMP) timed on this box's host cores on a bounded sample:
     whole passes over the sample until ~target_s seconds of CPU work have been done."""
     from oracle import cv_oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     O.predict(arch, P, x_sample[:4096], nthreads=cores)            # warm-up (thread pool, page faults)
     t0 = time.time(); out = O.predict(arch, P, x_sample, nthreads=cores); dt = time.time() - t0
     passes, total = 1, dt
