@@ -66,6 +66,56 @@ def cpu_baseline(arch, P, x_sample, target_s=12.0):
                       "%d OpenMP threads, %.1f s" % (passes, n, cores, total)}, out, n
 
 
+def train_main(args):
+    """--mode train: a step = one optimizer step (forward, backward, all-reduce, Adam) on a global batch of
+    param.trainBatchSize = 10 000 synthetic labelled tensors (strong scaling: the batch is split)."""
+    import torch
+    import torch.distributed as dist
+    from clairvoyante_amd import clairvoyante_v3, clairvoyante_v3_slim, parallel, param, synth
+    rank, ws, local = parallel.init_from_env()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    m = clairvoyante_v3.Clairvoyante() if args.arch == "full" else clairvoyante_v3_slim.Clairvoyante()
+    m._seed_rng.seed(1234)
+    m.init()
+    parallel.broadcast_parameters(m)
+    gb = param.trainBatchSize
+    lo, hi = parallel.shard_range(gb, rank, ws)
+    xt, cls, rf, alt, il = synth.make_candidates(gb, seed=synth.BASE_SEED, device=dev, return_class=True)
+    y = synth.make_labels(cls, rf, alt, il)[lo:hi].contiguous(); x = xt[lo:hi].contiguous()
+    use_dist = dist.is_initialized()
+    steps = args.steps if args.steps != 64 else 20
+    for _ in range(args.warmup):
+        m.train(x, y)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _s = m.train(x, y)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "training candidate tensors/sec", "value": steps * gb / dt, "unit": "candidates/s",
+                          "n_gpus": ws, "steps": steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic",
+                          "config": {"workload": "v3 %s training, Adam step on a global batch of %d synthetic labelled "
+                                                 "[33,4,4] tensors, dropout 0.5, lambda 1e-3" % (args.arch, gb),
+                                     "arch": args.arch, "global_batch": gb, "parallelism": "dp%d" % ws},
+                          "final_loss": float(loss)}), flush=True)
+    m.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +124,10 @@ def main():
     ap.add_argument("--arch", default="full", choices=["full", "slim"])
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer (default, the headline metric) or train: Adam steps on the reference's global "
+                         "batch of 10 000 split over the ranks, one RCCL gradient all-reduce per step "
+                         "(BASELINE.json configs[3])")
     args = ap.parse_args()
 
     import numpy as np
@@ -83,6 +137,8 @@ def main():
     from oracle import cv_oracle as O
     from clairvoyante_amd import clairvoyante_v3, clairvoyante_v3_slim, parallel, synth, _lib
 
+    if args.mode == "train":
+        return train_main(args)
     rank, ws, local = parallel.init_from_env()
     if ws != args.gpus:
         if rank == 0:
