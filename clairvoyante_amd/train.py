@@ -132,15 +132,55 @@ class _Job(Thread):
             raise self.err
 
 
+def load_dataset(args, utils):
+    """(total, XC, YC, posC) from --bin_fn or from --tensor_fn/--var_fn/--bed_fn (train.py:39-49)"""
+    if args.bin_fn is not None:
+        return utils.LoadBin(args.bin_fn) if hasattr(utils, "LoadBin") else _load_bin(args.bin_fn)
+    return utils.GetTrainingArray(args.tensor_fn, args.var_fn, args.bed_fn)
+
+
+def run_epoch(stream, m, rank, ws, writer, epoch, validationStart):
+    """One pass over the data set (train.py:83-123): every batch that ends strictly before
+    validationStart is trained, the others are evaluated; the next batch is decompressed while the
+    GPU works; the batch that reaches the end of the data set is evaluated synchronously.
+    Returns (sum of training losses, sum of validation losses)."""
+    from . import parallel
+
+    def mine(a):
+        return _shard(a, rank, ws)
+
+    def reduced(v):
+        return parallel.allreduce_scalar(float(v), m) if ws > 1 else float(v)
+
+    train_sum = 0
+    val_sum = 0
+    stream.rewind()
+    X, Y, start, count, last = stream.fetch(param.trainBatchSize)
+    while True:
+        training = start + count < validationStart
+        job = _Job(m.trainNoRT if training else m.getLossNoRT, mine(X), mine(Y))
+        job.start()
+        nxt = stream.fetch(stream.next_size())
+        job.finish()
+        if training:
+            train_sum += m.trainLossRTVal
+            if writer is not None:
+                writer.add_summary(m.trainSummaryRTVal, epoch)
+        else:
+            val_sum += reduced(m.getLossLossRTVal)
+        X, Y, start, count, last = nxt
+        if last:
+            break
+    val_sum += reduced(m.getLoss(mine(X), mine(Y)))
+    return train_sum, val_sum
+
+
 def TrainAll(args, m, utils):
     """train.py:37-218"""
     from . import parallel
     rank, ws = parallel.world()
     logging.info("Loading the training dataset ...")
-    if args.bin_fn is not None:
-        total, XC, YC, _posC = utils.LoadBin(args.bin_fn) if hasattr(utils, "LoadBin") else _load_bin(args.bin_fn)
-    else:
-        total, XC, YC, _posC = utils.GetTrainingArray(args.tensor_fn, args.var_fn, args.bed_fn)
+    total, XC, YC, _posC = load_dataset(args, utils)
     logging.info("The size of training dataset: {}".format(total))
 
     writer = m.summaryFileWriter(args.olog_dir) if (args.olog_dir is not None and rank == 0) else None
@@ -159,35 +199,9 @@ def TrainAll(args, m, utils):
     epoch = 1 if args.chkpnt_fn is None else int(args.chkpnt_fn[-param.parameterOutputPlaceHolder:]) + 1
     stream = _BatchStream(utils, XC, YC, total, validationStart)
 
-    def mine(a):
-        return _shard(a, rank, ws)
-
-    def reduced(v):
-        return parallel.allreduce_scalar(float(v), m) if ws > 1 else float(v)
-
     while epoch < param.maxEpoch:
         t_epoch = time.time()
-        train_sum = 0
-        val_sum = 0
-        stream.rewind()
-        X, Y, start, count, last = stream.fetch(param.trainBatchSize)
-        while True:
-            # the batch is trained iff it ends strictly before validationStart (train.py:88-91)
-            training = start + count < validationStart
-            job = _Job(m.trainNoRT if training else m.getLossNoRT, mine(X), mine(Y))
-            job.start()
-            nxt = stream.fetch(stream.next_size())         # decompress while the GPU works
-            job.finish()
-            if training:
-                train_sum += m.trainLossRTVal
-                if writer is not None:
-                    writer.add_summary(m.trainSummaryRTVal, epoch)
-            else:
-                val_sum += reduced(m.getLossLossRTVal)
-            X, Y, start, count, last = nxt
-            if last:
-                break
-        val_sum += reduced(m.getLoss(mine(X), mine(Y)))    # the final batch, synchronously (train.py:122)
+        train_sum, val_sum = run_epoch(stream, m, rank, ws, writer, epoch, validationStart)
         logging.info(" ".join([str(epoch), "Training loss:", str(train_sum / trainingTotal), "Validation loss: ",
                                str(val_sum / numValItems)]))
         logging.info("Epoch time elapsed: %.2f s" % (time.time() - t_epoch))
@@ -210,6 +224,12 @@ def TrainAll(args, m, utils):
     logging.info("Best validation loss at batch: %d" % history[0][1])
 
     logging.info("Testing on the training and validation dataset ...")
+    PredictAndReport(m, utils, total, XC, YC)
+
+
+def PredictAndReport(m, utils, total, XC, YC):
+    """train.py:163-218 / evaluate.py:51-107: predict the whole set in batches of 1 000 (the first
+    batch's end flag is not looked at), then the accuracy / confusion-matrix report"""
     t_pred = time.time()
     step = param.predictBatchSize
     outs = [[], [], [], []]
@@ -266,12 +286,29 @@ _SWITCHES = (("--v3", True, "Use Clairvoyante version 3"), ("--v2", False, "Use 
              ("--slim", False, "Train using the slim version of Clairvoyante, optional"))
 
 
-def main():
-    parser = argparse.ArgumentParser(description="Train Clairvoyante")
-    for flag, typ, default, text in _CLI:
-        parser.add_argument(flag, type=typ, default=default, help=text)
-    for flag, default, text in _SWITCHES:
+def build_parser(description, cli=_CLI, switches=_SWITCHES):
+    parser = argparse.ArgumentParser(description=description)
+    for spec in cli:
+        flag, typ, default, text = spec[:4]
+        parser.add_argument(flag, type=typ, default=default, help=text, **(spec[4] if len(spec) > 4 else {}))
+    for flag, default, text in switches:
         parser.add_argument(flag, type=param.str2bool, nargs='?', const=True, default=default, help=text)
+    return parser
+
+
+def pick_model(args):
+    """the reference's --v2 / --v3 / --slim switch (train.py:16-27); v2 topologies are not built"""
+    if args.v2:
+        sys.exit("Clairvoyante v2 topologies are not part of this build (v3 / v3 slim only)")
+    if args.slim:
+        from . import clairvoyante_v3_slim as cv
+    else:
+        from . import clairvoyante_v3 as cv
+    return cv
+
+
+def main():
+    parser = build_parser("Train Clairvoyante")
     args = parser.parse_args()
     if not sys.argv[1:]:
         parser.print_help()

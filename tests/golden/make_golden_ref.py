@@ -41,9 +41,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference/clairvoyante"
 
 
-def prepare_reference():
+def prepare_reference(extra=()):
     tmp = tempfile.mkdtemp(prefix="cv_ref23_")
-    for f in ("callVar.py", "utils_v2.py", "param.py", "tensor2Bin.py", "train.py"):
+    for f in ("callVar.py", "utils_v2.py", "param.py", "tensor2Bin.py", "train.py") + tuple(extra):
         shutil.copy(os.path.join(REF, f), tmp)
     subprocess.check_call(["/opt/conda/bin/2to3", "-nw"] + [os.path.join(tmp, f) for f in os.listdir(tmp)],
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -52,9 +52,10 @@ def prepare_reference():
     src = open(up).read().replace("stdout=subprocess.PIPE, bufsize=8388608)",
                                   "stdout=subprocess.PIPE, bufsize=8388608, universal_newlines=True)")
     open(up, "w").write(src)
-    tp = os.path.join(tmp, "train.py")      # np.int was removed from NumPy 1.24 (reference era: alias of int)
-    tsrc = open(tp).read().replace("dtype=np.int )", "dtype=int)").replace("dtype=np.int)", "dtype=int)")
-    open(tp, "w").write(tsrc)
+    for f in ("train.py",) + tuple(extra):  # np.int was removed from NumPy 1.24 (reference era: alias of int)
+        tp = os.path.join(tmp, f)
+        tsrc = open(tp).read().replace("dtype=np.int )", "dtype=int)").replace("dtype=np.int)", "dtype=int)")
+        open(tp, "w").write(tsrc)
     # shim modules the image lacks (python-blosc) / changed API (intervaltree 3: search -> at)
     blosc = types.ModuleType("blosc")
     lib = ctypes.CDLL("/opt/conda/lib/libblosc.so.1")
