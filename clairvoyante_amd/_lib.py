@@ -67,6 +67,21 @@ _SIGS = {
     "cv_blosc_compress_lz4": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
                                              ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     "cv_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int64]),
+    # pileup front end
+    "cv_pileup_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_void_p)]),
+    "cv_pileup_destroy": (None, [ctypes.c_void_p]),
+    "cv_pileup_set_reference": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64]),
+    "cv_pileup_set_candidates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
+    "cv_pileup_add_sam": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "cv_pileup_pending": (ctypes.c_int64, [ctypes.c_void_p]),
+    "cv_pileup_flush": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "cv_pileup_finish": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_int, ctypes.c_void_p]),
+    "cv_pileup_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64)]),
+    "cv_format_tensor_row": (ctypes.c_int64, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64,
+                                              ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
 }
 
 EXPORTS = sorted(_SIGS)

@@ -1,0 +1,104 @@
+"""Host handle of the on-GPU pileup (include/clairvoyante_amd.h, "pileup front end"): SAM text in,
+[n,33,4,4] count tensors in HBM out.  Behaviour of /root/reference/dataPrepScripts/CreateTensor.py
+(OutputAlnTensor :93-246, GenerateTensor :23-54); see csrc/cv_pileup.hip for the decomposition.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+FLANK = 16
+WIDTH = 2 * FLANK + 1
+FLUSH_COLUMNS = 1 << 26         # queue at most this many alignment columns on the host before a scatter launch
+
+
+class Pileup(object):
+    def __init__(self, device=None, minMQ=0, dcov=250, considerleftedge=True):
+        import torch
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.CvError("the pileup kernels need an MI355X (no GPU visible); there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.h = ctypes.c_void_p()
+        _lib.check(self.lib.cv_pileup_create(self.device.index, int(minMQ), int(dcov), int(bool(considerleftedge)),
+                                             ctypes.byref(self.h)))
+        self.n = 0
+        self.centers = np.zeros(0, dtype=np.int64)
+        self._tail = b""
+        self.reads_kept = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cv_pileup_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _stream(self):
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_reference(self, seq, first_pos0=0):
+        """seq: the bases `samtools faidx` printed (str/bytes); seq[0] is 0-based position first_pos0"""
+        b = seq.encode() if isinstance(seq, str) else bytes(seq)
+        _lib.check(self.lib.cv_pileup_set_reference(self.h, b, len(b), int(first_pos0)))
+
+    def set_candidates(self, centers):
+        """1-based candidate positions; sorted and de-duplicated here"""
+        c = np.unique(np.asarray(centers, dtype=np.int64))
+        self.centers = np.ascontiguousarray(c)
+        self.n = len(c)
+        _lib.check(self.lib.cv_pileup_set_candidates(self.h, self.centers.ctypes.data_as(ctypes.c_void_p), self.n))
+
+    def add_sam(self, chunk, final=False):
+        """feed SAM text (bytes) in arbitrary chunks; an incomplete last line is kept for the next call"""
+        data = self._tail + chunk if self._tail else chunk
+        consumed = ctypes.c_int64(0)
+        kept = ctypes.c_int64(0)
+        _lib.check(self.lib.cv_pileup_add_sam(self.h, data, len(data), int(final), ctypes.byref(consumed),
+                                              ctypes.byref(kept)))
+        self._tail = data[consumed.value:]
+        self.reads_kept += kept.value
+        if self.lib.cv_pileup_pending(self.h) >= FLUSH_COLUMNS:
+            _lib.check(self.lib.cv_pileup_flush(self.h, self._stream()))
+        return kept.value
+
+    def finish(self, subtract=False, want_tensors=True):
+        """-> (tensors [n,33,4,4] fp32 on the device, depth [n] int32, touched [n] bool)"""
+        import torch
+        if self._tail:
+            self.add_sam(b"", final=True)
+        t = torch.empty((self.n, WIDTH, 4, 4), dtype=torch.float32, device=self.device) if want_tensors else None
+        d = torch.empty((self.n,), dtype=torch.int32, device=self.device)
+        u = torch.empty((self.n,), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.cv_pileup_finish(self.h, ctypes.c_void_p(t.data_ptr()) if want_tensors and self.n else None,
+                                             ctypes.c_void_p(d.data_ptr()) if self.n else None,
+                                             ctypes.c_void_p(u.data_ptr()) if self.n else None, int(bool(subtract)),
+                                             self._stream()))
+        return t, d, u.bool()
+
+    def stats(self):
+        ms = (ctypes.c_float * 2)()
+        cnt = (ctypes.c_int64 * 3)()
+        _lib.check(self.lib.cv_pileup_stats(self.h, ms, cnt))
+        return {"scatter_ms": ms[0], "finalize_ms": ms[1], "columns": cnt[0], "segments": cnt[1], "launches": cnt[2]}
+
+
+def format_rows(ctg, centers, ref_seq, ref_shift, counts):
+    """CreateTensor.py:50-52 text rows for host arrays: centers [k] (1-based), counts [k,33,4,4] raw.
+    ref_shift = refStart-1 (0 when the whole contig was loaded)."""
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(64 + len(ctg) + WIDTH + WIDTH * 16 * 16)
+    cb = ctg.encode()
+    rb = ref_seq.encode() if isinstance(ref_seq, str) else ref_seq
+    counts = np.ascontiguousarray(counts, dtype=np.float32)
+    rows = []
+    for k, c in enumerate(centers):
+        new_pos = int(c) - ref_shift
+        seq = rb[new_pos - (FLANK + 1):new_pos + FLANK]
+        n = lib.cv_format_tensor_row(cb, int(c), seq, len(seq), counts[k].ctypes.data_as(ctypes.c_void_p), buf, len(buf))
+        if n < 0:
+            raise _lib.CvError("cv_format_tensor_row: buffer too small")
+        rows.append(buf.raw[:n])
+    return rows

@@ -163,6 +163,60 @@ int cv_blosc_compress_lz4(const uint8_t *src, int64_t n, int typesize, uint8_t *
  * bundle written by saveParameters and read by restoreParameters (v3.py:243-251).        */
 uint32_t cv_crc32c(uint32_t crc, const void *data, int64_t n);
 
+/* ---- pileup front end: alignments -> count tensors -------------------------
+ * Replaces the body of dataPrepScripts/CreateTensor.py: the per-read CIGAR walk of
+ * OutputAlnTensor (:140-246) and the per-candidate accumulation of GenerateTensor (:23-54).
+ * The host parses SAM text (what `samtools view -F 2308` prints, :128-130) into alignment
+ * segments; a scatter kernel adds every alignment column to the counters of the candidates whose
+ * 33-position window holds it; a finalize kernel writes the [n,33,4,4] tensors in HBM, either raw
+ * (what CreateTensor.py prints with "%0.1f", :52) or already with matrices 1..3 minus matrix 0
+ * (what utils_v2.GetTensor hands to the network, utils_v2.py:46) so they can feed cv_forward
+ * without the text round trip.  Not modelled: the reference's 10 000 000-column buffering cap
+ * (`availableSlots`, :96) which silently drops columns in extremely deep regions.             */
+typedef struct cv_pileup cv_pileup;
+
+/* min_mq: --minMQ (:153); dcov: --dcov, reads beyond that many sharing one POS are skipped
+ * (:165-172); consider_left_edge: --considerleftedge (:63-71).                                 */
+int cv_pileup_create(int device, int min_mq, int dcov, int consider_left_edge, cv_pileup **out);
+void cv_pileup_destroy(cv_pileup *p);
+
+/* Reference bases as `samtools faidx` printed them (case and N kept: only upper-case ACGT count,
+ * :28-31).  seq[0] is the 0-based contig position `first_pos0` (refStart-1, :99-104).  Copied.  */
+int cv_pileup_set_reference(cv_pileup *p, const char *seq, int64_t len, int64_t first_pos0);
+
+/* Candidate centres: 1-based positions, strictly ascending (GetCandidate :56-62 after its contig /
+ * range filter).  Allocates and zeroes the device counters.  Copied.                           */
+int cv_pileup_set_candidates(cv_pileup *p, const int64_t *centers, int64_t n);
+
+/* Parse whole SAM lines from text[0..nbytes); *consumed = bytes up to the last complete line (feed
+ * the rest again with the next chunk; pass final != 0 to take an unterminated last line too).
+ * Header lines, reads below min_mq and reads beyond dcov are dropped exactly like :146-172; the
+ * POS / depth-cap state carries over between calls.  *kept = reads queued by this call.          */
+int cv_pileup_add_sam(cv_pileup *p, const char *text, int64_t nbytes, int final, int64_t *consumed,
+                      int64_t *kept);
+
+/* Bases queued on the host and not yet scattered (callers flush when this gets large).          */
+int64_t cv_pileup_pending(const cv_pileup *p);
+
+/* Upload the queued segments and run the scatter kernel on `stream`; returns after the launch.   */
+int cv_pileup_flush(cv_pileup *p, void *stream);
+
+/* Flush, then write per candidate i: tensors_dev[i] = [33,4,4] fp32 counts (subtract != 0: matrices
+ * 1..3 minus matrix 0), depth_dev[i] = aligned depth at the centre column (the --minCoverage test,
+ * :51), touched_dev[i] = 1 iff some read was activated for it (only those get a row, :232-246).
+ * Any output pointer may be NULL.  Counters stay valid: more reads may be added afterwards.     */
+int cv_pileup_finish(cv_pileup *p, float *tensors_dev, int32_t *depth_dev, uint8_t *touched_dev,
+                     int subtract, void *stream);
+
+/* HIP-event time of the scatter / finalize launches since creation: ms[0] scatter total, ms[1]
+ * finalize total; counts[0] alignment columns scattered, counts[1] segments, counts[2] launches. */
+int cv_pileup_stats(cv_pileup *p, float ms[2], int64_t counts[3]);
+
+/* One text row of CreateTensor.py (:52): "<ctg> <center> <seq33> " + 528 x "%0.1f" (no newline).
+ * counts: [33,4,4] fp32 raw counts (host).  Returns the length written, or -1 if cap is small.  */
+int64_t cv_format_tensor_row(const char *ctg, int64_t center, const char *seq, int64_t seqlen,
+                             const float *counts, char *dst, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif
