@@ -47,3 +47,27 @@ def test_oracle_rows_equal_reference_rows(name):
     # every golden row is a distinct candidate; ours come out in ascending order
     pos = [int(r.split()[1]) for r in got]
     assert pos == sorted(pos) and len(set(pos)) == len(pos)
+
+
+EVC_CASES = ["plain", "region_bed", "noisy", "lowcov"]
+
+
+def load_evc_case(name):
+    meta = json.load(open(os.path.join(G, name + ".evc.args.json")))
+    contigs, sam, _, _, _ = load_case(meta["alignments"])
+    opts = dict(meta["options"])
+    bed_rows = None
+    if "bed_fn" in opts:
+        bed_rows = [l.rstrip("\n") for l in open(os.path.join(G, opts.pop("bed_fn")))]
+    want = gzip.open(os.path.join(G, name + ".evc.gz"), "rt").read().splitlines()
+    return meta["alignments"], contigs, sam, opts, bed_rows, want
+
+
+@pytest.mark.parametrize("name", EVC_CASES)
+def test_candidate_oracle_rows_equal_reference_rows(name):
+    from oracle import extract_candidates as ec
+    _, contigs, sam, opts, bed_rows, want = load_evc_case(name)
+    bed = ec.bed_intervals(bed_rows, "ctgA") if bed_rows is not None else None
+    got = ec.candidates("ctgA", contigs["ctgA"], sam, bed=bed, **opts)
+    assert len(want) > 30
+    assert got == want                 # same rows in the same order, late rows included
