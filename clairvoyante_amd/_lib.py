@@ -80,6 +80,17 @@ _SIGS = {
     "cv_pileup_finish": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_int, ctypes.c_void_p]),
     "cv_pileup_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64)]),
+    "cv_pileup_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
+    "cv_pileup_set_contig": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
+    "cv_pileup_extract_candidates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+                                                    ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
+    "cv_pileup_get_extracted": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p]),
+    "cv_pileup_adopt_candidates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                                  ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
+    "cv_pileup_get_candidates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                                ctypes.POINTER(ctypes.c_int64)]),
     "cv_format_tensor_row": (ctypes.c_int64, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64,
                                               ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
 }

@@ -21,15 +21,28 @@
 //   final  : one thread per (candidate, offset): 9 counters -> 16 floats (64 B), optional
 //            "matrices 1..3 minus matrix 0" (utils_v2.py:46), centre depth for --minCoverage.
 //
+//   candidates (optional, ExtractVariantCandidates.py :118-246): with option "evc" the same segments
+//            first feed per-position counters A,C,G,T,I,D,N (+ the "late" I/D pair, below); a select pass
+//            (hipCUB DeviceSelect over positions) applies OutputCandidate (:22-42) and the region / BED
+//            tests; with option "retain" the uploaded segments stay in HBM, so the tensor scatter for
+//            the selected candidates re-reads them there -- the SAM text is parsed and uploaded once.
+//            The reference sweeps finished positions while it reads (:176-212); an insertion / deletion
+//            that opens a read is booked at POS-1, which an earlier read with the same POS has already
+//            swept: those "late" events form a second entry for that position (reported at the end,
+//            :215-241).  The parser flags them, the counters keep them apart (slots 7, 8).
+//
 // HBM-bound integer work: per column 1 SEQ byte + 1 reference byte + one L2 atomic per covering
 // candidate; per candidate 1 188 B of counters read once and 2 112 B of tensor written once.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/clairvoyante_amd.h"
@@ -53,12 +66,15 @@ constexpr int NCNT = 9;                   // counters per (candidate, offset)
 constexpr int SEG_MAX = 64;               // columns per segment = lanes per wave
 constexpr int BUCKET_SHIFT = 4;           // candidate lookup table: one entry per 16 positions
 
+constexpr int NPOS = 9;                   // per-position counters: A C G T I D N | late I, late D
+
 enum { T_MATCH = 0, T_INS = 1, T_DEL = 2 };
+enum { F_CT = 1 << 10, F_EVC = 1 << 11, F_LATE = 1 << 12, F_FIRST = 1 << 13 };   // in seg_t::info
 
 struct seg_t {
     int32_t r0;      // 0-based reference position of the first column (insert: the position it precedes)
     uint32_t q0;     // offset of the first query base in the SEQ byte buffer (unused for deletes)
-    int32_t info;    // columns (1..64) | type << 8
+    int32_t info;    // columns (1..64) | type << 8 | F_* (which consumer the read passed, first segment of its run)
     int32_t adv0;    // insert: index of the first column inside its insertion (queryAdv, :203-211)
     int32_t pos;     // the read's POS (0-based)
 };
@@ -94,8 +110,8 @@ pileup_scatter(const seg_t *__restrict__ segs, int64_t nseg, const uint8_t *__re
     const seg_t sg = segs[s];
     const int lane = threadIdx.x & 63;
     const int len = sg.info & 0xff;
-    const int type = sg.info >> 8;
-    if (lane >= len) return;
+    const int type = (sg.info >> 8) & 3;
+    if (lane >= len || !(sg.info & F_CT)) return;
     const int32_t r = type == T_INS ? sg.r0 : sg.r0 + lane;
     const int q = type == T_DEL ? -1 : base_code(seq[(size_t)sg.q0 + lane]);
     int rb = -1;
@@ -132,6 +148,92 @@ pileup_scatter(const seg_t *__restrict__ segs, int64_t nseg, const uint8_t *__re
     }
 }
 
+// ExtractVariantCandidates.py:152-174: per-position symbol counts
+__global__ void __launch_bounds__(256)
+evc_count(const seg_t *__restrict__ segs, int64_t nseg, const uint8_t *__restrict__ seq, int64_t ref_first,
+          int64_t ref_len, int32_t *__restrict__ pc)
+{
+    int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (s >= nseg) return;
+    const seg_t sg = segs[s];
+    if (!(sg.info & F_EVC)) return;
+    const int lane = threadIdx.x & 63;
+    const int len = sg.info & 0xff;
+    const int type = (sg.info >> 8) & 3;
+    if (type == T_MATCH) {
+        if (lane >= len) return;
+        const uint8_t ch = seq[(size_t)sg.q0 + lane];
+        const int k = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : ch == 'N' ? 6 : -1;
+        const int64_t ri = (int64_t)sg.r0 + lane - ref_first;
+        if (k >= 0 && ri >= 0 && ri < ref_len) atomicAdd(pc + ri * NPOS + k, 1);
+    } else if (lane == 0 && (sg.info & F_FIRST)) {          // one count per insertion / deletion run, at r-1
+        const int64_t ri = (int64_t)sg.r0 - 1 - ref_first;
+        const int k = (sg.info & F_LATE) ? (type == T_INS ? 7 : 8) : (type == T_INS ? 4 : 5);
+        if (ri >= 0 && ri < ref_len) atomicAdd(pc + ri * NPOS + k, 1);
+    }
+}
+
+// OutputCandidate (:22-42) + the region / BED tests (:181-196) for entry j: position j>>1, kind j&1
+// (0 = the regular entry, 1 = the late insertion/deletion entry)
+struct evc_pred {
+    const int32_t *pc;
+    const uint8_t *ref;
+    int64_t ref_first;
+    double thr, mincov;
+    int has_region;
+    int64_t cs, ce;
+    const int64_t *bb, *be;
+    int nbed;                      // -1: no BED file
+
+    __device__ bool operator()(const int64_t &j) const
+    {
+        const int64_t ri = j >> 1;
+        const int32_t *c9 = pc + ri * NPOS;
+        int c[7];
+        if (j & 1) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) c[k] = 0;
+            c[4] = c9[7]; c[5] = c9[8];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) c[k] = c9[k];
+        }
+        int total = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) total += c[k];
+        if (total == 0) return false;                      // no pileup entry at all
+        const int64_t p = ref_first + ri;
+        if (has_region && (p < cs || p > ce)) return false;
+        if (nbed >= 0) {
+            int l = 0, h = nbed;                           // disjoint, sorted: last interval with begin <= p
+            while (l < h) { int m = (l + h) >> 1; if (bb[m] <= p) l = m + 1; else h = m; }
+            if (l == 0 || p >= be[l - 1]) return false;
+        }
+        if ((double)total < mincov) return false;
+        int i0 = 0;
+#pragma unroll
+        for (int k = 1; k < 7; ++k) if (c[k] > c[i0]) i0 = k;       // stable descending sort: first maximum
+        int i1 = i0 == 0 ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) if (k != i0 && k != i1 && c[k] > c[i1]) i1 = k;
+        // among equal seconds the stable sort keeps the lowest index: the scan above only replaces on '>'
+        // but started from index 0/1, which is the lowest candidate
+        const double p0 = (double)c[i0] / (double)total, p1 = (double)c[i1] / (double)total;
+        const char sym[8] = "ACGTIDN";
+        return (p0 <= 1.0 - thr && p1 >= thr) || (uint8_t)sym[i0] != ref[ri];
+    }
+};
+
+__global__ void evc_gather(const int64_t *__restrict__ sel, int64_t n, const int32_t *__restrict__ pc,
+                           int32_t *__restrict__ out7)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int64_t j = sel[t];
+    const int32_t *c9 = pc + (j >> 1) * NPOS;
+    for (int k = 0; k < 7; ++k) out7[t * 7 + k] = (j & 1) ? (k == 4 ? c9[7] : k == 5 ? c9[8] : 0) : c9[k];
+}
+
 __global__ void __launch_bounds__(256)
 pileup_finalize(const int32_t *__restrict__ cnt, const int32_t *__restrict__ cands, int64_t n,
                 const uint8_t *__restrict__ ref, int64_t ref_first, int64_t ref_len, float *__restrict__ out,
@@ -165,8 +267,16 @@ pileup_finalize(const int32_t *__restrict__ cnt, const int32_t *__restrict__ can
 
 }  // namespace
 
+struct dev_batch {                // one uploaded batch of segments
+    seg_t *segs = nullptr;
+    uint8_t *seq = nullptr;
+    size_t nseg = 0, segs_cap = 0, seq_cap = 0;
+};
+
 struct cv_pileup {
     int device = 0, min_mq = 0, dcov = 250, left = 1;
+    int retain = 0, evc = 0, evc_min_mq = 0;
+    std::string contig;                 // RNAME test of the candidate pass (ExtractVariantCandidates.py:137-139)
     uint8_t *ref_dev = nullptr;
     int64_t ref_len = 0, ref_first = 0;
     int32_t *cand_dev = nullptr;
@@ -176,17 +286,21 @@ struct cv_pileup {
     int64_t nb = 0;
     int32_t *cnt_dev = nullptr;
     uint8_t *touched_dev = nullptr;
+    int32_t *pos_cnt = nullptr;         // [ref_len, NPOS], candidate pass
     std::vector<seg_t> segs;
     std::vector<uint8_t> seq;
     int64_t pending_cols = 0;
-    seg_t *segs_dev = nullptr;
-    size_t segs_cap = 0;
-    uint8_t *seq_dev = nullptr;
-    size_t seq_cap = 0;
+    dev_batch work;                     // reused staging batch (retain == 0)
+    std::vector<dev_batch> kept;        // resident batches (retain == 1)
     int64_t prev_pos = 0, depth_cap = 0;   // CreateTensor.py:139,165-172
+    int64_t evc_prev_pos = INT64_MIN;      // POS of the last read the candidate pass took
+    int64_t evc_reads = 0;                 // processedReads (:150)
+    std::vector<int64_t> sel_host;         // extracted entries: position << 1 | kind
+    std::vector<int32_t> sel_counts;       // [n,7]
     std::vector<hipEvent_t> ev;            // pairs, scatter launches not yet accumulated
     std::vector<hipEvent_t> evf;           // pairs, finalize launches
-    float ms_scatter = 0.f, ms_final = 0.f;
+    std::vector<hipEvent_t> eve;           // pairs, candidate-pass launches
+    float ms_scatter = 0.f, ms_final = 0.f, ms_evc = 0.f;
     int64_t cols = 0, nsegs = 0, launches = 0;
 };
 
@@ -204,6 +318,22 @@ static int drain(std::vector<hipEvent_t> &ev, float &acc)
     return 0;
 }
 
+struct timed {                     // brackets launches with an event pair kept for cv_pileup_stats
+    std::vector<hipEvent_t> &v;
+    hipStream_t st;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = true;
+    timed(std::vector<hipEvent_t> &vec, hipStream_t s) : v(vec), st(s)
+    {
+        ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess &&
+             hipEventRecord(e0, st) == hipSuccess;
+    }
+    ~timed()
+    {
+        if (ok && hipEventRecord(e1, st) == hipSuccess) { v.push_back(e0); v.push_back(e1); }
+    }
+};
+
 extern "C" int cv_pileup_create(int device, int min_mq, int dcov, int consider_left_edge, cv_pileup **out)
 {
     if (!out) { cv_set_error("cv_pileup_create: null argument"); return 1; }
@@ -220,15 +350,44 @@ extern "C" int cv_pileup_create(int device, int min_mq, int dcov, int consider_l
     return 0;
 }
 
+static void free_batch(dev_batch &b)
+{
+    hipFree(b.segs); hipFree(b.seq);
+    b = dev_batch();
+}
+
 extern "C" void cv_pileup_destroy(cv_pileup *p)
 {
     if (!p) return;
     hipSetDevice(p->device);
     float sink = 0.f;
-    drain(p->ev, sink); drain(p->evf, sink);
+    drain(p->ev, sink); drain(p->evf, sink); drain(p->eve, sink);
     hipFree(p->ref_dev); hipFree(p->cand_dev); hipFree(p->bucket_dev); hipFree(p->cnt_dev);
-    hipFree(p->touched_dev); hipFree(p->segs_dev); hipFree(p->seq_dev);
+    hipFree(p->touched_dev); hipFree(p->pos_cnt);
+    free_batch(p->work);
+    for (auto &b : p->kept) free_batch(b);
     delete p;
+}
+
+extern "C" int cv_pileup_set_option(cv_pileup *p, const char *key, int64_t value)
+{
+    if (!p || !key) { cv_set_error("cv_pileup_set_option: null argument"); return 1; }
+    if (!p->segs.empty() || p->cols) {
+        cv_set_error("cv_pileup_set_option(%s): set options before the first read is added", key);
+        return 1;
+    }
+    if (!strcmp(key, "retain")) p->retain = value != 0;
+    else if (!strcmp(key, "evc")) p->evc = value != 0;
+    else if (!strcmp(key, "evc_min_mq")) p->evc_min_mq = (int)value;
+    else { cv_set_error("cv_pileup_set_option: unknown key '%s'", key); return 1; }
+    return 0;
+}
+
+extern "C" int cv_pileup_set_contig(cv_pileup *p, const char *name)
+{
+    if (!p || !name) { cv_set_error("cv_pileup_set_contig: null argument"); return 1; }
+    p->contig = name;
+    return 0;
 }
 
 extern "C" int cv_pileup_set_reference(cv_pileup *p, const char *seq, int64_t len, int64_t first_pos0)
@@ -236,26 +395,16 @@ extern "C" int cv_pileup_set_reference(cv_pileup *p, const char *seq, int64_t le
     if (!p || (!seq && len > 0) || len < 0) { cv_set_error("cv_pileup_set_reference: bad argument"); return 1; }
     PL_HIP(hipSetDevice(p->device));
     if (p->ref_dev) { PL_HIP(hipFree(p->ref_dev)); p->ref_dev = nullptr; }
+    if (p->pos_cnt) { PL_HIP(hipFree(p->pos_cnt)); p->pos_cnt = nullptr; }
     PL_HIP(hipMalloc(&p->ref_dev, (size_t)(len > 0 ? len : 1)));
     if (len > 0) PL_HIP(hipMemcpy(p->ref_dev, seq, (size_t)len, hipMemcpyHostToDevice));
     p->ref_len = len; p->ref_first = first_pos0;
     return 0;
 }
 
-extern "C" int cv_pileup_set_candidates(cv_pileup *p, const int64_t *centers, int64_t n)
+static int install_candidates(cv_pileup *p, const std::vector<int32_t> &c32)
 {
-    if (!p || (!centers && n > 0) || n < 0) { cv_set_error("cv_pileup_set_candidates: bad argument"); return 1; }
-    if (!p->segs.empty()) { cv_set_error("cv_pileup_set_candidates: reads are queued; flush first"); return 1; }
-    PL_HIP(hipSetDevice(p->device));
-    std::vector<int32_t> c32((size_t)n);
-    for (int64_t i = 0; i < n; ++i) {
-        if (centers[i] < -(1LL << 30) || centers[i] > (1LL << 31) - 64 || (i && centers[i] <= centers[i - 1])) {
-            cv_set_error("cv_pileup_set_candidates: centres must be strictly ascending 1-based positions below 2^31 "
-                         "(index %lld: %lld)", (long long)i, (long long)centers[i]);
-            return 1;
-        }
-        c32[(size_t)i] = (int32_t)centers[i];
-    }
+    const int64_t n = (int64_t)c32.size();
     hipFree(p->cand_dev); hipFree(p->bucket_dev); hipFree(p->cnt_dev); hipFree(p->touched_dev);
     p->cand_dev = nullptr; p->bucket_dev = nullptr; p->cnt_dev = nullptr; p->touched_dev = nullptr;
     p->n = n;
@@ -281,11 +430,28 @@ extern "C" int cv_pileup_set_candidates(cv_pileup *p, const int64_t *centers, in
     return 0;
 }
 
+extern "C" int cv_pileup_set_candidates(cv_pileup *p, const int64_t *centers, int64_t n)
+{
+    if (!p || (!centers && n > 0) || n < 0) { cv_set_error("cv_pileup_set_candidates: bad argument"); return 1; }
+    if (!p->segs.empty()) { cv_set_error("cv_pileup_set_candidates: reads are queued; flush first"); return 1; }
+    PL_HIP(hipSetDevice(p->device));
+    std::vector<int32_t> c32((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (centers[i] < -(1LL << 30) || centers[i] > (1LL << 31) - 64 || (i && centers[i] <= centers[i - 1])) {
+            cv_set_error("cv_pileup_set_candidates: centres must be strictly ascending 1-based positions below 2^31 "
+                         "(index %lld: %lld)", (long long)i, (long long)centers[i]);
+            return 1;
+        }
+        c32[(size_t)i] = (int32_t)centers[i];
+    }
+    return install_candidates(p, c32);
+}
+
 // ---- SAM text -> segments ---------------------------------------------------------------------
 
 static inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
 
-static void emit(cv_pileup *p, int type, int64_t r0, uint64_t q0, int64_t n, int64_t pos, bool ref_advances)
+static void emit(cv_pileup *p, int type, int flags, int64_t r0, uint64_t q0, int64_t n, int64_t pos, bool ref_advances)
 {
     int64_t done = 0;
     while (done < n) {
@@ -293,7 +459,7 @@ static void emit(cv_pileup *p, int type, int64_t r0, uint64_t q0, int64_t n, int
         seg_t s;
         s.r0 = (int32_t)(ref_advances ? r0 + done : r0);
         s.q0 = (uint32_t)(q0 + (type == T_DEL ? 0 : (uint64_t)done));
-        s.info = (int32_t)len | (type << 8);
+        s.info = (int32_t)len | (type << 8) | flags | (done == 0 ? F_FIRST : 0);
         s.adv0 = type == T_INS ? (int32_t)done : 0;
         s.pos = (int32_t)pos;
         p->segs.push_back(s);
@@ -326,27 +492,49 @@ static int parse_record(cv_pileup *p, const char *line, const char *end, int64_t
     char *endp = nullptr;
     const int64_t pos = strtoll(f[3], &endp, 10) - 1;      // 0-based (:147)
     const int64_t mq = strtoll(f[4], &endp, 10);
-    if (mq < p->min_mq) return 0;                           // :155
-    if (p->prev_pos != pos) { p->prev_pos = pos; p->depth_cap = 0; }
-    else if (++p->depth_cap >= p->dcov) return 0;           // :165-172
-    if (pos < -(1LL << 30) || pos > (1LL << 31) - (1 << 24)) {
-        cv_set_error("cv_pileup_add_sam: POS %lld out of range", (long long)pos + 1);
-        return 1;
-    }
     const char *cg = f[5], *cge = fe[5];
     const int64_t seqlen = fe[9] - f[9];
-    // query bases the CIGAR asks for (a short or absent SEQ is padded with 'not ACGT')
-    int64_t need = 0;
+    // one scan of the CIGAR: query bases it asks for, all run lengths, soft-clipped bases
+    int64_t need = 0, total = 0, clipped = 0;
     for (const char *q = cg; q < cge;) {
         if (*q < '0' || *q > '9') { ++q; continue; }
         int64_t v = 0;
         while (q < cge && *q >= '0' && *q <= '9') v = v * 10 + (*q++ - '0');
-        if (q < cge && (*q == 'M' || *q == 'I' || *q == 'S' || *q == '=' || *q == 'X')) need += v;
+        if (q >= cge) break;
+        const char op = *q;
+        if (op == 'M' || op == 'I' || op == 'S' || op == '=' || op == 'X') need += v;
+        if (op == 'M' || op == 'I' || op == 'D' || op == 'N' || op == 'S' || op == 'H' || op == 'P' || op == '=' ||
+            op == 'X') { total += v; if (op == 'S') clipped += v; }
+    }
+    // tensor pass: --minMQ, then the per-POS depth cap (CreateTensor.py:155,165-172)
+    bool ct_ok = mq >= p->min_mq;
+    if (ct_ok) {
+        if (p->prev_pos != pos) { p->prev_pos = pos; p->depth_cap = 0; }
+        else if (++p->depth_cap >= p->dcov) ct_ok = false;
+    }
+    // candidate pass: contig, --minMQ, at least 55 % of the read aligned (ExtractVariantCandidates.py:137-160)
+    bool evc_ok = p->evc != 0 && mq >= p->evc_min_mq;
+    if (evc_ok && !p->contig.empty()) {
+        const size_t ln = (size_t)(fe[2] - f[2]);
+        evc_ok = ln == p->contig.size() && !memcmp(f[2], p->contig.data(), ln);
+    }
+    if (evc_ok && 1.0 - (double)clipped / (double)(total + 1) < 0.55) evc_ok = false;
+    bool late_read = false;
+    if (evc_ok) {
+        late_read = p->evc_prev_pos == pos;     // an earlier read with this POS has swept POS-1 already (:176)
+        p->evc_prev_pos = pos;
+        p->evc_reads += 1;
+    }
+    if (!ct_ok && !evc_ok) return 0;
+    if (pos < -(1LL << 30) || pos > (1LL << 31) - (1 << 24)) {
+        cv_set_error("cv_pileup_add_sam: POS %lld out of range", (long long)pos + 1);
+        return 1;
     }
     if ((uint64_t)p->seq.size() + (uint64_t)(need > seqlen ? need : seqlen) >= 0xffffffffull) {
         cv_set_error("cv_pileup_add_sam: more than 4 Gi query bases queued; call cv_pileup_flush more often");
         return 1;
     }
+    const int rf = (ct_ok ? F_CT : 0) | (evc_ok ? F_EVC : 0);
     const uint64_t base = p->seq.size();
     p->seq.insert(p->seq.end(), (const uint8_t *)f[9], (const uint8_t *)fe[9]);
     if (need > seqlen) p->seq.insert(p->seq.end(), (size_t)(need - seqlen), (uint8_t)'?');
@@ -357,10 +545,11 @@ static int parse_record(cv_pileup *p, const char *line, const char *end, int64_t
         while (s < cge && *s >= '0' && *s <= '9') v = v * 10 + (*s++ - '0');
         if (s >= cge) break;
         const char op = *s;
+        const int lf = rf | ((late_read && r == pos) ? F_LATE : 0);
         if (op == 'S') { q += v; ++s; }
-        else if (op == 'M' || op == '=' || op == 'X') { emit(p, T_MATCH, r, base + q, v, pos, true); r += v; q += v; ++s; }
-        else if (op == 'I') { emit(p, T_INS, r, base + q, v, pos, false); q += v; ++s; }
-        else if (op == 'D') { emit(p, T_DEL, r, 0, v, pos, true); r += v; ++s; }
+        else if (op == 'M' || op == '=' || op == 'X') { emit(p, T_MATCH, rf, r, base + q, v, pos, true); r += v; q += v; ++s; }
+        else if (op == 'I') { emit(p, T_INS, lf, r, base + q, v, pos, false); q += v; ++s; }
+        else if (op == 'D') { emit(p, T_DEL, lf, r, 0, v, pos, true); r += v; ++s; }
         else if (op == 'N' || op == 'H' || op == 'P') { ++s; }   // no branch in the reference: nothing moves
         // any other character: the regex does not match at these digits; rescan from the next character
     }
@@ -389,50 +578,194 @@ extern "C" int cv_pileup_add_sam(cv_pileup *p, const char *text, int64_t nbytes,
 
 extern "C" int64_t cv_pileup_pending(const cv_pileup *p) { return p ? p->pending_cols : 0; }
 
+static int launch_scatter(cv_pileup *p, const dev_batch &b, hipStream_t st)
+{
+    if (p->n <= 0 || b.nseg == 0) return 0;
+    if (p->ev.size() >= 128 && drain(p->ev, p->ms_scatter)) return 1;
+    {
+        timed t(p->ev, st);
+        const int waves = 4;
+        pileup_scatter<<<(unsigned)((b.nseg + waves - 1) / waves), waves * 64, 0, st>>>(
+            b.segs, (int64_t)b.nseg, b.seq, p->ref_dev, p->ref_first, p->ref_len, p->cand_dev, (int)p->n, p->bucket_dev,
+            p->bucket_lo, p->nb, p->cnt_dev, p->touched_dev, p->left);
+    }
+    PL_HIP(hipGetLastError());
+    p->launches += 1;
+    return 0;
+}
+
 extern "C" int cv_pileup_flush(cv_pileup *p, void *stream)
 {
     if (!p) { cv_set_error("cv_pileup_flush: null handle"); return 1; }
     if (p->segs.empty()) { p->seq.clear(); return 0; }
-    if (!p->cand_dev || !p->ref_dev) {
+    if (!p->ref_dev || (!p->cand_dev && !p->evc)) {
         cv_set_error("cv_pileup_flush: set the reference and the candidates first");
         return 1;
     }
     PL_HIP(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;
     const size_t ns = p->segs.size(), nq = p->seq.size() + 64;
-    if (ns > p->segs_cap) {
+    dev_batch fresh;
+    dev_batch &b = p->retain ? fresh : p->work;
+    if (ns > b.segs_cap) {
         PL_HIP(hipStreamSynchronize(st));
-        hipFree(p->segs_dev); p->segs_dev = nullptr;
-        p->segs_cap = ns + ns / 4;
-        PL_HIP(hipMalloc(&p->segs_dev, p->segs_cap * sizeof(seg_t)));
+        hipFree(b.segs); b.segs = nullptr;
+        b.segs_cap = p->retain ? ns : ns + ns / 4;
+        PL_HIP(hipMalloc(&b.segs, b.segs_cap * sizeof(seg_t)));
     }
-    if (nq > p->seq_cap) {
+    if (nq > b.seq_cap) {
         PL_HIP(hipStreamSynchronize(st));
-        hipFree(p->seq_dev); p->seq_dev = nullptr;
-        p->seq_cap = nq + nq / 4;
-        PL_HIP(hipMalloc(&p->seq_dev, p->seq_cap));
+        hipFree(b.seq); b.seq = nullptr;
+        b.seq_cap = p->retain ? nq : nq + nq / 4;
+        PL_HIP(hipMalloc(&b.seq, b.seq_cap));
     }
+    b.nseg = ns;
     p->seq.resize(nq, (uint8_t)'?');       // a 64-byte tail keeps every lane's read in range
-    PL_HIP(hipMemcpyAsync(p->segs_dev, p->segs.data(), ns * sizeof(seg_t), hipMemcpyHostToDevice, st));
-    PL_HIP(hipMemcpyAsync(p->seq_dev, p->seq.data(), nq, hipMemcpyHostToDevice, st));
-    if (p->n > 0) {
-        if (p->ev.size() >= 128 && drain(p->ev, p->ms_scatter)) return 1;
-        hipEvent_t e0, e1;
-        PL_HIP(hipEventCreate(&e0)); PL_HIP(hipEventCreate(&e1));
-        PL_HIP(hipEventRecord(e0, st));
-        const int waves = 4;
-        pileup_scatter<<<(unsigned)((ns + waves - 1) / waves), waves * 64, 0, st>>>(
-            p->segs_dev, (int64_t)ns, p->seq_dev, p->ref_dev, p->ref_first, p->ref_len, p->cand_dev, (int)p->n,
-            p->bucket_dev, p->bucket_lo, p->nb, p->cnt_dev, p->touched_dev, p->left);
+    PL_HIP(hipMemcpyAsync(b.segs, p->segs.data(), ns * sizeof(seg_t), hipMemcpyHostToDevice, st));
+    PL_HIP(hipMemcpyAsync(b.seq, p->seq.data(), nq, hipMemcpyHostToDevice, st));
+    if (p->evc) {
+        if (!p->pos_cnt) {
+            const size_t bytes = (size_t)(p->ref_len > 0 ? p->ref_len : 1) * NPOS * sizeof(int32_t);
+            PL_HIP(hipMalloc(&p->pos_cnt, bytes));
+            PL_HIP(hipMemsetAsync(p->pos_cnt, 0, bytes, st));
+        }
+        if (p->eve.size() >= 128 && drain(p->eve, p->ms_evc)) return 1;
+        {
+            timed t(p->eve, st);
+            const int waves = 4;
+            evc_count<<<(unsigned)((ns + waves - 1) / waves), waves * 64, 0, st>>>(b.segs, (int64_t)ns, b.seq, p->ref_first,
+                                                                                     p->ref_len, p->pos_cnt);
+        }
         PL_HIP(hipGetLastError());
-        PL_HIP(hipEventRecord(e1, st));
-        p->ev.push_back(e0); p->ev.push_back(e1);
-        p->launches += 1;
     }
+    if (p->cand_dev && launch_scatter(p, b, st)) return 1;
     // pageable copies are staged before hipMemcpyAsync returns only for small sizes: wait for them
     PL_HIP(hipStreamSynchronize(st));
+    if (p->retain) p->kept.push_back(b);
     p->cols += p->pending_cols; p->nsegs += (int64_t)ns;
     p->segs.clear(); p->seq.clear(); p->pending_cols = 0;
+    return 0;
+}
+
+extern "C" int cv_pileup_extract_candidates(cv_pileup *p, double threshold, double min_coverage, int has_region,
+                                            int64_t ctg_start, int64_t ctg_end, const int64_t *bed_begin,
+                                            const int64_t *bed_end, int64_t nbed, void *stream, int64_t *n_out)
+{
+    if (!p || !n_out) { cv_set_error("cv_pileup_extract_candidates: null argument"); return 1; }
+    if (!p->evc) { cv_set_error("cv_pileup_extract_candidates: option 'evc' was not set"); return 1; }
+    if (cv_pileup_flush(p, stream)) return 1;
+    PL_HIP(hipSetDevice(p->device));
+    hipStream_t st = (hipStream_t)stream;
+    p->sel_host.clear(); p->sel_counts.clear();
+    *n_out = 0;
+    if (!p->pos_cnt || p->ref_len <= 0) return 0;         // no read reached the candidate pass
+    // BED intervals: sorted, merged -> disjoint (membership is all the reference asks of its interval tree)
+    std::vector<std::pair<int64_t, int64_t>> iv;
+    for (int64_t i = 0; i < nbed; ++i) if (bed_end[i] > bed_begin[i]) iv.emplace_back(bed_begin[i], bed_end[i]);
+    std::sort(iv.begin(), iv.end());
+    std::vector<int64_t> bb, be;
+    for (auto &x : iv) {
+        if (!bb.empty() && x.first <= be.back()) be.back() = std::max(be.back(), x.second);
+        else { bb.push_back(x.first); be.push_back(x.second); }
+    }
+    int64_t *bb_dev = nullptr, *be_dev = nullptr;
+    if (nbed >= 0) {
+        const size_t nb1 = bb.size() ? bb.size() : 1;
+        PL_HIP(hipMalloc(&bb_dev, nb1 * sizeof(int64_t)));
+        PL_HIP(hipMalloc(&be_dev, nb1 * sizeof(int64_t)));
+        if (!bb.empty()) {
+            PL_HIP(hipMemcpy(bb_dev, bb.data(), bb.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+            PL_HIP(hipMemcpy(be_dev, be.data(), be.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        }
+    }
+    evc_pred pred{p->pos_cnt, p->ref_dev, p->ref_first, threshold, min_coverage, has_region, ctg_start, ctg_end,
+                  bb_dev, be_dev, nbed >= 0 ? (int)bb.size() : -1};
+    const int64_t items = p->ref_len * 2;
+    int64_t *sel_dev = nullptr, *nsel_dev = nullptr;
+    PL_HIP(hipMalloc(&sel_dev, (size_t)items * sizeof(int64_t)));
+    PL_HIP(hipMalloc(&nsel_dev, sizeof(int64_t)));
+    int64_t nsel = 0;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    // DeviceSelect takes an int item count: walk the positions in slices
+    const int64_t SLICE = 1LL << 30;
+    int64_t written = 0;
+    for (int64_t off = 0; off < items; off += SLICE) {
+        const int cnt = (int)std::min<int64_t>(SLICE, items - off);
+        hipcub::CountingInputIterator<int64_t> it(off);
+        size_t need = 0;
+        PL_HIP(hipcub::DeviceSelect::If(nullptr, need, it, sel_dev + written, nsel_dev, cnt, pred, st));
+        if (need > tmp_bytes) { hipFree(tmp); tmp = nullptr; PL_HIP(hipMalloc(&tmp, need)); tmp_bytes = need; }
+        {
+            timed t(p->eve, st);
+            PL_HIP(hipcub::DeviceSelect::If(tmp, need, it, sel_dev + written, nsel_dev, cnt, pred, st));
+        }
+        PL_HIP(hipMemcpyAsync(&nsel, nsel_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        PL_HIP(hipStreamSynchronize(st));
+        written += nsel;
+    }
+    p->sel_host.resize((size_t)written);
+    p->sel_counts.resize((size_t)written * 7);
+    if (written) {
+        int32_t *c7 = nullptr;
+        PL_HIP(hipMalloc(&c7, (size_t)written * 7 * sizeof(int32_t)));
+        evc_gather<<<(unsigned)((written + 255) / 256), 256, 0, st>>>(sel_dev, written, p->pos_cnt, c7);
+        PL_HIP(hipGetLastError());
+        PL_HIP(hipMemcpyAsync(p->sel_host.data(), sel_dev, (size_t)written * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        PL_HIP(hipMemcpyAsync(p->sel_counts.data(), c7, (size_t)written * 7 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        PL_HIP(hipStreamSynchronize(st));
+        hipFree(c7);
+    }
+    hipFree(tmp); hipFree(sel_dev); hipFree(nsel_dev); hipFree(bb_dev); hipFree(be_dev);
+    *n_out = written;
+    return 0;
+}
+
+extern "C" int cv_pileup_get_extracted(cv_pileup *p, int64_t *pos0, int32_t *late, int32_t *counts7,
+                                       int64_t info[2])
+{
+    if (!p) { cv_set_error("cv_pileup_get_extracted: null handle"); return 1; }
+    for (size_t i = 0; i < p->sel_host.size(); ++i) {
+        if (pos0) pos0[i] = p->ref_first + (p->sel_host[i] >> 1);
+        if (late) late[i] = (int32_t)(p->sel_host[i] & 1);
+    }
+    if (counts7 && !p->sel_counts.empty()) memcpy(counts7, p->sel_counts.data(), p->sel_counts.size() * sizeof(int32_t));
+    if (info) { info[0] = p->evc_reads; info[1] = p->evc_prev_pos; }
+    return 0;
+}
+
+extern "C" int cv_pileup_adopt_candidates(cv_pileup *p, int has_range, int64_t lo1, int64_t hi1, void *stream,
+                                          int64_t *n_out)
+{
+    if (!p) { cv_set_error("cv_pileup_adopt_candidates: null handle"); return 1; }
+    if (!p->retain) { cv_set_error("cv_pileup_adopt_candidates: option 'retain' was not set"); return 1; }
+    if (cv_pileup_flush(p, stream)) return 1;
+    PL_HIP(hipSetDevice(p->device));
+    std::vector<int32_t> c32;
+    for (size_t i = 0; i < p->sel_host.size(); ++i) {
+        const int64_t c = p->ref_first + (p->sel_host[i] >> 1) + 1;          // the row prints pos+1 (:38)
+        if (has_range && (c < lo1 || c > hi1)) continue;                      // CreateTensor.py:60-61
+        if (!c32.empty() && c32.back() == (int32_t)c) continue;               // regular + late entry of one position
+        c32.push_back((int32_t)c);
+    }
+    if (install_candidates(p, c32)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    for (const auto &b : p->kept) if (launch_scatter(p, b, st)) return 1;
+    if (n_out) *n_out = (int64_t)c32.size();
+    return 0;
+}
+
+extern "C" int cv_pileup_get_candidates(cv_pileup *p, int64_t *centers, int64_t cap, int64_t *n_out)
+{
+    if (!p) { cv_set_error("cv_pileup_get_candidates: null handle"); return 1; }
+    if (n_out) *n_out = p->n;
+    if (centers && p->n > 0) {
+        if (cap < p->n) { cv_set_error("cv_pileup_get_candidates: buffer holds %lld, need %lld", (long long)cap, (long long)p->n); return 1; }
+        std::vector<int32_t> c32((size_t)p->n);
+        PL_HIP(hipSetDevice(p->device));
+        PL_HIP(hipMemcpy(c32.data(), p->cand_dev, (size_t)p->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < p->n; ++i) centers[i] = c32[(size_t)i];
+    }
     return 0;
 }
 
@@ -448,28 +781,24 @@ extern "C" int cv_pileup_finish(cv_pileup *p, float *tensors_dev, int32_t *depth
     hipStream_t st = (hipStream_t)stream;
     if (p->n == 0) return 0;
     if (tensors_dev || depth_dev) {
-        hipEvent_t e0, e1;
-        PL_HIP(hipEventCreate(&e0)); PL_HIP(hipEventCreate(&e1));
-        PL_HIP(hipEventRecord(e0, st));
+        timed t(p->evf, st);
         const int64_t total = p->n * WIDTH;
         pileup_finalize<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(p->cnt_dev, p->cand_dev, p->n, p->ref_dev,
                                                                            p->ref_first, p->ref_len, tensors_dev,
                                                                            depth_dev, subtract);
-        PL_HIP(hipGetLastError());
-        PL_HIP(hipEventRecord(e1, st));
-        p->evf.push_back(e0); p->evf.push_back(e1);
     }
+    PL_HIP(hipGetLastError());
     if (touched_dev)
         PL_HIP(hipMemcpyAsync(touched_dev, p->touched_dev, (size_t)p->n, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
-extern "C" int cv_pileup_stats(cv_pileup *p, float ms[2], int64_t counts[3])
+extern "C" int cv_pileup_stats(cv_pileup *p, float ms[3], int64_t counts[3])
 {
     if (!p) { cv_set_error("cv_pileup_stats: null handle"); return 1; }
     PL_HIP(hipSetDevice(p->device));
-    if (drain(p->ev, p->ms_scatter) || drain(p->evf, p->ms_final)) return 1;
-    if (ms) { ms[0] = p->ms_scatter; ms[1] = p->ms_final; }
+    if (drain(p->ev, p->ms_scatter) || drain(p->evf, p->ms_final) || drain(p->eve, p->ms_evc)) return 1;
+    if (ms) { ms[0] = p->ms_scatter; ms[1] = p->ms_final; ms[2] = p->ms_evc; }
     if (counts) { counts[0] = p->cols; counts[1] = p->nsegs; counts[2] = p->launches; }
     return 0;
 }

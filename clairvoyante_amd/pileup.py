@@ -14,7 +14,8 @@ FLUSH_COLUMNS = 1 << 26         # queue at most this many alignment columns on t
 
 
 class Pileup(object):
-    def __init__(self, device=None, minMQ=0, dcov=250, considerleftedge=True):
+    def __init__(self, device=None, minMQ=0, dcov=250, considerleftedge=True, evc=False, retain=False, evc_minMQ=0,
+                 contig=None):
         import torch
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -23,6 +24,13 @@ class Pileup(object):
         self.h = ctypes.c_void_p()
         _lib.check(self.lib.cv_pileup_create(self.device.index, int(minMQ), int(dcov), int(bool(considerleftedge)),
                                              ctypes.byref(self.h)))
+        if evc:
+            _lib.check(self.lib.cv_pileup_set_option(self.h, b"evc", 1))
+            _lib.check(self.lib.cv_pileup_set_option(self.h, b"evc_min_mq", int(evc_minMQ)))
+            if contig is not None:
+                _lib.check(self.lib.cv_pileup_set_contig(self.h, contig.encode()))
+        if retain:
+            _lib.check(self.lib.cv_pileup_set_option(self.h, b"retain", 1))
         self.n = 0
         self.centers = np.zeros(0, dtype=np.int64)
         self._tail = b""
@@ -78,11 +86,51 @@ class Pileup(object):
                                              self._stream()))
         return t, d, u.bool()
 
+    def extract_candidates(self, threshold=0.125, minCoverage=4, region=None, bed=None):
+        """ExtractVariantCandidates.py's selection over the reads added so far (needs evc=True).
+        region: (ctgStart, ctgEnd) as the reference compares them with the 0-based position (:181-183);
+        bed: list of half-open (begin, end), or None.  -> dict(pos0, late, counts [n,7] in A,C,G,T,I,D,N
+        order, reads)"""
+        if self._tail:
+            self.add_sam(b"", final=True)
+        n = ctypes.c_int64(0)
+        if bed is not None:
+            bb = np.ascontiguousarray([b for b, _ in bed], dtype=np.int64)
+            be = np.ascontiguousarray([e for _, e in bed], dtype=np.int64)
+            nbed = len(bed)
+        else:
+            bb = be = np.zeros(1, dtype=np.int64)
+            nbed = -1
+        _lib.check(self.lib.cv_pileup_extract_candidates(
+            self.h, float(threshold), float(minCoverage), int(region is not None), int(region[0]) if region else 0,
+            int(region[1]) if region else 0, bb.ctypes.data_as(ctypes.c_void_p), be.ctypes.data_as(ctypes.c_void_p),
+            nbed, self._stream(), ctypes.byref(n)))
+        k = n.value
+        pos0 = np.zeros(k, dtype=np.int64); late = np.zeros(k, dtype=np.int32); c7 = np.zeros((k, 7), dtype=np.int32)
+        info = (ctypes.c_int64 * 2)()
+        _lib.check(self.lib.cv_pileup_get_extracted(self.h, pos0.ctypes.data_as(ctypes.c_void_p),
+                                                    late.ctypes.data_as(ctypes.c_void_p),
+                                                    c7.ctypes.data_as(ctypes.c_void_p), info))
+        return {"pos0": pos0, "late": late, "counts": c7, "reads": info[0], "last_pos": info[1]}
+
+    def adopt_candidates(self, lo1=None, hi1=None):
+        """make the extracted positions (+1, optionally inside [lo1, hi1]) the candidate centres and scatter
+        the retained alignments for them (needs retain=True)"""
+        n = ctypes.c_int64(0)
+        _lib.check(self.lib.cv_pileup_adopt_candidates(self.h, int(lo1 is not None), int(lo1 or 0), int(hi1 or 0),
+                                                       self._stream(), ctypes.byref(n)))
+        self.n = n.value
+        self.centers = np.zeros(self.n, dtype=np.int64)
+        _lib.check(self.lib.cv_pileup_get_candidates(self.h, self.centers.ctypes.data_as(ctypes.c_void_p), self.n,
+                                                     ctypes.byref(n)))
+        return self.centers
+
     def stats(self):
-        ms = (ctypes.c_float * 2)()
+        ms = (ctypes.c_float * 3)()
         cnt = (ctypes.c_int64 * 3)()
         _lib.check(self.lib.cv_pileup_stats(self.h, ms, cnt))
-        return {"scatter_ms": ms[0], "finalize_ms": ms[1], "columns": cnt[0], "segments": cnt[1], "launches": cnt[2]}
+        return {"scatter_ms": ms[0], "finalize_ms": ms[1], "candidate_ms": ms[2], "columns": cnt[0], "segments": cnt[1],
+                "launches": cnt[2]}
 
 
 def format_rows(ctg, centers, ref_seq, ref_shift, counts):

@@ -208,9 +208,44 @@ int cv_pileup_flush(cv_pileup *p, void *stream);
 int cv_pileup_finish(cv_pileup *p, float *tensors_dev, int32_t *depth_dev, uint8_t *touched_dev,
                      int subtract, void *stream);
 
-/* HIP-event time of the scatter / finalize launches since creation: ms[0] scatter total, ms[1]
- * finalize total; counts[0] alignment columns scattered, counts[1] segments, counts[2] launches. */
-int cv_pileup_stats(cv_pileup *p, float ms[2], int64_t counts[3]);
+/* HIP-event time of the launches since creation: ms[0] scatter total, ms[1] finalize total, ms[2]
+ * candidate pass (count + select); counts[0] alignment columns queued, counts[1] segments,
+ * counts[2] scatter launches.                                                                   */
+int cv_pileup_stats(cv_pileup *p, float ms[3], int64_t counts[3]);
+
+/* ---- candidate extraction on the same alignments ------------------------------------------------
+ * Replaces the body of dataPrepScripts/ExtractVariantCandidates.py (MakeCandidates :118-246,
+ * OutputCandidate :22-42).  Options (before the first read): "evc" = 1 also books every read that
+ * passes the candidate filters (contig, "evc_min_mq", >= 55 % aligned, :137-160) into per-position
+ * counters A,C,G,T,I,D,N over the reference window; "retain" = 1 keeps the uploaded alignments in
+ * HBM so that cv_pileup_adopt_candidates can run the tensor scatter over them again -- the SAM text
+ * is parsed once for both steps (the reference pipes `samtools view` twice, callVarBam.py:116-131).  */
+int cv_pileup_set_option(cv_pileup *p, const char *key, int64_t value);
+int cv_pileup_set_contig(cv_pileup *p, const char *name);        /* RNAME test of the candidate pass */
+
+/* Flush, then select the positions OutputCandidate would print: total count >= min_coverage and
+ * (top fraction <= 1 - threshold and second fraction >= threshold, or top symbol != reference base);
+ * has_region: 0-based position in [ctg_start, ctg_end] as the reference compares them (:181-183, i.e.
+ * ctg_start already +1); nbed >= 0: position inside one of the half-open BED intervals (:90-103), -1 =
+ * no BED file.  Ties keep the order A,C,G,T,I,D,N (insertion order; see tests/golden/make_golden_evc.py).
+ * *n_out = entries selected (a position may have a second, "late" entry, :215-241).               */
+int cv_pileup_extract_candidates(cv_pileup *p, double threshold, double min_coverage, int has_region,
+                                 int64_t ctg_start, int64_t ctg_end, const int64_t *bed_begin,
+                                 const int64_t *bed_end, int64_t nbed, void *stream, int64_t *n_out);
+
+/* The selected entries (host arrays of n_out elements; any may be NULL): 0-based position, 1 for a
+ * late entry, the seven counts in A,C,G,T,I,D,N order; info[0] = reads the pass took (processedReads,
+ * :150), info[1] = 0-based POS of the last of them (positions from there on are reported by the
+ * reference's final loop, :215-241, together with the late entries).                            */
+int cv_pileup_get_extracted(cv_pileup *p, int64_t *pos0, int32_t *late, int32_t *counts7, int64_t info[2]);
+
+/* Make the selected positions (+1, optionally restricted to [lo1, hi1] like CreateTensor.py:60-61)
+ * the candidate centres and scatter the retained alignments into their counters.               */
+int cv_pileup_adopt_candidates(cv_pileup *p, int has_range, int64_t lo1, int64_t hi1, void *stream,
+                               int64_t *n_out);
+
+/* Current candidate centres (1-based); centers may be NULL to query the count.                  */
+int cv_pileup_get_candidates(cv_pileup *p, int64_t *centers, int64_t cap, int64_t *n_out);
 
 /* One text row of CreateTensor.py (:52): "<ctg> <center> <seq33> " + 528 x "%0.1f" (no newline).
  * counts: [33,4,4] fp32 raw counts (host).  Returns the length written, or -1 if cap is small.  */

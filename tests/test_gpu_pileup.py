@@ -169,3 +169,83 @@ def test_bad_inputs_are_reported():
         pl.add_sam(b"r1\t0\tctgA\t5\t60\t4M\t*\t0\t0\tACGT\t*\n")
         pl.finish()                      # no reference / candidates yet
     pl.close()
+
+
+# ---- candidate extraction (ExtractVariantCandidates.py) -------------------------------------------
+
+from test_pileup_oracle import EVC_CASES, load_evc_case  # noqa: E402
+
+
+def evc_args(aln, tmp_path, **over):
+    base = os.path.join(G, aln)
+    a = dict(bam_fn=base + ".sam", ref_fn=base + ".fa", bed_fn=None, can_fn=str(tmp_path / "can.gz"), threshold=0.125,
+             minCoverage=4, minMQ=0, gen4Training=False, candidates=7000000, genomeSize=3000000000, ctgName="ctgA",
+             ctgStart=None, ctgEnd=None, samtools=FAKE)
+    a.update(over)
+    return types.SimpleNamespace(**a)
+
+
+@pytest.mark.parametrize("name", EVC_CASES)
+def test_extract_candidates_rows_equal_reference_rows(name, tmp_path):
+    from clairvoyante_amd import ExtractVariantCandidates as evc
+    aln, _, _, opts, _, want = load_evc_case(name)
+    opts = dict(opts)
+    meta = __import__("json").load(open(os.path.join(G, name + ".evc.args.json")))["options"]
+    if "bed_fn" in meta:
+        opts["bed_fn"] = os.path.join(G, meta["bed_fn"])
+    args = evc_args(aln, tmp_path, **opts)
+    evc.MakeCandidates(args)
+    got = gzip.open(args.can_fn, "rt").read().splitlines()
+    assert got == want                      # same rows, same order (late entries at the end)
+
+
+@pytest.mark.parametrize("seed,profile,mincov,thr", [(21, "default", 4, 0.125), (22, "noisy", 1, 0.05),
+                                                     (23, "noisy", 0, 0.3), (24, "default", 6, 0.2)])
+def test_extract_candidates_equals_oracle_on_random_alignments(seed, profile, mincov, thr):
+    from clairvoyante_amd import ExtractVariantCandidates as evc
+    from clairvoyante_amd import synth_pileup as sp
+    from clairvoyante_amd.pileup import Pileup
+    from oracle import extract_candidates as ec
+    prof = sp.NOISY_PROFILE if profile == "noisy" else sp.DEFAULT_PROFILE
+    ref, lines = sp.make_alignments(seed=700 + seed, ref_len=8000, n_reads=1500, profile=prof, stack=6)
+    want = ec.candidates("ctgA", ref, lines, minMQ=5, minCoverage=mincov, threshold=thr)
+    pl = Pileup(evc=True, evc_minMQ=5, contig="ctgA", minMQ=1 << 30)
+    pl.set_reference(ref, 0)
+    text = ("\n".join(lines) + "\n").encode()
+    for s in range(0, len(text), 30011):
+        pl.add_sam(text[s:s + 30011])
+    res = pl.extract_candidates(thr, mincov)
+    pl.close()
+    got = evc.candidate_rows("ctgA", res, ref.encode(), 0)
+    assert len(want) > 20
+    assert got == want
+
+
+def test_fused_extract_then_tensors_equals_the_two_step_pipeline(tmp_path):
+    """one parse of the SAM text (evc + retain) == ExtractVariantCandidates rows piped into CreateTensor"""
+    from clairvoyante_amd import CreateTensor
+    from clairvoyante_amd import ExtractVariantCandidates as evc
+    from clairvoyante_amd.pileup import Pileup
+    contigs, sam, _, _, _ = load_case("noisy")
+    a = evc_args("noisy", tmp_path, ctgStart=0, ctgEnd=2000, minCoverage=2)
+    evc.MakeCandidates(a)
+    c = ct_args("noisy", tmp_path, can_fn=a.can_fn, ctgStart=0, ctgEnd=2000, dcov=3)
+    two = CreateTensor.pileup_region(c)
+    # fused
+    cs, ce, rs, re_ = CreateTensor.region_of(types.SimpleNamespace(ctgStart=0, ctgEnd=2000))
+    ref_seq = contigs["ctgA"][rs - 1:re_].encode()
+    pl = Pileup(evc=True, retain=True, contig="ctgA", dcov=3)
+    pl.set_reference(ref_seq, rs - 1)
+    import shlex
+    import subprocess
+    text = subprocess.check_output(shlex.split("%s view -F 2308 %s ctgA:%d-%d" % (FAKE, c.bam_fn, cs, ce)))
+    half = len(text) // 2
+    pl.add_sam(text[:half]); pl.lib.cv_pileup_flush(pl.h, pl._stream()); pl.add_sam(text[half:])
+    pl.extract_candidates(0.125, 2, (cs, ce))
+    centers = pl.adopt_candidates(cs, ce)
+    t, d, u = pl.finish()
+    keep = u.cpu().numpy() & ((centers - (rs - 1) - 17) >= 0)
+    assert np.array_equal(centers[keep], two["centers"])
+    assert np.array_equal(t.cpu().numpy()[keep], two["tensors"].cpu().numpy())
+    assert len(two["centers"]) > 50
+    pl.close()
