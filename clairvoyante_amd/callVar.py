@@ -188,6 +188,40 @@ def OutputFromDevice(args, call_fh, num, XBatch, posBatch, call, qual):
         call_fh.write("\n".join(lines) + "\n")
 
 
+def predict_and_reduce(m, xd):
+    """network + per-candidate reductions on the device: x [n,33,4,4] -> (call [n,8] int32, qual [n,4] fp32)"""
+    import torch
+    from . import _lib
+    num = xd.shape[0]
+    out = m.predict_device(xd)
+    call = torch.empty((num, 8), dtype=torch.int32, device=m.device)
+    qual = torch.empty((num, 4), dtype=torch.float32, device=m.device)
+    _lib.check(m._lib.cv_call_postproc(m._h, ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(out.data_ptr()), num,
+                                       ctypes.c_void_p(call.data_ptr()), ctypes.c_void_p(qual.data_ptr()), m._stream()))
+    return call, qual
+
+
+def CallFromDevice(args, m, call_fh, X_dev, pos_of, batch=65536):
+    """VCF records for tensors that are already in HBM (callVarBam's fused path): X_dev [n,33,4,4] with
+    matrices 1..3 minus matrix 0; pos_of(i) -> "chrom:coord:seq33" of row i.  Only the rows that produce a
+    record (non-REF calls, or all with --showRef) are copied to the host."""
+    import torch
+    n = X_dev.shape[0]
+    with torch.cuda.device(m.device):
+        for s in range(0, n, batch):
+            xd = X_dev[s:s + batch].contiguous()
+            call_d, qual_d = predict_and_reduce(m, xd)
+            call = call_d.cpu().numpy()
+            qual = qual_d.cpu().numpy()
+            keep = np.arange(len(call)) if args.showRef else np.nonzero(call[:, 0] != 0)[0]
+            if len(keep) == 0:
+                continue
+            xs = xd.index_select(0, torch.from_numpy(keep).to(m.device)).cpu().numpy()
+            X = {int(j): xs[k] for k, j in enumerate(keep)}
+            P = {int(j): pos_of(s + int(j)) for j in keep}
+            OutputFromDevice(args, call_fh, len(call), X, P, call, qual)
+
+
 def Run(args):
     """callVar.py:21-47"""
     logging.info("Loading model ...")
@@ -245,13 +279,7 @@ def Test(args, m, utils):
                 end, num, X, pos = item
                 if num > 0:
                     xd = torch.from_numpy(X).to(m.device, non_blocking=True)
-                    out = m.predict_device(xd)
-                    call = torch.empty((num, 8), dtype=torch.int32, device=m.device)
-                    qual = torch.empty((num, 4), dtype=torch.float32, device=m.device)
-                    _lib.check(lib.cv_call_postproc(m._h, ctypes.c_void_p(xd.data_ptr()),
-                                                    ctypes.c_void_p(out.data_ptr()), num,
-                                                    ctypes.c_void_p(call.data_ptr()),
-                                                    ctypes.c_void_p(qual.data_ptr()), m._stream()))
+                    call, qual = predict_and_reduce(m, xd)
                     nxt = (num, X, pos, call, qual)
             if pending is not None:      # format batch k while the GPU works on batch k+1
                 pnum, pX, ppos, pcall, pqual = pending

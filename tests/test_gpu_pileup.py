@@ -249,3 +249,87 @@ def test_fused_extract_then_tensors_equals_the_two_step_pipeline(tmp_path):
     assert np.array_equal(t.cpu().numpy()[keep], two["tensors"].cpu().numpy())
     assert len(two["centers"]) > 50
     pl.close()
+
+
+# ---- callVarBam: BAM -> VCF fused on the device ------------------------------------------------------
+
+def _checkpoint(oracle, tmp_path, arch="full"):
+    from clairvoyante_amd import clairvoyante_v3, clairvoyante_v3_slim
+    from common import bench_params
+    m = (clairvoyante_v3 if arch == "full" else clairvoyante_v3_slim).Clairvoyante()
+    m.init()
+    m.setParameters(bench_params(oracle, arch, seed=11))
+    prefix = str(tmp_path / "model-000001")
+    m.saveParameters(prefix)
+    m.close()
+    return prefix
+
+
+@pytest.mark.parametrize("case,over", [("plain", {}), ("noisy", {"ctgStart": 0, "ctgEnd": 2000, "minCoverage": 2, "dcov": 3}),
+                                       ("region", {"ctgStart": 600, "ctgEnd": 2900, "threshold": 0.2, "bed": True,
+                                                   "slim": True})])
+def test_callvarbam_vcf_equals_the_three_stage_pipeline(case, over, tmp_path, oracle):
+    """fused BAM->VCF == ExtractVariantCandidates | CreateTensor | callVar run as separate text stages"""
+    sys.path.insert(0, HERE)
+    from clairvoyante_amd import CreateTensor, callVar, callVarBam
+    from clairvoyante_amd import ExtractVariantCandidates as evc
+    over = dict(over)
+    slim = over.pop("slim", False)
+    bed = os.path.join(G, "region_bed.bed") if over.pop("bed", False) else None
+    chk = _checkpoint(oracle, tmp_path, "slim" if slim else "full")
+    base = os.path.join(G, case)
+    region = {k: over[k] for k in ("ctgStart", "ctgEnd") if k in over}
+    thr = over.get("threshold", 0.125); mincov = over.get("minCoverage", 4); dcov = over.get("dcov", 250)
+    # three stages through files
+    a = evc_args(case, tmp_path, threshold=thr, minCoverage=mincov, bed_fn=bed, **region)
+    evc.MakeCandidates(a)
+    c = ct_args(case, tmp_path, can_fn=a.can_fn, dcov=dcov, **region)
+    CreateTensor.OutputAlnTensor(c)
+    v = types.SimpleNamespace(tensor_fn=c.tensor_fn, chkpnt_fn=chk, call_fn=str(tmp_path / "staged.vcf"), qual=None,
+                              sampleName="SAMPLE", ref_fn=base + ".fa", threads=None, showRef=False, v3=True, v2=False,
+                              slim=slim)
+    callVar.Run(v)
+    # fused
+    f = callVarBam.build_parser().parse_args(
+        ["--chkpnt_fn", chk, "--bam_fn", base + ".sam", "--ref_fn", base + ".fa", "--ctgName", "ctgA", "--call_fn",
+         str(tmp_path / "fused.vcf"), "--samtools", FAKE, "--threshold", str(thr), "--minCoverage", str(mincov),
+         "--dcov", str(dcov)] + (["--bed_fn", bed] if bed else []) + (["--slim"] if slim else []) +
+        sum([["--" + k, str(x)] for k, x in region.items()], []))
+    res = callVarBam.Run(f)
+    staged = open(v.call_fn).read().splitlines()
+    fused = open(f.call_fn).read().splitlines()
+    body = lambda L: [l for l in L if not l.startswith("#")]
+    assert [l for l in staged if l.startswith("#")] == [l for l in fused if l.startswith("#")]
+    assert body(fused) == body(staged)
+    assert len(body(fused)) > 10 and res["candidates"] >= len(res["centers"]) > 20
+
+
+def test_callvarbam_with_candidate_sites_from_a_vcf(tmp_path, oracle):
+    """--vcf_fn: sites come from the VCF (GetTruth rows) instead of the candidate pass (callVarBam.py:121-125)"""
+    sys.path.insert(0, HERE)
+    from clairvoyante_amd import CreateTensor, callVar, callVarBam, GetTruth
+    chk = _checkpoint(oracle, tmp_path)
+    base = os.path.join(G, "plain")
+    sites = tmp_path / "sites.vcf"
+    want_pos = [120, 455, 456, 457, 1010, 1500, 2222, 2950]
+    with open(sites, "w") as fh:
+        fh.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n")
+        for k, p in enumerate(want_pos):
+            gt = ["0/1", "1|1", "1/2", "./1"][k % 4]
+            fh.write("ctgA\t%d\t.\tA\t%s\t50\tPASS\t.\tGT:DP\t%s:30\n" % (p, "C,CT" if gt == "1/2" else "C", gt))
+        fh.write("other\t5\t.\tA\tC\t50\tPASS\t.\tGT\t0/1\n")
+    g = types.SimpleNamespace(vcf_fn=str(sites), var_fn=str(tmp_path / "var.gz"), ctgName="ctgA", ctgStart=None, ctgEnd=None)
+    GetTruth.OutputVariant(g)
+    rows = gzip.open(g.var_fn, "rt").read().splitlines()
+    assert [int(r.split()[1]) for r in rows] == want_pos
+    assert rows[2].split()[2:] == ["A", "C", "0", "1"] and rows[1].split()[4:] == ["1", "1"] and rows[3].split()[4:] == ["0", "1"]
+    c = ct_args("plain", tmp_path, can_fn=g.var_fn)
+    CreateTensor.OutputAlnTensor(c)
+    v = types.SimpleNamespace(tensor_fn=c.tensor_fn, chkpnt_fn=chk, call_fn=str(tmp_path / "staged.vcf"), qual=30,
+                              sampleName="S1", ref_fn=base + ".fa", threads=None, showRef=False, v3=True, v2=False, slim=False)
+    callVar.Run(v)
+    f = callVarBam.build_parser().parse_args(
+        ["--chkpnt_fn", chk, "--bam_fn", base + ".sam", "--ref_fn", base + ".fa", "--ctgName", "ctgA", "--call_fn",
+         str(tmp_path / "fused.vcf"), "--samtools", FAKE, "--vcf_fn", str(sites), "--qual", "30", "--sampleName", "S1"])
+    callVarBam.Run(f)
+    assert open(f.call_fn).read() == open(v.call_fn).read()
