@@ -154,3 +154,39 @@ def test_nonstop_cli_defaults():
     parser = trainNonstop.build_parser("x")
     args = parser.parse_args(["--bin_fn", "nope.bin"])
     assert args.ochk_prefix is None and args.learning_rate == 1e-3 and args.v3 is True and args.slim is False
+
+
+@pytest.mark.parametrize("tag,extra", [("plain", ["--includingAllContigs"]),
+                                       ("bed", ["--bed_fn", "regions.bed", "--qual", "100", "--threshold", "0.25",
+                                                "--refChunkSize", "5000000"])])
+def test_callvarbamparallel_prints_the_reference_command_list(tag, extra, tmp_path, capsys):
+    """golden: tests/golden/parallel/cmds_*.txt, printed by the reference's callVarBamParallel.py
+    (tests/golden/make_golden_parallel.py)"""
+    import shutil
+    from clairvoyante_amd import callVarBamParallel as par
+    P = os.path.join(G, "parallel")
+    work = str(tmp_path)
+    for f in ("model.meta", "in.bam", "ref.fa"):
+        open(os.path.join(work, f), "w").write("x")
+    shutil.copy(os.path.join(P, "ref.fa.fai"), os.path.join(work, "ref.fa.fai"))
+    shutil.copy(os.path.join(P, "regions.bed"), os.path.join(work, "regions.bed"))
+    extra = [os.path.join(work, e) if e == "regions.bed" else e for e in extra]
+    args = par.build_parser().parse_args(
+        ["--chkpnt_fn", os.path.join(work, "model"), "--bam_fn", os.path.join(work, "in.bam"), "--ref_fn",
+         os.path.join(work, "ref.fa"), "--output_prefix", "out/calls", "--pypy", "python3", "--samtools", "gzip",
+         "--sampleName", "NA1"] + extra)
+    par.Run(args)
+    got = capsys.readouterr().out.replace(work, "@DIR@").replace(os.path.dirname(os.path.abspath(par.__file__)), "@REF@")
+    assert got == open(os.path.join(P, "cmds_%s.txt" % tag)).read()
+
+
+@pytest.mark.parametrize("tag,region", [("all", (None, None)), ("region", (400, 1500))])
+def test_gettruth_rows_equal_reference_rows(tag, region, tmp_path, capfd):
+    """golden: tests/golden/truth/rows_*.txt, printed by the reference's GetTruth.py (make_golden_truth.py)"""
+    from clairvoyante_amd import GetTruth
+    T = os.path.join(G, "truth")
+    args = types.SimpleNamespace(vcf_fn=os.path.join(T, "sites.vcf"), var_fn=str(tmp_path / "rows.gz"), ctgName="ctgA",
+                                 ctgStart=region[0], ctgEnd=region[1])
+    GetTruth.OutputVariant(args)
+    import gzip
+    assert gzip.open(args.var_fn, "rt").read() == open(os.path.join(T, "rows_%s.txt" % tag)).read()
