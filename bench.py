@@ -66,6 +66,111 @@ def cpu_baseline(arch, P, x_sample, target_s=12.0):
                       "%d OpenMP threads, %.1f s" % (passes, n, cores, total)}, out, n
 
 
+def pileup_main(args):
+    """--mode pileup: a step = one device pass of the BAM front end over alignments already in HBM:
+    candidate counters (evc_count) + selection + tensor scatter + finalize; value = alignment columns/s.
+    Workload per rank: 2 000 000 reads x 150 bp (30x over a 10 Mbp contig, 1 % substitutions); ranks hold
+    different contigs (weak scaling, no collective).  Parsing the SAM text on the host is reported
+    beside it (`host_inclusive`), never as `value`."""
+    import torch
+    import torch.distributed as dist
+    from clairvoyante_amd import parallel, synth_pileup
+    from clairvoyante_amd.pileup import Pileup
+    rank, ws, local = parallel.init_from_env()
+    torch.cuda.set_device(local)
+    n_reads, L, read_len = 2000000, 10000000, 150
+    thr, mincov = 0.06, 4
+    ref, text = synth_pileup.fast_alignments(n_reads, L, read_len, seed=3 + rank)
+    pl = Pileup(evc=True, retain=True, contig="ctgA")
+    pl.set_reference(ref, 0)
+    t0 = time.perf_counter()
+    for s in range(0, len(text), 64 << 20):
+        pl.add_sam(text[s:s + (64 << 20)])
+    pl.extract_candidates(thr, mincov)
+    centers = pl.adopt_candidates()
+    tens, depth, touched = pl.finish(subtract=True)
+    torch.cuda.synchronize()
+    host_s = time.perf_counter() - t0
+    base = pl.stats()
+    check = (int(len(centers)), float(tens.sum().item()), int(depth.sum().item()))
+    steps = args.steps if args.steps != 64 else 20
+
+    def one_pass():
+        _lib_check(pl.lib.cv_pileup_recount(pl.h, pl._stream()))
+        pl.extract_candidates(thr, mincov)
+        pl.adopt_candidates()
+        return pl.finish(subtract=True)
+
+    from clairvoyante_amd._lib import check as _lib_check
+    for _ in range(args.warmup):
+        one_pass()
+    torch.cuda.synchronize()
+    use_dist = dist.is_available() and dist.is_initialized()
+    if use_dist:
+        dist.barrier()
+    s0 = pl.stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tens, depth, touched = one_pass()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    s1 = pl.stats()
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    same = check == (int(pl.n), float(tens.sum().item()), int(depth.sum().item()))
+    columns = n_reads * read_len
+    if rank == 0:
+        ms = {k: (s1[k] - s0[k]) / steps for k in ("candidate_ms", "scatter_ms", "finalize_ms")}
+        # Algorithmic HBM bytes per pass: every kernel reads the segments once (1 SEQ byte + 20/64 segment bytes per
+        # column); the candidate pass also writes the 36-byte counter row of every position, the scatter the
+        # 1 188-byte counter block of every candidate.  `roofline` is the slower of the two.
+        stream_bytes = columns * (1 + 20.0 / 64)
+        kernels = {"evc_count + select (candidate pass)": (ms["candidate_ms"], stream_bytes + L * 36.0),
+                   "pileup_scatter (tensor pass)": (ms["scatter_ms"], stream_bytes + columns / 64.0 + pl.n * 1188.0)}
+        kname = max(kernels, key=lambda k: kernels[k][0])
+        kern_ms, alg_bytes = kernels[kname]
+        roof = {"bound": "hbm", "kernel": kname, "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9,
+                "peak": 8000.0, "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                "avg_pass_ms": kern_ms, "note": "latency-bound candidate lookups per column (bucket table -> candidate list), "
+                "counters privatised in LDS; far from the HBM roof by construction: %.0f G columns/s" % (
+                    columns / (kern_ms * 1e-3) / 1e9),
+                "candidate_ms": ms["candidate_ms"], "scatter_ms": ms["scatter_ms"], "finalize_ms": ms["finalize_ms"],
+                "finalize_GBps": pl.n * (33 * 9 * 4 + 33 * 64) / (ms["finalize_ms"] * 1e-3) / 1e9}
+        cpu = None
+        if not args.no_cpu:
+            from oracle import create_tensor as oct_, extract_candidates as oec
+            lines = text[:100000 * (len(text) // n_reads)].decode().splitlines()        # first 100 000 reads
+            span = int(lines[-1].split("\t")[3]) + read_len
+            refs = ref[:span + 64].decode()
+            tc = time.perf_counter()
+            rows = oec.candidates("ctgA", refs, lines, minCoverage=mincov, threshold=thr)
+            cands = [int(r.split()[1]) for r in rows]
+            oct_.pileup(refs, None, lines, cands)
+            cs = time.perf_counter() - tc
+            cpu = {"value": len(lines) * read_len / cs, "unit": "alignment columns/s", "cores": 1, "kind": "port",
+                   "sample": "first %d reads of the timed set through oracle/extract_candidates.py + oracle/create_tensor.py "
+                             "(CPython restatement of the reference scripts), %.1f s" % (len(lines), cs)}
+        print(json.dumps({"metric": "alignment columns/sec (candidates + tensors)", "value": ws * steps * columns / dt,
+                          "unit": "columns/s", "n_gpus": ws, "steps": steps, "warmup": args.warmup,
+                          "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "i32", "data": "synthetic",
+                          "config": {"workload": "pileup front end: %d reads x %d bp over a %d bp contig per GPU, candidate "
+                                                 "threshold %.2f, min coverage %d; %d candidates" % (n_reads, read_len, L, thr,
+                                                                                                       mincov, pl.n)},
+                          "roofline": roof, "cpu_baseline": cpu,
+                          "host_inclusive": {"seconds": host_s, "sam_MB_per_s": len(text) / host_s / 1e6,
+                                             "columns_per_s": columns / host_s},
+                          "parity": {"repeat_passes_identical": bool(same)}}), flush=True)
+    pl.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def train_main(args):
     """--mode train: a step = one optimizer step (forward, backward, all-reduce, Adam) on a global batch of
     param.trainBatchSize = 10 000 synthetic labelled tensors (strong scaling: the batch is split)."""
@@ -124,10 +229,11 @@ def main():
     ap.add_argument("--arch", default="full", choices=["full", "slim"])
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "pileup"],
                     help="infer (default, the headline metric) or train: Adam steps on the reference's global "
                          "batch of 10 000 split over the ranks, one RCCL gradient all-reduce per step "
-                         "(BASELINE.json configs[3])")
+                         "(BASELINE.json configs[3]); pileup: candidate extraction + tensor generation over "
+                         "alignments resident in HBM (SURVEY.md 8f N4)")
     args = ap.parse_args()
 
     import numpy as np
@@ -139,6 +245,8 @@ def main():
 
     if args.mode == "train":
         return train_main(args)
+    if args.mode == "pileup":
+        return pileup_main(args)
     rank, ws, local = parallel.init_from_env()
     if ws != args.gpus:
         if rank == 0:

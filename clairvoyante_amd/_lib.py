@@ -89,6 +89,7 @@ _SIGS = {
                                                ctypes.c_void_p]),
     "cv_pileup_adopt_candidates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                                   ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
+    "cv_pileup_recount": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "cv_pileup_get_candidates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                                 ctypes.POINTER(ctypes.c_int64)]),
     "cv_format_tensor_row": (ctypes.c_int64, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64,

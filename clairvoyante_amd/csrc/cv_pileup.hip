@@ -99,77 +99,155 @@ __global__ void bucket_build(const int32_t *__restrict__ cands, int n, int32_t l
     first[b] = l;
 }
 
-__global__ void __launch_bounds__(256)
+// A workgroup takes SC_SEGS consecutive segments.  The alignments are position-sorted, so their columns
+// fall on a short stretch of the contig and on a handful of candidates: the counters of the first SC_CANDS
+// candidates at or after (first read's POS - 16) live in LDS and are flushed once (non-zero entries only);
+// columns that reach later candidates go to the global counters directly.  Any input order is handled.
+constexpr int SC_SEGS = 512;
+constexpr int SC_CANDS = 40;              // 40 x 33 x 9 x 4 B = 47.5 KB of LDS
+
+__global__ void __launch_bounds__(1024)
 pileup_scatter(const seg_t *__restrict__ segs, int64_t nseg, const uint8_t *__restrict__ seq,
                const uint8_t *__restrict__ ref, int64_t ref_first, int64_t ref_len,
                const int32_t *__restrict__ cands, int n, const int32_t *__restrict__ bucket_first,
                int32_t bucket_lo, int64_t nb, int32_t *__restrict__ cnt, uint8_t *__restrict__ touched, int left)
 {
-    int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (s >= nseg) return;
-    const seg_t sg = segs[s];
-    const int lane = threadIdx.x & 63;
-    const int len = sg.info & 0xff;
-    const int type = (sg.info >> 8) & 3;
-    if (lane >= len || !(sg.info & F_CT)) return;
-    const int32_t r = type == T_INS ? sg.r0 : sg.r0 + lane;
-    const int q = type == T_DEL ? -1 : base_code(seq[(size_t)sg.q0 + lane]);
-    int rb = -1;
-    if (type != T_INS) {
-        int64_t ri = (int64_t)r - ref_first;
-        if (ri >= 0 && ri < ref_len) rb = base_code(ref[ri]);
+    __shared__ int32_t tab[SC_CANDS * WIDTH * NCNT];
+    const int64_t s0 = (int64_t)blockIdx.x * SC_SEGS;
+    const int64_t s1 = s0 + SC_SEGS < nseg ? s0 + SC_SEGS : nseg;
+    for (int k = threadIdx.x; k < SC_CANDS * WIDTH * NCNT; k += blockDim.x) tab[k] = 0;
+    // first candidate any column of this workgroup can reach
+    int i0;
+    {
+        const int64_t lo_c = (int64_t)segs[s0].pos - FLANK;
+        int64_t b = (lo_c - bucket_lo) >> BUCKET_SHIFT;
+        if (b < 0) b = 0;
+        if (b >= nb) b = nb - 1;
+        i0 = bucket_first[b];
+        while (i0 < n && (int64_t)cands[i0] < lo_c) ++i0;
     }
-    // candidates c with r - 16 <= c <= r + 17
-    const int64_t lo_c = (int64_t)r - FLANK, hi_c = (int64_t)r + FLANK + 1;
-    int64_t b = (lo_c - bucket_lo) >> BUCKET_SHIFT;
-    if (b < 0) b = 0;
-    if (b >= nb) return;
-    int i = bucket_first[b];
-    while (i < n && (int64_t)cands[i] < lo_c) ++i;
-    for (; i < n; ++i) {
-        const int64_t c = cands[i];
-        if (c > hi_c) break;
-        const int p = (int)(r - c) + FLANK + 1;
-        if (type != T_INS && (left || p == 0)) touched[i] = 1;
-        if (!left && (int64_t)sg.pos > c - (FLANK + 1)) continue;
-        if (p > WIDTH - 1) continue;
-        int32_t *row = cnt + ((size_t)i * WIDTH) * NCNT;
-        if (type == T_MATCH) {
-            if (rb >= 0 && q >= 0) atomicAdd(row + p * NCNT + 5 + q, 1);
-        } else if (p >= 1 && r > sg.pos) {
-            if (type == T_DEL) {
-                if (rb >= 0) atomicAdd(row + p * NCNT + 4, 1);
-            } else if (q >= 0) {
-                int idx = p + sg.adv0 + lane;
-                if (idx > WIDTH - 1 || idx < 0) idx = WIDTH - 1;
-                atomicAdd(row + idx * NCNT + q, 1);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int nw = blockDim.x >> 6;
+    constexpr int U = 4;                  // segments in flight per wave: the loop is a chain of dependent loads
+    for (int64_t sb = s0 + (threadIdx.x >> 6); sb < s1; sb += (int64_t)nw * U) {
+        seg_t sg[U];
+        bool on[U];
+        int32_t r[U];
+        int q[U], rb[U], ci[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t s = sb + (int64_t)u * nw;
+            on[u] = s < s1;
+            sg[u] = segs[on[u] ? s : s0];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int len = sg[u].info & 0xff;
+            const int type = (sg[u].info >> 8) & 3;
+            on[u] = on[u] && lane < len && (sg[u].info & F_CT);
+            r[u] = type == T_INS ? sg[u].r0 : sg[u].r0 + lane;
+            uint8_t qc = '?', rc = '?';
+            if (on[u] && type != T_DEL) qc = seq[(size_t)sg[u].q0 + lane];
+            const int64_t ri = (int64_t)r[u] - ref_first;
+            if (on[u] && type != T_INS && ri >= 0 && ri < ref_len) rc = ref[ri];
+            q[u] = base_code(qc);
+            rb[u] = base_code(rc);
+            int64_t b = ((int64_t)r[u] - FLANK - bucket_lo) >> BUCKET_SHIFT;
+            if (b < 0) b = 0;
+            if (b >= nb) on[u] = false;
+            ci[u] = on[u] ? bucket_first[b] : n;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!on[u]) continue;
+            const int type = (sg[u].info >> 8) & 3;
+            // candidates c with r - 16 <= c <= r + 17
+            const int64_t lo_c = (int64_t)r[u] - FLANK, hi_c = (int64_t)r[u] + FLANK + 1;
+            int i = ci[u];
+            while (i < n && (int64_t)cands[i] < lo_c) ++i;
+            for (; i < n; ++i) {
+                const int64_t c = cands[i];
+                if (c > hi_c) break;
+                const int p = (int)(r[u] - c) + FLANK + 1;
+                if (type != T_INS && (left || p == 0)) touched[i] = 1;
+                if (!left && (int64_t)sg[u].pos > c - (FLANK + 1)) continue;
+                if (p > WIDTH - 1) continue;
+                int slot = -1;
+                if (type == T_MATCH) {
+                    if (rb[u] >= 0 && q[u] >= 0) slot = p * NCNT + 5 + q[u];
+                } else if (p >= 1 && r[u] > sg[u].pos) {
+                    if (type == T_DEL) {
+                        if (rb[u] >= 0) slot = p * NCNT + 4;
+                    } else if (q[u] >= 0) {
+                        int idx = p + sg[u].adv0 + lane;
+                        if (idx > WIDTH - 1 || idx < 0) idx = WIDTH - 1;
+                        slot = idx * NCNT + q[u];
+                    }
+                }
+                if (slot < 0) continue;
+                const int j = i - i0;
+                if (j >= 0 && j < SC_CANDS) atomicAdd(&tab[j * WIDTH * NCNT + slot], 1);
+                else atomicAdd(cnt + ((size_t)i * WIDTH) * NCNT + slot, 1);
             }
         }
+    }
+    __syncthreads();
+    const int live = n - i0 < SC_CANDS ? n - i0 : SC_CANDS;
+    for (int k = threadIdx.x; k < live * WIDTH * NCNT; k += blockDim.x) {
+        const int v = tab[k];
+        if (v) atomicAdd(cnt + (size_t)i0 * WIDTH * NCNT + k, v);
     }
 }
 
 // ExtractVariantCandidates.py:152-174: per-position symbol counts
-__global__ void __launch_bounds__(256)
+// Same tiling: EVC_SEGS consecutive segments per workgroup, the counters of the EVC_WIN positions from
+// (first read's POS - 1) on live in LDS, non-zero entries are flushed once; columns outside go to HBM.
+constexpr int EVC_SEGS = 512;
+constexpr int EVC_WIN = 1536;             // 1536 x 9 x 4 B = 54 KB of LDS
+
+__global__ void __launch_bounds__(1024)
 evc_count(const seg_t *__restrict__ segs, int64_t nseg, const uint8_t *__restrict__ seq, int64_t ref_first,
           int64_t ref_len, int32_t *__restrict__ pc)
 {
-    int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (s >= nseg) return;
-    const seg_t sg = segs[s];
-    if (!(sg.info & F_EVC)) return;
+    __shared__ int32_t tab[EVC_WIN * NPOS];
+    const int64_t s0 = (int64_t)blockIdx.x * EVC_SEGS;
+    const int64_t s1 = s0 + EVC_SEGS < nseg ? s0 + EVC_SEGS : nseg;
+    for (int k = threadIdx.x; k < EVC_WIN * NPOS; k += blockDim.x) tab[k] = 0;
+    const int64_t base = (int64_t)segs[s0].pos - 1;
+    __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int len = sg.info & 0xff;
-    const int type = (sg.info >> 8) & 3;
-    if (type == T_MATCH) {
-        if (lane >= len) return;
-        const uint8_t ch = seq[(size_t)sg.q0 + lane];
-        const int k = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : ch == 'N' ? 6 : -1;
-        const int64_t ri = (int64_t)sg.r0 + lane - ref_first;
-        if (k >= 0 && ri >= 0 && ri < ref_len) atomicAdd(pc + ri * NPOS + k, 1);
-    } else if (lane == 0 && (sg.info & F_FIRST)) {          // one count per insertion / deletion run, at r-1
-        const int64_t ri = (int64_t)sg.r0 - 1 - ref_first;
-        const int k = (sg.info & F_LATE) ? (type == T_INS ? 7 : 8) : (type == T_INS ? 4 : 5);
-        if (ri >= 0 && ri < ref_len) atomicAdd(pc + ri * NPOS + k, 1);
+    for (int64_t s = s0 + (threadIdx.x >> 6); s < s1; s += (blockDim.x >> 6)) {
+        const seg_t sg = segs[s];
+        if (!(sg.info & F_EVC)) continue;
+        const int len = sg.info & 0xff;
+        const int type = (sg.info >> 8) & 3;
+        int64_t r;
+        int k;
+        if (type == T_MATCH) {
+            if (lane >= len) continue;
+            const uint8_t ch = seq[(size_t)sg.q0 + lane];
+            k = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : ch == 'N' ? 6 : -1;
+            r = (int64_t)sg.r0 + lane;
+        } else {
+            if (lane != 0 || !(sg.info & F_FIRST)) continue;       // one count per insertion / deletion run, at r-1
+            k = (sg.info & F_LATE) ? (type == T_INS ? 7 : 8) : (type == T_INS ? 4 : 5);
+            r = (int64_t)sg.r0 - 1;
+        }
+        if (k < 0) continue;
+        const int64_t off = r - base;
+        if (off >= 0 && off < EVC_WIN) atomicAdd(&tab[off * NPOS + k], 1);
+        else {
+            const int64_t ri = r - ref_first;
+            if (ri >= 0 && ri < ref_len) atomicAdd(pc + ri * NPOS + k, 1);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < EVC_WIN * NPOS; k += blockDim.x) {
+        const int v = tab[k];
+        if (!v) continue;
+        const int64_t ri = base + k / NPOS - ref_first;
+        if (ri >= 0 && ri < ref_len) atomicAdd(pc + ri * NPOS + k % NPOS, v);
     }
 }
 
@@ -584,8 +662,7 @@ static int launch_scatter(cv_pileup *p, const dev_batch &b, hipStream_t st)
     if (p->ev.size() >= 128 && drain(p->ev, p->ms_scatter)) return 1;
     {
         timed t(p->ev, st);
-        const int waves = 4;
-        pileup_scatter<<<(unsigned)((b.nseg + waves - 1) / waves), waves * 64, 0, st>>>(
+        pileup_scatter<<<(unsigned)((b.nseg + SC_SEGS - 1) / SC_SEGS), 1024, 0, st>>>(
             b.segs, (int64_t)b.nseg, b.seq, p->ref_dev, p->ref_first, p->ref_len, p->cand_dev, (int)p->n, p->bucket_dev,
             p->bucket_lo, p->nb, p->cnt_dev, p->touched_dev, p->left);
     }
@@ -632,9 +709,8 @@ extern "C" int cv_pileup_flush(cv_pileup *p, void *stream)
         if (p->eve.size() >= 128 && drain(p->eve, p->ms_evc)) return 1;
         {
             timed t(p->eve, st);
-            const int waves = 4;
-            evc_count<<<(unsigned)((ns + waves - 1) / waves), waves * 64, 0, st>>>(b.segs, (int64_t)ns, b.seq, p->ref_first,
-                                                                                     p->ref_len, p->pos_cnt);
+            evc_count<<<(unsigned)((ns + EVC_SEGS - 1) / EVC_SEGS), 1024, 0, st>>>(b.segs, (int64_t)ns, b.seq, p->ref_first,
+                                                                                   p->ref_len, p->pos_cnt);
         }
         PL_HIP(hipGetLastError());
     }
@@ -752,6 +828,25 @@ extern "C" int cv_pileup_adopt_candidates(cv_pileup *p, int has_range, int64_t l
     hipStream_t st = (hipStream_t)stream;
     for (const auto &b : p->kept) if (launch_scatter(p, b, st)) return 1;
     if (n_out) *n_out = (int64_t)c32.size();
+    return 0;
+}
+
+extern "C" int cv_pileup_recount(cv_pileup *p, void *stream)
+{
+    if (!p) { cv_set_error("cv_pileup_recount: null handle"); return 1; }
+    if (!p->evc || !p->retain) { cv_set_error("cv_pileup_recount: needs options 'evc' and 'retain'"); return 1; }
+    if (cv_pileup_flush(p, stream)) return 1;
+    if (!p->pos_cnt) return 0;
+    PL_HIP(hipSetDevice(p->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (p->eve.size() >= 128 && drain(p->eve, p->ms_evc)) return 1;
+    PL_HIP(hipMemsetAsync(p->pos_cnt, 0, (size_t)p->ref_len * NPOS * sizeof(int32_t), st));
+    for (const auto &b : p->kept) {
+        timed t(p->eve, st);
+        evc_count<<<(unsigned)((b.nseg + EVC_SEGS - 1) / EVC_SEGS), 1024, 0, st>>>(b.segs, (int64_t)b.nseg, b.seq,
+                                                                                   p->ref_first, p->ref_len, p->pos_cnt);
+    }
+    PL_HIP(hipGetLastError());
     return 0;
 }
 

@@ -130,3 +130,26 @@ def candidate_rows(ctg, positions, other_ctg=None):
             rows.append("%s %d X 9 A 5 C 4 G 0 T 0" % (other_ctg, p))      # must be ignored (:59)
         rows.append("%s %d X 9 A 5 C 4 G 0 T 0" % (ctg, p))
     return rows
+
+
+def fast_alignments(n_reads, ref_len, read_len=150, seed=3, sub=0.01, ctg="ctgA"):
+    """bench-scale workload built with array ops (~1 s per million reads): position-sorted reads of one
+    shape (<read_len>M) over a random contig, substitution rate `sub`.  -> (reference bytes, SAM text bytes)"""
+    rng = np.random.RandomState(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ref = acgt[rng.randint(0, 4, ref_len)]
+    pos = np.sort(rng.randint(0, ref_len - read_len, n_reads))
+    seq = ref[pos[:, None] + np.arange(read_len)[None, :]]
+    mut = rng.rand(n_reads, read_len) < sub
+    seq = np.where(mut, acgt[rng.randint(0, 4, (n_reads, read_len))], seq)
+    head = np.frombuffer(("r\t0\t%s\t" % ctg).encode(), dtype=np.uint8)
+    mid = np.frombuffer(("\t60\t%dM\t*\t0\t0\t" % read_len).encode(), dtype=np.uint8)
+    tail = np.frombuffer(b"\t*\n", dtype=np.uint8)
+    digits = 10
+    p1 = pos + 1
+    pd = np.empty((n_reads, digits), dtype=np.uint8)
+    for k in range(digits):
+        pd[:, digits - 1 - k] = 48 + (p1 // 10 ** k) % 10
+    line = np.concatenate([np.broadcast_to(head, (n_reads, len(head))), pd, np.broadcast_to(mid, (n_reads, len(mid))),
+                           seq, np.broadcast_to(tail, (n_reads, len(tail)))], axis=1)
+    return ref.tobytes(), np.ascontiguousarray(line).tobytes()

@@ -244,6 +244,10 @@ int cv_pileup_get_extracted(cv_pileup *p, int64_t *pos0, int32_t *late, int32_t 
 int cv_pileup_adopt_candidates(cv_pileup *p, int has_range, int64_t lo1, int64_t hi1, void *stream,
                                int64_t *n_out);
 
+/* Zero the per-position counters and run the candidate-pass count kernel again over the retained
+ * alignments (measurement: repeats the device pass without re-parsing; same result).            */
+int cv_pileup_recount(cv_pileup *p, void *stream);
+
 /* Current candidate centres (1-based); centers may be NULL to query the count.                  */
 int cv_pileup_get_candidates(cv_pileup *p, int64_t *centers, int64_t cap, int64_t *n_out);
 

@@ -43,19 +43,24 @@ def main():
     rng = np.random.RandomState(9)
     centers = np.unique(rng.randint(20, L - 20, L // spacing)).astype(np.int64)
     gen_s = time.time() - t0
-    pl = Pileup()
+    fused = os.environ.get("CV_PILEUP_FUSED", "0") == "1"
+    pl = Pileup(evc=fused, retain=fused, contig="ctgA")
     pl.set_reference(ref, 0)
-    pl.set_candidates(centers)
+    if not fused:
+        pl.set_candidates(centers)
     torch.cuda.synchronize()
     t0 = time.time()
     step = 64 << 20
     for s in range(0, len(text), step):
         pl.add_sam(text[s:s + step])
+    if fused:       # candidates from the alignments themselves (substitution rate 1 % -> threshold picks the noisy sites)
+        pl.extract_candidates(float(os.environ.get("CV_PILEUP_THR", "0.06")), 4)
+        centers = pl.adopt_candidates()
     t, d, u = pl.finish(subtract=True)
     torch.cuda.synchronize()
     wall = time.time() - t0
     st = pl.stats()
-    out = {"reads": n_reads, "contig": L, "candidates": int(len(centers)), "sam_bytes": len(text), "gen_s": gen_s,
+    out = {"fused": fused, "reads": n_reads, "contig": L, "candidates": int(len(centers)), "sam_bytes": len(text), "gen_s": gen_s,
            "wall_s": wall, "host_MBps": len(text) / wall / 1e6, "stats": st,
            "scatter_Gcol_per_s": st["columns"] / (st["scatter_ms"] * 1e-3) / 1e9 if st["scatter_ms"] else None,
            "finalize_GBps": len(centers) * (33 * 9 * 4 + 33 * 64) / (st["finalize_ms"] * 1e-3) / 1e9,
