@@ -11,27 +11,6 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
-def fast_sam(n_reads, L, read_len=150, seed=3, sub=0.01):
-    """fixed-shape reads (<read_len>M) built with array ops: ~1 s per million reads"""
-    rng = np.random.RandomState(seed)
-    ref = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.randint(0, 4, L)]
-    pos = np.sort(rng.randint(0, L - read_len, n_reads))
-    seq = ref[pos[:, None] + np.arange(read_len)[None, :]]
-    mut = rng.rand(n_reads, read_len) < sub
-    seq = np.where(mut, np.frombuffer(b"ACGT", dtype=np.uint8)[rng.randint(0, 4, (n_reads, read_len))], seq)
-    head = np.frombuffer(b"r\t0\tctgA\t", dtype=np.uint8)
-    mid = np.frombuffer(("\t60\t%dM\t*\t0\t0\t" % read_len).encode(), dtype=np.uint8)
-    tail = np.frombuffer(b"\t*\n", dtype=np.uint8)
-    digits = 10
-    p1 = pos + 1
-    pd = np.empty((n_reads, digits), dtype=np.uint8)
-    for k in range(digits):
-        pd[:, digits - 1 - k] = 48 + (p1 // 10 ** k) % 10
-    line = np.concatenate([np.broadcast_to(head, (n_reads, len(head))), pd, np.broadcast_to(mid, (n_reads, len(mid))),
-                           seq, np.broadcast_to(tail, (n_reads, len(tail)))], axis=1)
-    return ref.tobytes(), np.ascontiguousarray(line).tobytes(), pos
-
-
 def main():
     import torch
     from clairvoyante_amd.pileup import Pileup
@@ -39,7 +18,8 @@ def main():
     L = int(sys.argv[2]) if len(sys.argv) > 2 else 10000000
     spacing = int(sys.argv[3]) if len(sys.argv) > 3 else 100
     t0 = time.time()
-    ref, text, _ = fast_sam(n_reads, L)
+    from clairvoyante_amd.synth_pileup import fast_alignments
+    ref, text = fast_alignments(n_reads, L)
     rng = np.random.RandomState(9)
     centers = np.unique(rng.randint(20, L - 20, L // spacing)).astype(np.int64)
     gen_s = time.time() - t0
