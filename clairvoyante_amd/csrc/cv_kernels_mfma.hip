@@ -103,6 +103,25 @@ __global__ void pack_dense(const float *__restrict__ w, float *__restrict__ wp, 
     wp[t] = (k < K && o < N) ? w[(size_t)k * N + o] : 0.0f;
 }
 
+// forward weights of a dense layer in NSLAB slabs of NBS output fragments (padded to NBSP per k step):
+// [slab][kb][NBSP][lane][s] -- small batches run one workgroup per (group block, slab), so that a layer
+// with few groups still fills the chip
+__global__ void pack_dense_slabs(const float *__restrict__ w, float *__restrict__ wp, int K, int N, int KB, int NBS,
+                                 int NBSP, int NSLAB)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)NSLAB * KB * NBSP * 256;
+    if (t >= total) return;
+    int s = (int)(t & 3), lane = (int)((t >> 2) & 63);
+    int64_t frag = t >> 8;
+    int obs = (int)(frag % NBSP); frag /= NBSP;
+    int kb = (int)(frag % KB);
+    int slab = (int)(frag / KB);
+    int i = lane & 15, kq = lane >> 4;
+    int k = 16 * kb + 4 * s + kq, o = 16 * (slab * NBS + obs) + cv_sigma(i);
+    wp[t] = (obs < NBS && k < K && o < N) ? w[(size_t)k * N + o] : 0.0f;
+}
+
 // data-gradient weights of a dense layer: out feature = original input k, in feature =
 // original output j; fragments [slab][jb][ob_in_slab][lane][s] (slabs of NBS output fragments)
 __global__ void pack_dense_dgrad(const float *__restrict__ w, float *__restrict__ wp, int K, int N, int JB,
@@ -843,13 +862,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 2) void dense_tm(const f4 *__re
 #pragma unroll
     for (int ob = 0; ob < NB; ob++) {
         if constexpr (EPI == 0) {
-            const f4 b4 = load_bias4(bias, ob, q, nout);
+            const f4 b4 = load_bias4(bias, (int)blockIdx.y * NB + ob, q, nout);
             op[ob * 64] = selu4(acc[ob] + b4);
         } else {
             op[ob * 64] = acc[ob];
         }
     }
 }
+
+// up to this many groups (16 candidates each) fc4 runs as 3 output slabs per group block: 8-wave workgroups
+// x 3 slabs fill the 256 CUs from ~700 groups on; above the threshold one workgroup keeps all 21 tiles
+constexpr int CV_FC4_SLAB_MAX_G = 2048;
 
 inline unsigned nblk(int64_t total, int bs) { return (unsigned)((total + bs - 1) / bs); }
 
@@ -927,6 +950,10 @@ int cv_pack_weights(cv_model *m, hipStream_t st)
         pack_dense<<<nblk(tot, 256), 256, 0, st>>>(P + o[6], m->wp_fc4, s.flat, m->arch.fc4, s.kb4, nbp4);
         tot = (int64_t)s.nb4 * nbp5 * 256;
         pack_dense<<<nblk(tot, 256), 256, 0, st>>>(P + o[8], m->wp_fc5, m->arch.fc4, m->arch.fc5, s.nb4, nbp5);
+        if (m->wps_fc4) {       // full topology: fc4 in 3 slabs of 7 fragments for small batches
+            tot = (int64_t)3 * s.kb4 * 8 * 256;
+            pack_dense_slabs<<<nblk(tot, 256), 256, 0, st>>>(P + o[6], m->wps_fc4, s.flat, m->arch.fc4, s.kb4, 7, 8, 3);
+        }
     }
     pack_heads<<<nblk((int64_t)(s.nb4 + s.nb5) * 256, 256), 256, 0, st>>>(P + o[10], P + o[12], P + o[14], P + o[16],
                                                                           m->arch.fc4, m->arch.fc5, s.nb4, s.nb5,
@@ -989,7 +1016,8 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         else rc |= launch_conv<3, 2, 3, 3, 26, 0>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st);
         cv_prof_end(m, 2, st);
         cv_prof_begin(m, 3, st);
-        if (m->variant & 4) rc |= launch_dense<21, 8>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
+        if (G <= CV_FC4_SLAB_MAX_G) rc |= launch_dense<7, 8>(m->tm_p3, s.kb4, m->wps_fc4, P + o[7], a.fc4, m->tm_h4, G, st, 3);
+        else if (m->variant & 4) rc |= launch_dense<21, 8>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
         else rc |= launch_dense<21, 4>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
         cv_prof_end(m, 3, st);
         cv_prof_begin(m, 4, st);
@@ -1357,7 +1385,10 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
     const cv_shapes &s = m->sh;
     const int G = (int)((n + 15) / 16);
     if (is_full(a)) {
-        if (layer == 4) return launch_dense<21, 8>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);
+        if (layer == 4) {
+            if (G <= CV_FC4_SLAB_MAX_G) return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3);
+            return launch_dense<21, 8>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);
+        }
         return launch_dense<11, 4>(in_tm, s.nb4, m->wp_fc5, P + o[9], a.fc5, out_tm, G, st);
     }
     if (layer == 4) return launch_dense<3, 4>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);
