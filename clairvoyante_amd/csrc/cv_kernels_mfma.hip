@@ -1460,8 +1460,10 @@ int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_cm, const float *
     const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
     const int G = (int)((n + 15) / 16);
     float *Gd = m->grads; const int64_t *o = m->poff;
-    const int splits = G >= 64 ? 16 : 1;
+    int splits = G >= 64 ? 16 : 1;
     if (layer == 4) {
+        // 8-wave workgroups with 42 accumulator tiles per wave: one per CU, so keep the grid within 256
+        if (splits > 1) splits = 256 / ((s.kb4 + 15) / 16);
         dim3 grid((s.kb4 + 15) / 16, splits);
         if (is_full(a)) wgrad_dense_cm<21><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.kb4, (const f4 *)g_cm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7]);
         else wgrad_dense_cm<3><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.kb4, (const f4 *)g_cm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7]);
@@ -1481,7 +1483,9 @@ int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_cm, const float *
     const int G = (int)((n + 15) / 16);
     float *dw = m->grads + m->poff[2 * layer];
     float *db = m->grads + m->poff[2 * layer + 1];
-    const int splits = G < 256 ? (G > 0 ? G : 1) : 256;
+    // one wave per (output fragment, split): enough splits for ~2 waves per SIMD (1024 SIMDs)
+    const int want = (2048 + s.ntile[layer] - 1) / s.ntile[layer];
+    const int splits = G < want ? (G > 0 ? G : 1) : want;
     dim3 grid(s.ntile[layer], splits);
     const int cin = s.cin[layer], cout = a.cout[layer];
     if (is_full(a)) {
