@@ -410,42 +410,76 @@ __global__ void b_selu_tm(const tf4 *__restrict__ gact, const tf4 *__restrict__ 
     gpre[t] = r;
 }
 
-// max-pool backward + selu' on TM maps: one thread per (group, base*tile, lane) walks the positions.
-// act: H rows, gpool: H-p+1 rows, gpre: H rows; row stride = 4*NT fragments.
+// max-pool backward + selu' on TM maps: one thread per (group, base*tile, lane) streams over the positions
+// with the P rows of the current pooling window and their gradient accumulators in registers: per pooled
+// row one activation row and one gradient row are read and one finished row is written.  The gradient of a
+// pooled value goes to the FIRST maximum of its window; contributions are added in ascending window order.
+// act: H rows, gpool: H-P+1 rows, gpre: H rows; row stride = 4*NT fragments.
+template <int P>
 __global__ void b_pool_selu_tm(const tf4 *__restrict__ gpool, const tf4 *__restrict__ act, tf4 *__restrict__ gpre,
-                               int64_t G, int H, int NT, int p)
+                               int64_t G, int H, int NT)
 {
     const int cols = 4 * NT * 64;                     // f4 columns per group row
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= G * cols) return;
     const int col = (int)(t % cols);
     const int64_t g = t / cols;
-    const int Ho = H - p + 1;
+    const int Ho = H - P + 1;
     const tf4 *a = act + (size_t)g * H * cols + col;
     const tf4 *gp = gpool + (size_t)g * Ho * cols + col;
     tf4 *o = gpre + (size_t)g * H * cols + col;
-    for (int h = 0; h < H; h++) {
-        const tf4 me = a[(size_t)h * cols];
-        tf4 acc = (tf4){0.f, 0.f, 0.f, 0.f};
-        for (int ho = h - p + 1; ho <= h; ho++) {
-            if (ho < 0 || ho >= Ho) continue;
-            bool win[4] = {true, true, true, true};
-            for (int d = 0; d < p; d++) {
-                const int hh = ho + d;
-                if (hh == h) continue;
-                const tf4 v = a[(size_t)hh * cols];
+    const tf4 zero = (tf4){0.f, 0.f, 0.f, 0.f};
+    tf4 w[P], ac[P];
 #pragma unroll
-                for (int k = 0; k < 4; k++) win[k] = win[k] && (hh < h ? v[k] < me[k] : v[k] <= me[k]);
+    for (int d = 0; d + 1 < P; d++) { w[d] = a[(size_t)d * cols]; ac[d] = zero; }
+    for (int ho = 0; ho < Ho; ho++) {
+        w[P - 1] = a[(size_t)(ho + P - 1) * cols];
+        ac[P - 1] = zero;
+        const tf4 gv = gp[(size_t)ho * cols];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float mx = w[0][k];
+            int idx = 0;
+#pragma unroll
+            for (int d = 1; d < P; d++) {
+                const bool gt = w[d][k] > mx;
+                mx = gt ? w[d][k] : mx;
+                idx = gt ? d : idx;
             }
-            const tf4 gv = gp[(size_t)ho * cols];
 #pragma unroll
-            for (int k = 0; k < 4; k++) acc[k] += win[k] ? gv[k] : 0.0f;
+            for (int d = 0; d < P; d++) ac[d][k] += idx == d ? gv[k] : 0.0f;
         }
         tf4 r;
 #pragma unroll
-        for (int k = 0; k < 4; k++) r[k] = acc[k] * selu_grad_from_out(me[k]);
-        o[(size_t)h * cols] = r;
+        for (int k = 0; k < 4; k++) r[k] = ac[0][k] * selu_grad_from_out(w[0][k]);
+        o[(size_t)ho * cols] = r;                     // row ho belongs to no later window
+#pragma unroll
+        for (int d = 0; d + 1 < P; d++) { w[d] = w[d + 1]; ac[d] = ac[d + 1]; }
     }
+#pragma unroll
+    for (int d = 0; d + 1 < P; d++) {                 // the last P-1 rows
+        tf4 r;
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = ac[d][k] * selu_grad_from_out(w[d][k]);
+        o[(size_t)(Ho + d) * cols] = r;
+    }
+}
+
+static int launch_pool_selu(const float *gpool, const float *act, float *gpre, int64_t G, int H, int NT, int p,
+                            hipStream_t st)
+{
+    const unsigned grid = (unsigned)((G * 4 * NT * 64 + 255) / 256);
+    const tf4 *gi = (const tf4 *)gpool, *ai = (const tf4 *)act;
+    tf4 *go = (tf4 *)gpre;
+    switch (p) {
+    case 1: b_pool_selu_tm<1><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); break;
+    case 2: b_pool_selu_tm<2><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); break;
+    case 3: b_pool_selu_tm<3><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); break;
+    case 4: b_pool_selu_tm<4><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); break;
+    case 5: b_pool_selu_tm<5><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); break;
+    default: cv_set_error("pooling window %d is not supported by the tile backward pass", p); return 1;
+    }
+    return 0;
 }
 
 // heads on TM inputs: same as t_heads with cv_tm_index addressing
@@ -621,7 +655,7 @@ static int train_slice_plain(cv_model *m, const float *x, const float *y, int64_
     CV_HIP(hipGetLastError());
     if (!backward) return 0;
     // ---- backward
-    const int NS = 32;   // batch slices for the weight-gradient reductions
+    const int NS = 128;     // candidate-range splits of the head weight gradients (short serial loops, few atomics)   // batch slices for the weight-gradient reductions
     // heads: columns of ghpre: 0..3 base (input d4), 4..5 / 6..9 / 10..15 (input h5)
     b_dense_wgrad<<<dim3(nblk((a.fc4 + 1) * 4, 256), NS), 256, 0, st>>>(d4, a.fc4, ghpre + 0, 16, n, a.fc4, 4, G + o[10], G + o[11]);
     b_dense_wgrad<<<dim3(nblk((a.fc5 + 1) * 2, 256), NS), 256, 0, st>>>(h5, a.fc5, ghpre + 4, 16, n, a.fc5, 2, G + o[12], G + o[13]);
@@ -696,7 +730,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     float *tx = sb.take(np * 33 * 16), *cx = sb.take(np * 33 * 16);
     if (!cx) { cv_set_error("training workspace too small"); return 1; }
     if (cv_pack_train_weights(m, st)) return 1;
-    const int NS = 32;
+    const int NS = 128;     // candidate-range splits of the head weight gradients (short serial loops, few atomics)
     // heads: weight gradients (inputs read from TM), data gradients written to TM
     b_head_wgrad_tm<<<dim3(nblk((a.fc4 + 1) * 4, 256), NS), 256, 0, st>>>(td4, s.nb4, ghpre, 0, n, a.fc4, 4, G + o[10], G + o[11]);
     b_head_wgrad_tm<<<dim3(nblk((a.fc5 + 1) * 2, 256), NS), 256, 0, st>>>(th5, s.nb5, ghpre, 4, n, a.fc5, 2, G + o[12], G + o[13]);
@@ -722,7 +756,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     // conv stack
     for (int l = 2; l >= 0; l--) {
         const int H = s.hc[l], NT = s.ntile[l];
-        b_pool_selu_tm<<<nblk(Gn * 4 * NT * 64, 256), 256, 0, st>>>((const tf4 *)tgin[l], (const tf4 *)ta[l], (tf4 *)tgpre[l], Gn, H, NT, a.pool[l]);
+        if (launch_pool_selu(tgin[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st)) return 1;
         cv_tm_to_cm(tgpre[l], cgpre[l], Gn * H * 4 * NT, st);
         if (l == 0) {        // first layer: X viewed as [33][16] fragments
             cv_natural_to_tm(x, 33, 16, 16, 33, n, tx, st);
