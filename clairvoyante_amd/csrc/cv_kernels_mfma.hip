@@ -398,7 +398,9 @@ struct front_source {
 // convolution  gIn[h][w][ci] = sum g[h-kh+pt][w-kw+1][co] W[kh][kw][ci][co]  on flipped,
 // in/out-swapped packed weights (pack_conv_dgrad): padding 2 left / 1 right and
 // KH-1-(KH-1)/2 on top, no bias, no activation, no pooling.
-template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT, int MODE>
+// HSPLIT > 1 (no pooling, no fused first layer): HSPLIT waves share a (group, tile), each producing a
+// contiguous range of positions -- more waves in flight when a batch has few groups.
+template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT, int MODE, int HSPLIT = 1>
 __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, const float *__restrict__ x,
                                                    int64_t n, const float *__restrict__ wp1,
                                                    const float *__restrict__ bias1, int cout1,
@@ -407,6 +409,7 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
 {
     static_assert(FRONT == 0 || CINB == 1, "the fused first layer feeds one 16-channel fragment");
     static_assert(MODE != 2 || (POOL == 1 && FRONT == 0), "the data-gradient pass has no pooling / first layer");
+    static_assert(HSPLIT == 1 || (POOL == 1 && FRONT == 0), "position ranges need independent output rows");
     extern __shared__ __attribute__((aligned(16))) f4 ldsw[];
     constexpr int PADT = MODE == 2 ? KH - 1 - (KH - 1) / 2 : (KH - 1) / 2;
     constexpr int PADL = MODE == 2 ? 2 : 1;
@@ -416,8 +419,10 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int g = wv / NT, nt = wv % NT;
+    const int hs = wv % HSPLIT, gt = wv / HSPLIT;
+    const int g = gt / NT, nt = gt % NT;
     if (g >= G) return;
+    const int hbeg = HIN * hs / HSPLIT, hend = HIN * (hs + 1) / HSPLIT;      // positions [hbeg, hend)
     const int q = lane >> 4;
     const f4 b4 = MODE == 2 ? (f4){0.f, 0.f, 0.f, 0.f} : load_bias4(bias, nt, q, cout);
     const f4 *inp = in_tm + (size_t)g * (HIN * 4 * CINB * 64) + lane;
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
     // prologue: rows -PADT .. KH-2-PADT -> win[0..KH-2]; row KH-1-PADT -> nxt
 #pragma unroll
     for (int j = 0; j < KH; j++) {
-        const int hr = j - PADT;
+        const int hr = hbeg + j - PADT;
         f4 tmp[4][CINB];
 #pragma unroll
         for (int w = 0; w < 4; w++)
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
             }
     }
 #pragma unroll 1
-    for (int h = 0; h < HIN; h++) {
+    for (int h = hbeg; h < hend; h++) {
 #pragma unroll
         for (int w = 0; w < 4; w++)
 #pragma unroll
@@ -884,15 +889,15 @@ int set_lds(K kernel, size_t bytes)
     return 0;
 }
 
-template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT, int MODE = 0>
+template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT, int MODE = 0, int HSPLIT = 1>
 int launch_conv(const float *in, const float *x, int64_t n, const float *wp1, const float *bias1, int cout1,
                 const float *wp, const float *bias, int cout, float *out, int G, hipStream_t st,
                 float *act = nullptr)
 {
-    auto k = conv_tm<KH, CINB, NT, POOL, HIN, FRONT, MODE>;
+    auto k = conv_tm<KH, CINB, NT, POOL, HIN, FRONT, MODE, HSPLIT>;
     size_t lds = (size_t)NT * KH * 4 * CINB * 1024;
     if (set_lds(k, lds)) return 1;
-    unsigned grid = nblk((int64_t)G * NT, 4);
+    unsigned grid = nblk((int64_t)G * NT * HSPLIT, 4);
     k<<<grid, 256, lds, st>>>((const f4 *)in, x, n, wp1, bias1, cout1, (const f4 *)wp, bias, cout, (f4 *)out,
                               (f4 *)act, G);
     CV_HIP(hipGetLastError());
@@ -1418,11 +1423,20 @@ int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm,
     const cv_arch &a = m->arch;
     const int G = (int)((n + 15) / 16);
     const float *W = m->wpd_conv[layer];
+    const bool few = G <= 1024;        // train.py's batch of 10 000 is 625 groups: split the positions over more waves
     if (is_full(a)) {
-        if (layer == 2) return launch_conv<3, 3, 2, 1, 26, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
+        if (layer == 2) {
+            if (few) return launch_conv<3, 3, 2, 1, 26, 0, 2, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
+            return launch_conv<3, 3, 2, 1, 26, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
+        }
+        if (few) return launch_conv<2, 2, 1, 1, 29, 0, 2, 4>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
         return launch_conv<2, 2, 1, 1, 29, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
     }
-    if (layer == 2) return launch_conv<5, 2, 1, 1, 33, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
+    if (layer == 2) {
+        if (few) return launch_conv<5, 2, 1, 1, 33, 0, 2, 4>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
+        return launch_conv<5, 2, 1, 1, 33, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
+    }
+    if (few) return launch_conv<3, 1, 1, 1, 33, 0, 2, 4>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
     return launch_conv<3, 1, 1, 1, 33, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
 }
 
