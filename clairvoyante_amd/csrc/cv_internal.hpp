@@ -62,6 +62,8 @@ struct cv_model {
     float *wp_fc5;       // [nb4][nb5][64][4]
     float *wpd_conv[3];  // data-gradient weights of conv2 / conv3 (pack_conv_dgrad)
     float *wpd_fc4;      // data-gradient weights of fc4 [slab][jb][24][64][4]
+    float *wg_part;      // per-split tiles of the dense weight gradients (two-pass combine), owned
+    size_t wg_part_bytes;
     float *wps_fc4;      // forward weights of fc4 in 3 slabs [slab][kb][8][64][4] (full topology, small batches)
     float *wpd_fc5;      // data-gradient weights of fc5 [jb][24 | 4][64][4]
     float *wp_heads0;    // [nb4][64][4]  base head (rows 0..3)

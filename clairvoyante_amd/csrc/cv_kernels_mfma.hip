@@ -1108,7 +1108,8 @@ __global__ __launch_bounds__(256) void tm_to_cm(const f4 *__restrict__ tm, f4 *_
 template <int NJB>
 __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_cm, int KB,
                                                        const f4 *__restrict__ g_cm, int G, int K, int N,
-                                                       float *__restrict__ dw, float *__restrict__ db)
+                                                       float *__restrict__ dw, float *__restrict__ db,
+                                                       f4 *__restrict__ part)
 {
     __shared__ __attribute__((aligned(16))) f4 gl[2][NJB * 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1164,6 +1165,17 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_c
             if (jb < NJB && lane < 16 && j < N) atomicAdd(&db[j], v);
         }
     }
+    if (part) {     // two-pass combine: this split's tiles as whole fragments, summed by wgrad_dense_reduce
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const int kb = kb0 + a;
+            if (kb >= KB) continue;
+            f4 *pp = part + (((size_t)blockIdx.y * KB + kb) * NJB) * 64 + lane;
+#pragma unroll
+            for (int jb = 0; jb < NJB; jb++) pp[jb * 64] = acc[a][jb];
+        }
+        return;
+    }
     // scatter-add the tiles: lane (c', q) register r  <->  dW[16 kb + 4q + r][16 jb + c']
     const int cq = lane & 15, q = lane >> 4;
 #pragma unroll
@@ -1179,6 +1191,28 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_c
                 if (k < K && j < N) atomicAdd(&dw[(size_t)k * N + j], acc[a][jb][r]);
             }
         }
+    }
+}
+
+// second pass of the dense weight gradient: dW += sum over splits (ascending: a fixed summation order),
+// one thread per (kb, jb, lane) fragment element quadruple
+__global__ void wgrad_dense_reduce(const f4 *__restrict__ part, int splits, int KB, int NJB, int K, int N,
+                                   float *__restrict__ dw)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = (int64_t)KB * NJB * 64;
+    if (t >= per) return;
+    f4 v = part[t];
+    for (int sidx = 1; sidx < splits; sidx++) v += part[(size_t)sidx * per + t];
+    const int lane = (int)(t & 63);
+    const int64_t frag = t >> 6;
+    const int jb = (int)(frag % NJB), kb = (int)(frag / NJB);
+    const int j = 16 * jb + (lane & 15), q = lane >> 4;
+    if (j >= N) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int k = 16 * kb + 4 * q + r;
+        if (k < K) dw[(size_t)k * N + j] += v[r];
     }
 }
 
@@ -1468,26 +1502,44 @@ int cv_tm_to_cm(const float *tm, float *cm, int64_t nfrag, hipStream_t st)
     return 0;
 }
 
-// layer 4 = fc4 (x = pool3 CM, g = fc4 pre-activation gradient CM), 5 = fc5
+// layer 4 = fc4 (x = pool3 CM, g = fc4 pre-activation gradient CM), 5 = fc5.  The candidate range is split over
+// enough workgroups to cover the chip once (one 8-wave workgroup per CU); the per-split tiles go to a scratch
+// buffer and are summed in a fixed order by wgrad_dense_reduce (no float atomics on the weights).
+template <int NJB>
+static int dense_wgrad_launch(cv_model *m, const float *x_cm, int KB, const float *g_cm, int G, int K, int N, float *dw,
+                              float *db, hipStream_t st)
+{
+    const int kblocks = (KB + 15) / 16;
+    int splits = 256 / kblocks;
+    if (splits > G) splits = G;
+    if (splits < 1) splits = 1;
+    const size_t need = (size_t)splits * KB * NJB * 256 * sizeof(float);
+    if (m->wg_part_bytes < need) {
+        CV_HIP(hipStreamSynchronize(st));
+        if (m->wg_part) CV_HIP(hipFree(m->wg_part));
+        m->wg_part = nullptr; m->wg_part_bytes = 0;
+        CV_HIP(hipMalloc(&m->wg_part, need));
+        m->wg_part_bytes = need;
+    }
+    wgrad_dense_cm<NJB><<<dim3(kblocks, splits), 512, 0, st>>>((const f4 *)x_cm, KB, (const f4 *)g_cm, G, K, N, dw, db,
+                                                               (f4 *)m->wg_part);
+    const int64_t per = (int64_t)KB * NJB * 64;
+    wgrad_dense_reduce<<<nblk(per, 256), 256, 0, st>>>((const f4 *)m->wg_part, splits, KB, NJB, K, N, dw);
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
 int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_cm, const float *g_cm, int64_t n, hipStream_t st)
 {
     const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
     const int G = (int)((n + 15) / 16);
     float *Gd = m->grads; const int64_t *o = m->poff;
-    int splits = G >= 64 ? 16 : 1;
     if (layer == 4) {
-        // 8-wave workgroups with 42 accumulator tiles per wave: one per CU, so keep the grid within 256
-        if (splits > 1) splits = 256 / ((s.kb4 + 15) / 16);
-        dim3 grid((s.kb4 + 15) / 16, splits);
-        if (is_full(a)) wgrad_dense_cm<21><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.kb4, (const f4 *)g_cm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7]);
-        else wgrad_dense_cm<3><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.kb4, (const f4 *)g_cm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7]);
-    } else {
-        dim3 grid((s.nb4 + 15) / 16, splits);
-        if (is_full(a)) wgrad_dense_cm<11><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.nb4, (const f4 *)g_cm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9]);
-        else wgrad_dense_cm<2><<<grid, 512, 0, st>>>((const f4 *)x_cm, s.nb4, (const f4 *)g_cm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9]);
+        if (is_full(a)) return dense_wgrad_launch<21>(m, x_cm, s.kb4, g_cm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7], st);
+        return dense_wgrad_launch<3>(m, x_cm, s.kb4, g_cm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7], st);
     }
-    CV_HIP(hipGetLastError());
-    return 0;
+    if (is_full(a)) return dense_wgrad_launch<11>(m, x_cm, s.nb4, g_cm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9], st);
+    return dense_wgrad_launch<2>(m, x_cm, s.nb4, g_cm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9], st);
 }
 
 // layer 1 = conv2 (in = pool1 CM), 2 = conv3 (in = pool2 CM); g = pre-activation gradient CM
