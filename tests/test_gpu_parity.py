@@ -95,3 +95,25 @@ def test_plain_and_tile_kernels_agree_bitwise(setup):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), variant
     m.setOption("variant", 15)
     assert np.array_equal(a.view(np.uint32), ref["out"].view(np.uint32))     # ... the oracle's bits
+
+
+def test_large_pass_kernels_equal_small_pass_kernels(setup):
+    """A pass of more than 2 048 groups runs fc4 with all 21 output tiles per workgroup, smaller passes in
+    three output slabs: both must give the same bits (the small-pass bits are the oracle's, see above)."""
+    import torch
+    from clairvoyante_amd import synth
+    arch, P, m, x, ref = setup
+    n = 40000
+    xd = synth.make_candidates(n, seed=77, device="cuda")
+    m.setOption("impl", 1)
+    m.setOption("chunk", 8192)
+    small = m.predict_device(xd).cpu().numpy()
+    for variant in (15, 11):                 # 8-wave and 4-wave fc4 workgroups
+        m.setOption("variant", variant)
+        m.setOption("chunk", 65536)
+        big = m.predict_device(xd).cpu().numpy()
+        assert np.array_equal(small.view(np.uint32), big.view(np.uint32)), variant
+    m.setOption("variant", 15)
+    m.setOption("chunk", 65536)
+    head = m.predict(xd[:256].cpu().numpy())
+    assert np.array_equal(np.concatenate(head, axis=1), small[:256])
