@@ -133,9 +133,15 @@ def pileup_main(args):
                    "pileup_scatter (tensor pass)": (ms["scatter_ms"], stream_bytes + columns / 64.0 + pl.n * 1188.0)}
         kname = max(kernels, key=lambda k: kernels[k][0])
         kern_ms, alg_bytes = kernels[kname]
+        traffic = None
+        try:        # HBM bytes per pass from the committed PMC passes (same workload), see profiles/pmc_traffic.json
+            pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))["pileup"]
+            traffic = pm["evc_count" if kname.startswith("evc") else "pileup_scatter"]["hbm_bytes_per_pass"]
+        except Exception:
+            pass
         roof = {"bound": "hbm", "kernel": kname, "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9,
-                "peak": 8000.0, "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
-                "avg_pass_ms": kern_ms, "note": "latency-bound candidate lookups per column (bucket table -> candidate list), "
+                "peak": 8000.0, "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic,
+                "algorithmic_bytes": alg_bytes, "avg_pass_ms": kern_ms, "note": "latency-bound candidate lookups per column (bucket table -> candidate list), "
                 "counters privatised in LDS; far from the HBM roof by construction: %.0f G columns/s" % (
                     columns / (kern_ms * 1e-3) / 1e9),
                 "candidate_ms": ms["candidate_ms"], "scatter_ms": ms["scatter_ms"], "finalize_ms": ms["finalize_ms"],
