@@ -32,21 +32,8 @@ PEAK_HBM_GBS = 8000.0
 
 
 def usable_cores():
-    """host threads this process may actually use: affinity mask capped by the cgroup CPU quota
-    (the GPU box reports 256 logical CPUs under a 16-CPU quota; oversubscribing it throttles)"""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(round(float(quota) / float(period)))))
-    except Exception:
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, int(round(q / p_))))
-        except Exception:
-            pass
-    return n
+    from clairvoyante_amd._lib import usable_cores as f
+    return f()
 
 
 def cpu_baseline(arch, P, x_sample, target_s=12.0):
@@ -85,7 +72,7 @@ def pileup_main(args):
     pl.set_reference(ref, 0)
     t0 = time.perf_counter()
     for s in range(0, len(text), 64 << 20):
-        pl.add_sam(text[s:s + (64 << 20)])
+        pl.add_sam(text[s:s + (64 << 20)])          # 64 MiB pieces, like a pipe reader would hand them over
     pl.extract_candidates(thr, mincov)
     centers = pl.adopt_candidates()
     tens, depth, touched = pl.finish(subtract=True)

@@ -73,7 +73,7 @@ _SIGS = {
     "cv_pileup_destroy": (None, [ctypes.c_void_p]),
     "cv_pileup_set_reference": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64]),
     "cv_pileup_set_candidates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
-    "cv_pileup_add_sam": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int,
+    "cv_pileup_add_sam": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "cv_pileup_pending": (ctypes.c_int64, [ctypes.c_void_p]),
     "cv_pileup_flush": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -119,6 +119,25 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def usable_cores():
+    """host threads this process may actually use: affinity mask capped by the cgroup CPU quota (a box can
+    report 256 logical CPUs under a 16-CPU quota; oversubscribing it throttles)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(round(float(quota) / float(period)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(round(q / per))))
+        except Exception:
+            pass
+    return n
 
 
 def check(rc):

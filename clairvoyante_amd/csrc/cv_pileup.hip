@@ -43,6 +43,7 @@
 #include <algorithm>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/clairvoyante_amd.h"
@@ -353,7 +354,7 @@ struct dev_batch {                // one uploaded batch of segments
 
 struct cv_pileup {
     int device = 0, min_mq = 0, dcov = 250, left = 1;
-    int retain = 0, evc = 0, evc_min_mq = 0;
+    int retain = 0, evc = 0, evc_min_mq = 0, threads = 1;
     std::string contig;                 // RNAME test of the candidate pass (ExtractVariantCandidates.py:137-139)
     uint8_t *ref_dev = nullptr;
     int64_t ref_len = 0, ref_first = 0;
@@ -457,6 +458,7 @@ extern "C" int cv_pileup_set_option(cv_pileup *p, const char *key, int64_t value
     if (!strcmp(key, "retain")) p->retain = value != 0;
     else if (!strcmp(key, "evc")) p->evc = value != 0;
     else if (!strcmp(key, "evc_min_mq")) p->evc_min_mq = (int)value;
+    else if (!strcmp(key, "threads")) p->threads = value < 1 ? 1 : value > 64 ? 64 : (int)value;
     else { cv_set_error("cv_pileup_set_option: unknown key '%s'", key); return 1; }
     return 0;
 }
@@ -526,10 +528,30 @@ extern "C" int cv_pileup_set_candidates(cv_pileup *p, const int64_t *centers, in
 }
 
 // ---- SAM text -> segments ---------------------------------------------------------------------
+// Two steps, so that the text can be parsed by several threads: (1) every record is parsed on its own
+// (fields, CIGAR runs -> segments, the filters that need nothing but the record); (2) one cheap sequential
+// pass over the READS applies the two pieces of running state the reference keeps -- the per-POS depth cap
+// of the tensor pass (CreateTensor.py:165-172) and "an earlier read with this POS has swept POS-1" of the
+// candidate pass (ExtractVariantCandidates.py:176) -- by clearing flag bits in the segments of the reads
+// concerned (a segment with no flag left is skipped by both kernels).
 
 static inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
 
-static void emit(cv_pileup *p, int type, int flags, int64_t r0, uint64_t q0, int64_t n, int64_t pos, bool ref_advances)
+struct read_rec {                 // what step (2) needs of a read
+    int64_t pos;
+    uint32_t seg0, nseg;          // its segments inside the part
+    uint8_t ct, evc, leading;     // passed the stateless tensor / candidate filters; has a leading indel run
+};
+
+struct sam_part {                 // output of one parser thread
+    std::vector<seg_t> segs;
+    std::vector<uint8_t> seq;
+    std::vector<read_rec> reads;
+    int64_t cols = 0;
+    std::string err;
+};
+
+static void emit(sam_part &out, int type, int flags, int64_t r0, uint64_t q0, int64_t n, int64_t pos, bool ref_advances)
 {
     int64_t done = 0;
     while (done < n) {
@@ -540,14 +562,14 @@ static void emit(cv_pileup *p, int type, int flags, int64_t r0, uint64_t q0, int
         s.info = (int32_t)len | (type << 8) | flags | (done == 0 ? F_FIRST : 0);
         s.adv0 = type == T_INS ? (int32_t)done : 0;
         s.pos = (int32_t)pos;
-        p->segs.push_back(s);
+        out.segs.push_back(s);
         done += len;
     }
-    p->pending_cols += n;
+    out.cols += n;
 }
 
-// one SAM record (fields split on white space like `l.split()`, CreateTensor.py:141-152)
-static int parse_record(cv_pileup *p, const char *line, const char *end, int64_t *kept)
+// one SAM record (fields split on white space like `l.split()`, CreateTensor.py:141-152); false = error in out.err
+static bool parse_record(const cv_pileup *p, sam_part &out, const char *line, const char *end)
 {
     const char *f[10];
     const char *fe[10];
@@ -561,11 +583,13 @@ static int parse_record(cv_pileup *p, const char *line, const char *end, int64_t
         fe[nf] = c;
         ++nf;
     }
-    if (nf == 0) return 0;                 // blank line
-    if (f[0][0] == '@') return 0;          // header (:142)
+    if (nf == 0) return true;              // blank line
+    if (f[0][0] == '@') return true;       // header (:142)
+    char msg[160];
     if (nf < 10) {
-        cv_set_error("cv_pileup_add_sam: record with %d fields (need 10): %.60s", nf, line);
-        return 1;
+        snprintf(msg, sizeof(msg), "cv_pileup_add_sam: record with %d fields (need 10): %.60s", nf, line);
+        out.err = msg;
+        return false;
     }
     char *endp = nullptr;
     const int64_t pos = strtoll(f[3], &endp, 10) - 1;      // 0-based (:147)
@@ -584,38 +608,27 @@ static int parse_record(cv_pileup *p, const char *line, const char *end, int64_t
         if (op == 'M' || op == 'I' || op == 'D' || op == 'N' || op == 'S' || op == 'H' || op == 'P' || op == '=' ||
             op == 'X') { total += v; if (op == 'S') clipped += v; }
     }
-    // tensor pass: --minMQ, then the per-POS depth cap (CreateTensor.py:155,165-172)
-    bool ct_ok = mq >= p->min_mq;
-    if (ct_ok) {
-        if (p->prev_pos != pos) { p->prev_pos = pos; p->depth_cap = 0; }
-        else if (++p->depth_cap >= p->dcov) ct_ok = false;
-    }
-    // candidate pass: contig, --minMQ, at least 55 % of the read aligned (ExtractVariantCandidates.py:137-160)
+    // tensor pass: --minMQ (CreateTensor.py:155).  Candidate pass: contig, --minMQ, at least 55 % of the read
+    // aligned (ExtractVariantCandidates.py:137-160)
+    const bool ct_ok = mq >= p->min_mq;
     bool evc_ok = p->evc != 0 && mq >= p->evc_min_mq;
     if (evc_ok && !p->contig.empty()) {
         const size_t ln = (size_t)(fe[2] - f[2]);
         evc_ok = ln == p->contig.size() && !memcmp(f[2], p->contig.data(), ln);
     }
     if (evc_ok && 1.0 - (double)clipped / (double)(total + 1) < 0.55) evc_ok = false;
-    bool late_read = false;
-    if (evc_ok) {
-        late_read = p->evc_prev_pos == pos;     // an earlier read with this POS has swept POS-1 already (:176)
-        p->evc_prev_pos = pos;
-        p->evc_reads += 1;
-    }
-    if (!ct_ok && !evc_ok) return 0;
+    if (!ct_ok && !evc_ok) return true;
     if (pos < -(1LL << 30) || pos > (1LL << 31) - (1 << 24)) {
-        cv_set_error("cv_pileup_add_sam: POS %lld out of range", (long long)pos + 1);
-        return 1;
-    }
-    if ((uint64_t)p->seq.size() + (uint64_t)(need > seqlen ? need : seqlen) >= 0xffffffffull) {
-        cv_set_error("cv_pileup_add_sam: more than 4 Gi query bases queued; call cv_pileup_flush more often");
-        return 1;
+        snprintf(msg, sizeof(msg), "cv_pileup_add_sam: POS %lld out of range", (long long)pos + 1);
+        out.err = msg;
+        return false;
     }
     const int rf = (ct_ok ? F_CT : 0) | (evc_ok ? F_EVC : 0);
-    const uint64_t base = p->seq.size();
-    p->seq.insert(p->seq.end(), (const uint8_t *)f[9], (const uint8_t *)fe[9]);
-    if (need > seqlen) p->seq.insert(p->seq.end(), (size_t)(need - seqlen), (uint8_t)'?');
+    const uint64_t base = out.seq.size();
+    out.seq.insert(out.seq.end(), (const uint8_t *)f[9], (const uint8_t *)fe[9]);
+    if (need > seqlen) out.seq.insert(out.seq.end(), (size_t)(need - seqlen), (uint8_t)'?');   // short / absent SEQ
+    read_rec rr;
+    rr.pos = pos; rr.seg0 = (uint32_t)out.segs.size(); rr.ct = ct_ok; rr.evc = evc_ok; rr.leading = 0;
     int64_t r = pos, q = 0;
     for (const char *s = cg; s < cge;) {                    // re.finditer(r"(\d+)([MIDNSHP=X])") (:174)
         if (*s < '0' || *s > '9') { ++s; continue; }
@@ -623,33 +636,104 @@ static int parse_record(cv_pileup *p, const char *line, const char *end, int64_t
         while (s < cge && *s >= '0' && *s <= '9') v = v * 10 + (*s++ - '0');
         if (s >= cge) break;
         const char op = *s;
-        const int lf = rf | ((late_read && r == pos) ? F_LATE : 0);
+        // an insertion / deletion run that opens the read (r == POS) is provisionally "late"; step (2) keeps the
+        // mark only for reads that follow another candidate-pass read with the same POS
+        const int lf = rf | ((evc_ok && r == pos) ? F_LATE : 0);
         if (op == 'S') { q += v; ++s; }
-        else if (op == 'M' || op == '=' || op == 'X') { emit(p, T_MATCH, rf, r, base + q, v, pos, true); r += v; q += v; ++s; }
-        else if (op == 'I') { emit(p, T_INS, lf, r, base + q, v, pos, false); q += v; ++s; }
-        else if (op == 'D') { emit(p, T_DEL, lf, r, 0, v, pos, true); r += v; ++s; }
+        else if (op == 'M' || op == '=' || op == 'X') { emit(out, T_MATCH, rf, r, base + q, v, pos, true); r += v; q += v; ++s; }
+        else if (op == 'I') { if (lf & F_LATE) rr.leading = 1; emit(out, T_INS, lf, r, base + q, v, pos, false); q += v; ++s; }
+        else if (op == 'D') { if (lf & F_LATE) rr.leading = 1; emit(out, T_DEL, lf, r, 0, v, pos, true); r += v; ++s; }
         else if (op == 'N' || op == 'H' || op == 'P') { ++s; }   // no branch in the reference: nothing moves
         // any other character: the regex does not match at these digits; rescan from the next character
     }
-    ++*kept;
-    return 0;
+    rr.nseg = (uint32_t)out.segs.size() - rr.seg0;
+    out.reads.push_back(rr);
+    return true;
+}
+
+static void parse_range(const cv_pileup *p, sam_part *out, const char *cur, const char *end)
+{
+    out->segs.reserve((size_t)(end - cur) / 48);
+    out->seq.reserve((size_t)(end - cur) * 3 / 4);
+    while (cur < end) {
+        const char *nl = (const char *)memchr(cur, '\n', (size_t)(end - cur));
+        const char *le = nl ? nl : end;
+        if (!parse_record(p, *out, cur, le)) return;
+        cur = nl ? nl + 1 : end;
+    }
 }
 
 extern "C" int cv_pileup_add_sam(cv_pileup *p, const char *text, int64_t nbytes, int final, int64_t *consumed,
                                  int64_t *kept)
 {
     if (!p || (!text && nbytes > 0) || nbytes < 0) { cv_set_error("cv_pileup_add_sam: bad argument"); return 1; }
-    int64_t k = 0, done = 0;
-    const char *cur = text, *end = text + nbytes;
-    while (cur < end) {
-        const char *nl = (const char *)memchr(cur, '\n', (size_t)(end - cur));
-        if (!nl && !final) break;
-        const char *le = nl ? nl : end;
-        if (parse_record(p, cur, le, &k)) return 1;
-        cur = nl ? nl + 1 : end;
-        done = cur - text;
+    // whole lines only (unless final)
+    int64_t usable = nbytes;
+    if (!final) {
+        while (usable > 0 && text[usable - 1] != '\n') --usable;
     }
-    if (consumed) *consumed = done;
+    if (consumed) *consumed = usable;
+    if (kept) *kept = 0;
+    if (usable == 0) return 0;
+    // (1) parse, in line-aligned slices
+    int T = p->threads > 1 && usable >= (1 << 20) ? p->threads : 1;
+    std::vector<sam_part> parts((size_t)T);
+    std::vector<const char *> cut((size_t)T + 1);
+    cut[0] = text; cut[(size_t)T] = text + usable;
+    for (int t = 1; t < T; ++t) {
+        const char *c = text + usable * t / T;
+        const char *nl = (const char *)memchr(c, '\n', (size_t)(text + usable - c));
+        cut[(size_t)t] = nl ? nl + 1 : text + usable;
+        if (cut[(size_t)t] < cut[(size_t)t - 1]) cut[(size_t)t] = cut[(size_t)t - 1];
+    }
+    if (T == 1) {
+        parse_range(p, &parts[0], cut[0], cut[1]);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back(parse_range, p, &parts[(size_t)t], cut[(size_t)t], cut[(size_t)t + 1]);
+        for (auto &x : th) x.join();
+    }
+    for (auto &part : parts)
+        if (!part.err.empty()) { cv_set_error("%s", part.err.c_str()); return 1; }
+    // (2) running state over the reads, then append to the queue
+    int64_t k = 0;
+    for (auto &part : parts) {
+        for (const read_rec &rr : part.reads) {
+            int clear = 0;
+            if (rr.ct) {                                              // CreateTensor.py:165-172
+                if (p->prev_pos != rr.pos) { p->prev_pos = rr.pos; p->depth_cap = 0; }
+                else if (++p->depth_cap >= p->dcov) clear |= F_CT;
+            }
+            bool late = false;
+            if (rr.evc) {                                             // ExtractVariantCandidates.py:150,176
+                late = p->evc_prev_pos == rr.pos;
+                p->evc_prev_pos = rr.pos;
+                p->evc_reads += 1;
+            }
+            if (rr.leading && !late) clear |= F_LATE;
+            if (clear) {
+                bool alive = false;
+                for (uint32_t i = rr.seg0; i < rr.seg0 + rr.nseg; ++i) {
+                    part.segs[i].info &= ~clear;
+                    alive = alive || (part.segs[i].info & (F_CT | F_EVC));
+                }
+                if (alive) ++k;
+            } else {
+                ++k;
+            }
+        }
+        if ((uint64_t)p->seq.size() + (uint64_t)part.seq.size() >= 0xffffffffull) {
+            cv_set_error("cv_pileup_add_sam: more than 4 Gi query bases queued; call cv_pileup_flush more often");
+            return 1;
+        }
+        const uint32_t qbase = (uint32_t)p->seq.size();
+        const size_t s0 = p->segs.size();
+        p->segs.insert(p->segs.end(), part.segs.begin(), part.segs.end());
+        if (qbase)
+            for (size_t i = s0; i < p->segs.size(); ++i) p->segs[i].q0 += qbase;
+        p->seq.insert(p->seq.end(), part.seq.begin(), part.seq.end());
+        p->pending_cols += part.cols;
+    }
     if (kept) *kept = k;
     return 0;
 }

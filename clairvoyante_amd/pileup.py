@@ -15,7 +15,7 @@ FLUSH_COLUMNS = 1 << 26         # queue at most this many alignment columns on t
 
 class Pileup(object):
     def __init__(self, device=None, minMQ=0, dcov=250, considerleftedge=True, evc=False, retain=False, evc_minMQ=0,
-                 contig=None):
+                 contig=None, threads=None):
         import torch
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -31,6 +31,9 @@ class Pileup(object):
                 _lib.check(self.lib.cv_pileup_set_contig(self.h, contig.encode()))
         if retain:
             _lib.check(self.lib.cv_pileup_set_option(self.h, b"retain", 1))
+        # SAM text is parsed by several host threads (chunks of >= 1 MiB); the result does not depend on the count
+        self.threads = min(_lib.usable_cores(), 16) if threads is None else int(threads)
+        _lib.check(self.lib.cv_pileup_set_option(self.h, b"threads", self.threads))
         self.n = 0
         self.centers = np.zeros(0, dtype=np.int64)
         self._tail = b""
@@ -59,18 +62,39 @@ class Pileup(object):
         self.n = len(c)
         _lib.check(self.lib.cv_pileup_set_candidates(self.h, self.centers.ctypes.data_as(ctypes.c_void_p), self.n))
 
-    def add_sam(self, chunk, final=False):
-        """feed SAM text (bytes) in arbitrary chunks; an incomplete last line is kept for the next call"""
-        data = self._tail + chunk if self._tail else chunk
+    def _feed(self, data, off, final):
+        """parse data[off:] in place (no copy); returns the bytes consumed"""
+        n = len(data) - off
+        if n <= 0:
+            return 0
         consumed = ctypes.c_int64(0)
         kept = ctypes.c_int64(0)
-        _lib.check(self.lib.cv_pileup_add_sam(self.h, data, len(data), int(final), ctypes.byref(consumed),
+        base = ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p).value        # data stays referenced by the caller
+        _lib.check(self.lib.cv_pileup_add_sam(self.h, ctypes.c_void_p(base + off), n, int(final), ctypes.byref(consumed),
                                               ctypes.byref(kept)))
-        self._tail = data[consumed.value:]
         self.reads_kept += kept.value
+        self._kept_now += kept.value
+        return consumed.value
+
+    def add_sam(self, chunk, final=False):
+        """feed SAM text (bytes) in arbitrary chunks; an incomplete last line is kept for the next call"""
+        self._kept_now = 0
+        off = 0
+        if self._tail:
+            nl = chunk.find(b"\n")
+            if nl < 0 and not final:
+                self._tail += chunk
+                return 0
+            head = self._tail + (chunk if nl < 0 else chunk[:nl + 1])           # one line: the only bytes copied
+            self._tail = b""
+            self._feed(head, 0, final and nl < 0)
+            off = len(chunk) if nl < 0 else nl + 1
+        off += self._feed(chunk, off, final)
+        if off < len(chunk):
+            self._tail = chunk[off:]
         if self.lib.cv_pileup_pending(self.h) >= FLUSH_COLUMNS:
             _lib.check(self.lib.cv_pileup_flush(self.h, self._stream()))
-        return kept.value
+        return self._kept_now
 
     def finish(self, subtract=False, want_tensors=True):
         """-> (tensors [n,33,4,4] fp32 on the device, depth [n] int32, touched [n] bool)"""

@@ -333,3 +333,28 @@ def test_callvarbam_with_candidate_sites_from_a_vcf(tmp_path, oracle):
          str(tmp_path / "fused.vcf"), "--samtools", FAKE, "--vcf_fn", str(sites), "--qual", "30", "--sampleName", "S1"])
     callVarBam.Run(f)
     assert open(f.call_fn).read() == open(v.call_fn).read()
+
+
+def test_parser_thread_count_does_not_change_the_result():
+    """2 MiB chunks parsed by 1 thread and by 7 threads: identical candidates, tensors, depths and read counts
+    (per-POS depth cap and late-entry state cross the slice boundaries)"""
+    from clairvoyante_amd import synth_pileup as sp
+    from clairvoyante_amd.pileup import Pileup
+    ref, lines = sp.make_alignments(seed=901, ref_len=40000, n_reads=24000, profile=sp.NOISY_PROFILE, stack=9, read_len=(40, 120))
+    text = ("\n".join(lines) + "\n").encode()
+    assert len(text) > (2 << 20)
+    outs = []
+    for threads in (1, 7):
+        pl = Pileup(evc=True, retain=True, contig="ctgA", dcov=3, minMQ=3, evc_minMQ=5, threads=threads)
+        pl.set_reference(ref, 0)
+        for s0 in range(0, len(text), 2 << 20):
+            pl.add_sam(text[s0:s0 + (2 << 20)])
+        res = pl.extract_candidates(0.1, 3)
+        centers = pl.adopt_candidates()
+        t, d, u = pl.finish()
+        outs.append((res["pos0"], res["late"], res["counts"], res["reads"], centers, t.cpu().numpy(), d.cpu().numpy(),
+                     u.cpu().numpy(), pl.reads_kept))
+        pl.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    assert outs[0][1].sum() > 0 and len(outs[0][4]) > 1000          # late entries exist, many candidates
