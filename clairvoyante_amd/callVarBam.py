@@ -94,7 +94,8 @@ def region_tensors(args, device=None):
     return out
 
 
-def Run(args):
+def Run(args, model=None):
+    """`model`: an already restored Clairvoyante object to reuse (callVarBamParallel --run keeps one per rank)"""
     from . import callVar
     chkpnt_fn = CheckFileExist(args.chkpnt_fn, sfx=".meta")
     args.bam_fn = CheckFileExist(args.bam_fn)
@@ -115,9 +116,12 @@ def Run(args):
     else:
         from . import clairvoyante_v3 as cv
     t0 = time.time()
-    m = cv.Clairvoyante()
-    m.init()
-    m.restoreParameters(chkpnt_fn)
+    if model is None:
+        m = cv.Clairvoyante()
+        m.init()
+        m.restoreParameters(chkpnt_fn)
+    else:
+        m = model
     res = region_tensors(args, device=m.device.index)
     t1 = time.time()
     cargs = argparse.Namespace(call_fn=args.call_fn, qual=args.qual, sampleName=args.sampleName, ref_fn=args.ref_fn,
@@ -133,7 +137,8 @@ def Run(args):
                  "finalize %.1f ms), calling %.2f s" % (res["reads"], res["candidates"], len(centers), t1 - t0,
                                                         st["candidate_ms"], st["scatter_ms"], st["finalize_ms"],
                                                         time.time() - t1))
-    m.close()
+    if model is None:
+        m.close()
     return res
 
 

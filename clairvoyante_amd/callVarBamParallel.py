@@ -81,6 +81,13 @@ def Run(args):
     # --run: this rank's share of the chunks, in this process
     from . import callVarBam, parallel
     rank, ws, _local = parallel.init_from_env()
+    if args.slim:
+        from . import clairvoyante_v3_slim as cv
+    else:
+        from . import clairvoyante_v3 as cv
+    m = cv.Clairvoyante()                      # one model per rank, restored once
+    m.init()
+    m.restoreParameters(chk)
     for k, (name, start, end, out) in enumerate(todo):
         if k % ws != rank:
             continue
@@ -90,7 +97,8 @@ def Run(args):
              "--samtools", args.samtools, "--sampleName", args.sampleName, "--considerleftedge", str(bool(args.considerleftedge))]
             + (["--bed_fn", bed] if bed else []) + (["--vcf_fn", args.vcf_fn] if args.vcf_fn else [])
             + (["--qual", str(args.qual)] if args.qual else []) + (["--slim"] if args.slim else []))
-        callVarBam.Run(a)
+        callVarBam.Run(a, model=m)
+    m.close()
     return todo
 
 

@@ -358,3 +358,32 @@ def test_parser_thread_count_does_not_change_the_result():
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(np.asarray(a), np.asarray(b))
     assert outs[0][1].sum() > 0 and len(outs[0][4]) > 1000          # late entries exist, many candidates
+
+
+def test_callvarbamparallel_run_executes_the_chunks(tmp_path, oracle):
+    """--run: the chunks of the command list are executed in this process (rank 0 of 1), one VCF per chunk,
+    each equal to a stand-alone callVarBam of that region"""
+    sys.path.insert(0, HERE)
+    from clairvoyante_amd import callVarBam, callVarBamParallel
+    chk = _checkpoint(oracle, tmp_path)
+    base = os.path.join(G, "plain")
+    import shutil
+    fa = str(tmp_path / "ref.fa")
+    shutil.copy(base + ".fa", fa)
+    with open(fa + ".fai", "w") as fh:
+        fh.write("ctgA\t3000\t16\t70\t71\nother\t10\t3100\t10\t11\n")
+    prefix = str(tmp_path / "calls")
+    a = callVarBamParallel.build_parser().parse_args(
+        ["--chkpnt_fn", chk, "--bam_fn", base + ".sam", "--ref_fn", fa, "--output_prefix", prefix, "--samtools", FAKE,
+         "--refChunkSize", "1600", "--includingAllContigs", "--threshold", "0.125", "--run"])
+    todo = callVarBamParallel.Run(a)
+    assert [(c, s, e) for c, s, e, _ in todo] == [("ctgA", 0, 1600), ("ctgA", 1600, 3000), ("other", 0, 10)]
+    total = 0
+    for ctg, s0, e0, out in todo:
+        f = callVarBam.build_parser().parse_args(
+            ["--chkpnt_fn", chk, "--bam_fn", base + ".sam", "--ref_fn", fa, "--ctgName", ctg, "--ctgStart", str(s0),
+             "--ctgEnd", str(e0), "--call_fn", str(tmp_path / "single.vcf"), "--samtools", FAKE, "--threshold", "0.125"])
+        callVarBam.Run(f)
+        assert open(out).read() == open(f.call_fn).read()
+        total += sum(1 for l in open(out) if not l.startswith("#"))
+    assert total > 10
