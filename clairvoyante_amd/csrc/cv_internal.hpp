@@ -118,10 +118,9 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
 int cv_tile_fc5_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
 int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
 int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
-int cv_tm_to_cm(const float *tm, float *cm, int64_t nfrag, hipStream_t st);
-int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_cm, const float *g_cm, int64_t n, hipStream_t st);
-int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_cm, const float *g_cm, int64_t n, hipStream_t st);
-int cv_tile_conv1_wgrad(cv_model *m, const float *x_cm, const float *g_cm, int64_t n, hipStream_t st);
+int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_tm, const float *g_tm, int64_t n, hipStream_t st);
+int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_tm, const float *g_tm, int64_t n, hipStream_t st);
+int cv_tile_conv1_wgrad(cv_model *m, const float *x_tm, const float *g_tm, int64_t n, hipStream_t st);
 int cv_natural_to_tm(const float *nat, int KB, int FPP, int FP, int npos, int64_t n, float *tm, hipStream_t st);
 int cv_dropout_tm(cv_model *m, const float *h4, float *d4, float *amask, int64_t n, float rate, uint64_t seed,
                   uint64_t step, int64_t cand0, hipStream_t st);

@@ -1078,41 +1078,44 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
 // ("CM" fragment: lane (f, rg) register t = value(feature f, candidate 4*rg + t)).  The
 // transpose itself is done by the matrix core: feeding TM register s as the A operand and
 // the constant 0/1 matrix B_s[k][j] = (j == 4s + k) accumulates D[c][f] = value(c, f) in four
-// steps -- exact (products with 1.0 and 0.0 only).  CM fragments of the layer input (A operand)
+// steps -- exact (products with 1.0 and 0.0 only; `cm_of` below).  CM fragments of the layer input (A operand)
 // and of the pre-activation gradient (B operand) then give  dW[i][j] += sum_c X[c][i] G[c][j]
 // with four MFMA steps per 16 candidates; partial sums over candidate ranges are combined
 // with float atomics (the order of a training reduction is not part of the parity contract).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tm_to_cm(const f4 *__restrict__ tm, f4 *__restrict__ cm, int64_t nfrag)
-{
-    const int lane = threadIdx.x & 63;
-    const int j = lane & 15, k = lane >> 4;
+// TM fragment -> CM fragment in registers (four MFMA steps against the constant 0/1 matrices, exact): the
+// weight-gradient kernels below read the tile-major buffers of the forward / backward pass directly and
+// transpose each fragment on the way in, so no candidate-major copy of any tensor exists in HBM.
+struct cm_of {
     float Bc[4];
+    __device__ __forceinline__ explicit cm_of(int lane)
+    {
+        const int j = lane & 15, k = lane >> 4;
 #pragma unroll
-    for (int s = 0; s < 4; s++) Bc[s] = (j == 4 * s + k) ? 1.0f : 0.0f;
-    int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    for (int64_t fr = wv; fr < nfrag; fr += stride) {
-        const f4 v = tm[fr * 64 + lane];
+        for (int s = 0; s < 4; s++) Bc[s] = (j == 4 * s + k) ? 1.0f : 0.0f;
+    }
+    __device__ __forceinline__ f4 operator()(const f4 v) const
+    {
         f4 d = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; s++) d = mfma4(v[s], Bc[s], d);
-        cm[fr * 64 + lane] = d;
+        return d;
     }
-}
+};
 
 // dense layer: dW[k][j] += sum_cand X[cand][k] G[cand][j], db[j] += sum_cand G[cand][j].
 // Workgroup = 8 waves = 16 input fragments (two per wave) x all NJB output fragments; the
 // G fragments of a group are staged once per workgroup in a double-buffered LDS slot.
 // grid = (ceil(KB/16), group splits).
 template <int NJB>
-__global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_cm, int KB,
-                                                       const f4 *__restrict__ g_cm, int G, int K, int N,
+__global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_tm, int KB,
+                                                       const f4 *__restrict__ g_tm, int G, int K, int N,
                                                        float *__restrict__ dw, float *__restrict__ db,
                                                        f4 *__restrict__ part)
 {
     __shared__ __attribute__((aligned(16))) f4 gl[2][NJB * 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const cm_of T(lane);
     const int kb0 = blockIdx.x * 16 + wid * 2;
     const int per = (G + gridDim.y - 1) / gridDim.y;
     const int g0 = blockIdx.y * per, g1 = g0 + per < G ? g0 + per : G;
@@ -1129,17 +1132,17 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_c
     for (int i = 0; i < NBS; i++) bs[i] = zero;
     const bool do_bias = blockIdx.x == 0 && db != nullptr;
     if (g0 < g1) {
-        for (int i = tid; i < NJB * 64; i += 512) gl[0][i] = g_cm[(size_t)g0 * NJB * 64 + i];
+        for (int i = tid; i < NJB * 64; i += 512) gl[0][i] = T(g_tm[(size_t)g0 * NJB * 64 + i]);
     }
     __syncthreads();
     int buf = 0;
     for (int g = g0; g < g1; g++) {
         if (g + 1 < g1) {
-            for (int i = tid; i < NJB * 64; i += 512) gl[buf ^ 1][i] = g_cm[(size_t)(g + 1) * NJB * 64 + i];
+            for (int i = tid; i < NJB * 64; i += 512) gl[buf ^ 1][i] = T(g_tm[(size_t)(g + 1) * NJB * 64 + i]);
         }
         f4 X0 = zero, X1 = zero;
-        if (v0) X0 = x_cm[((size_t)g * KB + kb0) * 64 + lane];
-        if (v1) X1 = x_cm[((size_t)g * KB + kb0 + 1) * 64 + lane];
+        if (v0) X0 = T(x_tm[((size_t)g * KB + kb0) * 64 + lane]);
+        if (v1) X1 = T(x_tm[((size_t)g * KB + kb0 + 1) * 64 + lane]);
 #pragma unroll
         for (int jb = 0; jb < NJB; jb++) {
             const f4 B = gl[buf][jb * 64 + lane];
@@ -1221,12 +1224,13 @@ __global__ void wgrad_dense_reduce(const f4 *__restrict__ part, int splits, int 
 // that cob in registers and streams over groups and positions with a KH-row window of input
 // CM fragments.  grid = (NT, splits), 64 threads.
 template <int KH, int CINB, int NT, int HIN>
-__global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_cm, const f4 *__restrict__ g_cm,
+__global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm, const f4 *__restrict__ g_tm,
                                                      int G, int cin, int cout, float *__restrict__ dw,
                                                      float *__restrict__ db)
 {
     constexpr int PADT = (KH - 1) / 2;
     const int lane = threadIdx.x;
+    const cm_of T(lane);
     const int cob = blockIdx.x;
     const int per = (G + gridDim.y - 1) / gridDim.y;
     const int g0 = blockIdx.y * per, g1 = g0 + per < G ? g0 + per : G;
@@ -1240,8 +1244,8 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_cm
             for (int c = 0; c < CINB; c++) acc[a][b][c] = zero;
     f4 bsum = zero;
     for (int g = g0; g < g1; g++) {
-        const f4 *ip = in_cm + (size_t)g * (HIN * 4 * CINB * 64) + lane;
-        const f4 *gp = g_cm + (size_t)g * (HIN * 4 * NT * 64) + (size_t)cob * 64 + lane;
+        const f4 *ip = in_tm + (size_t)g * (HIN * 4 * CINB * 64) + lane;
+        const f4 *gp = g_tm + (size_t)g * (HIN * 4 * NT * 64) + (size_t)cob * 64 + lane;
         f4 win[KH][4][CINB];     // win[kh] = input row h + kh - PADT
 #pragma unroll
         for (int j = 0; j < KH; j++) {
@@ -1250,7 +1254,7 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_cm
             for (int w = 0; w < 4; w++)
 #pragma unroll
                 for (int cb = 0; cb < CINB; cb++)
-                    win[j][w][cb] = (hr >= 0 && hr < HIN && j < KH - 1) ? ip[(size_t)((hr * 4 + w) * CINB + cb) * 64] : zero;
+                    win[j][w][cb] = (hr >= 0 && hr < HIN && j < KH - 1) ? T(ip[(size_t)((hr * 4 + w) * CINB + cb) * 64]) : zero;
         }
 #pragma unroll 1
         for (int h = 0; h < HIN; h++) {
@@ -1260,11 +1264,11 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_cm
                 for (int w = 0; w < 4; w++)
 #pragma unroll
                     for (int cb = 0; cb < CINB; cb++)
-                        win[KH - 1][w][cb] = hr < HIN ? ip[(size_t)((hr * 4 + w) * CINB + cb) * 64] : zero;
+                        win[KH - 1][w][cb] = hr < HIN ? T(ip[(size_t)((hr * 4 + w) * CINB + cb) * 64]) : zero;
             }
             f4 Gr[4];
 #pragma unroll
-            for (int w = 0; w < 4; w++) Gr[w] = gp[(size_t)(h * 4 + w) * (NT * 64)];
+            for (int w = 0; w < 4; w++) Gr[w] = T(gp[(size_t)(h * 4 + w) * (NT * 64)]);
             bsum += (Gr[0] + Gr[1]) + (Gr[2] + Gr[3]);
 #pragma unroll
             for (int kh = 0; kh < KH; kh++) {
@@ -1319,26 +1323,27 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_cm
 // first layer (k(1,4), 4 input channels): the 16 (base, matrix) values of a position form ONE
 // fragment, so  T_wo[(wi, ci)][co] += X[h][(wi, ci)] G[h][wo][co]  gives every tap at once:
 // dW[kw][ci][co] = sum_wo T_wo[(wo + kw - 1, ci)][co].  One wave per candidate-range split.
-__global__ __launch_bounds__(64) void wgrad_conv1_cm(const f4 *__restrict__ x_cm, const f4 *__restrict__ g_cm,
+__global__ __launch_bounds__(64) void wgrad_conv1_cm(const f4 *__restrict__ x_tm, const f4 *__restrict__ g_tm,
                                                       int G, int cout, float *__restrict__ dw,
                                                       float *__restrict__ db)
 {
     constexpr int HIN = CV_INPUT_H;
     const int lane = threadIdx.x;
+    const cm_of T(lane);
     const int per = (G + gridDim.x - 1) / gridDim.x;
     const int g0 = blockIdx.x * per, g1 = g0 + per < G ? g0 + per : G;
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
     f4 acc[4] = {zero, zero, zero, zero};
     f4 bsum = zero;
     for (int g = g0; g < g1; g++) {
-        const f4 *xp = x_cm + (size_t)g * HIN * 64 + lane;
-        const f4 *gp = g_cm + (size_t)g * HIN * 4 * 64 + lane;
+        const f4 *xp = x_tm + (size_t)g * HIN * 64 + lane;
+        const f4 *gp = g_tm + (size_t)g * HIN * 4 * 64 + lane;
 #pragma unroll 3
         for (int h = 0; h < HIN; h++) {
-            const f4 X = xp[(size_t)h * 64];
+            const f4 X = T(xp[(size_t)h * 64]);
 #pragma unroll
             for (int wo = 0; wo < 4; wo++) {
-                const f4 Gf = gp[(size_t)(h * 4 + wo) * 64];
+                const f4 Gf = T(gp[(size_t)(h * 4 + wo) * 64]);
                 bsum += Gf;
 #pragma unroll
                 for (int t = 0; t < 4; t++) acc[wo] = mfma4(X[t], Gf[t], acc[wo]);
@@ -1493,20 +1498,11 @@ int cv_dropout_tm(cv_model *m, const float *h4, float *d4, float *amask, int64_t
     return 0;
 }
 
-int cv_tm_to_cm(const float *tm, float *cm, int64_t nfrag, hipStream_t st)
-{
-    if (nfrag <= 0) return 0;
-    unsigned grid = (unsigned)(nfrag / 4 + 1 < 4096 ? nfrag / 4 + 1 : 4096);
-    tm_to_cm<<<grid, 256, 0, st>>>((const f4 *)tm, (f4 *)cm, nfrag);
-    CV_HIP(hipGetLastError());
-    return 0;
-}
-
-// layer 4 = fc4 (x = pool3 CM, g = fc4 pre-activation gradient CM), 5 = fc5.  The candidate range is split over
+// layer 4 = fc4 (x = pool3 TM, g = fc4 pre-activation gradient TM), 5 = fc5.  The candidate range is split over
 // enough workgroups to cover the chip once (one 8-wave workgroup per CU); the per-split tiles go to a scratch
 // buffer and are summed in a fixed order by wgrad_dense_reduce (no float atomics on the weights).
 template <int NJB>
-static int dense_wgrad_launch(cv_model *m, const float *x_cm, int KB, const float *g_cm, int G, int K, int N, float *dw,
+static int dense_wgrad_launch(cv_model *m, const float *x_tm, int KB, const float *g_tm, int G, int K, int N, float *dw,
                               float *db, hipStream_t st)
 {
     const int kblocks = (KB + 15) / 16;
@@ -1521,7 +1517,7 @@ static int dense_wgrad_launch(cv_model *m, const float *x_cm, int KB, const floa
         CV_HIP(hipMalloc(&m->wg_part, need));
         m->wg_part_bytes = need;
     }
-    wgrad_dense_cm<NJB><<<dim3(kblocks, splits), 512, 0, st>>>((const f4 *)x_cm, KB, (const f4 *)g_cm, G, K, N, dw, db,
+    wgrad_dense_cm<NJB><<<dim3(kblocks, splits), 512, 0, st>>>((const f4 *)x_tm, KB, (const f4 *)g_tm, G, K, N, dw, db,
                                                                (f4 *)m->wg_part);
     const int64_t per = (int64_t)KB * NJB * 64;
     wgrad_dense_reduce<<<nblk(per, 256), 256, 0, st>>>((const f4 *)m->wg_part, splits, KB, NJB, K, N, dw);
@@ -1529,21 +1525,21 @@ static int dense_wgrad_launch(cv_model *m, const float *x_cm, int KB, const floa
     return 0;
 }
 
-int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_cm, const float *g_cm, int64_t n, hipStream_t st)
+int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_tm, const float *g_tm, int64_t n, hipStream_t st)
 {
     const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
     const int G = (int)((n + 15) / 16);
     float *Gd = m->grads; const int64_t *o = m->poff;
     if (layer == 4) {
-        if (is_full(a)) return dense_wgrad_launch<21>(m, x_cm, s.kb4, g_cm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7], st);
-        return dense_wgrad_launch<3>(m, x_cm, s.kb4, g_cm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7], st);
+        if (is_full(a)) return dense_wgrad_launch<21>(m, x_tm, s.kb4, g_tm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7], st);
+        return dense_wgrad_launch<3>(m, x_tm, s.kb4, g_tm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7], st);
     }
-    if (is_full(a)) return dense_wgrad_launch<11>(m, x_cm, s.nb4, g_cm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9], st);
-    return dense_wgrad_launch<2>(m, x_cm, s.nb4, g_cm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9], st);
+    if (is_full(a)) return dense_wgrad_launch<11>(m, x_tm, s.nb4, g_tm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9], st);
+    return dense_wgrad_launch<2>(m, x_tm, s.nb4, g_tm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9], st);
 }
 
-// layer 1 = conv2 (in = pool1 CM), 2 = conv3 (in = pool2 CM); g = pre-activation gradient CM
-int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_cm, const float *g_cm, int64_t n, hipStream_t st)
+// layer 1 = conv2 (in = pool1 TM), 2 = conv3 (in = pool2 TM); g = pre-activation gradient TM
+int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_tm, const float *g_tm, int64_t n, hipStream_t st)
 {
     const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
     const int G = (int)((n + 15) / 16);
@@ -1555,23 +1551,23 @@ int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_cm, const float *
     dim3 grid(s.ntile[layer], splits);
     const int cin = s.cin[layer], cout = a.cout[layer];
     if (is_full(a)) {
-        if (layer == 2) wgrad_conv_cm<3, 2, 3, 26><<<grid, 64, 0, st>>>((const f4 *)in_cm, (const f4 *)g_cm, G, cin, cout, dw, db);
-        else wgrad_conv_cm<2, 1, 2, 29><<<grid, 64, 0, st>>>((const f4 *)in_cm, (const f4 *)g_cm, G, cin, cout, dw, db);
+        if (layer == 2) wgrad_conv_cm<3, 2, 3, 26><<<grid, 64, 0, st>>>((const f4 *)in_tm, (const f4 *)g_tm, G, cin, cout, dw, db);
+        else wgrad_conv_cm<2, 1, 2, 29><<<grid, 64, 0, st>>>((const f4 *)in_tm, (const f4 *)g_tm, G, cin, cout, dw, db);
     } else {
-        if (layer == 2) wgrad_conv_cm<5, 1, 2, 33><<<grid, 64, 0, st>>>((const f4 *)in_cm, (const f4 *)g_cm, G, cin, cout, dw, db);
-        else wgrad_conv_cm<3, 1, 1, 33><<<grid, 64, 0, st>>>((const f4 *)in_cm, (const f4 *)g_cm, G, cin, cout, dw, db);
+        if (layer == 2) wgrad_conv_cm<5, 1, 2, 33><<<grid, 64, 0, st>>>((const f4 *)in_tm, (const f4 *)g_tm, G, cin, cout, dw, db);
+        else wgrad_conv_cm<3, 1, 1, 33><<<grid, 64, 0, st>>>((const f4 *)in_tm, (const f4 *)g_tm, G, cin, cout, dw, db);
     }
     CV_HIP(hipGetLastError());
     return 0;
 }
 
-// first layer: x_cm = CM fragments of X viewed as [33 positions][16 = base*4 + matrix], g = CM of its
+// first layer: x_tm = TM fragments of X viewed as [33 positions][16 = base*4 + matrix], g = TM of its
 // pre-activation gradient ([33*4] fragments per group)
-int cv_tile_conv1_wgrad(cv_model *m, const float *x_cm, const float *g_cm, int64_t n, hipStream_t st)
+int cv_tile_conv1_wgrad(cv_model *m, const float *x_tm, const float *g_tm, int64_t n, hipStream_t st)
 {
     const int G = (int)((n + 15) / 16);
     const int splits = G < 512 ? (G > 0 ? G : 1) : 512;
-    wgrad_conv1_cm<<<splits, 64, 0, st>>>((const f4 *)x_cm, (const f4 *)g_cm, G, m->arch.cout[0], m->grads + m->poff[0],
+    wgrad_conv1_cm<<<splits, 64, 0, st>>>((const f4 *)x_tm, (const f4 *)g_tm, G, m->arch.cout[0], m->grads + m->poff[0],
                                           m->grads + m->poff[1]);
     CV_HIP(hipGetLastError());
     return 0;

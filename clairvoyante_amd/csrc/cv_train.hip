@@ -608,10 +608,7 @@ static size_t train_floats_per_cand(const cv_model *m)
     // padded channel counts, plus the dense TM buffers
     for (int l = 0; l < 3; l++) f += (size_t)(2 * s.hc[l] + 2 * s.hp[l]) * 4 * s.ntile[l] * 16;
     f += 6 * (size_t)s.nb4 * 16 + 2 * (size_t)s.nb5 * 16;
-    // candidate-major operand copies of the weight-gradient kernels
-    for (int l = 0; l < 3; l++) f += (size_t)(s.hp[l] + s.hc[l]) * 4 * s.ntile[l] * 16;
-    f += 2 * (size_t)s.nb4 * 16 + 2 * (size_t)s.nb5 * 16;
-    f += 2 * 33 * 16 + 2 * (size_t)s.hc[0] * 4 * s.ntile[0] * 16;     // first-layer weight gradient operands
+    f += 33 * 16;                                   // X as tile-major fragments (first-layer weight gradient)
     return f + 64 * 80;
 }
 
@@ -719,16 +716,12 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
                                             backward ? ghpre : nullptr, m->loss_dev);
     CV_HIP(hipGetLastError());
     if (!backward) return 0;
-    // ---- backward buffers (TM gradients, CM operand copies)
+    // ---- backward buffers (TM gradients; the weight-gradient kernels transpose their operands in registers)
     float *tg5 = sb.take(np * f5u), *tg5pre = sb.take(np * f5u), *tgd4 = sb.take(np * f4u), *tg4pre = sb.take(np * f4u);
-    float *tgpre[3], *tgin[3], *cgpre[3], *cp[3];
-    for (int l = 0; l < 3; l++) {
-        tgpre[l] = sb.take(np * fa[l]); tgin[l] = sb.take(np * fp[l]);
-        cgpre[l] = sb.take(np * fa[l]); cp[l] = sb.take(np * fp[l]);
-    }
-    float *cd4 = sb.take(np * f4u), *cg4 = sb.take(np * f4u), *cg5 = sb.take(np * f5u);
-    float *tx = sb.take(np * 33 * 16), *cx = sb.take(np * 33 * 16);
-    if (!cx) { cv_set_error("training workspace too small"); return 1; }
+    float *tgpre[3], *tgin[3];
+    for (int l = 0; l < 3; l++) { tgpre[l] = sb.take(np * fa[l]); tgin[l] = sb.take(np * fp[l]); }
+    float *tx = sb.take(np * 33 * 16);
+    if (!tx) { cv_set_error("training workspace too small"); return 1; }
     if (cv_pack_train_weights(m, st)) return 1;
     const int NS = 128;     // candidate-range splits of the head weight gradients (short serial loops, few atomics)
     // heads: weight gradients (inputs read from TM), data gradients written to TM
@@ -740,31 +733,24 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
                                                                s.nb5, n, Gn, 0, tg5);
     // fc5
     b_selu_tm<<<nblk(np * f5u / 4, 256), 256, 0, st>>>((const tf4 *)tg5, (const tf4 *)th5, nullptr, (tf4 *)tg5pre, np * f5u / 4);
-    cv_tm_to_cm(td4, cd4, Gn * s.nb4, st);
-    cv_tm_to_cm(tg5pre, cg5, Gn * s.nb5, st);
-    if (cv_tile_dense_wgrad(m, 5, cd4, cg5, n, st)) return 1;
+    if (cv_tile_dense_wgrad(m, 5, td4, tg5pre, n, st)) return 1;
     if (cv_tile_fc5_dgrad(m, tg5pre, tgd4, n, st)) return 1;
     b_head_dgrad_tm<<<nblk(Gn * s.nb4 * 256, 256), 256, 0, st>>>(ghpre, P + o[10], P + o[12], P + o[14], P + o[16], a.fc4,
                                                                s.nb4, n, Gn, 1, tgd4);
     // dropout4 + selu' (h4 is the SELU output before dropout)
     b_selu_tm<<<nblk(np * f4u / 4, 256), 256, 0, st>>>((const tf4 *)tgd4, (const tf4 *)th4, (const tf4 *)tmask, (tf4 *)tg4pre, np * f4u / 4);
     // fc4
-    cv_tm_to_cm(tp[2], cp[2], Gn * s.kb4, st);
-    cv_tm_to_cm(tg4pre, cg4, Gn * s.nb4, st);
-    if (cv_tile_dense_wgrad(m, 4, cp[2], cg4, n, st)) return 1;
+    if (cv_tile_dense_wgrad(m, 4, tp[2], tg4pre, n, st)) return 1;
     if (cv_tile_fc4_dgrad(m, tg4pre, tgin[2], n, st)) return 1;
     // conv stack
     for (int l = 2; l >= 0; l--) {
         const int H = s.hc[l], NT = s.ntile[l];
         if (launch_pool_selu(tgin[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st)) return 1;
-        cv_tm_to_cm(tgpre[l], cgpre[l], Gn * H * 4 * NT, st);
         if (l == 0) {        // first layer: X viewed as [33][16] fragments
             cv_natural_to_tm(x, 33, 16, 16, 33, n, tx, st);
-            cv_tm_to_cm(tx, cx, Gn * 33, st);
-            if (cv_tile_conv1_wgrad(m, cx, cgpre[0], n, st)) return 1;
+            if (cv_tile_conv1_wgrad(m, tx, tgpre[0], n, st)) return 1;
         } else {
-            cv_tm_to_cm(tp[l - 1], cp[l - 1], Gn * s.hp[l - 1] * 4 * s.ntile[l - 1], st);
-            if (cv_tile_conv_wgrad(m, l, cp[l - 1], cgpre[l], n, st)) return 1;
+            if (cv_tile_conv_wgrad(m, l, tp[l - 1], tgpre[l], n, st)) return 1;
             if (cv_tile_conv_dgrad(m, l, tgpre[l], tgin[l - 1], n, st)) return 1;
         }
     }
