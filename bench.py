@@ -53,6 +53,30 @@ def cpu_baseline(arch, P, x_sample, target_s=12.0):
                       "%d OpenMP threads, %.1f s" % (passes, n, cores, total)}, out, n
 
 
+def cpu_torch_line(arch, P, x_sample, ref_out, target_s=6.0):
+    """Second CPU line: the same network in stock torch CPU ops (oneDNN convolutions / GEMMs,
+    fp32) -- the closest stand-in available here for the reference's TensorFlow-CPU kernels.  Not bit-identical
+    to the oracle (library summation order); its distance to the oracle is reported."""
+    import numpy as np
+    import torch
+    import torch_ref
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    bs = 8192
+    with torch.no_grad():
+        torch_ref.forward(arch, P, x_sample[:bs], dtype=torch.float32)                 # warm-up
+        t0 = time.time(); done = 0; outs = []
+        while time.time() - t0 < target_s and done < len(x_sample):
+            outs.append(torch_ref.forward(arch, P, x_sample[done:done + bs], dtype=torch.float32)["out"].numpy())
+            done += bs
+        dt = time.time() - t0
+    got = np.concatenate(outs)
+    n = got.shape[0]
+    return {"value": n / dt, "unit": "candidates/s", "cores": cores, "kind": "torch CPU ops (oneDNN), fp32 -- a "
+            "stand-in for TF-CPU, not the reference", "sample": "first %d candidates of the timed set, %.1f s" % (n, dt),
+            "max_abs_dprob_vs_oracle": float(np.abs(got - ref_out[:n]).max())}
+
+
 def pileup_main(args):
     """--mode pileup: a step = one device pass of the BAM front end over alignments already in HBM:
     candidate counters (evc_count) + selection + tensor scatter + finalize; value = alignment columns/s.
@@ -325,6 +349,10 @@ def main():
             cb, ref, n = cpu_baseline(args.arch, P, xs)
             got = m.predict_device(torch.from_numpy(xs[:n]).to(dev)).cpu().numpy()
             line["cpu_baseline"] = cb
+            try:
+                line["cpu_baseline_torch"] = cpu_torch_line(args.arch, P, xs, ref)
+            except Exception as e:      # informational only
+                line["cpu_baseline_torch"] = {"error": str(e)}
             line["parity"] = {"n": n, "argmax_match_per_head": common.argmax_match(got, ref),
                               "max_abs_dprob": float(np.abs(got - ref).max()),
                               "bitwise_equal_frac": common.bitwise_frac(got, ref)}
