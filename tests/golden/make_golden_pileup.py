@@ -37,7 +37,26 @@ CASES = {
               {"ctgStart": 0, "ctgEnd": 2000, "dcov": 2}),
     "eqx": (dict(seed=15, ref_len=2000, n_reads=260, profile=dict(sp.DEFAULT_PROFILE, eqx=True)), dict(n=60),
             {"minCoverage": 9}),
+    "handmade_dcov1": ("handmade", None, {"dcov": 1}),
+    "handmade": ("handmade", None, {}),
 }
+
+
+def handmade():
+    """a few records that hit the reference's corners: the very first read at POS 1 with --dcov 1 (previousPos
+    starts at 0, CreateTensor.py:139), a read that opens with a long insertion, runs of more than 64 columns, a
+    clipped-only record, P and H runs"""
+    ref = "ACGTTGCA" * 40
+    recs = [
+        "a\t0\tctgA\t1\t60\t20M\t*\t0\t0\t" + ref[0:20] + "\t*",
+        "b\t0\tctgA\t1\t60\t10M5I10M\t*\t0\t0\t" + ref[0:10] + "GGGGG" + ref[10:20] + "\t*",
+        "d\t0\tctgA\t5\t60\t70I1M\t*\t0\t0\t" + "A" * 70 + "C\t*",
+        "e\t0\tctgA\t9\t60\t5S100M20D50M3H\t*\t0\t0\t" + "T" * 5 + ref[8:108] + ref[128:178] + "\t*",
+        "f\t0\tctgA\t9\t60\t8S\t*\t0\t0\tACGTACGT\t*",
+        "g\t0\tctgA\t40\t60\t3M2P4M\t*\t0\t0\t" + ref[39:46] + "\t*",
+        "h\t0\tctgA\t300\t60\t12M\t*\t0\t0\t" + ref[299:311] + "\t*",
+    ]
+    return ref, recs, [1, 2, 17, 18, 19, 25, 40, 60, 100, 129, 150, 300, 310, len(ref)]
 
 
 def prepare():
@@ -62,8 +81,11 @@ def main():
     try:
         for name, (gkw, ckw, opts) in CASES.items():
             ctg = "ctgA"
-            ref, lines = sp.make_alignments(ctg=ctg, **gkw)
-            pos = sp.make_candidate_positions(gkw["seed"], len(ref), **ckw)
+            if gkw == "handmade":
+                ref, lines, pos = handmade()
+            else:
+                ref, lines = sp.make_alignments(ctg=ctg, **gkw)
+                pos = sp.make_candidate_positions(gkw["seed"], len(ref), **ckw)
             base = os.path.join(OUT, name)
             with open(base + ".fa", "w") as fh:
                 fh.write(">%s synthetic\n" % ctg)

@@ -387,3 +387,48 @@ def test_callvarbamparallel_run_executes_the_chunks(tmp_path, oracle):
         assert open(out).read() == open(f.call_fn).read()
         total += sum(1 for l in open(out) if not l.startswith("#"))
     assert total > 10
+
+
+def test_pileup_corner_cases_equal_oracle():
+    """hand-made records: first read at POS 1 under --dcov 1 (the reference's previousPos starts at 0, so that read
+    is already 'the second at its POS' and is dropped, CreateTensor.py:139,165-172), SEQ '*', a read that is one
+    long insertion, runs longer than 64 columns, clipped-only and padded CIGARs, no reads / no candidates"""
+    from clairvoyante_amd.pileup import Pileup
+    from oracle import create_tensor as ct
+    ref = ("ACGTTGCA" * 40)
+    L = len(ref)
+    recs = [
+        "a\t0\tctgA\t1\t60\t20M\t*\t0\t0\t" + ref[0:20] + "\t*",
+        "b\t0\tctgA\t1\t60\t10M5I10M\t*\t0\t0\t" + ref[0:10] + "GGGGG" + ref[10:20] + "\t*",
+        "c\t0\tctgA\t3\t60\t30M\t*\t0\t0\t*\t*",                                   # no SEQ
+        "d\t0\tctgA\t5\t60\t70I1M\t*\t0\t0\t" + "A" * 70 + "C\t*",                 # opens with a long insertion
+        "e\t0\tctgA\t9\t60\t5S100M20D50M3H\t*\t0\t0\t" + "T" * 5 + ref[8:108] + ref[128:178] + "\t*",
+        "f\t0\tctgA\t9\t60\t8S\t*\t0\t0\tACGTACGT\t*",                             # nothing aligned
+        "g\t0\tctgA\t40\t60\t3M2P4M\t*\t0\t0\t" + ref[39:46] + "\t*",
+        "h\t0\tctgA\t300\t60\t12M\t*\t0\t0\t" + ref[299:311] + "\t*",
+    ]
+    centers = np.asarray([1, 2, 17, 18, 19, 25, 40, 60, 100, 129, 150, 300, 310, L], dtype=np.int64)
+    for dcov, left in ((1, True), (250, True), (250, False)):
+        pl = Pileup(dcov=dcov, considerleftedge=left)
+        pl.set_reference(ref, 0)
+        pl.set_candidates(centers)
+        pl.add_sam("\n".join(recs).encode(), final=True)
+        t, d, u = pl.finish()
+        acc = ct.pileup(ref, None, recs, list(centers), 0, dcov, left)
+        T = t.cpu().numpy(); U = u.cpu().numpy()
+        for i, c in enumerate(centers):
+            assert bool(U[i]) == (int(c) in acc), (dcov, left, c)
+            exp = np.asarray(acc[int(c)].counts, dtype=np.float32) if int(c) in acc else np.zeros(528, np.float32)
+            assert np.array_equal(T[i].reshape(-1), exp), (dcov, left, c)
+        pl.close()
+    # no reads at all / no candidates at all
+    pl = Pileup()
+    pl.set_reference(ref, 0)
+    pl.set_candidates(centers)
+    t, d, u = pl.finish()
+    assert float(t.abs().sum()) == 0.0 and not bool(u.any())
+    pl.set_candidates([])
+    pl.add_sam(("\n".join(recs) + "\n").encode())
+    t, d, u = pl.finish()
+    assert t.shape[0] == 0
+    pl.close()

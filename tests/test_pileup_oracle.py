@@ -10,7 +10,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, ".."))
 G = os.path.join(HERE, "golden", "pileup")
-CASES = ["plain", "region", "noleftedge", "noisy", "eqx"]
+CASES = ["plain", "region", "noleftedge", "noisy", "eqx", "handmade", "handmade_dcov1"]
 
 
 def load_case(name):
@@ -42,7 +42,7 @@ def test_oracle_rows_equal_reference_rows(name):
     from oracle import create_tensor as ct
     contigs, sam, can, opts, want = load_case(name)
     got = ct.create_tensor("ctgA", contigs["ctgA"], sam, can, **norm_opts(opts))
-    assert len(want) > 40
+    assert len(want) > (40 if not name.startswith("handmade") else 5)
     assert sorted(got) == sorted(want)
     # every golden row is a distinct candidate; ours come out in ascending order
     pos = [int(r.split()[1]) for r in got]
