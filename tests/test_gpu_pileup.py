@@ -36,7 +36,7 @@ def test_createtensor_rows_equal_reference_rows(name, tmp_path):
     res = CreateTensor.OutputAlnTensor(args)
     got = gzip.open(args.tensor_fn, "rt").read().splitlines()
     assert sorted(got) == sorted(want)
-    assert res["stats"]["columns"] > 1000 and res["stats"]["launches"] >= 1
+    assert res["stats"]["columns"] > (1000 if not name.startswith("handmade") else 100) and res["stats"]["launches"] >= 1
 
 
 def run_pileup(ref, first0, lines, centers, chunk, **kw):
