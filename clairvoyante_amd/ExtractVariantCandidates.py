@@ -64,7 +64,8 @@ def candidate_rows(ctgName, res, ref_seq, shift):
     return rows
 
 
-def stream_alignments(args, pl, ctgStart, ctgEnd):
+def view_chunks(args, ctgStart, ctgEnd):
+    """the text of `samtools view -F 2308 BAM CTG[:S-E]` (CreateTensor.py:128-130) in READ_CHUNK pieces"""
     where = args.ctgName if ctgStart is None else "%s:%d-%d" % (args.ctgName, ctgStart, ctgEnd)
     p2 = subprocess.Popen(shlex.split("%s view -F 2308 %s %s" % (args.samtools, args.bam_fn, where)),
                           stdout=subprocess.PIPE, bufsize=8388608)
@@ -72,9 +73,16 @@ def stream_alignments(args, pl, ctgStart, ctgEnd):
         chunk = p2.stdout.read(READ_CHUNK)
         if not chunk:
             break
-        pl.add_sam(chunk)
+        yield chunk
     p2.stdout.close()
     p2.wait()
+
+
+def stream_alignments(args, pl, ctgStart, ctgEnd, source=None):
+    """feed the alignments of the region to the pileup; `source`: already fetched text pieces (a prefetching
+    caller), default: spawn samtools now"""
+    for chunk in (view_chunks(args, ctgStart, ctgEnd) if source is None else source):
+        pl.add_sam(chunk)
 
 
 def MakeCandidates(args):

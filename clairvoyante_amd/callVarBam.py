@@ -55,7 +55,7 @@ def truth_positions(args, ctgStart, ctgEnd):
     return np.unique(np.asarray(pos, dtype=np.int64))
 
 
-def region_tensors(args, device=None):
+def region_tensors(args, device=None, source=None):
     """candidates + tensors of one region, on the device.  -> dict(centers, tensors (matrices 1..3 minus
     matrix 0), seqs, stats, reads, candidates)"""
     import torch
@@ -66,14 +66,14 @@ def region_tensors(args, device=None):
         pl = Pileup(device=device, dcov=args.dcov, considerleftedge=args.considerleftedge)
         pl.set_reference(ref_seq, shift)
         pl.set_candidates(truth_positions(args, ctgStart, ctgEnd))
-        stream_alignments(args, pl, ctgStart, ctgEnd)
+        stream_alignments(args, pl, ctgStart, ctgEnd, source)
         n_candidates = pl.n
     else:
         bed = read_bed(args.bed_fn, args.ctgName) if args.bed_fn is not None else None
         pl = Pileup(device=device, dcov=args.dcov, considerleftedge=args.considerleftedge, evc=True, retain=True,
                     contig=args.ctgName)
         pl.set_reference(ref_seq, shift)
-        stream_alignments(args, pl, ctgStart, ctgEnd)
+        stream_alignments(args, pl, ctgStart, ctgEnd, source)
         pl.extract_candidates(args.threshold, args.minCoverage, (ctgStart, ctgEnd) if ctgStart is not None else None, bed)
         pl.adopt_candidates(ctgStart, ctgEnd)
         n_candidates = pl.n
@@ -94,8 +94,9 @@ def region_tensors(args, device=None):
     return out
 
 
-def Run(args, model=None):
-    """`model`: an already restored Clairvoyante object to reuse (callVarBamParallel --run keeps one per rank)"""
+def Run(args, model=None, source=None):
+    """`model`: an already restored Clairvoyante object to reuse (callVarBamParallel --run keeps one per rank);
+    `source`: the region's `samtools view` text, already fetched (pieces of bytes)"""
     from . import callVar
     chkpnt_fn = CheckFileExist(args.chkpnt_fn, sfx=".meta")
     args.bam_fn = CheckFileExist(args.bam_fn)
@@ -122,7 +123,7 @@ def Run(args, model=None):
         m.restoreParameters(chkpnt_fn)
     else:
         m = model
-    res = region_tensors(args, device=m.device.index)
+    res = region_tensors(args, device=m.device.index, source=source)
     t1 = time.time()
     cargs = argparse.Namespace(call_fn=args.call_fn, qual=args.qual, sampleName=args.sampleName, ref_fn=args.ref_fn,
                                showRef=False)

@@ -88,16 +88,39 @@ def Run(args):
     m = cv.Clairvoyante()                      # one model per rank, restored once
     m.init()
     m.restoreParameters(chk)
-    for k, (name, start, end, out) in enumerate(todo):
-        if k % ws != rank:
-            continue
-        a = callVarBam.build_parser().parse_args(
+    mine = [t for k, t in enumerate(todo) if k % ws == rank]
+
+    def chunk_args(name, start, end, out):
+        return callVarBam.build_parser().parse_args(
             ["--chkpnt_fn", chk, "--ref_fn", ref, "--bam_fn", bam, "--ctgName", name, "--ctgStart", str(start), "--ctgEnd",
              str(end), "--call_fn", out, "--threshold", str(args.threshold), "--minCoverage", str(args.minCoverage),
              "--samtools", args.samtools, "--sampleName", args.sampleName, "--considerleftedge", str(bool(args.considerleftedge))]
             + (["--bed_fn", bed] if bed else []) + (["--vcf_fn", args.vcf_fn] if args.vcf_fn else [])
             + (["--qual", str(args.qual)] if args.qual else []) + (["--slim"] if args.slim else []))
-        callVarBam.Run(a, model=m)
+
+    # `samtools view` (BAM decoding) is the slow producer: fetch the text of the next chunks in background
+    # threads while the GPU works on the current one
+    from concurrent.futures import ThreadPoolExecutor
+    from .CreateTensor import region_of
+    from .ExtractVariantCandidates import view_chunks
+
+    def fetch(a):
+        cs, ce, _rs, _re = region_of(a)
+        return list(view_chunks(a, cs, ce))
+
+    jobs = [chunk_args(*t) for t in mine]
+    for a in jobs:      # callVarBam.Run's own normalisation of the region (callVarBam.py:94-97)
+        if not (a.ctgStart is not None and a.ctgEnd is not None and int(a.ctgStart) <= int(a.ctgEnd)):
+            a.ctgStart = a.ctgEnd = None
+    depth = max(1, int(args.prefetch))
+    with ThreadPoolExecutor(max_workers=depth) as pool:
+        pending = [pool.submit(fetch, a) for a in jobs[:depth]]
+        for i, a in enumerate(jobs):
+            text = pending[i].result()
+            pending[i] = None
+            if i + depth < len(jobs):
+                pending.append(pool.submit(fetch, jobs[i + depth]))
+            callVarBam.Run(a, model=m, source=text)
     m.close()
     return todo
 
@@ -120,6 +143,7 @@ _CLI = (
     ("--samtools", str, "samtools", "Path to the 'samtools', default: %(default)s"),
     ("--pypy", str, "pypy", "Path to the 'pypy', default: %(default)s"),
     ("--delay", int, 10, "Wait a short while for no more than %(default)s to start the job."),
+    ("--prefetch", int, 3, "(--run) chunks whose `samtools view` text is fetched ahead, default: %(default)s"),
 )
 _SWITCHES = (("--includingAllContigs", False, "Call variants on all contigs, default: chr{1..22,X,Y,M,MT} and {1..22,X,Y,MT}"),
              ("--considerleftedge", True, "Count the left-most base-pairs of a read for coverage even if the starting "
