@@ -158,7 +158,7 @@ def pileup_main(args):
                 "candidate_ms": ms["candidate_ms"], "scatter_ms": ms["scatter_ms"], "finalize_ms": ms["finalize_ms"],
                 "finalize_GBps": pl.n * (33 * 9 * 4 + 33 * 64) / (ms["finalize_ms"] * 1e-3) / 1e9}
         cpu = None
-        if not args.no_cpu:
+        if not args.no_cpu and ws == 1:          # the CPU leg runs at N = 1 only
             from oracle import create_tensor as oct_, extract_candidates as oec
             lines = text[:100000 * (len(text) // n_reads)].decode().splitlines()        # first 100 000 reads
             span = int(lines[-1].split("\t")[3]) + read_len
@@ -344,7 +344,7 @@ def main():
                                        "batch %d x %d steps per GPU" % (args.arch, args.batch, args.steps),
                            "arch": args.arch, "batch": args.batch, "parallelism": "shard%d" % ws},
                 "roofline": roof, "kernels": stages}
-        if not args.no_cpu:
+        if not args.no_cpu and ws == 1:          # the CPU leg (and the parity block it feeds) runs at N = 1 only
             xs = torch.cat([b_ for b_ in batches[:4]])[:262144].cpu().numpy()
             cb, ref, n = cpu_baseline(args.arch, P, xs)
             got = m.predict_device(torch.from_numpy(xs[:n]).to(dev)).cpu().numpy()
