@@ -190,3 +190,23 @@ def test_gettruth_rows_equal_reference_rows(tag, region, tmp_path, capfd):
     GetTruth.OutputVariant(args)
     import gzip
     assert gzip.open(args.var_fn, "rt").read() == open(os.path.join(T, "rows_%s.txt" % tag)).read()
+
+
+def test_submodule_invocator_lists_and_dispatches(capsys, monkeypatch):
+    """python -m clairvoyante_amd SubmoduleName ... (the reference's clairvoyante.py:12-45)"""
+    import runpy
+    monkeypatch.setattr(sys, "argv", ["clairvoyante_amd"])
+    with pytest.raises(SystemExit) as e:
+        runpy.run_module("clairvoyante_amd", run_name="__main__")
+    assert e.value.code == 0
+    out = capsys.readouterr().out
+    for name in ("callVarBam", "callVar", "train", "CreateTensor", "ExtractVariantCandidates"):
+        assert "- %s\n" % name in out
+    monkeypatch.setattr(sys, "argv", ["clairvoyante_amd", "train"])          # no options: the submodule prints its help
+    with pytest.raises(SystemExit) as e:
+        runpy.run_module("clairvoyante_amd", run_name="__main__")
+    assert e.value.code == 1 and "--bin_fn" in capsys.readouterr().out
+    monkeypatch.setattr(sys, "argv", ["clairvoyante_amd", "demoRun"])
+    with pytest.raises(SystemExit) as e:
+        runpy.run_module("clairvoyante_amd", run_name="__main__")
+    assert "not part of this build" in str(e.value.code)
