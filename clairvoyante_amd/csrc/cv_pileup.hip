@@ -86,6 +86,12 @@ __device__ __forceinline__ int base_code(uint8_t ch)
     return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1;
 }
 
+__global__ void rebase_q0(seg_t *__restrict__ segs, int64_t n, uint32_t base)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) segs[t].q0 += base;
+}
+
 __global__ void bucket_build(const int32_t *__restrict__ cands, int n, int32_t lo, int64_t nb,
                              int32_t *__restrict__ first)
 {
@@ -346,6 +352,20 @@ pileup_finalize(const int32_t *__restrict__ cnt, const int32_t *__restrict__ can
 
 }  // namespace
 
+struct read_rec {                 // what step (2) needs of a read
+    int64_t pos;
+    uint32_t seg0, nseg;          // its segments inside the part
+    uint8_t ct, evc, leading;     // passed the stateless tensor / candidate filters; has a leading indel run
+};
+
+struct sam_part {                 // output of one parser thread
+    std::vector<seg_t> segs;
+    std::vector<uint8_t> seq;
+    std::vector<read_rec> reads;
+    int64_t cols = 0;
+    std::string err;
+};
+
 struct dev_batch {                // one uploaded batch of segments
     seg_t *segs = nullptr;
     uint8_t *seq = nullptr;
@@ -366,11 +386,10 @@ struct cv_pileup {
     int32_t *cnt_dev = nullptr;
     uint8_t *touched_dev = nullptr;
     int32_t *pos_cnt = nullptr;         // [ref_len, NPOS], candidate pass
-    std::vector<seg_t> segs;
-    std::vector<uint8_t> seq;
+    std::vector<sam_part> queue;        // parsed, not yet uploaded (one entry per parser slice)
     int64_t pending_cols = 0;
     dev_batch work;                     // reused staging batch (retain == 0)
-    std::vector<dev_batch> kept;        // resident batches (retain == 1)
+    std::vector<dev_batch> kept;        // resident batches / views (retain == 1)
     int64_t prev_pos = 0, depth_cap = 0;   // CreateTensor.py:139,165-172
     int64_t evc_prev_pos = INT64_MIN;      // POS of the last read the candidate pass took
     int64_t evc_reads = 0;                 // processedReads (:150)
@@ -451,7 +470,7 @@ extern "C" void cv_pileup_destroy(cv_pileup *p)
 extern "C" int cv_pileup_set_option(cv_pileup *p, const char *key, int64_t value)
 {
     if (!p || !key) { cv_set_error("cv_pileup_set_option: null argument"); return 1; }
-    if (!p->segs.empty() || p->cols) {
+    if (!p->queue.empty() || p->cols) {
         cv_set_error("cv_pileup_set_option(%s): set options before the first read is added", key);
         return 1;
     }
@@ -513,7 +532,7 @@ static int install_candidates(cv_pileup *p, const std::vector<int32_t> &c32)
 extern "C" int cv_pileup_set_candidates(cv_pileup *p, const int64_t *centers, int64_t n)
 {
     if (!p || (!centers && n > 0) || n < 0) { cv_set_error("cv_pileup_set_candidates: bad argument"); return 1; }
-    if (!p->segs.empty()) { cv_set_error("cv_pileup_set_candidates: reads are queued; flush first"); return 1; }
+    if (!p->queue.empty()) { cv_set_error("cv_pileup_set_candidates: reads are queued; flush first"); return 1; }
     PL_HIP(hipSetDevice(p->device));
     std::vector<int32_t> c32((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
@@ -536,20 +555,6 @@ extern "C" int cv_pileup_set_candidates(cv_pileup *p, const int64_t *centers, in
 // concerned (a segment with no flag left is skipped by both kernels).
 
 static inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
-
-struct read_rec {                 // what step (2) needs of a read
-    int64_t pos;
-    uint32_t seg0, nseg;          // its segments inside the part
-    uint8_t ct, evc, leading;     // passed the stateless tensor / candidate filters; has a leading indel run
-};
-
-struct sam_part {                 // output of one parser thread
-    std::vector<seg_t> segs;
-    std::vector<uint8_t> seq;
-    std::vector<read_rec> reads;
-    int64_t cols = 0;
-    std::string err;
-};
 
 static void emit(sam_part &out, int type, int flags, int64_t r0, uint64_t q0, int64_t n, int64_t pos, bool ref_advances)
 {
@@ -722,17 +727,15 @@ extern "C" int cv_pileup_add_sam(cv_pileup *p, const char *text, int64_t nbytes,
                 ++k;
             }
         }
-        if ((uint64_t)p->seq.size() + (uint64_t)part.seq.size() >= 0xffffffffull) {
-            cv_set_error("cv_pileup_add_sam: more than 4 Gi query bases queued; call cv_pileup_flush more often");
+        if ((uint64_t)part.seq.size() >= 0xffffff00ull) {
+            cv_set_error("cv_pileup_add_sam: more than 4 Gi query bases in one slice; feed smaller chunks");
             return 1;
         }
-        const uint32_t qbase = (uint32_t)p->seq.size();
-        const size_t s0 = p->segs.size();
-        p->segs.insert(p->segs.end(), part.segs.begin(), part.segs.end());
-        if (qbase)
-            for (size_t i = s0; i < p->segs.size(); ++i) p->segs[i].q0 += qbase;
-        p->seq.insert(p->seq.end(), part.seq.begin(), part.seq.end());
         p->pending_cols += part.cols;
+        if (!part.segs.empty()) {
+            part.reads.clear(); part.reads.shrink_to_fit();
+            p->queue.push_back(std::move(part));
+        }
     }
     if (kept) *kept = k;
     return 0;
@@ -758,14 +761,17 @@ static int launch_scatter(cv_pileup *p, const dev_batch &b, hipStream_t st)
 extern "C" int cv_pileup_flush(cv_pileup *p, void *stream)
 {
     if (!p) { cv_set_error("cv_pileup_flush: null handle"); return 1; }
-    if (p->segs.empty()) { p->seq.clear(); return 0; }
+    if (p->queue.empty()) return 0;
     if (!p->ref_dev || (!p->cand_dev && !p->evc)) {
         cv_set_error("cv_pileup_flush: set the reference and the candidates first");
         return 1;
     }
     PL_HIP(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;
-    const size_t ns = p->segs.size(), nq = p->seq.size() + 64;
+    // one device allocation for everything queued; every parser slice is uploaded to its own range (its q0 offsets
+    // are relative to its own SEQ bytes: a small kernel rebases them in place), nothing is merged on the host
+    size_t ns = 0, nq = 64;                 // a 64-byte tail keeps every lane's read in range
+    for (const auto &part : p->queue) { ns += part.segs.size(); nq += (part.seq.size() + 15) / 16 * 16; }
     dev_batch fresh;
     dev_batch &b = p->retain ? fresh : p->work;
     if (ns > b.segs_cap) {
@@ -781,15 +787,22 @@ extern "C" int cv_pileup_flush(cv_pileup *p, void *stream)
         PL_HIP(hipMalloc(&b.seq, b.seq_cap));
     }
     b.nseg = ns;
-    p->seq.resize(nq, (uint8_t)'?');       // a 64-byte tail keeps every lane's read in range
-    PL_HIP(hipMemcpyAsync(b.segs, p->segs.data(), ns * sizeof(seg_t), hipMemcpyHostToDevice, st));
-    PL_HIP(hipMemcpyAsync(b.seq, p->seq.data(), nq, hipMemcpyHostToDevice, st));
+    if (p->evc && !p->pos_cnt) {
+        const size_t bytes = (size_t)(p->ref_len > 0 ? p->ref_len : 1) * NPOS * sizeof(int32_t);
+        PL_HIP(hipMalloc(&p->pos_cnt, bytes));
+        PL_HIP(hipMemsetAsync(p->pos_cnt, 0, bytes, st));
+    }
+    if (nq >= 0xffffff00ull) { cv_set_error("cv_pileup_flush: more than 4 Gi query bases queued; flush more often"); return 1; }
+    size_t so = 0, qo = 0;
+    for (const auto &part : p->queue) {
+        const size_t n1 = part.segs.size();
+        PL_HIP(hipMemcpyAsync(b.segs + so, part.segs.data(), n1 * sizeof(seg_t), hipMemcpyHostToDevice, st));
+        if (!part.seq.empty()) PL_HIP(hipMemcpyAsync(b.seq + qo, part.seq.data(), part.seq.size(), hipMemcpyHostToDevice, st));
+        if (qo) rebase_q0<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(b.segs + so, (int64_t)n1, (uint32_t)qo);
+        so += n1; qo += (part.seq.size() + 15) / 16 * 16;
+    }
+    PL_HIP(hipGetLastError());
     if (p->evc) {
-        if (!p->pos_cnt) {
-            const size_t bytes = (size_t)(p->ref_len > 0 ? p->ref_len : 1) * NPOS * sizeof(int32_t);
-            PL_HIP(hipMalloc(&p->pos_cnt, bytes));
-            PL_HIP(hipMemsetAsync(p->pos_cnt, 0, bytes, st));
-        }
         if (p->eve.size() >= 128 && drain(p->eve, p->ms_evc)) return 1;
         {
             timed t(p->eve, st);
@@ -799,11 +812,12 @@ extern "C" int cv_pileup_flush(cv_pileup *p, void *stream)
         PL_HIP(hipGetLastError());
     }
     if (p->cand_dev && launch_scatter(p, b, st)) return 1;
+    if (p->retain) p->kept.push_back(b);
+    p->nsegs += (int64_t)ns;
     // pageable copies are staged before hipMemcpyAsync returns only for small sizes: wait for them
     PL_HIP(hipStreamSynchronize(st));
-    if (p->retain) p->kept.push_back(b);
-    p->cols += p->pending_cols; p->nsegs += (int64_t)ns;
-    p->segs.clear(); p->seq.clear(); p->pending_cols = 0;
+    p->cols += p->pending_cols;
+    p->queue.clear(); p->pending_cols = 0;
     return 0;
 }
 
