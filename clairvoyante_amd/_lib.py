@@ -62,6 +62,7 @@ _SIGS = {
     "cv_parse_tensor_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
                                             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "cv_set_host_threads": (ctypes.c_int, [ctypes.c_int]),
     "cv_blosc_nbytes": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64]),
     "cv_blosc_decompress": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]),
     "cv_blosc_compress_lz4": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
@@ -118,6 +119,7 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    lib.cv_set_host_threads(min(usable_cores(), 16))
     return lib
 
 

@@ -15,6 +15,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <thread>
+#include <vector>
 #include "../../include/clairvoyante_amd.h"
 
 void cv_set_error(const char *fmt, ...);
@@ -61,24 +63,18 @@ inline bool parse_number(const char *&p, const char *end, float &out)
 
 }  // namespace
 
-// Parses complete lines from buf[0..len).  For every accepted row r (centre base of the
-// upper-cased refSeq in ACGT, utils_v2.py:38-40) writes 528 floats to x_out (matrices 1..3
-// minus matrix 0, utils_v2.py:45-46) and 6 int64 to meta_out: byte offsets/lengths of ctg,
-// pos, seq inside buf.  Stops after max_rows rows or at the last complete line.
-// *consumed = bytes eaten (whole lines only), *nrows = accepted rows, *nbad = malformed rows.
-extern "C" int cv_parse_tensor_text(const char *buf, int64_t len, int64_t max_rows, float *x_out,
-                                    int64_t *meta_out, int64_t *consumed, int64_t *nrows, int64_t *nbad)
+// Parses the complete lines of [p, end): for every accepted row (centre base of the upper-cased refSeq in ACGT,
+// utils_v2.py:38-40) 528 floats to x_out (matrices 1..3 minus matrix 0, utils_v2.py:45-46) and 6 int64 to
+// meta_out: byte offsets / lengths of ctg, pos, seq relative to `buf`.  Stops after max_rows rows.
+static const char *parse_lines(const char *buf, const char *p, const char *end, int64_t max_rows, float *x_out,
+                               int64_t *meta_out, int64_t *nrows, int64_t *nbad)
 {
-    if (!buf || !x_out || !meta_out || !consumed || !nrows) { cv_set_error("cv_parse_tensor_text: null argument"); return 1; }
     const int NV = CV_INPUT_H * CV_INPUT_W * CV_INPUT_C;
     int64_t rows = 0, bad = 0;
-    const char *p = buf, *end = buf + len;
-    const char *line_start = p;
     while (rows < max_rows) {
         const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
         if (!nl) break;
         const char *q = p;
-        line_start = p;
         p = nl + 1;
         // three string tokens
         const char *tok[3]; int64_t tl[3]; int nt = 0;
@@ -111,10 +107,81 @@ extern "C" int cv_parse_tensor_text(const char *buf, int64_t len, int64_t max_ro
         for (int k = 0; k < 3; k++) { mr[2 * k] = tok[k] - buf; mr[2 * k + 1] = tl[k]; }
         rows++;
     }
-    (void)line_start;
-    *consumed = p - buf;
     *nrows = rows;
-    if (nbad) *nbad = bad;
+    *nbad = bad;
+    return p;
+}
+
+static int g_host_threads = 1;
+
+extern "C" int cv_set_host_threads(int n)
+{
+    g_host_threads = n < 1 ? 1 : n > 64 ? 64 : n;
+    return 0;
+}
+
+// Parses complete lines from buf[0..len): see parse_lines.  Stops after max_rows rows or at the last complete
+// line.  *consumed = bytes eaten (whole lines only), *nrows = accepted rows, *nbad = malformed rows.
+// With cv_set_host_threads(T > 1) the first max_rows lines are cut into T slices parsed concurrently, each into
+// the row range its line count reserves; ranges are closed up afterwards if a slice dropped rows.  The result is
+// the single-threaded one.
+extern "C" int cv_parse_tensor_text(const char *buf, int64_t len, int64_t max_rows, float *x_out,
+                                    int64_t *meta_out, int64_t *consumed, int64_t *nrows, int64_t *nbad)
+{
+    if (!buf || !x_out || !meta_out || !consumed || !nrows) { cv_set_error("cv_parse_tensor_text: null argument"); return 1; }
+    const int NV = CV_INPUT_H * CV_INPUT_W * CV_INPUT_C;
+    const char *end = buf + len;
+    int T = g_host_threads;
+    if (T > 1 && (len < (1 << 20) || max_rows < 4 * T)) T = 1;
+    if (T == 1) {
+        int64_t r = 0, bd = 0;
+        const char *p = parse_lines(buf, buf, end, max_rows, x_out, meta_out, &r, &bd);
+        *consumed = p - buf; *nrows = r;
+        if (nbad) *nbad = bd;
+        return 0;
+    }
+    // the byte range of the first max_rows lines, cut into T slices of equal line counts
+    std::vector<const char *> cut;
+    std::vector<int64_t> first_line;
+    {
+        std::vector<const char *> starts;
+        starts.reserve((size_t)(max_rows < (1 << 20) ? max_rows + 1 : (1 << 20)));
+        const char *p = buf;
+        int64_t lines = 0;
+        while (lines < max_rows) {
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+            if (!nl) break;
+            starts.push_back(p);
+            p = nl + 1;
+            lines++;
+        }
+        starts.push_back(p);                                  // end of the last whole line taken
+        if (lines < 4 * T) T = 1;
+        for (int t = 0; t <= T; t++) { first_line.push_back(lines * t / T); cut.push_back(starts[(size_t)(lines * t / T)]); }
+    }
+    std::vector<int64_t> got((size_t)T, 0), bads((size_t)T, 0);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t]() {
+                parse_lines(buf, cut[(size_t)t], cut[(size_t)t + 1], first_line[(size_t)t + 1] - first_line[(size_t)t],
+                            x_out + (size_t)first_line[(size_t)t] * NV, meta_out + first_line[(size_t)t] * 6, &got[(size_t)t],
+                            &bads[(size_t)t]);
+            });
+        for (auto &x : th) x.join();
+    }
+    int64_t rows = 0, bd = 0;
+    for (int t = 0; t < T; t++) {                              // close the gaps left by dropped rows
+        if (rows != first_line[(size_t)t] && got[(size_t)t]) {
+            memmove(x_out + (size_t)rows * NV, x_out + (size_t)first_line[(size_t)t] * NV, (size_t)got[(size_t)t] * NV * sizeof(float));
+            memmove(meta_out + rows * 6, meta_out + first_line[(size_t)t] * 6, (size_t)got[(size_t)t] * 6 * sizeof(int64_t));
+        }
+        rows += got[(size_t)t];
+        bd += bads[(size_t)t];
+    }
+    *consumed = cut[(size_t)T] - buf;
+    *nrows = rows;
+    if (nbad) *nbad = bd;
     return 0;
 }
 

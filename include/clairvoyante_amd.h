@@ -150,6 +150,9 @@ int cv_flat_copy(cv_model *m, int which, float *caller_dev, int to_model, void *
 int cv_parse_tensor_text(const char *buf, int64_t len, int64_t max_rows, float *x_out,
                          int64_t *meta_out, int64_t *consumed, int64_t *nrows, int64_t *nbad);
 
+/* Host threads cv_parse_tensor_text may use (process-wide, default 1); the rows do not depend on it. */
+int cv_set_host_threads(int n);
+
 /* c-blosc 1.x chunk codec for the 500-item blocks of the `.bin` training file
  * (utils_v2.py:159-186 blosc.pack_array(cname='lz4hc'), :189-207 blosc.unpack_array;
  * tensor2Bin.py:24-28).  Decoder: LZ4/LZ4HC streams, byte shuffle, split blocks, memcpy'd

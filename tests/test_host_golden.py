@@ -136,3 +136,50 @@ def test_tensor2bin_writes_the_reference_layout(tmp_path):
     X, _, _ = utils_v2.DecompressArray(XC, 0, total, total)
     Y, _, _ = utils_v2.DecompressArray(YC, 0, total, total)
     assert np.array_equal(X, d["X"]) and np.array_equal(Y, d["Y"])
+
+
+def test_text_parser_thread_count_does_not_change_the_rows():
+    """cv_parse_tensor_text with 1 and with 6 host threads: same rows, same positions, same counters, also when
+    slices drop rows (non-ACGT centre base, malformed rows, blank lines) and when max_rows cuts the text"""
+    import ctypes
+    from clairvoyante_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(3)
+    n = 3000
+    vals = rng.randint(0, 60, size=(n, 528)).astype(np.float32)
+    lines = []
+    for i in range(n):
+        seq = "".join("ACGT"[k] for k in rng.randint(0, 4, 33))
+        if i % 97 == 5:
+            seq = seq[:16] + "N" + seq[17:]                  # dropped: centre base
+        if i % 211 == 7:
+            seq = seq.lower()                                # kept: upper-cased before the test
+        row = "chr%d %d %s " % (i % 3, 1000 + i, seq) + " ".join("%0.1f" % v for v in vals[i])
+        if i % 301 == 9:
+            row = row.rsplit(" ", 5)[0]                      # malformed: too few values
+        lines.append(row)
+        if i % 500 == 3:
+            lines.append("")
+    text = ("\n".join(lines) + "\n").encode()
+    assert len(text) > (2 << 20)
+
+    def run(threads, max_rows):
+        lib.cv_set_host_threads(threads)
+        x = np.full((max_rows, 528), -7, dtype=np.float32); meta = np.zeros((max_rows, 6), dtype=np.int64)
+        c = ctypes.c_int64(); r = ctypes.c_int64(); b = ctypes.c_int64()
+        _lib.check(lib.cv_parse_tensor_text(text, len(text), max_rows, x.ctypes.data_as(ctypes.c_void_p),
+                                            meta.ctypes.data_as(ctypes.c_void_p), ctypes.byref(c), ctypes.byref(r), ctypes.byref(b)))
+        return c.value, r.value, b.value, x[:r.value].copy(), meta[:r.value].copy()
+    try:
+        for max_rows in (n + 100, 1777):
+            one = run(1, max_rows)
+            six = run(6, max_rows)
+            # with a row limit the threaded parser stops after max_rows LINES (fewer rows if some were dropped);
+            # what it returns must be the single-threaded rows of exactly the bytes it consumed
+            assert six[1] > 1000 and six[0] <= one[0]
+            k = six[1]
+            assert np.array_equal(one[3][:k], six[3]) and np.array_equal(one[4][:k], six[4])
+            if max_rows > n:
+                assert one[:3] == six[:3] and one[2] >= 9
+    finally:
+        lib.cv_set_host_threads(min(_lib.usable_cores(), 16))
