@@ -65,6 +65,10 @@ _SIGS = {
     "cv_set_host_threads": (ctypes.c_int, [ctypes.c_int]),
     "cv_blosc_nbytes": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64]),
     "cv_blosc_decompress": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]),
+    "cv_blosc_decompress_many": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_int64, ctypes.c_void_p]),
+    "cv_blosc_unpack_blocks": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                              ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "cv_blosc_compress_lz4": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
                                              ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     "cv_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int64]),

@@ -17,6 +17,9 @@
 #include <math.h>
 #include <thread>
 #include <vector>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include "../../include/clairvoyante_amd.h"
 
 void cv_set_error(const char *fmt, ...);
@@ -197,7 +200,12 @@ int lz4_decompress(const uint8_t *src, int srclen, uint8_t *dst, int dstcap)
         size_t lit = token >> 4;
         if (lit == 15) { unsigned b; do { if (ip >= iend) return -1; b = *ip++; lit += b; } while (b == 255); }
         if ((size_t)(iend - ip) < lit || (size_t)(oend - op) < lit) return -1;
-        memcpy(op, ip, lit); op += lit; ip += lit;
+        if (lit <= 16 && (size_t)(iend - ip) >= 16 && (size_t)(oend - op) >= 16) {
+            memcpy(op, ip, 8); memcpy(op + 8, ip + 8, 8);           // fixed-size copies inline to two moves
+        } else {
+            memcpy(op, ip, lit);
+        }
+        op += lit; ip += lit;
         if (ip >= iend) break;                       // last sequence has no match
         if (iend - ip < 2) return -1;
         size_t off = ip[0] | ((size_t)ip[1] << 8); ip += 2;
@@ -207,7 +215,20 @@ int lz4_decompress(const uint8_t *src, int srclen, uint8_t *dst, int dstcap)
         ml += 4;
         if ((size_t)(oend - op) < ml) return -1;
         const uint8_t *m = op - off;
-        for (size_t i = 0; i < ml; i++) op[i] = m[i];  // overlapping copies are the point
+        if (off >= 16 && (size_t)(oend - op) >= ml + 16) {          // 16 bytes at a time (may write <= 15 bytes past ml,
+            for (size_t i = 0; i < ml; i += 16) memcpy(op + i, m + i, 16); // still inside the block: overwritten next)
+        } else if (off >= 8 && (size_t)(oend - op) >= ml + 8) {
+            for (size_t i = 0; i < ml; i += 8) memcpy(op + i, m + i, 8);
+        } else if (off == 1) {
+            memset(op, m[0], ml);                                    // a run of one byte (the usual case in byte planes)
+        } else if (ml >= 32 && (size_t)(oend - op) >= ml + 8) {     // short period: 16 bytes one by one, then 8 at a time
+            size_t i = 0;                                            // from a distance that is a multiple of the period
+            for (; i < 16; i++) op[i] = m[i];
+            const size_t o2 = off * ((7 + off) / off);               // 8 <= o2 <= 14
+            for (; i < ml; i += 8) memcpy(op + i, op + i - o2, 8);
+        } else {
+            for (size_t i = 0; i < ml; i++) op[i] = m[i];           // overlapping copies are the point
+        }
         op += ml;
     }
     return (int)(op - dst);
@@ -267,8 +288,24 @@ void shuffle_bytes(const uint8_t *src, uint8_t *dst, int n, int ts)
 void unshuffle_bytes(const uint8_t *src, uint8_t *dst, int n, int ts)
 {
     int ne = n / ts;
-    for (int i = 0; i < ne; i++)
-        for (int j = 0; j < ts; j++) dst[i * ts + j] = src[j * ne + i];
+    int i = 0;
+#if defined(__SSE2__)
+    if (ts == 4) {          // fp32 blocks: 16 elements per step, byte planes interleaved with two unpack levels
+        const uint8_t *p0 = src, *p1 = src + ne, *p2 = src + 2 * (size_t)ne, *p3 = src + 3 * (size_t)ne;
+        for (; i + 16 <= ne; i += 16) {
+            const __m128i a = _mm_loadu_si128((const __m128i *)(p0 + i)), b = _mm_loadu_si128((const __m128i *)(p1 + i));
+            const __m128i c = _mm_loadu_si128((const __m128i *)(p2 + i)), d = _mm_loadu_si128((const __m128i *)(p3 + i));
+            const __m128i ab0 = _mm_unpacklo_epi8(a, b), ab1 = _mm_unpackhi_epi8(a, b);
+            const __m128i cd0 = _mm_unpacklo_epi8(c, d), cd1 = _mm_unpackhi_epi8(c, d);
+            _mm_storeu_si128((__m128i *)(dst + (size_t)i * 4), _mm_unpacklo_epi16(ab0, cd0));
+            _mm_storeu_si128((__m128i *)(dst + (size_t)i * 4 + 16), _mm_unpackhi_epi16(ab0, cd0));
+            _mm_storeu_si128((__m128i *)(dst + (size_t)i * 4 + 32), _mm_unpacklo_epi16(ab1, cd1));
+            _mm_storeu_si128((__m128i *)(dst + (size_t)i * 4 + 48), _mm_unpackhi_epi16(ab1, cd1));
+        }
+    }
+#endif
+    for (; i < ne; i++)
+        for (int j = 0; j < ts; j++) dst[(size_t)i * ts + j] = src[(size_t)j * ne + i];
     memcpy(dst + (size_t)ne * ts, src + (size_t)ne * ts, (size_t)(n - ne * ts));
 }
 
@@ -328,6 +365,98 @@ extern "C" int cv_blosc_decompress(const uint8_t *chunk, int64_t clen, uint8_t *
     free(tmp);
     if (rc) cv_set_error("blosc: corrupt LZ4 stream");
     return rc;
+}
+
+// Several chunks at once, on the host threads of cv_set_host_threads (DecompressArray unpacks the 20 blocks of a
+// 10 000-item batch per call, utils_v2.py:196-203).  status[i] = 0 / 1 per chunk.
+extern "C" int cv_blosc_decompress_many(const uint8_t *const *chunks, const int64_t *clens, uint8_t *const *dsts,
+                                        const int64_t *dstcaps, int64_t n, int32_t *status)
+{
+    if ((!chunks || !clens || !dsts || !dstcaps || !status) && n > 0) { cv_set_error("blosc: null argument"); return 1; }
+    int T = g_host_threads;
+    if (T > n) T = (int)n;
+    if (T <= 1) {
+        for (int64_t i = 0; i < n; i++) status[i] = cv_blosc_decompress(chunks[i], clens[i], dsts[i], dstcaps[i]);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([=]() {
+                for (int64_t i = t; i < n; i += T) status[i] = cv_blosc_decompress(chunks[i], clens[i], dsts[i], dstcaps[i]);
+            });
+        for (auto &x : th) x.join();
+    }
+    for (int64_t i = 0; i < n; i++)
+        if (status[i]) { cv_set_error("blosc: chunk %lld is corrupt or unsupported", (long long)i); return 1; }
+    return 0;
+}
+
+// The raw data of ONE pickled ndarray inside a decompressed block: python-blosc's pack_array pickles the array with
+// the highest protocol (utils_v2.py:167-181), so the stream is a short header, one bytes object holding the data,
+// and a short trailer (protocol 5 puts dtype / shape after the data: < 100 bytes).  Finds that object by its opcode + length: BINBYTES 'B' (u32) / BINBYTES8 0x8e /
+// BYTEARRAY8 0x96 (u64) of protocols 3-5, BINSTRING 'T' (i32) of Python 2's protocol 2.  Returns the offset of the
+// data and its length, or false.
+static bool find_array_payload(const uint8_t *st, int64_t n, int64_t *off, int64_t *len)
+{
+    const int64_t head = n < 1024 ? n : 1024;
+    for (int64_t i = 0; i + 9 < head; i++) {
+        int64_t L = -1, h = 0;
+        if (st[i] == 'B' || st[i] == 'T') { L = (int64_t)(uint32_t)rd32(st + i + 1); h = 5; }
+        else if (st[i] == 0x8e || st[i] == 0x96) {
+            uint64_t v = 0;
+            for (int k = 7; k >= 0; k--) v = (v << 8) | st[i + 1 + k];
+            if (v < (1ull << 40)) L = (int64_t)v;
+            h = 9;
+        }
+        if (L < 0) continue;
+        const int64_t endp = i + h + L;
+        if (endp <= n && n - endp < 256 && L >= 16) { *off = i + h; *len = L; return true; }
+    }
+    return false;
+}
+
+// Blocks of one DecompressArray call straight into ONE destination array: chunk i is decompressed (host threads),
+// its ndarray payload located and copied to dst + i*block_bytes.  Every chunk but the last must hold exactly
+// block_bytes of data; lens[i] receives the payload bytes of chunk i.  status[i]: 0 ok, 1 corrupt chunk, 2 payload not
+// recognised / unexpected size (the caller falls back to un-pickling).  Returns 0 when every status is 0.
+extern "C" int cv_blosc_unpack_blocks(const uint8_t *const *chunks, const int64_t *clens, int64_t n, uint8_t *dst,
+                                      int64_t block_bytes, int64_t *lens, int32_t *status)
+{
+    if ((!chunks || !clens || !dst || !lens || !status) && n > 0) { cv_set_error("blosc: null argument"); return 1; }
+    int T = g_host_threads;
+    if (T > n) T = (int)n;
+    if (T < 1) T = 1;
+    auto work = [=](int t) {
+        uint8_t *scratch = nullptr;
+        int64_t cap = 0;
+        for (int64_t i = t; i < n; i += T) {
+            const int64_t nb = cv_blosc_nbytes(chunks[i], clens[i]);
+            status[i] = 1; lens[i] = 0;
+            if (nb < 0) continue;
+            if (nb > cap) { free(scratch); scratch = (uint8_t *)malloc((size_t)nb + 16); cap = nb; }
+            if (!scratch || cv_blosc_decompress(chunks[i], clens[i], scratch, nb)) continue;
+            int64_t off = 0, L = 0;
+            status[i] = 2;
+            if (!find_array_payload(scratch, nb, &off, &L)) {
+                // an empty trailing block pickles an array without a data object worth finding: accept a tiny stream
+                if (i == n - 1 && nb < 512) { status[i] = 0; lens[i] = 0; }
+                continue;
+            }
+            if ((i < n - 1 && L != block_bytes) || L > block_bytes) continue;
+            memcpy(dst + (size_t)i * (size_t)block_bytes, scratch + off, (size_t)L);
+            lens[i] = L;
+            status[i] = 0;
+        }
+        free(scratch);
+    };
+    if (T == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    for (int64_t i = 0; i < n; i++)
+        if (status[i]) { cv_set_error("blosc: block %lld: status %d", (long long)i, status[i]); return 1; }
+    return 0;
 }
 
 // Writes one chunk (single block, no split, byte shuffle when typesize > 1, LZ4 stream,

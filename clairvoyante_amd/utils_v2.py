@@ -160,6 +160,34 @@ def unpack_array(chunk):
         return pickle.loads(raw, encoding="latin1")
 
 
+def unpack_arrays(chunks):
+    """blosc.unpack_array of several blocks: the chunks are decompressed concurrently by the native host threads
+    (cv_blosc_decompress_many), then un-pickled"""
+    lib = _lib.load()
+    n = len(chunks)
+    if n == 0:
+        return []
+    raw = [c.encode("latin1") if isinstance(c, str) else bytes(c) for c in chunks]
+    sizes = [lib.cv_blosc_nbytes(r, len(r)) for r in raw]
+    if min(sizes) < 0:
+        raise _lib.CvError("blosc: truncated chunk")
+    outs = [bytearray(max(int(sz), 1)) for sz in sizes]
+    src = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(r), ctypes.c_void_p).value for r in raw])
+    dst = (ctypes.c_void_p * n)(*[ctypes.addressof((ctypes.c_char * len(o)).from_buffer(o)) for o in outs])
+    clen = (ctypes.c_int64 * n)(*[len(r) for r in raw])
+    cap = (ctypes.c_int64 * n)(*[len(o) for o in outs])
+    status = (ctypes.c_int32 * n)()
+    _lib.check(lib.cv_blosc_decompress_many(src, clen, dst, cap, n, status))
+    arrays = []
+    for o, sz in zip(outs, sizes):
+        view = memoryview(o)[:sz]
+        try:
+            arrays.append(pickle.loads(view))
+        except (UnicodeDecodeError, ValueError):
+            arrays.append(pickle.loads(view, encoding="latin1"))
+    return arrays
+
+
 def LoadBin(bin_fn):
     """The four back-to-back pickles of tensor2Bin.py:24-28 (also files written by Python 2)."""
     with open(bin_fn, "rb") as fh:
@@ -292,6 +320,41 @@ def GetTrainingArray(tensor_fn, var_fn, bed_fn, shuffle=True):
     return len(allPos), XC, YC, PC
 
 
+_block_layout = {}          # id(block list) -> (dtype, item shape) learnt from its first block
+
+
+def _unpack_into_one(blocks, key):
+    """the blocks of one DecompressArray call decompressed straight into one array (no per-block un-pickling, no
+    concatenation); None when the layout is not the plain one (the caller then takes the generic path)"""
+    lib = _lib.load()
+    lay = _block_layout.get(key) if key[2] is not None else None
+    if lay is None:
+        if len(_block_layout) > 64:
+            _block_layout.clear()
+        a0 = unpack_array(blocks[0]) if len(blocks) else None
+        if not isinstance(a0, np.ndarray) or a0.ndim < 1 or not a0.flags.c_contiguous or a0.dtype.hasobject \
+                or len(a0) != param.bloscBlockSize:
+            return None
+        lay = (a0.dtype, a0.shape[1:])
+        if key[2] is not None:
+            _block_layout[key] = lay
+    dtype, ishape = lay
+    bs = param.bloscBlockSize
+    item = int(np.prod(ishape, dtype=np.int64)) * dtype.itemsize
+    n = len(blocks)
+    raw = [c.encode("latin1") if isinstance(c, str) else bytes(c) for c in blocks]
+    out = np.empty((n * bs,) + tuple(ishape), dtype=dtype)
+    src = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(r), ctypes.c_void_p).value for r in raw])
+    clen = (ctypes.c_int64 * n)(*[len(r) for r in raw])
+    lens = (ctypes.c_int64 * n)()
+    status = (ctypes.c_int32 * n)()
+    if lib.cv_blosc_unpack_blocks(src, clen, n, out.ctypes.data_as(ctypes.c_void_p), bs * item, lens, status) != 0:
+        return None
+    if lens[n - 1] % item:
+        return None
+    return out[:(n - 1) * bs + lens[n - 1] // item]
+
+
 def DecompressArray(array, start, num, maximum):
     """utils_v2.py:189-207 -> (items [start, start+num) clipped at maximum, count, endFlag)."""
     endFlag = 0
@@ -302,10 +365,12 @@ def DecompressArray(array, start, num, maximum):
     leftEnd = start % bs
     first = int(start / bs)
     last = int((start + num - 1) / bs)
-    parts = [unpack_array(array[first])]
-    for i in range(first + 1, last + 1):
-        parts.append(unpack_array(array[i]))
-    out = np.concatenate(parts[:])
+    # layout cache key: the list object plus a fingerprint of its first block (ids are reused after a list dies)
+    key = (id(array), len(array), bytes(array[0][:48]) if len(array) and not isinstance(array[0], str) else None)
+    out = _unpack_into_one(array[first:last + 1], key)
+    if out is None:
+        parts = unpack_arrays(array[first:last + 1])
+        out = np.concatenate(parts[:]) if len(parts) > 1 else parts[0]
     if leftEnd != 0 or num % bs != 0:
         out = out[leftEnd:(leftEnd + num)]
     return out, num, endFlag

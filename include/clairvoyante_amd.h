@@ -161,6 +161,16 @@ int64_t cv_blosc_nbytes(const uint8_t *chunk, int64_t clen);
 int cv_blosc_decompress(const uint8_t *chunk, int64_t clen, uint8_t *dst, int64_t dstcap);
 int cv_blosc_compress_lz4(const uint8_t *src, int64_t n, int typesize, uint8_t *dst, int64_t dstcap,
                           int64_t *clen);
+/* n chunks at once on the host threads of cv_set_host_threads (the blocks of one DecompressArray call,
+ * utils_v2.py:196-203); status[i] != 0 marks a chunk that failed.                                  */
+int cv_blosc_decompress_many(const uint8_t *const *chunks, const int64_t *clens, uint8_t *const *dsts,
+                             const int64_t *dstcaps, int64_t n, int32_t *status);
+/* The same blocks straight into ONE array: each chunk holds one pickled ndarray (blosc.pack_array); its raw data is
+ * located inside the decompressed pickle and copied to dst + i*block_bytes (every block but the last must hold
+ * exactly block_bytes).  lens[i] = data bytes of block i; status[i] = 0 ok / 1 corrupt / 2 layout not recognised (the
+ * caller then un-pickles instead).  Returns 0 only if all blocks are ok.                                */
+int cv_blosc_unpack_blocks(const uint8_t *const *chunks, const int64_t *clens, int64_t n, uint8_t *dst,
+                           int64_t block_bytes, int64_t *lens, int32_t *status);
 
 /* CRC32C (Castagnoli) of the tensor bytes / table blocks of the TensorFlow V2 checkpoint
  * bundle written by saveParameters and read by restoreParameters (v3.py:243-251).        */

@@ -183,3 +183,48 @@ def test_text_parser_thread_count_does_not_change_the_rows():
                 assert one[:3] == six[:3] and one[2] >= 9
     finally:
         lib.cv_set_host_threads(min(_lib.usable_cores(), 16))
+
+
+def test_blosc_decoder_survives_corrupt_chunks():
+    """bit flips and truncations of a chunk written by this build and of one written by the real c-blosc (lz4hc):
+    the decoder may reject or return garbage, but never writes outside the destination"""
+    import ctypes
+    from clairvoyante_amd import _lib, utils_v2
+    lib = _lib.load()
+    rng = np.random.RandomState(1)
+    X = rng.randint(-30, 60, size=(500, 33, 4, 4)).astype(np.float32)
+    X[rng.rand(*X.shape) < 0.7] = 0
+    _, XC, _, _ = utils_v2.LoadBin(os.path.join(G, "mini.bin"))
+    real = XC[0].encode("latin1") if isinstance(XC[0], str) else bytes(XC[0])
+    for base in (bytearray(utils_v2.pack_array(X)), bytearray(real)):
+        n = lib.cv_blosc_nbytes(bytes(base), len(base))
+        out = ctypes.create_string_buffer(n + 64)
+        assert lib.cv_blosc_decompress(bytes(base), len(base), out, n) == 0
+        for trial in range(400):
+            c = bytearray(base)
+            for _ in range(rng.randint(1, 6)):
+                c[rng.randint(16 if trial % 3 else 0, len(c))] = rng.randint(0, 256)
+            if trial % 7 == 0:
+                c = c[:rng.randint(1, len(c))]
+            lib.cv_blosc_decompress(bytes(c), len(c), out, n)
+            assert out.raw[n:n + 64] == b"\0" * 64
+
+
+def test_decompressarray_fast_path_equals_unpickling():
+    """blocks decompressed straight into one array (cv_blosc_unpack_blocks) == un-pickling each block: float32
+    tensors, float64 labels, ranges that start / end inside blocks, the short last block, the empty trailing block"""
+    from clairvoyante_amd import utils_v2
+    rng = np.random.RandomState(2)
+    for total in (3000, 2750):
+        X = rng.randint(-9, 60, size=(total, 33, 4, 4)).astype(np.float32)
+        Y = rng.rand(total, 16)
+        XC = [utils_v2.pack_array(X[s:s + 500]) for s in range(0, total + 1, 500)]      # total 3000: last block is empty
+        YC = [utils_v2.pack_array(Y[s:s + 500]) for s in range(0, total + 1, 500)]
+        for st, nm in ((0, 1000), (250, 1000), (499, 2), (1000, 5000), (total - 3, 10), (0, total), (2500, 500)):
+            for arr, blocks in ((X, XC), (Y, YC)):
+                got, k, flag = utils_v2.DecompressArray(blocks, st, nm, total)
+                want = arr[st:min(st + nm, total)]
+                assert k == len(want) and flag == int(st + nm >= total)
+                assert got.dtype == arr.dtype and np.array_equal(got, want)
+                slow = np.concatenate([utils_v2.unpack_array(b) for b in blocks[st // 500:(st + k - 1) // 500 + 1]])
+                assert np.array_equal(slow[st % 500:st % 500 + k], got)
