@@ -102,6 +102,8 @@ class Clairvoyante(object):
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    accepts_device_batches = True      # train/getLoss/predict take torch tensors that already live on self.device
+
     def _to_dev(self, a, last):
         if torch.is_tensor(a):
             t = a.to(device=self.device, dtype=torch.float32).contiguous()

@@ -90,26 +90,112 @@ def _shard(a, rank, ws):
 class _BatchStream(object):
     """The batch sequence of one epoch (train.py:83-107): 10 000-candidate batches up to
     validationStart (the last one clipped to end exactly there), then batches aligned to multiples of
-    1 000; `last` marks the batch that reaches the end of the data set."""
+    1 000; `last` marks the batch that reaches the end of the data set.
+
+    `prefetch(size_fn, device)` starts a producer thread that walks the same sequence ahead of the consumer
+    (the sizes are a function of the pointer alone) and, when `device` is given, stages every batch in HBM
+    through a side stream -- decompression, host->device copy and the training step then overlap.  `fetch`
+    hands out the prefetched batch if it is the one asked for, and falls back to fetching in place otherwise."""
+
+    DEPTH = 3
 
     def __init__(self, utils, XC, YC, total, validationStart):
         self.utils, self.XC, self.YC, self.total, self.vstart = utils, XC, YC, total, validationStart
         self.ptr = 0
+        self._q = None
+        self._stop = None
 
     def rewind(self):
+        self._cancel()
         self.ptr = 0
 
-    def fetch(self, size):
-        X, xn, xe = self.utils.DecompressArray(self.XC, self.ptr, size, self.total)
-        Y, yn, ye = self.utils.DecompressArray(self.YC, self.ptr, size, self.total)
+    def _fetch_at(self, ptr, size):
+        X, xn, xe = self.utils.DecompressArray(self.XC, ptr, size, self.total)
+        Y, yn, ye = self.utils.DecompressArray(self.YC, ptr, size, self.total)
         if xn != yn or xe != ye:
             sys.exit("Inconsistency between decompressed arrays: %d/%d" % (xn, yn))
-        start = self.ptr
-        self.ptr += xn
-        return X, Y, start, xn, xe != 0
+        return X, Y, ptr, xn, xe != 0
+
+    def fetch(self, size):
+        if self._q is not None:
+            item = self._q.get()
+            if isinstance(item, BaseException):
+                self._cancel()
+                raise item
+            if item is not None and item[0] == (self.ptr, size):
+                _key, out, ready = item
+                if ready is not None:
+                    ready()                        # the consumer's stream waits for the staged copy
+                self.ptr += out[3]
+                if out[4]:
+                    self._cancel()
+                return out
+            self._cancel()                         # a different request than predicted: fetch in place
+        out = self._fetch_at(self.ptr, size)
+        self.ptr += out[3]
+        return out
 
     def next_size(self):
         return _next_batch_size(self.ptr, self.vstart)
+
+    # ---- producer side
+    def prefetch(self, first_size, size_fn, device=None):
+        from queue import Queue
+        from threading import Event
+        self._cancel()
+        q = self._q = Queue(maxsize=self.DEPTH)
+        stop = self._stop = Event()
+        start_ptr = self.ptr
+
+        def stage(X, Y):
+            import torch
+            with torch.cuda.device(device):
+                side = torch.cuda.Stream(device=device)
+                with torch.cuda.stream(side):
+                    xd = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(device, non_blocking=True)
+                    yd = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float32)).to(device, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+            ev.synchronize()                       # producer thread: the host arrays may go once the copy is done
+
+            def ready():
+                torch.cuda.current_stream(device).wait_event(ev)
+            return xd, yd, ready
+
+        def produce():
+            try:
+                ptr, size = start_ptr, first_size
+                while not stop.is_set():
+                    X, Y, st, n, last = self._fetch_at(ptr, size)
+                    ready = None
+                    if device is not None and n > 0:
+                        X, Y, ready = stage(X, Y)
+                    item = ((ptr, size), (X, Y, st, n, last), ready)
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.05)
+                            break
+                        except Exception:
+                            continue
+                    if last:
+                        break
+                    ptr += n
+                    size = size_fn(ptr)
+            except BaseException as e:             # surfaced by fetch()
+                q.put(e)
+        t = Thread(target=produce, daemon=True)
+        t.start()
+        self._thread = t
+
+    def _cancel(self):
+        if self._q is not None:
+            self._stop.set()
+            try:
+                while True:
+                    self._q.get_nowait()
+            except Exception:
+                pass
+            self._q = None
 
 
 class _Job(Thread):
@@ -155,6 +241,9 @@ def run_epoch(stream, m, rank, ws, writer, epoch, validationStart):
     train_sum = 0
     val_sum = 0
     stream.rewind()
+    # real models take batches that are already in HBM; mock / foreign model objects get the numpy arrays
+    device = getattr(m, "device", None) if getattr(m, "accepts_device_batches", False) else None
+    stream.prefetch(param.trainBatchSize, lambda p: _next_batch_size(p, validationStart), device)
     X, Y, start, count, last = stream.fetch(param.trainBatchSize)
     while True:
         training = start + count < validationStart

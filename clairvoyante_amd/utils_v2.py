@@ -323,6 +323,45 @@ def GetTrainingArray(tensor_fn, var_fn, bed_fn, shuffle=True):
 _block_layout = {}          # id(block list) -> (dtype, item shape) learnt from its first block
 
 
+class _PinnedPool(object):
+    """Page-locked host buffers for the arrays DecompressArray hands out: the training loop copies every batch to the
+    GPU right away, and a pinned source makes that copy a plain DMA.  A buffer goes back to the free list when the
+    last numpy view of it has been garbage-collected (weakref.finalize on the root array), so handing arrays out
+    is as safe as np.empty.  Without a GPU (or for very small / very large requests) np.empty is used."""
+    MIN_BYTES, MAX_BYTES, KEEP = 1 << 18, 1 << 28, 6
+
+    def __init__(self):
+        self.free = {}
+        self.enabled = None
+
+    def _give(self, cls, t):
+        lst = self.free.setdefault(cls, [])
+        if len(lst) < self.KEEP:
+            lst.append(t)
+
+    def empty(self, shape, dtype):
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        if self.enabled is None:
+            try:
+                import torch
+                self.enabled = bool(torch.cuda.is_available())
+            except Exception:
+                self.enabled = False
+        if not self.enabled or nbytes < self.MIN_BYTES or nbytes > self.MAX_BYTES:
+            return np.empty(shape, dtype=dtype)
+        import torch
+        import weakref
+        cls = (nbytes + (1 << 20) - 1) >> 20 << 20
+        lst = self.free.get(cls)
+        t = lst.pop() if lst else torch.empty(cls, dtype=torch.uint8, pin_memory=True)
+        root = t.numpy()
+        weakref.finalize(root, self._give, cls, t)
+        return root[:nbytes].view(dtype).reshape(shape)
+
+
+_pinned = _PinnedPool()
+
+
 def _unpack_into_one(blocks, key):
     """the blocks of one DecompressArray call decompressed straight into one array (no per-block un-pickling, no
     concatenation); None when the layout is not the plain one (the caller then takes the generic path)"""
@@ -343,7 +382,7 @@ def _unpack_into_one(blocks, key):
     item = int(np.prod(ishape, dtype=np.int64)) * dtype.itemsize
     n = len(blocks)
     raw = [c.encode("latin1") if isinstance(c, str) else bytes(c) for c in blocks]
-    out = np.empty((n * bs,) + tuple(ishape), dtype=dtype)
+    out = _pinned.empty((n * bs,) + tuple(ishape), dtype)
     src = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(r), ctypes.c_void_p).value for r in raw])
     clen = (ctypes.c_int64 * n)(*[len(r) for r in raw])
     lens = (ctypes.c_int64 * n)()
