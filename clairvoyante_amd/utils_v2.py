@@ -67,7 +67,7 @@ def GetTensor(tensor_fn, num, log=True):
     proc, fo = _open_tensor_stream(tensor_fn)
     total = 0
     pending = b""
-    rows = np.empty((num, _NV), dtype=np.float32)
+    rows = _pinned.empty((num, _NV), np.float32)      # page-locked when a GPU is present: the consumer copies it to HBM
     meta = np.empty((num, 6), dtype=np.int64)
     c = 0
     bufs = []          # (bytes, meta rows) pieces of the batch being filled
@@ -98,7 +98,7 @@ def GetTensor(tensor_fn, num, log=True):
                 if log:
                     print("Processed %d tensors" % total, file=sys.stderr)
                 yield 0, c, rows.reshape((num, 2 * param.flankingBaseNum + 1, 4, param.matrixNum)), _join_pos(bufs)
-                rows = np.empty((num, _NV), dtype=np.float32)
+                rows = _pinned.empty((num, _NV), np.float32)      # page-locked when a GPU is present: the consumer copies it to HBM
                 meta = np.empty((num, 6), dtype=np.int64)
                 c = 0
                 bufs = []
