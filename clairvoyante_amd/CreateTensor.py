@@ -37,6 +37,14 @@ def region_of(args):
 
 
 def load_reference(args, refStart, refEnd):
+    if args.samtools == "native":                       # REF.fai + a seek instead of `samtools faidx`
+        from .bam import faidx
+        seq = faidx(args.ref_fn, args.ctgName, refStart, refEnd)
+        if len(seq) == 0:
+            sys.stderr.write("Failed to load reference seqeunce. Please check if the provided reference fasta %s and the "
+                             "ctgName %s are correct.\n" % (args.ref_fn, args.ctgName))
+            sys.exit(1)
+        return seq
     where = args.ctgName if refStart is None else "%s:%d-%d" % (args.ctgName, refStart, refEnd)
     p = subprocess.Popen(shlex.split("%s faidx %s %s" % (args.samtools, args.ref_fn, where)), stdout=subprocess.PIPE,
                          bufsize=8388608)
@@ -90,16 +98,9 @@ def pileup_region(args, subtract=False, device=None):
     pl = Pileup(device=device, minMQ=args.minMQ, dcov=args.dcov, considerleftedge=args.considerleftedge)
     pl.set_reference(ref_seq, shift)
     pl.set_candidates(centers)
-    where = args.ctgName if ctgStart is None else "%s:%d-%d" % (args.ctgName, ctgStart, ctgEnd)
-    p2 = subprocess.Popen(shlex.split("%s view -F 2308 %s %s" % (args.samtools, args.bam_fn, where)),
-                          stdout=subprocess.PIPE, bufsize=8388608)
-    while True:
-        chunk = p2.stdout.read(READ_CHUNK)
-        if not chunk:
-            break
+    from .ExtractVariantCandidates import view_chunks
+    for chunk in view_chunks(args, ctgStart, ctgEnd):
         pl.add_sam(chunk)
-    p2.stdout.close()
-    p2.wait()
     t, depth, touched = pl.finish(subtract=subtract)
     inside = torch.from_numpy((pl.centers - shift - (FLANK + 1)) >= 0).to(t.device)
     keep = touched & inside & (depth >= args.minCoverage)

@@ -66,6 +66,13 @@ def candidate_rows(ctgName, res, ref_seq, shift):
 
 def view_chunks(args, ctgStart, ctgEnd):
     """the text of `samtools view -F 2308 BAM CTG[:S-E]` (CreateTensor.py:128-130) in READ_CHUNK pieces"""
+    if args.samtools == "native":                       # no external process: clairvoyante_amd/bam.py
+        from .bam import BamFile
+        bf = BamFile(args.bam_fn)
+        for chunk in bf.view(args.ctgName, ctgStart, ctgEnd, chunk=READ_CHUNK):
+            yield chunk
+        bf.close()
+        return
     where = args.ctgName if ctgStart is None else "%s:%d-%d" % (args.ctgName, ctgStart, ctgEnd)
     p2 = subprocess.Popen(shlex.split("%s view -F 2308 %s %s" % (args.samtools, args.bam_fn, where)),
                           stdout=subprocess.PIPE, bufsize=8388608)

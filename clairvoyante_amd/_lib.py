@@ -97,6 +97,15 @@ _SIGS = {
     "cv_pileup_recount": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "cv_pileup_get_candidates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                                 ctypes.POINTER(ctypes.c_int64)]),
+    "cv_bam_open": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "cv_bam_close": (None, [ctypes.c_void_p]),
+    "cv_bam_nref": (ctypes.c_int, [ctypes.c_void_p]),
+    "cv_bam_ref": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
+                                  ctypes.POINTER(ctypes.c_int64)]),
+    "cv_bam_has_index": (ctypes.c_int, [ctypes.c_void_p]),
+    "cv_bam_view_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                         ctypes.c_int]),
+    "cv_bam_view_read": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int)]),
     "cv_format_tensor_row": (ctypes.c_int64, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64,
                                               ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
 }

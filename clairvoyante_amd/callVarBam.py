@@ -37,6 +37,8 @@ def CheckFileExist(fn, sfx=""):
 
 
 def CheckCmdExist(cmd):
+    if cmd == "native":                 # the built-in BAM / FASTA readers (clairvoyante_amd/bam.py)
+        return cmd
     try:
         subprocess.check_output("which %s" % shlex.split(cmd)[0], shell=True)
     except Exception:

@@ -269,6 +269,23 @@ int cv_pileup_get_candidates(cv_pileup *p, int64_t *centers, int64_t cap, int64_
 int64_t cv_format_tensor_row(const char *ctg, int64_t center, const char *seq, int64_t seqlen,
                              const float *counts, char *dst, int64_t cap);
 
+/* ---- native `samtools view` (optional producer, host only) ------------------------------------
+ * The text of `samtools view -F <exclude_flags> BAM CTG[:S-E]` (CreateTensor.py:128-130,
+ * ExtractVariantCandidates.py:112-114) without the external process: BGZF blocks inflated by `threads`
+ * host threads, records of the region printed as SAM lines (11 columns, QUAL '*' unless with_qual;
+ * no auxiliary tags).  Uses BAM.bai / .bai (linear index) when present, otherwise scans from the start.
+ * Formats per the SAM/BAM specification; validated against files written by tests/bam_writer.py.      */
+typedef struct cv_bam cv_bam;
+int cv_bam_open(const char *path, int threads, cv_bam **out);
+void cv_bam_close(cv_bam *b);
+int cv_bam_nref(const cv_bam *b);
+int cv_bam_ref(const cv_bam *b, int i, const char **name, int64_t *len);
+int cv_bam_has_index(const cv_bam *b);
+/* beg1 / end1: 1-based inclusive region, both <= 0 for the whole contig.                              */
+int cv_bam_view_begin(cv_bam *b, const char *ref, int64_t beg1, int64_t end1, int exclude_flags, int with_qual);
+/* Whole SAM lines into buf[0, cap); returns bytes written (0 and *done = 1 at the end), -1 on error.   */
+int64_t cv_bam_view_read(cv_bam *b, char *buf, int64_t cap, int *done);
+
 #ifdef __cplusplus
 }
 #endif

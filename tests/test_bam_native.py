@@ -1,0 +1,125 @@
+"""Native `samtools view` (csrc/cv_bam.cpp through clairvoyante_amd/bam.py), host only: BAM files written by
+tests/bam_writer.py from the golden SAM text must come back as that text -- whole contig and regions, with and
+without the .bai, records straddling BGZF blocks, several contigs, the -F mask, optional QUAL; `faidx` against the
+test stand-in for samtools."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE); sys.path.insert(0, os.path.join(HERE, ".."))
+from bam_writer import write_bam  # noqa: E402
+
+G = os.path.join(HERE, "golden", "pileup")
+_CIG = re.compile(r"(\d+)([MIDNSHP=X])")
+
+
+def sam_records(name):
+    return [l.rstrip("\n") for l in open(os.path.join(G, name + ".sam")) if not l.startswith("@")]
+
+
+def expected(lines, ctg, start, end, mask=2308, with_qual=False):
+    out = []
+    for l in lines:
+        f = l.split("\t")
+        if f[2] != ctg or (int(f[1]) & mask):
+            continue
+        pos = int(f[3])
+        span = sum(int(n) for n, op in _CIG.findall(f[5]) if op in "MDN=X") or 1
+        if start is not None and (pos + span - 1 < start or pos > end):
+            continue
+        q = f[10] if with_qual and len(f[10]) == len(f[9]) else "*"
+        out.append("\t".join(f[:10] + [q]))
+    return out
+
+
+def view_text(path, ctg, start=None, end=None, **kw):
+    from clairvoyante_amd.bam import BamFile
+    bf = BamFile(path, threads=kw.pop("threads", 3))
+    text = b"".join(bf.view(ctg, start, end, **kw)).decode()
+    bf.close()
+    return text.splitlines()
+
+
+@pytest.mark.parametrize("case", ["plain", "noisy", "eqx", "handmade"])
+@pytest.mark.parametrize("payload,index", [(60000, True), (777, True), (4093, False)])
+def test_native_view_equals_the_sam_text(case, payload, index, tmp_path):
+    recs = sam_records(case)
+    L = 3000 if case != "handmade" else 320
+    bam = str(tmp_path / "a.bam")
+    write_bam(bam, recs, [("ctgA", max(L, 4000)), ("other", 10)], block_payload=payload, index=index)
+    from clairvoyante_amd.bam import BamFile
+    bf = BamFile(bam)
+    assert bf.references() == [("ctgA", max(L, 4000)), ("other", 10)] and bf.has_index() == index
+    bf.close()
+    assert view_text(bam, "ctgA") == expected(recs, "ctgA", None, None)
+    for start, end in ((1, 50), (601, 2900), (1500, 1500), (2990, 100000), (17, 33)):
+        assert view_text(bam, "ctgA", start, end) == expected(recs, "ctgA", start, end), (start, end)
+    assert view_text(bam, "other") == [] and view_text(bam, "nope") == []
+    assert view_text(bam, "ctgA", exclude_flags=16) == expected(recs, "ctgA", None, None, mask=16)
+    assert view_text(bam, "ctgA", 1, 400, with_qual=True, threads=1) == expected(recs, "ctgA", 1, 400, with_qual=True)
+
+
+def test_native_view_on_several_contigs_and_a_long_file(tmp_path):
+    from clairvoyante_amd import synth_pileup as sp
+    recs = []
+    refs = []
+    for k, (name, L) in enumerate((("c1", 40000), ("c2", 70000), ("c3", 1000))):
+        _ref, lines = sp.make_alignments(seed=40 + k, ref_len=L, n_reads=3000 if L > 1000 else 20, ctg=name,
+                                         profile=sp.NOISY_PROFILE, read_len=(30, 400))
+        recs += lines
+        refs.append((name, L))
+    bam = str(tmp_path / "m.bam")
+    write_bam(bam, recs, refs, block_payload=30011)
+    for ctg, L in refs:
+        assert view_text(bam, ctg, threads=5) == expected(recs, ctg, None, None)
+        for start in (1, L // 3, L - 500):
+            assert view_text(bam, ctg, start, start + 2000) == expected(recs, ctg, start, start + 2000)
+    nobai = str(tmp_path / "n.bam")
+    write_bam(nobai, recs, refs, block_payload=65000, index=False)
+    assert view_text(nobai, "c2", 30000, 31000) == expected(recs, "c2", 30000, 31000)
+
+
+def test_native_faidx_equals_the_stand_in(tmp_path):
+    from clairvoyante_amd.bam import faidx
+    rng = np.random.RandomState(4)
+    fa = str(tmp_path / "r.fa")
+    seqs = {"ctgA": "".join("ACGTNacgt"[i] for i in rng.randint(0, 9, 1234)), "b": "".join("ACGT"[i] for i in rng.randint(0, 4, 61))}
+    off = 0
+    with open(fa, "w") as fh, open(fa + ".fai", "w") as fi:
+        for name, s in seqs.items():
+            hdr = ">%s test\n" % name
+            fh.write(hdr); off += len(hdr)
+            fi.write("%s\t%d\t%d\t60\t61\n" % (name, len(s), off))
+            for i in range(0, len(s), 60):
+                fh.write(s[i:i + 60] + "\n"); off += len(s[i:i + 60]) + 1
+    fake = [sys.executable, os.path.join(HERE, "golden", "fake_samtools.py")]
+    for ctg, a, b in (("ctgA", None, None), ("ctgA", 1, 60), ("ctgA", 61, 61), ("ctgA", 59, 183), ("ctgA", 1200, 5000), ("b", 2, 61)):
+        region = ctg if a is None else "%s:%d-%d" % (ctg, a, b)
+        want = b"".join(subprocess.check_output(fake + ["faidx", fa, region]).split(b"\n")[1:])
+        assert faidx(fa, ctg, a, b) == want, region
+    assert faidx(fa, "missing") == b""
+
+
+def test_errors_are_reported(tmp_path):
+    from clairvoyante_amd import _lib
+    from clairvoyante_amd.bam import BamFile
+    with pytest.raises(_lib.CvError):
+        BamFile(str(tmp_path / "nope.bam"))
+    bad = tmp_path / "bad.bam"
+    bad.write_bytes(b"this is not a BGZF file" * 10)
+    with pytest.raises(_lib.CvError):
+        BamFile(str(bad))
+    recs = sam_records("plain")
+    bam = str(tmp_path / "t.bam")
+    write_bam(bam, recs, [("ctgA", 4000)], block_payload=5000)
+    blob = bytearray(open(bam, "rb").read())
+    blob[len(blob) // 2] ^= 0x55                         # a flipped byte inside some block: CRC / inflate failure
+    open(bam, "wb").write(bytes(blob))
+    os.remove(bam + ".bai")
+    with pytest.raises(_lib.CvError):
+        view_text(bam, "ctgA")

@@ -432,3 +432,31 @@ def test_pileup_corner_cases_equal_oracle():
     t, d, u = pl.finish()
     assert t.shape[0] == 0
     pl.close()
+
+
+def test_callvarbam_with_the_native_bam_reader(tmp_path, oracle):
+    """--samtools native: BAM (+.bai) and FASTA (+.fai) read in-process; same VCF as through the samtools stand-in"""
+    sys.path.insert(0, HERE)
+    import shutil
+    from bam_writer import write_bam
+    from clairvoyante_amd import callVarBam
+    chk = _checkpoint(oracle, tmp_path)
+    base = os.path.join(G, "noisy")
+    recs = [l.rstrip("\n") for l in open(base + ".sam") if not l.startswith("@")]
+    bam = str(tmp_path / "noisy.bam")
+    write_bam(bam, recs, [("ctgA", 2600), ("other", 10)], block_payload=9001)
+    fa = str(tmp_path / "ref.fa")
+    shutil.copy(base + ".fa", fa)
+    # .fai of the 70-column FASTA the generator writes: ">ctgA synthetic\n" is 16 bytes
+    with open(fa + ".fai", "w") as fh:
+        fh.write("ctgA\t2600\t16\t70\t71\n")
+    common_args = ["--chkpnt_fn", chk, "--ref_fn", fa, "--ctgName", "ctgA", "--threshold", "0.125", "--minCoverage", "2"]
+    for region in ([], ["--ctgStart", "300", "--ctgEnd", "1900"]):
+        a = callVarBam.build_parser().parse_args(common_args + region + ["--bam_fn", base + ".sam", "--samtools", FAKE,
+                                                                        "--call_fn", str(tmp_path / "fake.vcf")])
+        callVarBam.Run(a)
+        b = callVarBam.build_parser().parse_args(common_args + region + ["--bam_fn", bam, "--samtools", "native",
+                                                                        "--call_fn", str(tmp_path / "native.vcf")])
+        callVarBam.Run(b)
+        assert open(b.call_fn).read() == open(a.call_fn).read()
+        assert sum(1 for l in open(b.call_fn) if not l.startswith("#")) > 10
