@@ -41,6 +41,13 @@ def init_from_env(backend=None):
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+    # the ranks of a node share its cores: split the host threads of the native data plane between them
+    try:
+        from . import _lib
+        lws = max(int(os.environ.get("LOCAL_WORLD_SIZE", str(ws))), 1)
+        _lib.load().cv_set_host_threads(max(1, min(_lib.usable_cores() // lws, 16)))
+    except Exception:
+        pass
     return rank, ws, local
 
 

@@ -99,8 +99,9 @@ class _BatchStream(object):
 
     DEPTH = 3
 
-    def __init__(self, utils, XC, YC, total, validationStart):
+    def __init__(self, utils, XC, YC, total, validationStart, rank=0, ws=1):
         self.utils, self.XC, self.YC, self.total, self.vstart = utils, XC, YC, total, validationStart
+        self.rank, self.ws = rank, ws              # data parallel: this rank only decompresses its slice of a batch
         self.ptr = 0
         self._q = None
         self._stop = None
@@ -110,6 +111,17 @@ class _BatchStream(object):
         self.ptr = 0
 
     def _fetch_at(self, ptr, size):
+        """-> (X, Y, start, count of the WHOLE batch, last); with ws > 1 X / Y hold this rank's slice only"""
+        if self.ws > 1:
+            from . import parallel
+            n = max(min(size, self.total - ptr), 0) if ptr + size >= self.total else size
+            last = ptr + size >= self.total
+            lo, hi = parallel.shard_range(n, self.rank, self.ws)
+            X, xn, _ = self.utils.DecompressArray(self.XC, ptr + lo, hi - lo, self.total)
+            Y, yn, _ = self.utils.DecompressArray(self.YC, ptr + lo, hi - lo, self.total)
+            if xn != yn:
+                sys.exit("Inconsistency between decompressed arrays: %d/%d" % (xn, yn))
+            return X, Y, ptr, n, last
         X, xn, xe = self.utils.DecompressArray(self.XC, ptr, size, self.total)
         Y, yn, ye = self.utils.DecompressArray(self.YC, ptr, size, self.total)
         if xn != yn or xe != ye:
@@ -232,8 +244,8 @@ def run_epoch(stream, m, rank, ws, writer, epoch, validationStart):
     Returns (sum of training losses, sum of validation losses)."""
     from . import parallel
 
-    def mine(a):
-        return _shard(a, rank, ws)
+    def mine(a):                                    # the stream hands out this rank's slice already
+        return a
 
     def reduced(v):
         return parallel.allreduce_scalar(float(v), m) if ws > 1 else float(v)
@@ -286,7 +298,7 @@ def TrainAll(args, m, utils):
     history = []                     # (validation loss sum, epoch)
     since_switch = 0
     epoch = 1 if args.chkpnt_fn is None else int(args.chkpnt_fn[-param.parameterOutputPlaceHolder:]) + 1
-    stream = _BatchStream(utils, XC, YC, total, validationStart)
+    stream = _BatchStream(utils, XC, YC, total, validationStart, rank, ws)
 
     while epoch < param.maxEpoch:
         t_epoch = time.time()

@@ -21,7 +21,7 @@ import sys
 import time
 
 from . import param
-from .train import _BatchStream, _Job, _shard, build_parser, load_dataset, pick_model, run_epoch
+from .train import _BatchStream, _Job, build_parser, load_dataset, pick_model, run_epoch
 
 logging.basicConfig(format='%(message)s', level=logging.INFO)
 
@@ -50,7 +50,7 @@ def _epoch_all_training(stream, m, rank, ws, writer, epoch):
     stream.rewind()
     X, Y, _start, _count, _ = stream.fetch(size)
     while True:
-        job = _Job(m.trainNoRT, _shard(X, rank, ws), _shard(Y, rank, ws))
+        job = _Job(m.trainNoRT, X, Y)                 # the stream hands out this rank's slice
         job.start()
         nxt = stream.fetch(size)
         job.finish()
@@ -82,7 +82,7 @@ def TrainAll(args, m, utils, validate=True):
     else:
         trainingTotal = total
         validationStart = total + 1
-    stream = _BatchStream(utils, XC, YC, total, validationStart)
+    stream = _BatchStream(utils, XC, YC, total, validationStart, rank, ws)
     epoch = 1 if args.chkpnt_fn is None else int(args.chkpnt_fn[-param.parameterOutputPlaceHolder:]) + 1
     while epoch < param.maxEpoch:
         t_epoch = time.time()

@@ -96,3 +96,39 @@ def test_zigzag_rule():
     assert train._zigzag(mk([3, 4, 3, 4, 3, 4])) and train._zigzag(mk([4, 3, 4, 3, 4, 3]))
     assert train._zigzag(mk([2, 2, 9, 9, 9, 1]))            # flat first step
     assert not train._zigzag(mk([9, 8, 7, 6, 5, 4])) and not train._zigzag(mk([3, 4, 3, 4, 4, 3]))
+
+
+def test_sharded_batch_stream_covers_every_batch_exactly(tmp_path):
+    """data parallel: each rank's _BatchStream decompresses only its slice; the slices of all ranks, in rank order,
+    are the single-process batch -- for every batch of the epoch schedule, with and without the prefetch thread"""
+    from clairvoyante_amd import param, train, utils_v2
+    total = 23456
+    idx = np.arange(total)
+    X = idx.reshape(-1, 1).astype(np.float32)
+    Y = np.stack([idx * 2.0, idx * 3.0], axis=1)
+    XC = [utils_v2.pack_array(X[s:s + 500]) for s in range(0, total + 1, 500)]
+    YC = [utils_v2.pack_array(Y[s:s + 500]) for s in range(0, total + 1, 500)]
+    vstart = int(total * 0.9) + 1
+    for ws in (2, 3):
+        for use_prefetch in (False, True):
+            one = train._BatchStream(utils_v2, XC, YC, total, vstart)
+            ranks = [train._BatchStream(utils_v2, XC, YC, total, vstart, r, ws) for r in range(ws)]
+            streams = [one] + ranks
+            if use_prefetch:
+                for s in streams:
+                    s.prefetch(param.trainBatchSize, lambda p: train._next_batch_size(p, vstart))
+            size = param.trainBatchSize
+            nb = 0
+            while True:
+                full = one.fetch(size)
+                parts = [s.fetch(size) for s in ranks]
+                assert all(p[2:] == full[2:] for p in parts)                 # start, count of the whole batch, last
+                assert np.array_equal(np.concatenate([p[0] for p in parts]), full[0])
+                assert np.array_equal(np.concatenate([p[1] for p in parts]), full[1])
+                assert abs(len(parts[0][0]) - len(parts[-1][0])) <= 1
+                nb += 1
+                if full[4]:
+                    break
+                size = one.next_size()
+                assert all(s.next_size() == size for s in ranks)
+            assert nb > 5
