@@ -232,7 +232,9 @@ int cv_pileup_stats(cv_pileup *p, float ms[3], int64_t counts[3]);
  * passes the candidate filters (contig, "evc_min_mq", >= 55 % aligned, :137-160) into per-position
  * counters A,C,G,T,I,D,N over the reference window; "retain" = 1 keeps the uploaded alignments in
  * HBM so that cv_pileup_adopt_candidates can run the tensor scatter over them again -- the SAM text
- * is parsed once for both steps (the reference pipes `samtools view` twice, callVarBam.py:116-131).  */
+ * is parsed once for both steps (the reference pipes `samtools view` twice, callVarBam.py:116-131).
+ * "threads" = host threads cv_pileup_add_sam may use on chunks of >= 1 MiB (the result does not depend
+ * on it: records are parsed independently, the POS-run state is applied afterwards in read order).   */
 int cv_pileup_set_option(cv_pileup *p, const char *key, int64_t value);
 int cv_pileup_set_contig(cv_pileup *p, const char *name);        /* RNAME test of the candidate pass */
 
