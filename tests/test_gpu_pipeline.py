@@ -188,3 +188,29 @@ def test_evaluate_report_on_a_small_bin(oracle, tmp_path, caplog):
     top1 = int(np.sum(order[:, 0] == truth))
     assert "Dataset size: %d" % n in text
     assert "all/top1/top2/top1p/top2p: %d/%d/" % (n, top1) in text
+
+
+@pytest.mark.gpu
+def test_training_reduces_the_loss_and_keeps_predictions_finite():
+    """functional check of the whole step (forward, backward, Adam, dropout): 60 steps on one labelled batch bring
+    the loss far down and the network then predicts the labels of that batch"""
+    import torch
+    from clairvoyante_amd import clairvoyante_v3, synth
+    m = clairvoyante_v3.Clairvoyante()
+    m._seed_rng.seed(7)
+    m.init()
+    m.setLearningRate(1e-3)
+    xt, cls, rf, alt, il = synth.make_candidates(2000, seed=11, device="cuda", return_class=True)
+    y = synth.make_labels(cls, rf, alt, il)
+    first = m.getLoss(xt, y)
+    for _ in range(60):
+        loss, _ = m.train(xt, y)
+    last = m.getLoss(xt, y)
+    assert np.isfinite(first) and np.isfinite(last) and last < 0.25 * first
+    out = m.predict_device(xt).cpu().numpy()
+    assert np.isfinite(out).all()
+    yh = y.cpu().numpy()
+    zyg = (out[:, 4:6].argmax(1) == yh[:, 4:6].argmax(1)).mean()
+    typ = (out[:, 6:10].argmax(1) == yh[:, 6:10].argmax(1)).mean()
+    assert zyg > 0.9 and typ > 0.9
+    m.close()
