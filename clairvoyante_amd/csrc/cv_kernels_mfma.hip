@@ -772,8 +772,10 @@ __global__ __launch_bounds__(256) void heads_tm(const f4 *__restrict__ h4, const
 // EPI 0: + bias, SELU (forward layer).  EPI 1: raw accumulators (data-gradient pass: the same
 // kernel on transposed packed weights; blockIdx.y selects a slab of NB output fragments of a
 // wider result with NBT fragments per group).
-template <int NB, int WAVES, int EPI = 0>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 2) void dense_tm(const f4 *__restrict__ in_tm, int KB,
+// GR = groups per wave (1 or 2): with 2 a wave keeps two sets of accumulator tiles and every weight fragment read
+// from LDS feeds both -- twice the MFMA work per barrier and per LDS read, at 2 waves per SIMD.
+template <int NB, int WAVES, int EPI = 0, int GR = 1>
+__global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_tm(const f4 *__restrict__ in_tm, int KB,
                                                         const f4 *__restrict__ wp_all,
                                                         const float *__restrict__ bias, int nout,
                                                         f4 *__restrict__ out_tm, int G, int NBT = NB)
@@ -789,13 +791,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 2) void dense_tm(const f4 *__re
     const f4 *wp = wp_all + (size_t)blockIdx.y * KB * STAGE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = blockIdx.x * WAVES + wid;
-    const int gl = g < G ? g : G - 1;
-    const f4 *bp = in_tm + (size_t)gl * KB * 64 + lane;
-    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
-    f4 acc[NB];
+    const int g = (blockIdx.x * WAVES + wid) * GR;
+    const f4 *bp[GR];
 #pragma unroll
-    for (int ob = 0; ob < NB; ob++) acc[ob] = zero;
+    for (int r = 0; r < GR; r++) {
+        const int gl = g + r < G ? g + r : G - 1;
+        bp[r] = in_tm + (size_t)gl * KB * 64 + lane;
+    }
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 acc[GR][NB];
+#pragma unroll
+    for (int r = 0; r < GR; r++)
+#pragma unroll
+        for (int ob = 0; ob < NB; ob++) acc[r][ob] = zero;
     // global -> LDS DMA (global_load_lds_dwordx4): a wave moves one 1 KiB fragment per
     // instruction, destination = wave-uniform LDS base (M0) + lane*16 = the fragment layout
     // itself.  Issued from inline asm so that hipcc does not fence every following ds_read
@@ -823,8 +831,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 2) void dense_tm(const f4 *__re
     };
     stage_async(0, 0);
     stage_async(KB > 1 ? 1 : 0, 1);
-    f4 B = load_frag(bp);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(B) : : "memory");
+    f4 B[GR];
+#pragma unroll
+    for (int r = 0; r < GR; r++) B[r] = load_frag(bp[r]);
+#pragma unroll
+    for (int r = 0; r < GR; r++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(B[r]) : : "memory");
     __syncthreads();
     int slot = 0;
 #pragma unroll 1
@@ -834,7 +845,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 2) void dense_tm(const f4 *__re
         const int ks = kb + 2 < KB ? kb + 2 : KB - 1;
         const int kn = kb + 1 < KB ? kb + 1 : KB - 1;
         int wslot = slot + 2; if (wslot >= 3) wslot -= 3;
-        f4 Bn = load_frag(bp + (size_t)kn * 64);
+        f4 Bn[GR];
+#pragma unroll
+        for (int r = 0; r < GR; r++) Bn[r] = load_frag(bp[r] + (size_t)kn * 64);
         stage_async(ks, wslot);          // slot (kb+2)%3 was last read in step kb-1 (barrier passed)
         const f4 *wl = ring + slot * STAGE + lane;
 #pragma unroll
@@ -847,30 +860,37 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 2) void dense_tm(const f4 *__re
             for (int s = 0; s < 4; s++)
 #pragma unroll
                 for (int j = 0; j < 3; j++)
-                    if (ob + j < NB) acc[ob + j] = mfma4(A[j][s], B[s], acc[ob + j]);
+#pragma unroll
+                    for (int r = 0; r < GR; r++)
+                        if (ob + j < NB) acc[r][ob + j] = mfma4(A[j][s], B[r][s], acc[r][ob + j]);
         }
         __builtin_amdgcn_sched_barrier(0);                  // keep the MFMAs above the wait
         // Counted wait: leave THIS step's PER DMA pieces (stage kb+2, first read two steps from
         // now) in flight; everything older -- Bn and the pieces of stage kb+1 issued one step
         // ago -- has landed.  The barrier then publishes stage kb+1 to the whole workgroup.
-        if constexpr (PER == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(Bn) : : "memory");
-        else if constexpr (PER == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(Bn) : : "memory");
-        else if constexpr (PER == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(Bn) : : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(Bn) : : "memory");
+        if constexpr (PER == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(Bn[0]) : : "memory");
+        else if constexpr (PER == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(Bn[0]) : : "memory");
+        else if constexpr (PER == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(Bn[0]) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(Bn[0]) : : "memory");
+        if constexpr (GR == 2) asm volatile("" : "+v"(Bn[1]) : : "memory");      // the same wait covers the second fragment
         __syncthreads();
-        B = Bn;
+#pragma unroll
+        for (int r = 0; r < GR; r++) B[r] = Bn[r];
         slot = slot + 1 == 3 ? 0 : slot + 1;
     }
-    if (g >= G) return;
     const int q = lane >> 4;
-    f4 *op = out_tm + ((size_t)g * NBT + (size_t)blockIdx.y * NB) * 64 + lane;
 #pragma unroll
-    for (int ob = 0; ob < NB; ob++) {
-        if constexpr (EPI == 0) {
-            const f4 b4 = load_bias4(bias, (int)blockIdx.y * NB + ob, q, nout);
-            op[ob * 64] = selu4(acc[ob] + b4);
-        } else {
-            op[ob * 64] = acc[ob];
+    for (int r = 0; r < GR; r++) {
+        if (g + r >= G) break;
+        f4 *op = out_tm + ((size_t)(g + r) * NBT + (size_t)blockIdx.y * NB) * 64 + lane;
+#pragma unroll
+        for (int ob = 0; ob < NB; ob++) {
+            if constexpr (EPI == 0) {
+                const f4 b4 = load_bias4(bias, (int)blockIdx.y * NB + ob, q, nout);
+                op[ob * 64] = selu4(acc[r][ob] + b4);
+            } else {
+                op[ob * 64] = acc[r][ob];
+            }
         }
     }
 }
@@ -915,14 +935,14 @@ int launch_conv3_rot(const float *in, const float *wp, const float *bias, int co
     return 0;
 }
 
-template <int NB, int WAVES, int EPI = 0>
+template <int NB, int WAVES, int EPI = 0, int GR = 1>
 int launch_dense(const float *in, int KB, const float *wp, const float *bias, int nout, float *out, int G,
                  hipStream_t st, int slabs = 1)
 {
-    auto k = dense_tm<NB, WAVES, EPI>;
+    auto k = dense_tm<NB, WAVES, EPI, GR>;
     size_t lds = (size_t)3 * ((NB + WAVES - 1) / WAVES * WAVES) * 1024;
     if (set_lds(k, lds)) return 1;
-    k<<<dim3(nblk(G, WAVES), slabs), WAVES * 64, lds, st>>>((const f4 *)in, KB, (const f4 *)wp, bias, nout,
+    k<<<dim3(nblk(G, WAVES * GR), slabs), WAVES * 64, lds, st>>>((const f4 *)in, KB, (const f4 *)wp, bias, nout,
                                                             (f4 *)out, G, NB * slabs);
     CV_HIP(hipGetLastError());
     return 0;
@@ -1022,6 +1042,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         cv_prof_end(m, 2, st);
         cv_prof_begin(m, 3, st);
         if (G <= CV_FC4_SLAB_MAX_G) rc |= launch_dense<7, 8>(m->tm_p3, s.kb4, m->wps_fc4, P + o[7], a.fc4, m->tm_h4, G, st, 3);
+        else if (m->variant & 32) rc |= launch_dense<21, 8, 0, 2>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
         else if (m->variant & 4) rc |= launch_dense<21, 8>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
         else rc |= launch_dense<21, 4>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
         cv_prof_end(m, 3, st);

@@ -100,8 +100,9 @@ int cv_get_activation(cv_model *m, int layer, float *dst_dev, int64_t n, void *s
 /* knobs: "impl" (0 = plain one-thread-per-output kernels, 1 = MFMA tile kernels),
  * "chunk" (candidates per internal pass), "profile" (0/1, see cv_kernel_times),
  * "variant" (bit 0: first layer fused into the conv2 kernel, bit 1: MFMA heads kernel,
- * bit 2: 8-wave fc4 workgroups, bit 3: rotating-window conv3 kernel; default 15; the
- * alternatives give bit-identical results and exist for A/B timing).                                                              */
+ * bit 2: 8-wave fc4 workgroups, bit 3: rotating-window conv3 kernel, bit 5: fc4 with two groups of
+ * 16 candidates per wave; default 47; the alternatives give bit-identical results and exist for A/B
+ * timing).                                                                                          */
 int cv_set_option(cv_model *m, const char *key, int64_t value);
 int cv_get_option(const cv_model *m, const char *key, int64_t *value);
 

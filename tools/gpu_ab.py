@@ -15,7 +15,7 @@ from oracle import cv_oracle as O
 from clairvoyante_amd import clairvoyante_v3, clairvoyante_v3_slim, _lib, synth
 
 arch = sys.argv[1] if len(sys.argv) > 1 else "full"
-configs = [dict(variant=v, chunk=65536) for v in (7, 15)]
+configs = [dict(variant=v, chunk=65536) for v in (15, 47)]
 m = clairvoyante_v3.Clairvoyante() if arch == "full" else clairvoyante_v3_slim.Clairvoyante()
 P = common.bench_params(O, arch)
 m.setParameters(P)
