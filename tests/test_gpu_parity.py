@@ -103,7 +103,7 @@ def test_large_pass_kernels_equal_small_pass_kernels(setup):
     import torch
     from clairvoyante_amd import synth
     arch, P, m, x, ref = setup
-    n = 40000
+    n = 40010                                # 2 501 groups: odd, so one wave of the two-groups-per-wave fc4 is half empty
     xd = synth.make_candidates(n, seed=77, device="cuda")
     m.setOption("impl", 1)
     m.setOption("chunk", 8192)
