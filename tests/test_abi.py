@@ -62,3 +62,17 @@ def test_product_does_not_import_the_oracle():
             if fn.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
                 txt = open(os.path.join(dp, fn), errors="replace").read()
                 assert "cv_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn
+
+
+def test_product_never_imports_the_oracle():
+    """the oracle is test infrastructure: no module of the package (nor the C sources) may refer to it"""
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "clairvoyante_amd")
+    bad = []
+    for dirpath, _dirs, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|from\s+\.\.?\s*oracle|cv_oracle|cvo_", text, re.M):
+                    bad.append(f)
+    assert bad == []
