@@ -333,6 +333,8 @@ def PredictAndReport(m, utils, total, XC, YC):
     batch's end flag is not looked at), then the accuracy / confusion-matrix report"""
     t_pred = time.time()
     step = param.predictBatchSize
+    if getattr(m, "accepts_device_batches", False):
+        step *= 16          # same concatenated result; a call on 1 000 candidates is latency-bound on the GPU (DESIGN.md 4)
     outs = [[], [], [], []]
     ptr = 0
     while True:
