@@ -214,3 +214,35 @@ def test_training_reduces_the_loss_and_keeps_predictions_finite():
     typ = (out[:, 6:10].argmax(1) == yh[:, 6:10].argmax(1)).mean()
     assert zyg > 0.9 and typ > 0.9
     m.close()
+
+
+@pytest.mark.gpu
+def test_loss_and_gradient_are_additive_over_the_batch_at_scale(oracle):
+    """size-independent property at a size the oracle cannot reach: the loss is a SUM over candidates (v3.py:140-151),
+    so loss and data gradients of 40 000 candidates (three internal slices) equal those of two halves added up"""
+    import torch
+    from clairvoyante_amd import _lib, synth
+    m = _model("full")
+    m.setParameters(common.bench_params(oracle, "full"))
+    m.dropoutRateFC4Val = 0.0
+    m.setLearningRate(0.0)              # the Adam update must not move the weights between the calls
+    m.setL2RegularizationLambda(0.0)
+    n = 40000
+    xt, cls, rf, alt, il = synth.make_candidates(n, seed=21, device="cuda", return_class=True)
+    y = synth.make_labels(cls, rf, alt, il)
+
+    def grad_of(lo, hi):
+        loss, _ = m.train(xt[lo:hi].contiguous(), y[lo:hi].contiguous())
+        g = torch.empty(m.numParameters, device="cuda")
+        _lib.check(m._lib.cv_flat_copy(m._h, 1, ctypes.c_void_p(g.data_ptr()), 0, None))
+        return float(loss), g.double()
+    before = m.getParameter("fc4/kernel").copy()
+    l_all, g_all = grad_of(0, n)
+    l_a, g_a = grad_of(0, n // 2)
+    l_b, g_b = grad_of(n // 2, n)
+    assert np.array_equal(before, m.getParameter("fc4/kernel"))
+    assert abs(l_all - (l_a + l_b)) <= 1e-5 * abs(l_all)
+    err = (g_all - (g_a + g_b)).abs().max().item()
+    assert err <= 2e-5 * g_all.abs().max().item()
+    assert g_all.abs().max().item() > 0
+    m.close()
