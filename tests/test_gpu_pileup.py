@@ -460,3 +460,44 @@ def test_callvarbam_with_the_native_bam_reader(tmp_path, oracle):
         callVarBam.Run(b)
         assert open(b.call_fn).read() == open(a.call_fn).read()
         assert sum(1 for l in open(b.call_fn) if not l.startswith("#")) > 10
+
+
+def test_pileup_counts_are_additive_over_the_reads_at_scale():
+    """size-independent property at a size the Python oracle cannot reach (300 000 reads, 45 M alignment columns): the
+    tensors are counts, so the run over all reads equals the sum of the runs over the even and the odd reads (the
+    depth cap never triggers at 30x); matrix 3 at the centre sums to the reported depth; and the candidate pass finds the
+    same candidates when the text arrives in one piece or in 1 MiB pieces"""
+    from clairvoyante_amd import synth_pileup as sp
+    from clairvoyante_amd.pileup import Pileup
+    ref, text = sp.fast_alignments(300000, 1500000, sub=0.02)
+    lines = text.split(b"\n")[:-1]
+    centers = np.arange(50, 1500000 - 50, 97, dtype=np.int64)
+
+    def run(chunks):
+        pl = Pileup()
+        pl.set_reference(ref, 0)
+        pl.set_candidates(centers)
+        for c in chunks:
+            pl.add_sam(c)
+        t, d, u = pl.finish()
+        out = (t.cpu().numpy(), d.cpu().numpy(), u.cpu().numpy())
+        pl.close()
+        return out
+    full = run([text])
+    even = run([b"\n".join(lines[0::2]) + b"\n"])
+    odd = run([b"\n".join(lines[1::2]) + b"\n"])
+    assert np.array_equal(full[0], even[0] + odd[0])
+    assert np.array_equal(full[1], even[1] + odd[1]) and full[2].all()
+    assert np.array_equal(full[0][:, 16, :, 3].sum(axis=1), full[1].astype(np.float32))
+    assert 25 < full[1].mean() < 35
+    cands = []
+    for step in (len(text), 1 << 20):
+        pl = Pileup(evc=True, contig="ctgA", minMQ=1 << 30)
+        pl.set_reference(ref, 0)
+        for s0 in range(0, len(text), step):
+            pl.add_sam(text[s0:s0 + step])
+        res = pl.extract_candidates(0.1, 4)
+        cands.append((res["pos0"].copy(), res["counts"].copy(), res["reads"]))
+        pl.close()
+    assert np.array_equal(cands[0][0], cands[1][0]) and np.array_equal(cands[0][1], cands[1][1])
+    assert cands[0][2] == 300000 and len(cands[0][0]) > 1000
