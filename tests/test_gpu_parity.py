@@ -117,3 +117,23 @@ def test_large_pass_kernels_equal_small_pass_kernels(setup):
     m.setOption("chunk", 65536)
     head = m.predict(xd[:256].cpu().numpy())
     assert np.array_equal(np.concatenate(head, axis=1), small[:256])
+
+
+def test_candidates_are_independent_at_scale(setup):
+    """size-independent property on 300 000 candidates: a candidate's 16 outputs do not depend on which other candidates
+    share its pass, group of 16 or lane -- predicting a permuted batch gives the permuted outputs, bit for bit; and the
+    softmax heads sum to 1"""
+    import torch
+    from clairvoyante_amd import synth
+    arch, P, m, x, ref = setup
+    m.setOption("impl", 1); m.setOption("variant", 47); m.setOption("chunk", 65536)
+    n = 300000
+    xd = synth.make_candidates(n, seed=123, device="cuda")
+    out = m.predict_device(xd)
+    perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    outp = m.predict_device(xd[perm].contiguous())
+    assert torch.equal(outp, out[perm])
+    o = out.cpu().numpy()
+    assert np.isfinite(o).all() and (o >= 0).all() and (o <= 1).all()
+    for lo, hi in ((4, 6), (6, 10), (10, 16)):
+        assert np.abs(o[:, lo:hi].sum(axis=1) - 1).max() <= 2e-6
