@@ -2,9 +2,10 @@
 // "pileup front end").  Follows the behaviour of /root/reference/dataPrepScripts/CreateTensor.py
 // (OutputAlnTensor :93-246, GenerateTensor :23-54) with a different decomposition:
 //
-//   host   : one pass over the SAM text; every CIGAR run becomes alignment SEGMENTS of <= 64 columns
-//            (20 bytes each) + the read's SEQ bytes.  No per-candidate buffering.
-//   scatter: one wave per segment, one lane per alignment column.  Whether a column counts for a
+//   host   : one pass over the SAM text (several threads); every CIGAR run becomes alignment SEGMENTS of
+//            <= 64 columns (20 bytes each) + the read's SEQ bytes.  No per-candidate buffering.
+//   scatter: a workgroup per 512 consecutive segments, a lane per alignment column, counters of the
+//            candidates in reach privatised in LDS.  Whether a column counts for a
 //            candidate is a LOCAL rule (derived from the reference's activation state machine,
 //            :175-229, and checked against it in tests/): with c the 1-based centre, r the 0-based
 //            column position, p = r - c + 17 the window offset and POS the read's first position,
@@ -31,8 +32,8 @@
 //            swept: those "late" events form a second entry for that position (reported at the end,
 //            :215-241).  The parser flags them, the counters keep them apart (slots 7, 8).
 //
-// HBM-bound integer work: per column 1 SEQ byte + 1 reference byte + one L2 atomic per covering
-// candidate; per candidate 1 188 B of counters read once and 2 112 B of tensor written once.
+// Integer / byte work: per column 1 SEQ byte + 1 reference byte + one LDS atomic per covering candidate
+// (flushed once per workgroup); per candidate 1 188 B of counters read once and 2 112 B of tensor written once.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
