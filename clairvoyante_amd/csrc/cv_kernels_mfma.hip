@@ -1096,47 +1096,68 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
 //
 // A TM fragment has the candidate as the tile column.  For dW = X^T . G both operands need
 // the candidate as the MFMA k index instead, i.e. the 16x16 transpose of the fragment
-// ("CM" fragment: lane (f, rg) register t = value(feature f, candidate 4*rg + t)).  The
-// transpose itself is done by the matrix core: feeding TM register s as the A operand and
-// the constant 0/1 matrix B_s[k][j] = (j == 4s + k) accumulates D[c][f] = value(c, f) in four
-// steps -- exact (products with 1.0 and 0.0 only; `cm_of` below).  CM fragments of the layer input (A operand)
-// and of the pre-activation gradient (B operand) then give  dW[i][j] += sum_c X[c][i] G[c][j]
-// with four MFMA steps per 16 candidates; partial sums over candidate ranges are combined
-// with float atomics (the order of a training reduction is not part of the parity contract).
+// ("CM" fragment: lane (f, rg) register t = value(feature f, candidate 4*rg + t)).  CM fragments of the
+// layer input (A operand) and of the pre-activation gradient (B operand) then give
+// dW[i][j] += sum_c X[c][i] G[c][j]  with four MFMA steps per 16 candidates.
+//
+// The transpose rides on the global -> LDS DMA that brings the fragment in (`cm_stage`): every lane of the
+// DMA instruction fetches the 16 bytes of ANOTHER lane of the fragment (position p of the LDS slot receives
+// source lane 16 (p & 3) + 4 ((p >> 2) & 3) + (p >> 4)), which places the four values a CM lane needs 64
+// dwords apart and all 64 lanes of one such read in 64 different banks.  No candidate-major copy of any
+// tensor exists in HBM, the matrix pipe does none of the data movement, and the DMA of the next step runs
+// under the MFMAs of the current one.  Completion of a DMA is the explicit vmcnt wait; a slot is re-filled
+// only after the reads of its previous contents have returned (lgkmcnt wait).
 // ---------------------------------------------------------------------------
-// TM fragment -> CM fragment in registers (four MFMA steps against the constant 0/1 matrices, exact): the
-// weight-gradient kernels below read the tile-major buffers of the forward / backward pass directly and
-// transpose each fragment on the way in, so no candidate-major copy of any tensor exists in HBM.
-struct cm_of {
-    float Bc[4];
-    __device__ __forceinline__ explicit cm_of(int lane)
+struct cm_stage {
+    float *slots;           // LDS, 256 floats per fragment slot
+    unsigned base;          // LDS byte address of slots
+    int src_lane;           // fragment lane whose 16 bytes this lane's DMA piece fetches
+    int ridx;               // first dword this lane reads of a slot
+    __device__ __forceinline__ cm_stage(float *lds, int lane)
+        : slots(lds), base((unsigned)(size_t)(__attribute__((address_space(3))) float *)lds),
+          src_lane(16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (lane >> 4)),
+          ridx(16 * (lane >> 4) + 4 * (lane & 3) + ((lane & 15) >> 2)) {}
+    // frag: first f4 of a TM fragment (wave-uniform); slot: wave-uniform
+    __device__ __forceinline__ void fetch(const f4 *frag, int slot) const
     {
-        const int j = lane & 15, k = lane >> 4;
-#pragma unroll
-        for (int s = 0; s < 4; s++) Bc[s] = (j == 4 * s + k) ? 1.0f : 0.0f;
+        const f4 *gp = frag + src_lane;
+        const unsigned ldst = __builtin_amdgcn_readfirstlane(base + (unsigned)slot * 1024u);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gp), "s"(ldst) : "memory");
     }
-    __device__ __forceinline__ f4 operator()(const f4 v) const
+    __device__ __forceinline__ f4 read(int slot) const
     {
-        f4 d = (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 4; s++) d = mfma4(v[s], Bc[s], d);
-        return d;
+        const float *q = slots + slot * 256 + ridx;
+        return (f4){q[0], q[64], q[128], q[192]};
     }
+    template <int N> static __device__ __forceinline__ void landed()        // all but the newest N pieces
+    {
+        static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+    }
+    static __device__ __forceinline__ void reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); }
 };
 
 // dense layer: dW[k][j] += sum_cand X[cand][k] G[cand][j], db[j] += sum_cand G[cand][j].
-// Workgroup = 8 waves = 16 input fragments (two per wave) x all NJB output fragments; the
-// G fragments of a group are staged once per workgroup in a double-buffered LDS slot.
-// grid = (ceil(KB/16), group splits).
+// Workgroup = 8 waves = 16 input fragments (two per wave) x all NJB output fragments.  Per group the
+// workgroup stages the NJB gradient fragments (shared) and every wave its two input fragments, double
+// buffered: the pieces of group g+1 are in flight while group g is multiplied; one barrier per group.
+// grid = (ceil(KB/16), group splits); dynamic LDS = 2 * (NJB + 16) KiB.
 template <int NJB>
 __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_tm, int KB,
                                                        const f4 *__restrict__ g_tm, int G, int K, int N,
                                                        float *__restrict__ dw, float *__restrict__ db,
                                                        f4 *__restrict__ part)
 {
-    __shared__ __attribute__((aligned(16))) f4 gl[2][NJB * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const cm_of T(lane);
+    extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+    constexpr int NSLOT = NJB + 16;                  // per buffer: NJB gradient fragments, then 2 per wave
+    constexpr int PERG = (NJB + 7) / 8;              // gradient fragments each wave fetches (clamped: duplicates
+                                                     // of the last one land on identical bytes)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const cm_stage S(wg_lds, lane);
     const int kb0 = blockIdx.x * 16 + wid * 2;
     const int per = (G + gridDim.y - 1) / gridDim.y;
     const int g0 = blockIdx.y * per, g1 = g0 + per < G ? g0 + per : G;
@@ -1147,26 +1168,34 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
 #pragma unroll
         for (int jb = 0; jb < NJB; jb++) acc[a][jb] = zero;
     const bool v0 = kb0 < KB, v1 = kb0 + 1 < KB;
+    const int kc0 = v0 ? kb0 : KB - 1, kc1 = v1 ? kb0 + 1 : KB - 1;       // clamped: fetched, never multiplied
     constexpr int NBS = (NJB + 7) / 8;               // bias: wave w of column 0 sums fragments w, w+8, ..
     f4 bs[NBS];
 #pragma unroll
     for (int i = 0; i < NBS; i++) bs[i] = zero;
     const bool do_bias = blockIdx.x == 0 && db != nullptr;
-    if (g0 < g1) {
-        for (int i = tid; i < NJB * 64; i += 512) gl[0][i] = T(g_tm[(size_t)g0 * NJB * 64 + i]);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int g = g0; g < g1; g++) {
-        if (g + 1 < g1) {
-            for (int i = tid; i < NJB * 64; i += 512) gl[buf ^ 1][i] = T(g_tm[(size_t)(g + 1) * NJB * 64 + i]);
+    auto stage = [&](int g, int buf) {
+#pragma unroll
+        for (int i = 0; i < PERG; i++) {
+            const int jb = wid + 8 * i < NJB ? wid + 8 * i : NJB - 1;
+            S.fetch(g_tm + ((size_t)g * NJB + jb) * 64, buf * NSLOT + jb);
         }
-        f4 X0 = zero, X1 = zero;
-        if (v0) X0 = T(x_tm[((size_t)g * KB + kb0) * 64 + lane]);
-        if (v1) X1 = T(x_tm[((size_t)g * KB + kb0 + 1) * 64 + lane]);
+        S.fetch(x_tm + ((size_t)g * KB + kc0) * 64, buf * NSLOT + NJB + 2 * wid);
+        S.fetch(x_tm + ((size_t)g * KB + kc1) * 64, buf * NSLOT + NJB + 2 * wid + 1);
+    };
+    if (g0 < g1) stage(g0, 0);
+    int buf = 0;
+#pragma unroll 1
+    for (int g = g0; g < g1; g++) {
+        cm_stage::landed<0>();
+        __syncthreads();                     // group g is in LDS for everyone; buffer buf^1 is no longer read
+        if (g + 1 < g1) stage(g + 1, buf ^ 1);
+        f4 X0 = S.read(buf * NSLOT + NJB + 2 * wid), X1 = S.read(buf * NSLOT + NJB + 2 * wid + 1);
+        if (!v0) X0 = zero;
+        if (!v1) X1 = zero;
 #pragma unroll
         for (int jb = 0; jb < NJB; jb++) {
-            const f4 B = gl[buf][jb * 64 + lane];
+            const f4 B = S.read(buf * NSLOT + jb);
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 acc[0][jb] = mfma4(X0[t], B[t], acc[0][jb]);
@@ -1174,7 +1203,7 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
             }
             if (do_bias && (jb & 7) == wid) bs[jb >> 3] += B;
         }
-        __syncthreads();
+        cm_stage::reads_done();
         buf ^= 1;
     }
     if (do_bias) {
@@ -1242,16 +1271,21 @@ __global__ void wgrad_dense_reduce(const f4 *__restrict__ part, int splits, int 
 
 // conv layer: dW[kh][kw][ci][co] += sum_{cand,h,wo} In[cand][h+kh-PT][wo+kw-1][ci] G[cand][h][wo][co].
 // One wave per (output fragment cob, candidate-range split); it keeps all KH*4*CINB tiles of
-// that cob in registers and streams over groups and positions with a KH-row window of input
-// CM fragments.  grid = (NT, splits), 64 threads.
-template <int KH, int CINB, int NT, int HIN>
+// that cob in registers and streams over groups and rows with a KH-row window of input CM fragments.
+// Step s of a group brings in input row s and gradient row s - PRE (PRE = KH-1-PADT rows of lead; rows
+// outside the map are fetched clamped and replaced by zero), R steps in flight in a ring of private LDS
+// slots.  grid = (NT, splits), 64 threads, dynamic LDS = R * (4*CINB + 4) KiB.
+template <int KH, int CINB, int NT, int HIN, int R>
 __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm, const f4 *__restrict__ g_tm,
-                                                     int G, int cin, int cout, float *__restrict__ dw,
-                                                     float *__restrict__ db)
+                                                     int G, f4 *__restrict__ part)
 {
+    extern __shared__ __attribute__((aligned(16))) float wg_lds[];
     constexpr int PADT = (KH - 1) / 2;
+    constexpr int PRE = KH - 1 - PADT;
+    constexpr int NF = 4 * CINB + 4;                 // fragments per step
+    constexpr int STEPS = HIN + PRE;                 // steps per group
     const int lane = threadIdx.x;
-    const cm_of T(lane);
+    const cm_stage S(wg_lds, lane);
     const int cob = blockIdx.x;
     const int per = (G + gridDim.y - 1) / gridDim.y;
     const int g0 = blockIdx.y * per, g1 = g0 + per < G ? g0 + per : G;
@@ -1264,32 +1298,53 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm
 #pragma unroll
             for (int c = 0; c < CINB; c++) acc[a][b][c] = zero;
     f4 bsum = zero;
-    for (int g = g0; g < g1; g++) {
-        const f4 *ip = in_tm + (size_t)g * (HIN * 4 * CINB * 64) + lane;
-        const f4 *gp = g_tm + (size_t)g * (HIN * 4 * NT * 64) + (size_t)cob * 64 + lane;
-        f4 win[KH][4][CINB];     // win[kh] = input row h + kh - PADT
+    const int total = (g1 > g0 ? g1 - g0 : 0) * STEPS;
+    // flat step i = (g - g0) * STEPS + s; fetch cursor (fg, fs) runs R steps ahead of the compute cursor (g, s)
+    int fg = g0, fs = 0;
+    auto fetch_step = [&](int slot) {
+        const int gg = fg < g1 ? fg : g1 - 1;                            // surplus fetches of the tail re-read valid data
+        const int hr = fs < HIN ? fs : HIN - 1;
+        const int hg = fs - PRE < 0 ? 0 : fs - PRE;
+        const f4 *ip = in_tm + ((size_t)gg * HIN + hr) * (4 * CINB * 64);
+        const f4 *gp = g_tm + (((size_t)gg * HIN + hg) * 4 * NT + cob) * 64;
 #pragma unroll
-        for (int j = 0; j < KH; j++) {
-            const int hr = j - PADT;     // rows for h = 0; the last slot is (re)loaded in the loop
+        for (int f = 0; f < 4 * CINB; f++) S.fetch(ip + f * 64, slot * NF + f);
 #pragma unroll
-            for (int w = 0; w < 4; w++)
+        for (int w = 0; w < 4; w++) S.fetch(gp + (size_t)w * (NT * 64), slot * NF + 4 * CINB + w);
+        if (++fs == STEPS) { fs = 0; fg++; }
+    };
+    if (total > 0) {
 #pragma unroll
-                for (int cb = 0; cb < CINB; cb++)
-                    win[j][w][cb] = (hr >= 0 && hr < HIN && j < KH - 1) ? T(ip[(size_t)((hr * 4 + w) * CINB + cb) * 64]) : zero;
-        }
+        for (int r = 0; r < R; r++) fetch_step(r);
+    }
+    f4 win[KH][4][CINB];         // win[kh] = input row h + kh - PADT of the row h being accumulated
+    int s = 0, slot = 0;
 #pragma unroll 1
-        for (int h = 0; h < HIN; h++) {
-            {
-                const int hr = h + KH - 1 - PADT;
+    for (int i = 0; i < total; i++) {
+        if (s == 0) {
+#pragma unroll
+            for (int j = 0; j + 1 < KH; j++)
 #pragma unroll
                 for (int w = 0; w < 4; w++)
 #pragma unroll
-                    for (int cb = 0; cb < CINB; cb++)
-                        win[KH - 1][w][cb] = hr < HIN ? T(ip[(size_t)((hr * 4 + w) * CINB + cb) * 64]) : zero;
-            }
-            f4 Gr[4];
+                    for (int cb = 0; cb < CINB; cb++) win[j][w][cb] = zero;
+        }
+        cm_stage::landed<NF * (R - 1)>();
+        const bool row_in = s < HIN;
 #pragma unroll
-            for (int w = 0; w < 4; w++) Gr[w] = T(gp[(size_t)(h * 4 + w) * (NT * 64)]);
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int cb = 0; cb < CINB; cb++) {
+                const f4 v = S.read(slot * NF + w * CINB + cb);
+                win[KH - 1][w][cb] = row_in ? v : zero;
+            }
+        f4 Gr[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) Gr[w] = S.read(slot * NF + 4 * CINB + w);
+        cm_stage::reads_done();
+        fetch_step(slot);
+        const int h = s - PRE;
+        if (h >= 0) {
             bsum += (Gr[0] + Gr[1]) + (Gr[2] + Gr[3]);
 #pragma unroll
             for (int kh = 0; kh < KH; kh++) {
@@ -1309,84 +1364,164 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm
                         }
                 }
             }
-#pragma unroll
-            for (int j = 0; j + 1 < KH; j++)
-#pragma unroll
-                for (int w = 0; w < 4; w++)
-#pragma unroll
-                    for (int cb = 0; cb < CINB; cb++) win[j][w][cb] = win[j + 1][w][cb];
         }
+#pragma unroll
+        for (int j = 0; j + 1 < KH; j++)
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+#pragma unroll
+                for (int cb = 0; cb < CINB; cb++) win[j][w][cb] = win[j + 1][w][cb];
+        if (++s == STEPS) s = 0;
+        if (R > 1) slot = slot + 1 == R ? 0 : slot + 1;
     }
-    {   // bias gradient: sum of the G fragments over registers (t) and lanes rg
-        float v = (bsum[0] + bsum[1]) + (bsum[2] + bsum[3]);
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        const int cb_ = 16 * cob + (lane & 15);
-        if (lane < 16 && cb_ < cout) atomicAdd(&db[cb_], v);
-    }
-    // lane (c', q) register r  <->  dW[kh][kw][ci = 16 cb + 4q + r][co = 16 cob + c']
-    const int cq = lane & 15, q = lane >> 4;
-    const int co = 16 * cob + cq;
+    cm_stage::landed<0>();           // the surplus fetches of the last R steps
+    if (g0 >= g1) return;
+    // this split's tiles as whole fragments (+ the bias sums as one more), combined by wgrad_conv_reduce
+    constexpr int TILES = KH * 4 * CINB;
+    f4 *pp = part + ((size_t)blockIdx.y * NT + cob) * (TILES + 1) * 64 + lane;
 #pragma unroll
     for (int kh = 0; kh < KH; kh++)
 #pragma unroll
         for (int kw = 0; kw < 4; kw++)
 #pragma unroll
-            for (int cb = 0; cb < CINB; cb++)
+            for (int cb = 0; cb < CINB; cb++) pp[((kh * 4 + kw) * CINB + cb) * 64] = acc[kh][kw][cb];
+    pp[TILES * 64] = bsum;
+}
+
+// second pass of the convolution weight gradients: fragment f = cob * (TILES + 1) + tile of every split, summed
+// in a fixed order (16 strided partial sums, then those in ascending order) by one 1024-thread workgroup.
+// tile < TILES: lane (c', q) register r  <->  dW[kh][kw][ci = 16 cb + 4q + r][co = 16 cob + c'];
+// tile == TILES: CM bias sums, lane (f, rg) register t -> db[16 cob + f] (registers, then lanes rg).
+__global__ __launch_bounds__(1024) void wgrad_conv_reduce(const f4 *__restrict__ part, int splits, int NT, int TILES,
+                                                          int CINB, int cin, int cout, float *__restrict__ dw,
+                                                          float *__restrict__ db)
+{
+    __shared__ f4 sh[16][64];
+    const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int frag = blockIdx.x;
+    const size_t stride = (size_t)NT * (TILES + 1) * 64;
+    f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int sp = j; sp < splits; sp += 16) v += part[(size_t)sp * stride + (size_t)frag * 64 + lane];
+    sh[j][lane] = v;
+    __syncthreads();
+    if (j != 0) return;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int ci = 16 * cb + 4 * q + r;
-                    if (ci < cin && co < cout)
-                        atomicAdd(&dw[(((size_t)kh * 4 + kw) * cin + ci) * cout + co], acc[kh][kw][cb][r]);
-                }
+    for (int k = 1; k < 16; k++) v += sh[k][lane];
+    const int cob = frag / (TILES + 1), tile = frag % (TILES + 1);
+    const int cq = lane & 15, q = lane >> 4;
+    const int co = 16 * cob + cq;
+    if (tile == TILES) {
+        float b = (v[0] + v[1]) + (v[2] + v[3]);
+        b += __shfl_xor(b, 16);
+        b += __shfl_xor(b, 32);
+        if (lane < 16 && co < cout) db[co] += b;
+        return;
+    }
+    const int cb = tile % CINB, kk = tile / CINB;        // kk = kh * 4 + kw
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int ci = 16 * cb + 4 * q + r;
+        if (ci < cin && co < cout) dw[((size_t)kk * cin + ci) * cout + co] += v[r];
+    }
 }
 
 // first layer (k(1,4), 4 input channels): the 16 (base, matrix) values of a position form ONE
 // fragment, so  T_wo[(wi, ci)][co] += X[h][(wi, ci)] G[h][wo][co]  gives every tap at once:
-// dW[kw][ci][co] = sum_wo T_wo[(wo + kw - 1, ci)][co].  One wave per candidate-range split.
+// dW[kw][ci][co] = sum_wo T_wo[(wo + kw - 1, ci)][co].  One wave per candidate-range split; a step is one
+// position (1 + 4 fragments, 16 MFMAs), so R = 6 steps are kept in flight (30 KiB of LDS per wave).
+constexpr int CV_WG1_RING = 6;
 __global__ __launch_bounds__(64) void wgrad_conv1_cm(const f4 *__restrict__ x_tm, const f4 *__restrict__ g_tm,
-                                                      int G, int cout, float *__restrict__ dw,
-                                                      float *__restrict__ db)
+                                                      int G, f4 *__restrict__ part)
 {
+    extern __shared__ __attribute__((aligned(16))) float wg_lds[];
     constexpr int HIN = CV_INPUT_H;
+    constexpr int R = CV_WG1_RING;
     const int lane = threadIdx.x;
-    const cm_of T(lane);
+    const cm_stage S(wg_lds, lane);
     const int per = (G + gridDim.x - 1) / gridDim.x;
     const int g0 = blockIdx.x * per, g1 = g0 + per < G ? g0 + per : G;
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
     f4 acc[4] = {zero, zero, zero, zero};
     f4 bsum = zero;
-    for (int g = g0; g < g1; g++) {
-        const f4 *xp = x_tm + (size_t)g * HIN * 64 + lane;
-        const f4 *gp = g_tm + (size_t)g * HIN * 4 * 64 + lane;
-#pragma unroll 3
-        for (int h = 0; h < HIN; h++) {
-            const f4 X = T(xp[(size_t)h * 64]);
+    // positions of consecutive groups are consecutive in both buffers: flat position i of this split
+    const int total = (g1 > g0 ? g1 - g0 : 0) * HIN;
+    const f4 *xp = x_tm + (size_t)g0 * HIN * 64;
+    const f4 *gp = g_tm + (size_t)g0 * HIN * 4 * 64;
+    auto fetch_pos = [&](int i, int slot) {
+        const int ic = i < total ? i : total - 1;
+        S.fetch(xp + (size_t)ic * 64, slot * 5);
 #pragma unroll
-            for (int wo = 0; wo < 4; wo++) {
-                const f4 Gf = T(gp[(size_t)(h * 4 + wo) * 64]);
-                bsum += Gf;
+        for (int wo = 0; wo < 4; wo++) S.fetch(gp + ((size_t)ic * 4 + wo) * 64, slot * 5 + 1 + wo);
+    };
+    if (total > 0) {
 #pragma unroll
-                for (int t = 0; t < 4; t++) acc[wo] = mfma4(X[t], Gf[t], acc[wo]);
-            }
-        }
+        for (int r = 0; r < R; r++) fetch_pos(r, r);
     }
-    {
-        float v = (bsum[0] + bsum[1]) + (bsum[2] + bsum[3]);
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (lane < 16 && lane < cout) atomicAdd(&db[lane], v);
-    }
-    // lane (co, q) register r of T_wo: row i = 4q + r = wi*4 + ci  =>  wi = q, ci = r
-    const int co = lane & 15, wi = lane >> 4;
-    if (co < cout) {
+    int slot = 0;
+#pragma unroll 1
+    for (int i = 0; i < total; i++) {
+        cm_stage::landed<5 * (R - 1)>();
+        const f4 X = S.read(slot * 5);
+        f4 Gf[4];
+#pragma unroll
+        for (int wo = 0; wo < 4; wo++) Gf[wo] = S.read(slot * 5 + 1 + wo);
+        cm_stage::reads_done();
+        fetch_pos(i + R, slot);
 #pragma unroll
         for (int wo = 0; wo < 4; wo++) {
-            const int kw = wi - wo + 1;
-            if (kw < 0 || kw > 3) continue;
+            bsum += Gf[wo];
 #pragma unroll
-            for (int r = 0; r < 4; r++) atomicAdd(&dw[((size_t)kw * 4 + r) * cout + co], acc[wo][r]);
+            for (int t = 0; t < 4; t++) acc[wo] = mfma4(X[t], Gf[wo][t], acc[wo]);
         }
+        slot = slot + 1 == R ? 0 : slot + 1;
+    }
+    cm_stage::landed<0>();
+    if (g0 >= g1) return;
+    f4 *pp = part + (size_t)blockIdx.x * 5 * 64 + lane;       // T_0..T_3 and the bias sums of this split
+#pragma unroll
+    for (int wo = 0; wo < 4; wo++) pp[wo * 64] = acc[wo];
+    pp[4 * 64] = bsum;
+}
+
+// second pass, first layer.  lane (co, q) register r of T_wo: row i = 4q + r = wi*4 + ci  =>  wi = q, ci = r, and
+// dW[kw][ci][co] = sum_wo T_wo[wi = wo + kw - 1].  Workgroup kw < 4 gathers, for every wo, the 16 lanes of T_wo
+// that belong to its tap; workgroup 4 sums the bias fragment.  Fixed order: 16 strided partial sums over the
+// splits, those ascending, then wo ascending.
+__global__ __launch_bounds__(1024) void wgrad_conv1_reduce(const f4 *__restrict__ part, int splits, int cout,
+                                                           float *__restrict__ dw, float *__restrict__ db)
+{
+    __shared__ f4 sh[16][64];
+    const int l = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int kw = blockIdx.x;
+    const int co = l & 15, wo = l >> 4;
+    const int wi = wo + kw - 1;
+    const bool bias = kw == 4;
+    const bool valid = bias || (wi >= 0 && wi <= 3);
+    const int src = bias ? 4 * 64 + l : wo * 64 + wi * 16 + co;
+    f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+    if (valid)
+        for (int sp = j; sp < splits; sp += 16) v += part[(size_t)sp * 5 * 64 + src];
+    sh[j][l] = v;
+    __syncthreads();
+    if (j != 0) return;
+#pragma unroll
+    for (int k = 1; k < 16; k++) v += sh[k][l];
+    if (bias) {
+        float b = (v[0] + v[1]) + (v[2] + v[3]);
+        b += __shfl_xor(b, 16);
+        b += __shfl_xor(b, 32);
+        if (l < 16 && l < cout) db[l] += b;
+        return;
+    }
+    sh[0][l] = v;                   // wave 0 only from here on (its own earlier reads of sh are done)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (l < 16 && l < cout) {
+        f4 t = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; w++) t += sh[0][w * 16 + l];     // invalid (wo, kw) pairs hold zeros
+#pragma unroll
+        for (int r = 0; r < 4; r++) dw[((size_t)kw * 4 + r) * cout + l] += t[r];
     }
 }
 
@@ -1522,6 +1657,18 @@ int cv_dropout_tm(cv_model *m, const float *h4, float *d4, float *amask, int64_t
 // layer 4 = fc4 (x = pool3 TM, g = fc4 pre-activation gradient TM), 5 = fc5.  The candidate range is split over
 // enough workgroups to cover the chip once (one 8-wave workgroup per CU); the per-split tiles go to a scratch
 // buffer and are summed in a fixed order by wgrad_dense_reduce (no float atomics on the weights).
+// scratch for the per-split tiles of a weight gradient (one kernel pair at a time uses it, in stream order)
+static int wg_part_reserve(cv_model *m, size_t need, hipStream_t st)
+{
+    if (m->wg_part_bytes >= need) return 0;
+    CV_HIP(hipStreamSynchronize(st));
+    if (m->wg_part) CV_HIP(hipFree(m->wg_part));
+    m->wg_part = nullptr; m->wg_part_bytes = 0;
+    CV_HIP(hipMalloc(&m->wg_part, need));
+    m->wg_part_bytes = need;
+    return 0;
+}
+
 template <int NJB>
 static int dense_wgrad_launch(cv_model *m, const float *x_tm, int KB, const float *g_tm, int G, int K, int N, float *dw,
                               float *db, hipStream_t st)
@@ -1530,16 +1677,11 @@ static int dense_wgrad_launch(cv_model *m, const float *x_tm, int KB, const floa
     int splits = 256 / kblocks;
     if (splits > G) splits = G;
     if (splits < 1) splits = 1;
-    const size_t need = (size_t)splits * KB * NJB * 256 * sizeof(float);
-    if (m->wg_part_bytes < need) {
-        CV_HIP(hipStreamSynchronize(st));
-        if (m->wg_part) CV_HIP(hipFree(m->wg_part));
-        m->wg_part = nullptr; m->wg_part_bytes = 0;
-        CV_HIP(hipMalloc(&m->wg_part, need));
-        m->wg_part_bytes = need;
-    }
-    wgrad_dense_cm<NJB><<<dim3(kblocks, splits), 512, 0, st>>>((const f4 *)x_tm, KB, (const f4 *)g_tm, G, K, N, dw, db,
-                                                               (f4 *)m->wg_part);
+    if (wg_part_reserve(m, (size_t)splits * KB * NJB * 256 * sizeof(float), st)) return 1;
+    const size_t lds = (size_t)2 * (NJB + 16) * 1024;
+    if (set_lds(wgrad_dense_cm<NJB>, lds)) return 1;
+    wgrad_dense_cm<NJB><<<dim3(kblocks, splits), 512, lds, st>>>((const f4 *)x_tm, KB, (const f4 *)g_tm, G, K, N, dw, db,
+                                                                 (f4 *)m->wg_part);
     const int64_t per = (int64_t)KB * NJB * 64;
     wgrad_dense_reduce<<<nblk(per, 256), 256, 0, st>>>((const f4 *)m->wg_part, splits, KB, NJB, K, N, dw);
     CV_HIP(hipGetLastError());
@@ -1559,27 +1701,41 @@ int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_tm, const float *
     return dense_wgrad_launch<2>(m, x_tm, s.nb4, g_tm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9], st);
 }
 
-// layer 1 = conv2 (in = pool1 TM), 2 = conv3 (in = pool2 TM); g = pre-activation gradient TM
+// layer 1 = conv2 (in = pool1 TM), 2 = conv3 (in = pool2 TM); g = pre-activation gradient TM.
+// One wave per (output fragment, split): enough splits for ~2 waves per SIMD (1024 SIMDs); the per-split tiles go
+// to the scratch buffer and are summed in a fixed order by wgrad_conv_reduce (no float atomics).
+template <int KH, int CINB, int NT, int HIN, int R>
+static int conv_wgrad_launch(cv_model *m, const float *in_tm, const float *g_tm, int G, int cin, int cout, float *dw,
+                             float *db, hipStream_t st)
+{
+    constexpr int TILES = KH * 4 * CINB;
+    const int want = (2048 + NT - 1) / NT;
+    const int splits = G < want ? (G > 0 ? G : 1) : want;
+    const int per = (G + splits - 1) / splits;
+    const int used = per > 0 ? (G + per - 1) / per : 0;          // splits that own at least one group
+    if (used == 0) return 0;
+    if (wg_part_reserve(m, (size_t)splits * NT * (TILES + 1) * 256 * sizeof(float), st)) return 1;
+    wgrad_conv_cm<KH, CINB, NT, HIN, R><<<dim3(NT, splits), 64, R * (4 * CINB + 4) * 1024, st>>>(
+        (const f4 *)in_tm, (const f4 *)g_tm, G, (f4 *)m->wg_part);
+    wgrad_conv_reduce<<<NT * (TILES + 1), 1024, 0, st>>>((const f4 *)m->wg_part, used, NT, TILES, CINB, cin, cout, dw, db);
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
 int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_tm, const float *g_tm, int64_t n, hipStream_t st)
 {
     const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
     const int G = (int)((n + 15) / 16);
     float *dw = m->grads + m->poff[2 * layer];
     float *db = m->grads + m->poff[2 * layer + 1];
-    // one wave per (output fragment, split): enough splits for ~2 waves per SIMD (1024 SIMDs)
-    const int want = (2048 + s.ntile[layer] - 1) / s.ntile[layer];
-    const int splits = G < want ? (G > 0 ? G : 1) : want;
-    dim3 grid(s.ntile[layer], splits);
     const int cin = s.cin[layer], cout = a.cout[layer];
+    // ring depth R: as many steps in flight as 8 waves per CU leave LDS for (conv3: 12 KiB per step)
     if (is_full(a)) {
-        if (layer == 2) wgrad_conv_cm<3, 2, 3, 26><<<grid, 64, 0, st>>>((const f4 *)in_tm, (const f4 *)g_tm, G, cin, cout, dw, db);
-        else wgrad_conv_cm<2, 1, 2, 29><<<grid, 64, 0, st>>>((const f4 *)in_tm, (const f4 *)g_tm, G, cin, cout, dw, db);
-    } else {
-        if (layer == 2) wgrad_conv_cm<5, 1, 2, 33><<<grid, 64, 0, st>>>((const f4 *)in_tm, (const f4 *)g_tm, G, cin, cout, dw, db);
-        else wgrad_conv_cm<3, 1, 1, 33><<<grid, 64, 0, st>>>((const f4 *)in_tm, (const f4 *)g_tm, G, cin, cout, dw, db);
+        if (layer == 2) return conv_wgrad_launch<3, 2, 3, 26, 1>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
+        return conv_wgrad_launch<2, 1, 2, 29, 2>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
     }
-    CV_HIP(hipGetLastError());
-    return 0;
+    if (layer == 2) return conv_wgrad_launch<5, 1, 2, 33, 2>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
+    return conv_wgrad_launch<3, 1, 1, 33, 2>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
 }
 
 // first layer: x_tm = TM fragments of X viewed as [33 positions][16 = base*4 + matrix], g = TM of its
@@ -1587,8 +1743,13 @@ int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_tm, const float *
 int cv_tile_conv1_wgrad(cv_model *m, const float *x_tm, const float *g_tm, int64_t n, hipStream_t st)
 {
     const int G = (int)((n + 15) / 16);
-    const int splits = G < 512 ? (G > 0 ? G : 1) : 512;
-    wgrad_conv1_cm<<<splits, 64, 0, st>>>((const f4 *)x_tm, (const f4 *)g_tm, G, m->arch.cout[0], m->grads + m->poff[0],
+    if (G <= 0) return 0;
+    const int splits = G < 1024 ? G : 1024;
+    const int per = (G + splits - 1) / splits;
+    const int used = (G + per - 1) / per;
+    if (wg_part_reserve(m, (size_t)splits * 5 * 256 * sizeof(float), st)) return 1;
+    wgrad_conv1_cm<<<splits, 64, CV_WG1_RING * 5 * 1024, st>>>((const f4 *)x_tm, (const f4 *)g_tm, G, (f4 *)m->wg_part);
+    wgrad_conv1_reduce<<<5, 1024, 0, st>>>((const f4 *)m->wg_part, used, m->arch.cout[0], m->grads + m->poff[0],
                                           m->grads + m->poff[1]);
     CV_HIP(hipGetLastError());
     return 0;

@@ -175,9 +175,14 @@ __global__ __launch_bounds__(256) void t_heads(
     if (threadIdx.x < 4) atomicAdd(&loss[threadIdx.x], part[threadIdx.x]);
 }
 
-__global__ void t_l2(const float *__restrict__ w, int64_t count, double *__restrict__ out)
+struct l2_args { const float *w[CV_NUM_PARAMS / 2]; int64_t count[CV_NUM_PARAMS / 2]; };
+
+// sum of squares / 2 of every kernel (blockIdx.y), one launch
+__global__ void t_l2(l2_args a, double *__restrict__ out)
 {
     __shared__ double sh[256];
+    const float *__restrict__ w = a.w[blockIdx.y];
+    const int64_t count = a.count[blockIdx.y];
     double s = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
         s += (double)w[i] * (double)w[i];
@@ -502,6 +507,7 @@ __global__ __launch_bounds__(256) void t_heads_tm(
     else if (j < 10) { w = wt; b = bt; idx = j - 6;  nh = 4; K = K5; KB = KB5; src = h5; }
     else             { w = wl; b = bl; idx = j - 10; nh = 6; K = K5; KB = KB5; src = h5; }
     float acc = 0.0f;
+#pragma unroll 16
     for (int k = 0; k < K; k++) acc = __builtin_fmaf(src[cv_tm_index(cl, k, KB)], w[(size_t)k * nh + idx], acc);
     pre[c][j] = acc + b[idx];
     __syncthreads();
@@ -536,24 +542,29 @@ __global__ __launch_bounds__(256) void t_heads_tm(
     if (threadIdx.x < 4) atomicAdd(&loss[threadIdx.x], part[threadIdx.x]);
 }
 
-// heads: weight / bias gradients with the layer input read from a TM buffer
+// heads: weight / bias gradients of the four heads in one launch, layer inputs read from TM buffers
 // dW[k][j] += sum_n X[n][k] g[n][j0 + j] ; row k == K is the bias
-__global__ void b_head_wgrad_tm(const float *__restrict__ xtm, int KB, const float *__restrict__ g, int j0, int64_t n,
-                                int K, int N, float *__restrict__ dw, float *__restrict__ db)
+struct head_wg { const float *xtm; float *dw, *db; int KB, K, N, j0, t0; };
+struct head_wg4 { head_wg h[4]; int total; };
+
+__global__ void b_head_wgrad_tm(head_wg4 a, const float *__restrict__ g, int64_t n)
 {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)(K + 1) * N) return;
-    int j = (int)(t % N);
-    int k = (int)(t / N);
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.total) return;
+    int q = t >= a.h[2].t0 ? (t >= a.h[3].t0 ? 3 : 2) : (t >= a.h[1].t0 ? 1 : 0);
+    const head_wg h = a.h[q];
+    t -= h.t0;
+    int j = t % h.N;
+    int k = t / h.N;
     int64_t per = (n + gridDim.y - 1) / gridDim.y;
     int64_t n0 = per * blockIdx.y, n1 = n0 + per < n ? n0 + per : n;
     float acc = 0.0f;
-    if (k < K) {
-        for (int64_t i = n0; i < n1; i++) acc = __builtin_fmaf(xtm[cv_tm_index(i, k, KB)], g[(size_t)i * 16 + j0 + j], acc);
-        atomicAdd(&dw[(size_t)k * N + j], acc);
+    if (k < h.K) {
+        for (int64_t i = n0; i < n1; i++) acc = __builtin_fmaf(h.xtm[cv_tm_index(i, k, h.KB)], g[(size_t)i * 16 + h.j0 + j], acc);
+        atomicAdd(&h.dw[(size_t)k * h.N + j], acc);
     } else {
-        for (int64_t i = n0; i < n1; i++) acc += g[(size_t)i * 16 + j0 + j];
-        atomicAdd(&db[j], acc);
+        for (int64_t i = n0; i < n1; i++) acc += g[(size_t)i * 16 + h.j0 + j];
+        atomicAdd(&h.db[j], acc);
     }
 }
 
@@ -725,10 +736,19 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     if (cv_pack_train_weights(m, st)) return 1;
     const int NS = 128;     // candidate-range splits of the head weight gradients (short serial loops, few atomics)
     // heads: weight gradients (inputs read from TM), data gradients written to TM
-    b_head_wgrad_tm<<<dim3(nblk((a.fc4 + 1) * 4, 256), NS), 256, 0, st>>>(td4, s.nb4, ghpre, 0, n, a.fc4, 4, G + o[10], G + o[11]);
-    b_head_wgrad_tm<<<dim3(nblk((a.fc5 + 1) * 2, 256), NS), 256, 0, st>>>(th5, s.nb5, ghpre, 4, n, a.fc5, 2, G + o[12], G + o[13]);
-    b_head_wgrad_tm<<<dim3(nblk((a.fc5 + 1) * 4, 256), NS), 256, 0, st>>>(th5, s.nb5, ghpre, 6, n, a.fc5, 4, G + o[14], G + o[15]);
-    b_head_wgrad_tm<<<dim3(nblk((a.fc5 + 1) * 6, 256), NS), 256, 0, st>>>(th5, s.nb5, ghpre, 10, n, a.fc5, 6, G + o[16], G + o[17]);
+    {
+        head_wg4 hw;
+        const int hN[4] = {4, 2, 4, 6}, hj0[4] = {0, 4, 6, 10};
+        int t0 = 0;
+        for (int q = 0; q < 4; q++) {
+            head_wg &h = hw.h[q];
+            h.xtm = q == 0 ? td4 : th5; h.KB = q == 0 ? s.nb4 : s.nb5; h.K = q == 0 ? a.fc4 : a.fc5;
+            h.N = hN[q]; h.j0 = hj0[q]; h.dw = G + o[10 + 2 * q]; h.db = G + o[11 + 2 * q]; h.t0 = t0;
+            t0 += (h.K + 1) * h.N;
+        }
+        hw.total = t0;
+        b_head_wgrad_tm<<<dim3(nblk(t0, 256), NS), 256, 0, st>>>(hw, ghpre, n);
+    }
     b_head_dgrad_tm<<<nblk(Gn * s.nb5 * 256, 256), 256, 0, st>>>(ghpre, P + o[10], P + o[12], P + o[14], P + o[16], a.fc5,
                                                                s.nb5, n, Gn, 0, tg5);
     // fc5
@@ -789,9 +809,11 @@ static int train_pass(cv_model *m, const float *x, const float *y, int64_t n, bo
                         seed, step, st))
             return 1;
     }
-    if (lambda != 0.0f)
-        for (int p = 0; p < CV_NUM_PARAMS; p += 2)
-            t_l2<<<64, 256, 0, st>>>(m->params + m->poff[p], m->psize[p], m->loss_dev + 4);
+    if (lambda != 0.0f) {
+        l2_args la;
+        for (int p = 0; p < CV_NUM_PARAMS; p += 2) { la.w[p / 2] = m->params + m->poff[p]; la.count[p / 2] = m->psize[p]; }
+        t_l2<<<dim3(64, CV_NUM_PARAMS / 2), 256, 0, st>>>(la, m->loss_dev + 4);
+    }
     double h[8];
     CV_HIP(hipMemcpyAsync(h, m->loss_dev, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
     CV_HIP(hipStreamSynchronize(st));
