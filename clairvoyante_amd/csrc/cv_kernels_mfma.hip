@@ -1274,10 +1274,10 @@ __global__ void wgrad_dense_reduce(const f4 *__restrict__ part, int splits, int 
 // that cob in registers and streams over groups and rows with a KH-row window of input CM fragments.
 // Step s of a group brings in input row s and gradient row s - PRE (PRE = KH-1-PADT rows of lead; rows
 // outside the map are fetched clamped and replaced by zero), R steps in flight in a ring of private LDS
-// slots.  grid = (NT, splits), 64 threads, dynamic LDS = R * (4*CINB + 4) KiB.
+// slots.  grid = 8 * NT * ceil(splits / 8) one-wave workgroups, dynamic LDS = R * (4*CINB + 4) KiB.
 template <int KH, int CINB, int NT, int HIN, int R>
 __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm, const f4 *__restrict__ g_tm,
-                                                     int G, f4 *__restrict__ part)
+                                                     int G, int splits, f4 *__restrict__ part)
 {
     extern __shared__ __attribute__((aligned(16))) float wg_lds[];
     constexpr int PADT = (KH - 1) / 2;
@@ -1286,9 +1286,12 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm
     constexpr int STEPS = HIN + PRE;                 // steps per group
     const int lane = threadIdx.x;
     const cm_stage S(wg_lds, lane);
-    const int cob = blockIdx.x;
-    const int per = (G + gridDim.y - 1) / gridDim.y;
-    const int g0 = blockIdx.y * per, g1 = g0 + per < G ? g0 + per : G;
+    // workgroups go round-robin over the 8 XCDs: the NT waves of one split (same input rows) take ids 8 apart, so
+    // they share one XCD's L2 and start back to back
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int cob = rest % NT, split = (rest / NT) * 8 + xcd;
+    const int per = (G + splits - 1) / splits;
+    const int g0 = split * per, g1 = split >= splits ? g0 : (g0 + per < G ? g0 + per : G);
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
     f4 acc[KH][4][CINB];
 #pragma unroll
@@ -1317,68 +1320,58 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm
 #pragma unroll
         for (int r = 0; r < R; r++) fetch_step(r);
     }
-    f4 win[KH][4][CINB];         // win[kh] = input row h + kh - PADT of the row h being accumulated
+    // window of the KH newest input rows, rotating: flat step j keeps its row in win[j % KH], so tap kh of the row
+    // being accumulated (input row s - (KH-1-kh)) sits in win[(j - (KH-1-kh)) % KH] -- no register moves.  Rows
+    // outside the map are never multiplied (the hr test below), so stale or clamped contents are harmless.
+    f4 win[KH][4][CINB];
     int s = 0, slot = 0;
 #pragma unroll 1
-    for (int i = 0; i < total; i++) {
-        if (s == 0) {
+    for (int i = 0; i < total; i += KH) {
 #pragma unroll
-            for (int j = 0; j + 1 < KH; j++)
-#pragma unroll
-                for (int w = 0; w < 4; w++)
-#pragma unroll
-                    for (int cb = 0; cb < CINB; cb++) win[j][w][cb] = zero;
-        }
-        cm_stage::landed<NF * (R - 1)>();
-        const bool row_in = s < HIN;
-#pragma unroll
-        for (int w = 0; w < 4; w++)
-#pragma unroll
-            for (int cb = 0; cb < CINB; cb++) {
-                const f4 v = S.read(slot * NF + w * CINB + cb);
-                win[KH - 1][w][cb] = row_in ? v : zero;
-            }
-        f4 Gr[4];
-#pragma unroll
-        for (int w = 0; w < 4; w++) Gr[w] = S.read(slot * NF + 4 * CINB + w);
-        cm_stage::reads_done();
-        fetch_step(slot);
-        const int h = s - PRE;
-        if (h >= 0) {
-            bsum += (Gr[0] + Gr[1]) + (Gr[2] + Gr[3]);
-#pragma unroll
-            for (int kh = 0; kh < KH; kh++) {
-                const int hr = h + kh - PADT;
-                if (hr >= 0 && hr < HIN) {
-#pragma unroll
-                    for (int kw = 0; kw < 4; kw++)
-#pragma unroll
-                        for (int wo = 0; wo < 4; wo++) {
-                            const int wi = wo + kw - 1;
-                            if (wi < 0 || wi > 3) continue;
-#pragma unroll
-                            for (int t = 0; t < 4; t++)
-#pragma unroll
-                                for (int cb = 0; cb < CINB; cb++)
-                                    acc[kh][kw][cb] = mfma4(win[kh][wi][cb][t], Gr[wo][t], acc[kh][kw][cb]);
-                        }
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j + 1 < KH; j++)
+        for (int u = 0; u < KH; u++) {
+            if (i + u >= total) break;
+            cm_stage::landed<NF * (R - 1)>();
 #pragma unroll
             for (int w = 0; w < 4; w++)
 #pragma unroll
-                for (int cb = 0; cb < CINB; cb++) win[j][w][cb] = win[j + 1][w][cb];
-        if (++s == STEPS) s = 0;
-        if (R > 1) slot = slot + 1 == R ? 0 : slot + 1;
+                for (int cb = 0; cb < CINB; cb++) win[u][w][cb] = S.read(slot * NF + w * CINB + cb);
+            f4 Gr[4];
+#pragma unroll
+            for (int w = 0; w < 4; w++) Gr[w] = S.read(slot * NF + 4 * CINB + w);
+            cm_stage::reads_done();
+            fetch_step(slot);
+            const int h = s - PRE;
+            if (h >= 0) {
+                bsum += (Gr[0] + Gr[1]) + (Gr[2] + Gr[3]);
+#pragma unroll
+                for (int kh = 0; kh < KH; kh++) {
+                    const int hr = h + kh - PADT;
+                    const int ws = (u + kh + 1) % KH;           // = (u - (KH-1-kh)) mod KH
+                    if (hr >= 0 && hr < HIN) {
+#pragma unroll
+                        for (int kw = 0; kw < 4; kw++)
+#pragma unroll
+                            for (int wo = 0; wo < 4; wo++) {
+                                const int wi = wo + kw - 1;
+                                if (wi < 0 || wi > 3) continue;
+#pragma unroll
+                                for (int t = 0; t < 4; t++)
+#pragma unroll
+                                    for (int cb = 0; cb < CINB; cb++)
+                                        acc[kh][kw][cb] = mfma4(win[ws][wi][cb][t], Gr[wo][t], acc[kh][kw][cb]);
+                            }
+                    }
+                }
+            }
+            if (++s == STEPS) s = 0;
+            if (R > 1) slot = slot + 1 == R ? 0 : slot + 1;
+        }
     }
     cm_stage::landed<0>();           // the surplus fetches of the last R steps
     if (g0 >= g1) return;
     // this split's tiles as whole fragments (+ the bias sums as one more), combined by wgrad_conv_reduce
     constexpr int TILES = KH * 4 * CINB;
-    f4 *pp = part + ((size_t)blockIdx.y * NT + cob) * (TILES + 1) * 64 + lane;
+    f4 *pp = part + ((size_t)split * NT + cob) * (TILES + 1) * 64 + lane;
 #pragma unroll
     for (int kh = 0; kh < KH; kh++)
 #pragma unroll
@@ -1715,8 +1708,8 @@ static int conv_wgrad_launch(cv_model *m, const float *in_tm, const float *g_tm,
     const int used = per > 0 ? (G + per - 1) / per : 0;          // splits that own at least one group
     if (used == 0) return 0;
     if (wg_part_reserve(m, (size_t)splits * NT * (TILES + 1) * 256 * sizeof(float), st)) return 1;
-    wgrad_conv_cm<KH, CINB, NT, HIN, R><<<dim3(NT, splits), 64, R * (4 * CINB + 4) * 1024, st>>>(
-        (const f4 *)in_tm, (const f4 *)g_tm, G, (f4 *)m->wg_part);
+    wgrad_conv_cm<KH, CINB, NT, HIN, R><<<8 * NT * ((splits + 7) / 8), 64, R * (4 * CINB + 4) * 1024, st>>>(
+        (const f4 *)in_tm, (const f4 *)g_tm, G, splits, (f4 *)m->wg_part);
     wgrad_conv_reduce<<<NT * (TILES + 1), 1024, 0, st>>>((const f4 *)m->wg_part, used, NT, TILES, CINB, cin, cout, dw, db);
     CV_HIP(hipGetLastError());
     return 0;

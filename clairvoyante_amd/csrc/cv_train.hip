@@ -183,16 +183,21 @@ __global__ void t_l2(l2_args a, double *__restrict__ out)
     __shared__ double sh[256];
     const float *__restrict__ w = a.w[blockIdx.y];
     const int64_t count = a.count[blockIdx.y];
-    double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
-        s += (double)w[i] * (double)w[i];
-    sh[threadIdx.x] = s;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < count; i += 4 * stride) {          // four loads in flight
+        const float a = w[i], b = w[i + stride], c = w[i + 2 * stride], d = w[i + 3 * stride];
+        s0 += (double)a * (double)a; s1 += (double)b * (double)b; s2 += (double)c * (double)c; s3 += (double)d * (double)d;
+    }
+    for (; i < count; i += stride) s0 += (double)w[i] * (double)w[i];
+    sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     for (int k = 128; k > 0; k >>= 1) {
         if (threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd(out, sh[0] * 0.5);
+    if (threadIdx.x == 0 && sh[0] != 0.0) atomicAdd(out, sh[0] * 0.5);
 }
 
 // ---- backward pieces -------------------------------------------------------------
@@ -560,9 +565,11 @@ __global__ void b_head_wgrad_tm(head_wg4 a, const float *__restrict__ g, int64_t
     int64_t n0 = per * blockIdx.y, n1 = n0 + per < n ? n0 + per : n;
     float acc = 0.0f;
     if (k < h.K) {
+#pragma unroll 8
         for (int64_t i = n0; i < n1; i++) acc = __builtin_fmaf(h.xtm[cv_tm_index(i, k, h.KB)], g[(size_t)i * 16 + h.j0 + j], acc);
         atomicAdd(&h.dw[(size_t)k * h.N + j], acc);
     } else {
+#pragma unroll 8
         for (int64_t i = n0; i < n1; i++) acc += g[(size_t)i * 16 + h.j0 + j];
         atomicAdd(&h.db[j], acc);
     }
@@ -812,7 +819,7 @@ static int train_pass(cv_model *m, const float *x, const float *y, int64_t n, bo
     if (lambda != 0.0f) {
         l2_args la;
         for (int p = 0; p < CV_NUM_PARAMS; p += 2) { la.w[p / 2] = m->params + m->poff[p]; la.count[p / 2] = m->psize[p]; }
-        t_l2<<<dim3(64, CV_NUM_PARAMS / 2), 256, 0, st>>>(la, m->loss_dev + 4);
+        t_l2<<<dim3(256, CV_NUM_PARAMS / 2), 256, 0, st>>>(la, m->loss_dev + 4);
     }
     double h[8];
     CV_HIP(hipMemcpyAsync(h, m->loss_dev, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
