@@ -1273,17 +1273,21 @@ __global__ void wgrad_dense_reduce(const f4 *__restrict__ part, int splits, int 
 // One wave per (output fragment cob, candidate-range split); it keeps all KH*4*CINB tiles of
 // that cob in registers and streams over groups and rows with a KH-row window of input CM fragments.
 // Step s of a group brings in input row s and gradient row s - PRE (PRE = KH-1-PADT rows of lead; rows
-// outside the map are fetched clamped and replaced by zero), R steps in flight in a ring of private LDS
-// slots.  grid = 8 * NT * ceil(splits / 8) one-wave workgroups, dynamic LDS = R * (4*CINB + 4) KiB.
-template <int KH, int CINB, int NT, int HIN, int R>
+// outside the map are fetched clamped and never multiplied) through two private LDS slots, one per operand,
+// software-pipelined so that neither the DMA nor the LDS reads wait in front of the matrix pipe:
+//   taps kh < KA (older rows)  |  read input row s  |  taps KA..KH-2  |  DMA input row s+1, read G row s+1
+//   | tap KH-1 (the new row)   -- the DMA of G row s+1 goes out at the top of the step.
+// grid = 8 * NT * ceil(splits / 8) one-wave workgroups, dynamic LDS = (4*CINB + 4) KiB.
+template <int KH, int CINB, int NT, int HIN>
 __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm, const f4 *__restrict__ g_tm,
                                                      int G, int splits, f4 *__restrict__ part)
 {
     extern __shared__ __attribute__((aligned(16))) float wg_lds[];
     constexpr int PADT = (KH - 1) / 2;
     constexpr int PRE = KH - 1 - PADT;
-    constexpr int NF = 4 * CINB + 4;                 // fragments per step
+    constexpr int NI = 4 * CINB;                     // input fragments per step (slots 0..NI-1), then 4 of G
     constexpr int STEPS = HIN + PRE;                 // steps per group
+    constexpr int KA = KH >= 3 ? KH - 2 : KH - 1;    // taps multiplied before the new input row is read
     const int lane = threadIdx.x;
     const cm_stage S(wg_lds, lane);
     // workgroups go round-robin over the 8 XCDs: the NT waves of one split (same input rows) take ids 8 apart, so
@@ -1302,73 +1306,86 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm
             for (int c = 0; c < CINB; c++) acc[a][b][c] = zero;
     f4 bsum = zero;
     const int total = (g1 > g0 ? g1 - g0 : 0) * STEPS;
-    // flat step i = (g - g0) * STEPS + s; fetch cursor (fg, fs) runs R steps ahead of the compute cursor (g, s)
-    int fg = g0, fs = 0;
-    auto fetch_step = [&](int slot) {
-        const int gg = fg < g1 ? fg : g1 - 1;                            // surplus fetches of the tail re-read valid data
-        const int hr = fs < HIN ? fs : HIN - 1;
-        const int hg = fs - PRE < 0 ? 0 : fs - PRE;
-        const f4 *ip = in_tm + ((size_t)gg * HIN + hr) * (4 * CINB * 64);
-        const f4 *gp = g_tm + (((size_t)gg * HIN + hg) * 4 * NT + cob) * 64;
+    if (total == 0) return;
+    // fetch cursors (group, step) of the two operands; past the end they re-read valid data nobody uses
+    int ig = g0, is = 0, gg_ = g0, gs = 0;
+    auto fetch_in = [&]() {
+        const int gc = ig < g1 ? ig : g1 - 1;
+        const int hr = is < HIN ? is : HIN - 1;
+        const f4 *ip = in_tm + ((size_t)gc * HIN + hr) * (NI * 64);
 #pragma unroll
-        for (int f = 0; f < 4 * CINB; f++) S.fetch(ip + f * 64, slot * NF + f);
-#pragma unroll
-        for (int w = 0; w < 4; w++) S.fetch(gp + (size_t)w * (NT * 64), slot * NF + 4 * CINB + w);
-        if (++fs == STEPS) { fs = 0; fg++; }
+        for (int f = 0; f < NI; f++) S.fetch(ip + f * 64, f);
+        if (++is == STEPS) { is = 0; ig++; }
     };
-    if (total > 0) {
+    auto fetch_g = [&]() {
+        const int gc = gg_ < g1 ? gg_ : g1 - 1;
+        const int hg = gs - PRE < 0 ? 0 : gs - PRE;
+        const f4 *gp = g_tm + (((size_t)gc * HIN + hg) * 4 * NT + cob) * 64;
 #pragma unroll
-        for (int r = 0; r < R; r++) fetch_step(r);
-    }
+        for (int w = 0; w < 4; w++) S.fetch(gp + (size_t)w * (NT * 64), NI + w);
+        if (++gs == STEPS) { gs = 0; gg_++; }
+    };
     // window of the KH newest input rows, rotating: flat step j keeps its row in win[j % KH], so tap kh of the row
     // being accumulated (input row s - (KH-1-kh)) sits in win[(j - (KH-1-kh)) % KH] -- no register moves.  Rows
-    // outside the map are never multiplied (the hr test below), so stale or clamped contents are harmless.
+    // outside the map are never multiplied (the hr test), so stale or clamped contents are harmless.
     f4 win[KH][4][CINB];
-    int s = 0, slot = 0;
+    f4 Gr[4];
+    fetch_g();
+    fetch_in();
+    cm_stage::landed<NI>();                          // G row of step 0
+#pragma unroll
+    for (int w = 0; w < 4; w++) Gr[w] = S.read(NI + w);
+    cm_stage::reads_done();
+    int s = 0;
 #pragma unroll 1
     for (int i = 0; i < total; i += KH) {
 #pragma unroll
         for (int u = 0; u < KH; u++) {
             if (i + u >= total) break;
-            cm_stage::landed<NF * (R - 1)>();
+            const int h = s - PRE;
+            auto taps = [&](int kh) {                 // kh is a constant after unrolling
+                const int hr = h + kh - PADT;
+                const int ws = (u + kh + 1) % KH;     // = (u - (KH-1-kh)) mod KH
+                if (h >= 0 && hr >= 0 && hr < HIN) {
+#pragma unroll
+                    for (int kw = 0; kw < 4; kw++)
+#pragma unroll
+                        for (int wo = 0; wo < 4; wo++) {
+                            const int wi = wo + kw - 1;
+                            if (wi < 0 || wi > 3) continue;
+#pragma unroll
+                            for (int t = 0; t < 4; t++)
+#pragma unroll
+                                for (int cb = 0; cb < CINB; cb++)
+                                    acc[kh][kw][cb] = mfma4(win[ws][wi][cb][t], Gr[wo][t], acc[kh][kw][cb]);
+                        }
+                }
+            };
+            fetch_g();                                // G row of step j+1 (its slot was read one step ago)
+            if (h >= 0) bsum += (Gr[0] + Gr[1]) + (Gr[2] + Gr[3]);
+#pragma unroll
+            for (int kh = 0; kh < KA; kh++) taps(kh);
+            cm_stage::landed<4>();                    // input row of this step (the G pieces above may still fly)
 #pragma unroll
             for (int w = 0; w < 4; w++)
 #pragma unroll
-                for (int cb = 0; cb < CINB; cb++) win[u][w][cb] = S.read(slot * NF + w * CINB + cb);
-            f4 Gr[4];
+                for (int cb = 0; cb < CINB; cb++) win[u][w][cb] = S.read(w * CINB + cb);
 #pragma unroll
-            for (int w = 0; w < 4; w++) Gr[w] = S.read(slot * NF + 4 * CINB + w);
+            for (int kh = KA; kh < KH - 1; kh++) taps(kh);
             cm_stage::reads_done();
-            fetch_step(slot);
-            const int h = s - PRE;
-            if (h >= 0) {
-                bsum += (Gr[0] + Gr[1]) + (Gr[2] + Gr[3]);
+            fetch_in();                               // input row of step j+1
+            cm_stage::landed<NI>();                   // G row of step j+1
+            f4 Gn[4];
 #pragma unroll
-                for (int kh = 0; kh < KH; kh++) {
-                    const int hr = h + kh - PADT;
-                    const int ws = (u + kh + 1) % KH;           // = (u - (KH-1-kh)) mod KH
-                    if (hr >= 0 && hr < HIN) {
+            for (int w = 0; w < 4; w++) Gn[w] = S.read(NI + w);
+            taps(KH - 1);
+            cm_stage::reads_done();
 #pragma unroll
-                        for (int kw = 0; kw < 4; kw++)
-#pragma unroll
-                            for (int wo = 0; wo < 4; wo++) {
-                                const int wi = wo + kw - 1;
-                                if (wi < 0 || wi > 3) continue;
-#pragma unroll
-                                for (int t = 0; t < 4; t++)
-#pragma unroll
-                                    for (int cb = 0; cb < CINB; cb++)
-                                        acc[kh][kw][cb] = mfma4(win[ws][wi][cb][t], Gr[wo][t], acc[kh][kw][cb]);
-                            }
-                    }
-                }
-            }
+            for (int w = 0; w < 4; w++) Gr[w] = Gn[w];
             if (++s == STEPS) s = 0;
-            if (R > 1) slot = slot + 1 == R ? 0 : slot + 1;
         }
     }
-    cm_stage::landed<0>();           // the surplus fetches of the last R steps
-    if (g0 >= g1) return;
+    cm_stage::landed<0>();           // the surplus fetches of the last step
     // this split's tiles as whole fragments (+ the bias sums as one more), combined by wgrad_conv_reduce
     constexpr int TILES = KH * 4 * CINB;
     f4 *pp = part + ((size_t)split * NT + cob) * (TILES + 1) * 64 + lane;
@@ -1697,7 +1714,7 @@ int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_tm, const float *
 // layer 1 = conv2 (in = pool1 TM), 2 = conv3 (in = pool2 TM); g = pre-activation gradient TM.
 // One wave per (output fragment, split): enough splits for ~2 waves per SIMD (1024 SIMDs); the per-split tiles go
 // to the scratch buffer and are summed in a fixed order by wgrad_conv_reduce (no float atomics).
-template <int KH, int CINB, int NT, int HIN, int R>
+template <int KH, int CINB, int NT, int HIN>
 static int conv_wgrad_launch(cv_model *m, const float *in_tm, const float *g_tm, int G, int cin, int cout, float *dw,
                              float *db, hipStream_t st)
 {
@@ -1708,7 +1725,7 @@ static int conv_wgrad_launch(cv_model *m, const float *in_tm, const float *g_tm,
     const int used = per > 0 ? (G + per - 1) / per : 0;          // splits that own at least one group
     if (used == 0) return 0;
     if (wg_part_reserve(m, (size_t)splits * NT * (TILES + 1) * 256 * sizeof(float), st)) return 1;
-    wgrad_conv_cm<KH, CINB, NT, HIN, R><<<8 * NT * ((splits + 7) / 8), 64, R * (4 * CINB + 4) * 1024, st>>>(
+    wgrad_conv_cm<KH, CINB, NT, HIN><<<8 * NT * ((splits + 7) / 8), 64, (4 * CINB + 4) * 1024, st>>>(
         (const f4 *)in_tm, (const f4 *)g_tm, G, splits, (f4 *)m->wg_part);
     wgrad_conv_reduce<<<NT * (TILES + 1), 1024, 0, st>>>((const f4 *)m->wg_part, used, NT, TILES, CINB, cin, cout, dw, db);
     CV_HIP(hipGetLastError());
@@ -1722,13 +1739,12 @@ int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_tm, const float *
     float *dw = m->grads + m->poff[2 * layer];
     float *db = m->grads + m->poff[2 * layer + 1];
     const int cin = s.cin[layer], cout = a.cout[layer];
-    // ring depth R: as many steps in flight as 8 waves per CU leave LDS for (conv3: 12 KiB per step)
     if (is_full(a)) {
-        if (layer == 2) return conv_wgrad_launch<3, 2, 3, 26, 1>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
-        return conv_wgrad_launch<2, 1, 2, 29, 2>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
+        if (layer == 2) return conv_wgrad_launch<3, 2, 3, 26>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
+        return conv_wgrad_launch<2, 1, 2, 29>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
     }
-    if (layer == 2) return conv_wgrad_launch<5, 1, 2, 33, 2>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
-    return conv_wgrad_launch<3, 1, 1, 33, 2>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
+    if (layer == 2) return conv_wgrad_launch<5, 1, 2, 33>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
+    return conv_wgrad_launch<3, 1, 1, 33>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
 }
 
 // first layer: x_tm = TM fragments of X viewed as [33 positions][16 = base*4 + matrix], g = TM of its

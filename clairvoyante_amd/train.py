@@ -174,30 +174,56 @@ class _BatchStream(object):
                 torch.cuda.current_stream(device).wait_event(ev)
             return xd, yd, ready
 
-        def produce():
+        def put(queue, item):
+            while not stop.is_set():
+                try:
+                    queue.put(item, timeout=0.05)
+                    return True
+                except Exception:
+                    continue
+            return False
+
+        def produce(out_q):
+            """decompression: walks the batch sequence; items ((ptr, size), (X, Y, start, n, last), None)"""
             try:
                 ptr, size = start_ptr, first_size
                 while not stop.is_set():
                     X, Y, st, n, last = self._fetch_at(ptr, size)
-                    ready = None
-                    if device is not None and n > 0:
-                        X, Y, ready = stage(X, Y)
-                    item = ((ptr, size), (X, Y, st, n, last), ready)
-                    while not stop.is_set():
-                        try:
-                            q.put(item, timeout=0.05)
-                            break
-                        except Exception:
-                            continue
-                    if last:
+                    if not put(out_q, ((ptr, size), (X, Y, st, n, last), None)) or last:
                         break
                     ptr += n
                     size = size_fn(ptr)
             except BaseException as e:             # surfaced by fetch()
-                q.put(e)
-        t = Thread(target=produce, daemon=True)
-        t.start()
-        self._thread = t
+                put(out_q, e)
+
+        def stage_all(in_q):
+            """host -> device copies, one batch behind the decompression (its own thread: the two overlap)"""
+            try:
+                while not stop.is_set():
+                    try:
+                        item = in_q.get(timeout=0.05)
+                    except Exception:
+                        continue
+                    if isinstance(item, BaseException):
+                        put(q, item)
+                        break
+                    key, (X, Y, st, n, last), _ = item
+                    ready = None
+                    if n > 0:
+                        X, Y, ready = stage(X, Y)
+                    if not put(q, (key, (X, Y, st, n, last), ready)) or last:
+                        break
+            except BaseException as e:
+                put(q, e)
+
+        if device is None:
+            self._threads = [Thread(target=produce, args=(q,), daemon=True)]
+        else:
+            mid = Queue(maxsize=2)
+            self._threads = [Thread(target=produce, args=(mid,), daemon=True),
+                             Thread(target=stage_all, args=(mid,), daemon=True)]
+        for t in self._threads:
+            t.start()
 
     def _cancel(self):
         if self._q is not None:
