@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
     f4 bs[NBS];
 #pragma unroll
     for (int i = 0; i < NBS; i++) bs[i] = zero;
-    const bool do_bias = blockIdx.x == 0 && db != nullptr;
+    const bool do_bias = blockIdx.x == 0;
     auto stage = [&](int g, int buf) {
 #pragma unroll
         for (int i = 0; i < PERG; i++) {
@@ -1206,55 +1206,45 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
         cm_stage::reads_done();
         buf ^= 1;
     }
+    // this split's tiles as whole fragments, then its bias sums: combined by wgrad_dense_reduce
     if (do_bias) {
         // CM fragment: lane (f, rg) register t = G(feature f, candidate 4 rg + t): sum registers, then lanes rg
+        float *bpart = (float *)(part + (size_t)gridDim.y * KB * NJB * 64) + (size_t)blockIdx.y * NJB * 16;
 #pragma unroll
         for (int i = 0; i < NBS; i++) {
             const int jb = i * 8 + wid;
             float v = (bs[i][0] + bs[i][1]) + (bs[i][2] + bs[i][3]);
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            const int j = 16 * jb + (lane & 15);
-            if (jb < NJB && lane < 16 && j < N) atomicAdd(&db[j], v);
+            if (jb < NJB && lane < 16) bpart[16 * jb + lane] = v;
         }
     }
-    if (part) {     // two-pass combine: this split's tiles as whole fragments, summed by wgrad_dense_reduce
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            const int kb = kb0 + a;
-            if (kb >= KB) continue;
-            f4 *pp = part + (((size_t)blockIdx.y * KB + kb) * NJB) * 64 + lane;
-#pragma unroll
-            for (int jb = 0; jb < NJB; jb++) pp[jb * 64] = acc[a][jb];
-        }
-        return;
-    }
-    // scatter-add the tiles: lane (c', q) register r  <->  dW[16 kb + 4q + r][16 jb + c']
-    const int cq = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int a = 0; a < 2; a++) {
         const int kb = kb0 + a;
         if (kb >= KB) continue;
+        f4 *pp = part + (((size_t)blockIdx.y * KB + kb) * NJB) * 64 + lane;
 #pragma unroll
-        for (int jb = 0; jb < NJB; jb++) {
-            const int j = 16 * jb + cq;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int k = 16 * kb + 4 * q + r;
-                if (k < K && j < N) atomicAdd(&dw[(size_t)k * N + j], acc[a][jb][r]);
-            }
-        }
+        for (int jb = 0; jb < NJB; jb++) pp[jb * 64] = acc[a][jb];
     }
 }
 
 // second pass of the dense weight gradient: dW += sum over splits (ascending: a fixed summation order),
-// one thread per (kb, jb, lane) fragment element quadruple
+// one thread per (kb, jb, lane) fragment element quadruple; the threads behind those sum the bias parts
 __global__ void wgrad_dense_reduce(const f4 *__restrict__ part, int splits, int KB, int NJB, int K, int N,
-                                   float *__restrict__ dw)
+                                   float *__restrict__ dw, float *__restrict__ db)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t per = (int64_t)KB * NJB * 64;
-    if (t >= per) return;
+    if (t >= per) {
+        const int j = (int)(t - per);
+        if (j >= N || j >= NJB * 16) return;
+        const float *bpart = (const float *)(part + (size_t)splits * per);
+        float b = bpart[j];
+        for (int sidx = 1; sidx < splits; sidx++) b += bpart[(size_t)sidx * NJB * 16 + j];
+        db[j] += b;
+        return;
+    }
     f4 v = part[t];
     for (int sidx = 1; sidx < splits; sidx++) v += part[(size_t)sidx * per + t];
     const int lane = (int)(t & 63);
@@ -1687,13 +1677,13 @@ static int dense_wgrad_launch(cv_model *m, const float *x_tm, int KB, const floa
     int splits = 256 / kblocks;
     if (splits > G) splits = G;
     if (splits < 1) splits = 1;
-    if (wg_part_reserve(m, (size_t)splits * KB * NJB * 256 * sizeof(float), st)) return 1;
+    if (wg_part_reserve(m, (size_t)splits * (KB * NJB * 256 + NJB * 16) * sizeof(float), st)) return 1;
     const size_t lds = (size_t)2 * (NJB + 16) * 1024;
     if (set_lds(wgrad_dense_cm<NJB>, lds)) return 1;
     wgrad_dense_cm<NJB><<<dim3(kblocks, splits), 512, lds, st>>>((const f4 *)x_tm, KB, (const f4 *)g_tm, G, K, N, dw, db,
                                                                  (f4 *)m->wg_part);
     const int64_t per = (int64_t)KB * NJB * 64;
-    wgrad_dense_reduce<<<nblk(per, 256), 256, 0, st>>>((const f4 *)m->wg_part, splits, KB, NJB, K, N, dw);
+    wgrad_dense_reduce<<<nblk(per + NJB * 16, 256), 256, 0, st>>>((const f4 *)m->wg_part, splits, KB, NJB, K, N, dw, db);
     CV_HIP(hipGetLastError());
     return 0;
 }

@@ -548,14 +548,16 @@ __global__ __launch_bounds__(256) void t_heads_tm(
 }
 
 // heads: weight / bias gradients of the four heads in one launch, layer inputs read from TM buffers
-// dW[k][j] += sum_n X[n][k] g[n][j0 + j] ; row k == K is the bias
+// dW[k][j] += sum_n X[n][k] g[n][j0 + j] ; row k == K is the bias.  grid.y = candidate-range slices; every
+// slice leaves its partial sums in `part` and b_head_wgrad_sum adds them in slice order (no float atomics).
 struct head_wg { const float *xtm; float *dw, *db; int KB, K, N, j0, t0; };
 struct head_wg4 { head_wg h[4]; int total; };
 
-__global__ void b_head_wgrad_tm(head_wg4 a, const float *__restrict__ g, int64_t n)
+__global__ void b_head_wgrad_tm(head_wg4 a, const float *__restrict__ g, int64_t n, float *__restrict__ part)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.total) return;
+    float *out = part + (size_t)blockIdx.y * a.total + t;
     int q = t >= a.h[2].t0 ? (t >= a.h[3].t0 ? 3 : 2) : (t >= a.h[1].t0 ? 1 : 0);
     const head_wg h = a.h[q];
     t -= h.t0;
@@ -567,12 +569,26 @@ __global__ void b_head_wgrad_tm(head_wg4 a, const float *__restrict__ g, int64_t
     if (k < h.K) {
 #pragma unroll 8
         for (int64_t i = n0; i < n1; i++) acc = __builtin_fmaf(h.xtm[cv_tm_index(i, k, h.KB)], g[(size_t)i * 16 + h.j0 + j], acc);
-        atomicAdd(&h.dw[(size_t)k * h.N + j], acc);
     } else {
 #pragma unroll 8
         for (int64_t i = n0; i < n1; i++) acc += g[(size_t)i * 16 + h.j0 + j];
-        atomicAdd(&h.db[j], acc);
     }
+    *out = acc;
+}
+
+__global__ void b_head_wgrad_sum(head_wg4 a, const float *__restrict__ part, int slices)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.total) return;
+    float v = part[t];
+    for (int sl = 1; sl < slices; sl++) v += part[(size_t)sl * a.total + t];
+    int q = t >= a.h[2].t0 ? (t >= a.h[3].t0 ? 3 : 2) : (t >= a.h[1].t0 ? 1 : 0);
+    const head_wg h = a.h[q];
+    t -= h.t0;
+    int j = t % h.N;
+    int k = t / h.N;
+    if (k < h.K) h.dw[(size_t)k * h.N + j] += v;
+    else h.db[j] += v;
 }
 
 // heads: data gradients written into TM buffers.  mode 0: gh5_tm = sum over the three fc5-side
@@ -741,7 +757,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     float *tx = sb.take(np * 33 * 16);
     if (!tx) { cv_set_error("training workspace too small"); return 1; }
     if (cv_pack_train_weights(m, st)) return 1;
-    const int NS = 128;     // candidate-range splits of the head weight gradients (short serial loops, few atomics)
+    const int NS = 128;     // candidate-range slices of the head weight gradients (short serial loops)
     // heads: weight gradients (inputs read from TM), data gradients written to TM
     {
         head_wg4 hw;
@@ -754,7 +770,10 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
             t0 += (h.K + 1) * h.N;
         }
         hw.total = t0;
-        b_head_wgrad_tm<<<dim3(nblk(t0, 256), NS), 256, 0, st>>>(hw, ghpre, n);
+        float *hpart = sb.take((size_t)NS * t0);
+        if (!hpart) { cv_set_error("training workspace too small"); return 1; }
+        b_head_wgrad_tm<<<dim3(nblk(t0, 256), NS), 256, 0, st>>>(hw, ghpre, n, hpart);
+        b_head_wgrad_sum<<<nblk(t0, 256), 256, 0, st>>>(hw, hpart, NS);
     }
     b_head_dgrad_tm<<<nblk(Gn * s.nb5 * 256, 256), 256, 0, st>>>(ghpre, P + o[10], P + o[12], P + o[14], P + o[16], a.fc5,
                                                                s.nb5, n, Gn, 0, tg5);
@@ -801,7 +820,8 @@ static int train_pass(cv_model *m, const float *x, const float *y, int64_t n, bo
     if (drop4 < 0.0f || drop4 >= 1.0f) { cv_set_error("dropout rate must be in [0,1)"); return 1; }
     CV_HIP(hipSetDevice(m->device));
     const int64_t slice = 16384;        // one pass for train.py's batch of 10 000
-    const size_t need = train_floats_per_cand(m) * (size_t)((n < slice ? (n > 0 ? n : 1) : slice) + 16) * sizeof(float);
+    const size_t need = (train_floats_per_cand(m) * (size_t)((n < slice ? (n > 0 ? n : 1) : slice) + 16)
+                         + (size_t)128 * 4096 /* per-slice head gradients */) * sizeof(float);
     if (m->t_bytes < need) {
         if (m->t_buf) CV_HIP(hipFree(m->t_buf));
         m->t_buf = nullptr; m->t_bytes = 0;
