@@ -57,14 +57,16 @@ def Run(args):
     TrainAll(args, m, utils)
 
 
-def _next_batch_size(ptr, validationStart):
-    """train.py:95-102"""
+def _next_batch_size(ptr, validationStart, vbatch=None):
+    """train.py:95-102; vbatch = size of a validation batch (the reference: predictBatchSize)"""
+    if vbatch is None:
+        vbatch = param.predictBatchSize
     if ptr < validationStart:
         left = validationStart - ptr
         return left if left < param.trainBatchSize else param.trainBatchSize
-    if ptr % param.predictBatchSize != 0:
-        return param.predictBatchSize - (ptr % param.predictBatchSize)
-    return param.predictBatchSize
+    if ptr % vbatch != 0:
+        return vbatch - (ptr % vbatch)
+    return vbatch
 
 
 def _zigzag(v):
@@ -102,6 +104,7 @@ class _BatchStream(object):
     def __init__(self, utils, XC, YC, total, validationStart, rank=0, ws=1):
         self.utils, self.XC, self.YC, self.total, self.vstart = utils, XC, YC, total, validationStart
         self.rank, self.ws = rank, ws              # data parallel: this rank only decompresses its slice of a batch
+        self.vbatch = None                         # validation batch size (None: the reference's predictBatchSize)
         self.ptr = 0
         self._q = None
         self._stop = None
@@ -148,7 +151,7 @@ class _BatchStream(object):
         return out
 
     def next_size(self):
-        return _next_batch_size(self.ptr, self.vstart)
+        return _next_batch_size(self.ptr, self.vstart, self.vbatch)
 
     # ---- producer side
     def prefetch(self, first_size, size_fn, device=None):
@@ -281,7 +284,11 @@ def run_epoch(stream, m, rank, ws, writer, epoch, validationStart):
     stream.rewind()
     # real models take batches that are already in HBM; mock / foreign model objects get the numpy arrays
     device = getattr(m, "device", None) if getattr(m, "accepts_device_batches", False) else None
-    stream.prefetch(param.trainBatchSize, lambda p: _next_batch_size(p, validationStart), device)
+    # the validation loss is a sum over candidates: a real model takes it in passes of 16 000 instead of the
+    # reference's 1 000 (a pass over 1 000 candidates is launch-bound on the GPU) -- same sum
+    stream.vbatch = param.predictBatchSize * 16 if device is not None else None
+    vbatch = stream.vbatch
+    stream.prefetch(param.trainBatchSize, lambda p: _next_batch_size(p, validationStart, vbatch), device)
     X, Y, start, count, last = stream.fetch(param.trainBatchSize)
     while True:
         training = start + count < validationStart
