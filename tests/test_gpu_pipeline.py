@@ -276,3 +276,49 @@ def test_training_is_reproducible_bit_for_bit(arch):
     assert np.isfinite(w1).all() and l1[-1] < l1[0]
     assert np.array_equal(w1.view(np.uint32), w2.view(np.uint32))
     assert np.allclose(l1, l2, rtol=1e-12, atol=0)      # the loss sums are double-precision atomics: order may differ
+
+
+def test_epoch_sums_do_not_depend_on_the_validation_pass_size(tmp_path):
+    """run_epoch hands a real model validation passes of 16 000 candidates (device batches) where the reference asks
+    for 1 000 at a time (train.py:95-102); the loss is a sum over candidates, so both ways of walking the same
+    epoch give the same training and validation sums (learning rate 0: the weights do not move in between)"""
+    from clairvoyante_amd import param, synth, train, utils_v2
+    n = 40000
+    xt, cls, rf, alt, il = synth.make_candidates(n, seed=23, device="cuda", return_class=True)
+    y = synth.make_labels(cls, rf, alt, il).cpu().numpy().astype(np.float64); x = xt.cpu().numpy()
+    XC = [utils_v2.pack_array(x[s:s + 500]) for s in range(0, n + 1, 500)]
+    YC = [utils_v2.pack_array(y[s:s + 500]) for s in range(0, n + 1, 500)]
+    vstart = int(n * param.trainingDatasetPercentage) + 1
+    m = _model("full")
+    m._seed_rng.seed(3)
+    m.init()
+    m.setLearningRate(0.0)
+    m.dropoutRateFC4Val = 0.0
+
+    class HostOnly(object):              # the same model without the device-batch capability: the reference's sequence
+        accepts_device_batches = False
+
+        def __init__(self, inner):
+            self.inner, self.sizes = inner, []
+
+        def trainNoRT(self, X, Y):
+            self.inner.trainNoRT(X, Y); self.trainLossRTVal = self.inner.trainLossRTVal
+            self.trainSummaryRTVal = self.inner.trainSummaryRTVal
+
+        def getLossNoRT(self, X, Y):
+            self.sizes.append(len(X))
+            self.inner.getLossNoRT(X, Y); self.getLossLossRTVal = self.inner.getLossLossRTVal
+
+        def getLoss(self, X, Y):
+            self.sizes.append(len(X))
+            return self.inner.getLoss(X, Y)
+
+    stream = train._BatchStream(utils_v2, XC, YC, n, vstart)
+    t_dev, v_dev = train.run_epoch(stream, m, 0, 1, None, 1, vstart)
+    host = HostOnly(m)
+    t_ref, v_ref = train.run_epoch(stream, host, 0, 1, None, 1, vstart)
+    # the clipped batch that ends exactly at validationStart is evaluated, not trained (train.py:104); then 1 000s
+    assert max(host.sizes[1:]) <= param.predictBatchSize and len(host.sizes) >= 4
+    assert abs(t_dev - t_ref) <= 1e-6 * abs(t_ref) and abs(v_dev - v_ref) <= 1e-6 * abs(v_ref)
+    assert v_ref > 0 and t_ref > 0
+    m.close()
