@@ -160,24 +160,6 @@ __global__ void pack_conv_dgrad(const float *__restrict__ w, float *__restrict__
     wp[t] = (ci < cin && co < cout) ? w[(((size_t)(KH - 1 - kh) * 4 + (3 - kw)) * cin + ci) * cout + co] : 0.0f;
 }
 
-// natural [n][npos][FP] -> TM (KB = npos*FPP/16 fragments per group); padding features and the
-// candidates beyond n in the last group are written as zeros
-__global__ void natural_to_tm(const float *__restrict__ nat, int KB, int FPP, int FP, int npos, int64_t n,
-                              int64_t G, float *__restrict__ tm)
-{
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= G * KB * 256) return;
-    int s = (int)(t & 3), lane = (int)((t >> 2) & 63);
-    int64_t frag = t >> 8;
-    int kb = (int)(frag % KB);
-    int64_t g = frag / KB;
-    int c = lane & 15, kq = lane >> 4;
-    int k = 16 * kb + 4 * s + kq;
-    int pos = k / FPP, f = k % FPP;
-    int64_t cand = g * 16 + c;
-    tm[t] = (cand < n && f < FP) ? nat[((size_t)cand * npos + pos) * FP + f] : 0.0f;
-}
-
 // alpha-dropout on fc4 in TM layout (selu.py:34-69): d4 = a*(h4*keep + alpha'*(1-keep)) + b;
 // amask = a*keep is kept for the backward pass.  Counter-based stream of (seed, step, cand, unit).
 __global__ void dropout_tm(const float *__restrict__ h4, float *__restrict__ d4, float *__restrict__ amask,
@@ -895,6 +877,52 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
     }
 }
 
+// training: the same two tile products, stored as pre-activations (+ bias) in candidate-major [n][16] order
+// (base 0..3 | zygosity 4..5 | type 6..9 | length 10..15); loss and head gradients follow in t_heads_loss
+__global__ __launch_bounds__(256) void heads_pre_tm(const f4 *__restrict__ h4, const f4 *__restrict__ h5, int NB4,
+                                                     int NB5, const f4 *__restrict__ wp0, const f4 *__restrict__ wp1,
+                                                     const float *__restrict__ bb, const float *__restrict__ bz,
+                                                     const float *__restrict__ bt, const float *__restrict__ bl,
+                                                     int64_t n, float *__restrict__ pre16, int G)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const int c = lane & 15, q = lane >> 4;
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 a0 = zero, a1 = zero;
+    const f4 *p4 = h4 + (size_t)g * NB4 * 64 + lane;
+    const f4 *p5 = h5 + (size_t)g * NB5 * 64 + lane;
+#pragma unroll 3
+    for (int kb = 0; kb < NB4; kb++) {
+        const f4 B = p4[(size_t)kb * 64];
+        const f4 A = wp0[(size_t)kb * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 4; s++) a0 = mfma4(A[s], B[s], a0);
+    }
+#pragma unroll 3
+    for (int kb = 0; kb < NB5; kb++) {
+        const f4 B = p5[(size_t)kb * 64];
+        const f4 A = wp1[(size_t)kb * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 4; s++) a1 = mfma4(A[s], B[s], a1);
+    }
+    const int64_t cand = (int64_t)g * 16 + c;
+    if (cand >= n) return;
+    float *o = pre16 + (size_t)cand * 16;
+    // rows of the second tile: q 0 = zygosity (2), q 1 = type (4), q 2 = length 0..3, q 3 = length 4..5
+    if (q == 0) {
+        *reinterpret_cast<float4 *>(o) = make_float4(a0[0] + bb[0], a0[1] + bb[1], a0[2] + bb[2], a0[3] + bb[3]);
+        o[4] = a1[0] + bz[0]; o[5] = a1[1] + bz[1];
+    } else if (q == 1) {
+        o[6] = a1[0] + bt[0]; o[7] = a1[1] + bt[1]; o[8] = a1[2] + bt[2]; o[9] = a1[3] + bt[3];
+    } else if (q == 2) {
+        o[10] = a1[0] + bl[0]; o[11] = a1[1] + bl[1]; o[12] = a1[2] + bl[2]; o[13] = a1[3] + bl[3];
+    } else {
+        o[14] = a1[0] + bl[4]; o[15] = a1[1] + bl[5];
+    }
+}
+
 // up to this many groups (16 candidates each) fc4 runs as 3 output slabs per group block: 8-wave workgroups
 // x 3 slabs fill the 256 CUs from ~700 groups on; above the threshold one workgroup keeps all 21 tiles
 constexpr int CV_FC4_SLAB_MAX_G = 2048;
@@ -1132,6 +1160,27 @@ struct cm_stage {
         const float *q = slots + slot * 256 + ridx;
         return (f4){q[0], q[64], q[128], q[192]};
     }
+    // the same for a fragment that lies in NATURAL order in memory -- 16 candidates x 16 consecutive floats,
+    // candidate stride `cstride` floats: the lane feeding LDS position p fetches quarter (p & 3) of candidate
+    // 4 ((p >> 2) & 3) + (p >> 4); read_nat then finds value(f, 4 rg + t) at dword 64 t + lane.
+    // cand0 = first candidate of the group; candidates >= n are clamped to n - 1 (their gradients are zero).
+    __device__ __forceinline__ void fetch_nat(const float *base, int64_t cand0, int64_t n, size_t cstride, int slot,
+                                              int lane) const
+    {
+        int64_t cand = cand0 + 4 * ((lane >> 2) & 3) + (lane >> 4);
+        if (cand >= n) cand = n - 1;
+        const float *gp = base + (size_t)cand * cstride + 4 * (lane & 3);
+        const unsigned ldst = __builtin_amdgcn_readfirstlane(this->base + (unsigned)slot * 1024u);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gp), "s"(ldst) : "memory");
+    }
+    __device__ __forceinline__ f4 read_nat(int slot, int lane) const
+    {
+        const float *q = slots + slot * 256 + lane;
+        return (f4){q[0], q[64], q[128], q[192]};
+    }
     template <int N> static __device__ __forceinline__ void landed()        // all but the newest N pieces
     {
         static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
@@ -1246,7 +1295,15 @@ __global__ void wgrad_dense_reduce(const f4 *__restrict__ part, int splits, int 
         return;
     }
     f4 v = part[t];
-    for (int sidx = 1; sidx < splits; sidx++) v += part[(size_t)sidx * per + t];
+    int sidx = 1;
+    for (; sidx + 4 <= splits; sidx += 4) {      // four loads in flight, added in split order
+        f4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) w[u] = part[(size_t)(sidx + u) * per + t];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v += w[u];
+    }
+    for (; sidx < splits; sidx++) v += part[(size_t)sidx * per + t];
     const int lane = (int)(t & 63);
     const int64_t frag = t >> 6;
     const int jb = (int)(frag % NJB), kb = (int)(frag / NJB);
@@ -1401,7 +1458,15 @@ __global__ __launch_bounds__(1024) void wgrad_conv_reduce(const f4 *__restrict__
     const int frag = blockIdx.x;
     const size_t stride = (size_t)NT * (TILES + 1) * 64;
     f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-    for (int sp = j; sp < splits; sp += 16) v += part[(size_t)sp * stride + (size_t)frag * 64 + lane];
+    int sp = j;
+    for (; sp + 48 < splits; sp += 64) {         // four loads in flight, added in split order
+        f4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) w[u] = part[(size_t)(sp + 16 * u) * stride + (size_t)frag * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v += w[u];
+    }
+    for (; sp < splits; sp += 16) v += part[(size_t)sp * stride + (size_t)frag * 64 + lane];
     sh[j][lane] = v;
     __syncthreads();
     if (j != 0) return;
@@ -1430,7 +1495,7 @@ __global__ __launch_bounds__(1024) void wgrad_conv_reduce(const f4 *__restrict__
 // dW[kw][ci][co] = sum_wo T_wo[(wo + kw - 1, ci)][co].  One wave per candidate-range split; a step is one
 // position (1 + 4 fragments, 16 MFMAs), so R = 6 steps are kept in flight (30 KiB of LDS per wave).
 constexpr int CV_WG1_RING = 6;
-__global__ __launch_bounds__(64) void wgrad_conv1_cm(const f4 *__restrict__ x_tm, const f4 *__restrict__ g_tm,
+__global__ __launch_bounds__(64) void wgrad_conv1_cm(const float *__restrict__ x, int64_t n, const f4 *__restrict__ g_tm,
                                                       int G, f4 *__restrict__ part)
 {
     extern __shared__ __attribute__((aligned(16))) float wg_lds[];
@@ -1445,11 +1510,11 @@ __global__ __launch_bounds__(64) void wgrad_conv1_cm(const f4 *__restrict__ x_tm
     f4 bsum = zero;
     // positions of consecutive groups are consecutive in both buffers: flat position i of this split
     const int total = (g1 > g0 ? g1 - g0 : 0) * HIN;
-    const f4 *xp = x_tm + (size_t)g0 * HIN * 64;
     const f4 *gp = g_tm + (size_t)g0 * HIN * 4 * 64;
     auto fetch_pos = [&](int i, int slot) {
         const int ic = i < total ? i : total - 1;
-        S.fetch(xp + (size_t)ic * 64, slot * 5);
+        const int gi = ic / HIN, h = ic - gi * HIN;          // X is read where the caller left it: [n][33][16] floats
+        S.fetch_nat(x + (size_t)h * 16, (int64_t)(g0 + gi) * 16, n, (size_t)HIN * 16, slot * 5, lane);
 #pragma unroll
         for (int wo = 0; wo < 4; wo++) S.fetch(gp + ((size_t)ic * 4 + wo) * 64, slot * 5 + 1 + wo);
     };
@@ -1461,7 +1526,7 @@ __global__ __launch_bounds__(64) void wgrad_conv1_cm(const f4 *__restrict__ x_tm
 #pragma unroll 1
     for (int i = 0; i < total; i++) {
         cm_stage::landed<5 * (R - 1)>();
-        const f4 X = S.read(slot * 5);
+        const f4 X = S.read_nat(slot * 5, lane);
         f4 Gf[4];
 #pragma unroll
         for (int wo = 0; wo < 4; wo++) Gf[wo] = S.read(slot * 5 + 1 + wo);
@@ -1499,8 +1564,17 @@ __global__ __launch_bounds__(1024) void wgrad_conv1_reduce(const f4 *__restrict_
     const bool valid = bias || (wi >= 0 && wi <= 3);
     const int src = bias ? 4 * 64 + l : wo * 64 + wi * 16 + co;
     f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-    if (valid)
-        for (int sp = j; sp < splits; sp += 16) v += part[(size_t)sp * 5 * 64 + src];
+    if (valid) {
+        int sp = j;
+        for (; sp + 48 < splits; sp += 64) {     // four loads in flight, added in split order
+            f4 w[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) w[u] = part[(size_t)(sp + 16 * u) * 5 * 64 + src];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v += w[u];
+        }
+        for (; sp < splits; sp += 16) v += part[(size_t)sp * 5 * 64 + src];
+    }
     sh[j][l] = v;
     __syncthreads();
     if (j != 0) return;
@@ -1635,11 +1709,15 @@ int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm,
     return launch_conv<3, 1, 1, 1, 33, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
 }
 
-int cv_natural_to_tm(const float *nat, int KB, int FPP, int FP, int npos, int64_t n, float *tm, hipStream_t st)
+// heads of the training pass: pre-activations of the 16 outputs from the dropped-out fc4 output and fc5 (tile-major)
+int cv_tile_heads_pre(cv_model *m, const float *d4_tm, const float *h5_tm, int64_t n, float *pre16, hipStream_t st)
 {
-    if (n <= 0) return 0;
-    int64_t G = (n + 15) / 16;
-    natural_to_tm<<<nblk(G * KB * 256, 256), 256, 0, st>>>(nat, KB, FPP, FP, npos, n, G, tm);
+    const cv_shapes &s = m->sh;
+    const float *P = m->params; const int64_t *o = m->poff;
+    const int G = (int)((n + 15) / 16);
+    if (G <= 0) return 0;
+    heads_pre_tm<<<nblk(G, 4), 256, 0, st>>>((const f4 *)d4_tm, (const f4 *)h5_tm, s.nb4, s.nb5, (const f4 *)m->wp_heads0,
+                                            (const f4 *)m->wp_heads1, P + o[11], P + o[13], P + o[15], P + o[17], n, pre16, G);
     CV_HIP(hipGetLastError());
     return 0;
 }
@@ -1737,9 +1815,9 @@ int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_tm, const float *
     return conv_wgrad_launch<3, 1, 1, 33>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
 }
 
-// first layer: x_tm = TM fragments of X viewed as [33 positions][16 = base*4 + matrix], g = TM of its
-// pre-activation gradient ([33*4] fragments per group)
-int cv_tile_conv1_wgrad(cv_model *m, const float *x_tm, const float *g_tm, int64_t n, hipStream_t st)
+// first layer: X as the caller holds it ([n][33 positions][16 = base*4 + matrix] floats, transposed by the
+// fetch), g = TM of its pre-activation gradient ([33*4] fragments per group)
+int cv_tile_conv1_wgrad(cv_model *m, const float *x, const float *g_tm, int64_t n, hipStream_t st)
 {
     const int G = (int)((n + 15) / 16);
     if (G <= 0) return 0;
@@ -1747,7 +1825,7 @@ int cv_tile_conv1_wgrad(cv_model *m, const float *x_tm, const float *g_tm, int64
     const int per = (G + splits - 1) / splits;
     const int used = (G + per - 1) / per;
     if (wg_part_reserve(m, (size_t)splits * 5 * 256 * sizeof(float), st)) return 1;
-    wgrad_conv1_cm<<<splits, 64, CV_WG1_RING * 5 * 1024, st>>>((const f4 *)x_tm, (const f4 *)g_tm, G, (f4 *)m->wg_part);
+    wgrad_conv1_cm<<<splits, 64, CV_WG1_RING * 5 * 1024, st>>>(x, n, (const f4 *)g_tm, G, (f4 *)m->wg_part);
     wgrad_conv1_reduce<<<5, 1024, 0, st>>>((const f4 *)m->wg_part, used, m->arch.cout[0], m->grads + m->poff[0],
                                           m->grads + m->poff[1]);
     CV_HIP(hipGetLastError());

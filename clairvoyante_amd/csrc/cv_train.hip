@@ -492,53 +492,41 @@ static int launch_pool_selu(const float *gpool, const float *act, float *gpre, i
     return 0;
 }
 
-// heads on TM inputs: same as t_heads with cv_tm_index addressing
-__global__ __launch_bounds__(256) void t_heads_tm(
-    const float *__restrict__ d4, const float *__restrict__ h5, int K4, int K5, int KB4, int KB5,
-    const float *__restrict__ wb, const float *__restrict__ bb, const float *__restrict__ wz,
-    const float *__restrict__ bz, const float *__restrict__ wt, const float *__restrict__ bt,
-    const float *__restrict__ wl, const float *__restrict__ bl, const float *__restrict__ y, int64_t n,
-    float *__restrict__ ghpre, double *__restrict__ loss)
+// loss and head gradients from the 16 pre-activations of every candidate (cv_tile_heads_pre); the gradients
+// wrt the pre-activations replace them in place.  Thread = (candidate, head).
+__global__ __launch_bounds__(256) void t_heads_loss(float *__restrict__ pre, const float *__restrict__ y, int64_t n,
+                                                    int want_grad, double *__restrict__ loss)
 {
-    __shared__ float pre[16][17];
     __shared__ double part[4];
-    int c = threadIdx.x >> 4, j = threadIdx.x & 15;
     if (threadIdx.x < 4) part[threadIdx.x] = 0.0;
-    int64_t cand = (int64_t)blockIdx.x * 16 + c;
-    int64_t cl = cand < n ? cand : n - 1;
-    const float *w; const float *b; int idx, nh, K, KB; const float *src;
-    if (j < 4)       { w = wb; b = bb; idx = j;      nh = 4; K = K4; KB = KB4; src = d4; }
-    else if (j < 6)  { w = wz; b = bz; idx = j - 4;  nh = 2; K = K5; KB = KB5; src = h5; }
-    else if (j < 10) { w = wt; b = bt; idx = j - 6;  nh = 4; K = K5; KB = KB5; src = h5; }
-    else             { w = wl; b = bl; idx = j - 10; nh = 6; K = K5; KB = KB5; src = h5; }
-    float acc = 0.0f;
-#pragma unroll 16
-    for (int k = 0; k < K; k++) acc = __builtin_fmaf(src[cv_tm_index(cl, k, KB)], w[(size_t)k * nh + idx], acc);
-    pre[c][j] = acc + b[idx];
     __syncthreads();
-    if (cand < n && j < 4) {
+    const int64_t cand = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int j = threadIdx.x & 3;
+    if (cand < n) {
         const float *yi = y + (size_t)cand * 16;
-        float *g = ghpre ? ghpre + (size_t)cand * 16 : nullptr;
+        float *g = pre + (size_t)cand * 16;
         double l = 0.0;
         if (j == 0) {
+            float v[4];
+            for (int k = 0; k < 4; k++) v[k] = g[k];
             for (int k = 0; k < 4; k++) {
-                float s = cvm::sigmoid(pre[c][k]);
+                float s = cvm::sigmoid(v[k]);
                 float d = s - yi[k];
                 l += (double)d * d;
-                if (g) g[k] = 2.0f * d * s * (1.0f - s);
+                if (want_grad) g[k] = 2.0f * d * s * (1.0f - s);
             }
         } else {
             const int off = j == 1 ? 4 : (j == 2 ? 6 : 10);
             const int cnt = j == 1 ? 2 : (j == 2 ? 4 : 6);
-            float lg[6], p[6];
+            float v[6], lg[6], p[6];
             float mx = -__builtin_inff();
-            for (int k = 0; k < cnt; k++) { lg[k] = cvm::selu(pre[c][off + k]) + 1e-10f; mx = fmaxf(mx, lg[k]); }
+            for (int k = 0; k < cnt; k++) { v[k] = g[off + k]; lg[k] = cvm::selu(v[k]) + 1e-10f; mx = fmaxf(mx, lg[k]); }
             float se = 0.0f, ysum = 0.0f;
             for (int k = 0; k < cnt; k++) { p[k] = cvm::expf_fixed(lg[k] - mx); se += p[k]; ysum += yi[off + k]; }
             float lse = mx + logf(se);
             for (int k = 0; k < cnt; k++) {
                 l += -(double)yi[off + k] * (double)(lg[k] - lse);
-                if (g) g[off + k] = (p[k] / se * ysum - yi[off + k]) * cvm::selu_grad(pre[c][off + k]);
+                if (want_grad) g[off + k] = (p[k] / se * ysum - yi[off + k]) * cvm::selu_grad(v[k]);
             }
         }
         atomicAdd(&part[j], l);
@@ -580,8 +568,16 @@ __global__ void b_head_wgrad_sum(head_wg4 a, const float *__restrict__ part, int
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.total) return;
-    float v = part[t];
-    for (int sl = 1; sl < slices; sl++) v += part[(size_t)sl * a.total + t];
+    float v = 0.0f;
+    int sl = 0;
+    for (; sl + 8 <= slices; sl += 8) {          // eight loads in flight, added in slice order
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) w[u] = part[(size_t)(sl + u) * a.total + t];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v += w[u];
+    }
+    for (; sl < slices; sl++) v += part[(size_t)sl * a.total + t];
     int q = t >= a.h[2].t0 ? (t >= a.h[3].t0 ? 3 : 2) : (t >= a.h[1].t0 ? 1 : 0);
     const head_wg h = a.h[q];
     t -= h.t0;
@@ -642,7 +638,6 @@ static size_t train_floats_per_cand(const cv_model *m)
     // padded channel counts, plus the dense TM buffers
     for (int l = 0; l < 3; l++) f += (size_t)(2 * s.hc[l] + 2 * s.hp[l]) * 4 * s.ntile[l] * 16;
     f += 6 * (size_t)s.nb4 * 16 + 2 * (size_t)s.nb5 * 16;
-    f += 33 * 16;                                   // X as tile-major fragments (first-layer weight gradient)
     return f + 64 * 80;
 }
 
@@ -745,17 +740,15 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     if (cv_tile_dense_fwd(m, 4, tp[2], th4, n, st)) return 1;
     if (cv_dropout_tm(m, th4, td4, tmask, n, backward ? drop4 : 0.0f, seed, step, cand0, st)) return 1;
     if (cv_tile_dense_fwd(m, 5, td4, th5, n, st)) return 1;
-    t_heads_tm<<<nblk(n, 16), 256, 0, st>>>(td4, th5, a.fc4, a.fc5, s.nb4, s.nb5, P + o[10], P + o[11], P + o[12],
-                                            P + o[13], P + o[14], P + o[15], P + o[16], P + o[17], y, n,
-                                            backward ? ghpre : nullptr, m->loss_dev);
+    if (cv_tile_heads_pre(m, td4, th5, n, ghpre, st)) return 1;
+    t_heads_loss<<<nblk(n, 64), 256, 0, st>>>(ghpre, y, n, backward ? 1 : 0, m->loss_dev);
     CV_HIP(hipGetLastError());
     if (!backward) return 0;
-    // ---- backward buffers (TM gradients; the weight-gradient kernels transpose their operands in registers)
+    // ---- backward buffers (TM gradients; the weight-gradient kernels transpose their operands on the way in)
     float *tg5 = sb.take(np * f5u), *tg5pre = sb.take(np * f5u), *tgd4 = sb.take(np * f4u), *tg4pre = sb.take(np * f4u);
     float *tgpre[3], *tgin[3];
     for (int l = 0; l < 3; l++) { tgpre[l] = sb.take(np * fa[l]); tgin[l] = sb.take(np * fp[l]); }
-    float *tx = sb.take(np * 33 * 16);
-    if (!tx) { cv_set_error("training workspace too small"); return 1; }
+    if (!tgin[2]) { cv_set_error("training workspace too small"); return 1; }
     if (cv_pack_train_weights(m, st)) return 1;
     const int NS = 128;     // candidate-range slices of the head weight gradients (short serial loops)
     // heads: weight gradients (inputs read from TM), data gradients written to TM
@@ -792,9 +785,8 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     for (int l = 2; l >= 0; l--) {
         const int H = s.hc[l], NT = s.ntile[l];
         if (launch_pool_selu(tgin[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st)) return 1;
-        if (l == 0) {        // first layer: X viewed as [33][16] fragments
-            cv_natural_to_tm(x, 33, 16, 16, 33, n, tx, st);
-            if (cv_tile_conv1_wgrad(m, tx, tgpre[0], n, st)) return 1;
+        if (l == 0) {        // first layer: X viewed as [33][16] fragments, read in place
+            if (cv_tile_conv1_wgrad(m, x, tgpre[0], n, st)) return 1;
         } else {
             if (cv_tile_conv_wgrad(m, l, tp[l - 1], tgpre[l], n, st)) return 1;
             if (cv_tile_conv_dgrad(m, l, tgpre[l], tgin[l - 1], n, st)) return 1;
