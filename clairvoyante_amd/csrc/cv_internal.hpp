@@ -121,6 +121,7 @@ int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm,
 int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_tm, const float *g_tm, int64_t n, hipStream_t st);
 int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_tm, const float *g_tm, int64_t n, hipStream_t st);
 int cv_tile_conv1_wgrad(cv_model *m, const float *x, const float *g_tm, int64_t n, hipStream_t st);
+int cv_tile_heads_wgrad(cv_model *m, const float *d4_tm, const float *h5_tm, const float *g16, int64_t n, hipStream_t st);
 int cv_tile_heads_pre(cv_model *m, const float *d4_tm, const float *h5_tm, int64_t n, float *pre16, hipStream_t st);
 int cv_dropout_tm(cv_model *m, const float *h4, float *d4, float *amask, int64_t n, float rate, uint64_t seed,
                   uint64_t step, int64_t cand0, hipStream_t st);

@@ -1194,12 +1194,13 @@ struct cm_stage {
 // workgroup stages the NJB gradient fragments (shared) and every wave its two input fragments, double
 // buffered: the pieces of group g+1 are in flight while group g is multiplied; one barrier per group.
 // grid = (ceil(KB/16), group splits); dynamic LDS = 2 * (NJB + 16) KiB.
-template <int NJB>
+// GNAT (heads, NJB == 1): the gradient is the natural [n][16] array of the 16 head pre-activation gradients.
+template <int NJB, bool GNAT = false>
 __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_tm, int KB,
-                                                       const f4 *__restrict__ g_tm, int G, int K, int N,
-                                                       float *__restrict__ dw, float *__restrict__ db,
+                                                       const f4 *__restrict__ g_tm, int G, int64_t n,
                                                        f4 *__restrict__ part)
 {
+    static_assert(!GNAT || NJB == 1, "natural gradients: one fragment per group");
     extern __shared__ __attribute__((aligned(16))) float wg_lds[];
     constexpr int NSLOT = NJB + 16;                  // per buffer: NJB gradient fragments, then 2 per wave
     constexpr int PERG = (NJB + 7) / 8;              // gradient fragments each wave fetches (clamped: duplicates
@@ -1224,10 +1225,14 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
     for (int i = 0; i < NBS; i++) bs[i] = zero;
     const bool do_bias = blockIdx.x == 0;
     auto stage = [&](int g, int buf) {
+        if constexpr (GNAT) {
+            if (wid == 0) S.fetch_nat((const float *)g_tm, (int64_t)g * 16, n, 16, buf * NSLOT, lane);
+        } else {
 #pragma unroll
-        for (int i = 0; i < PERG; i++) {
-            const int jb = wid + 8 * i < NJB ? wid + 8 * i : NJB - 1;
-            S.fetch(g_tm + ((size_t)g * NJB + jb) * 64, buf * NSLOT + jb);
+            for (int i = 0; i < PERG; i++) {
+                const int jb = wid + 8 * i < NJB ? wid + 8 * i : NJB - 1;
+                S.fetch(g_tm + ((size_t)g * NJB + jb) * 64, buf * NSLOT + jb);
+            }
         }
         S.fetch(x_tm + ((size_t)g * KB + kc0) * 64, buf * NSLOT + NJB + 2 * wid);
         S.fetch(x_tm + ((size_t)g * KB + kc1) * 64, buf * NSLOT + NJB + 2 * wid + 1);
@@ -1244,7 +1249,17 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
         if (!v1) X1 = zero;
 #pragma unroll
         for (int jb = 0; jb < NJB; jb++) {
-            const f4 B = S.read(buf * NSLOT + jb);
+            f4 B;
+            if constexpr (GNAT) {
+                B = S.read_nat(buf * NSLOT, lane);
+                if (g == G - 1) {            // candidates past n were fetched clamped: they carry no gradient
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        if ((int64_t)g * 16 + 4 * (lane >> 4) + t >= n) B[t] = 0.0f;
+                }
+            } else {
+                B = S.read(buf * NSLOT + jb);
+            }
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 acc[0][jb] = mfma4(X0[t], B[t], acc[0][jb]);
@@ -1758,7 +1773,7 @@ static int dense_wgrad_launch(cv_model *m, const float *x_tm, int KB, const floa
     if (wg_part_reserve(m, (size_t)splits * (KB * NJB * 256 + NJB * 16) * sizeof(float), st)) return 1;
     const size_t lds = (size_t)2 * (NJB + 16) * 1024;
     if (set_lds(wgrad_dense_cm<NJB>, lds)) return 1;
-    wgrad_dense_cm<NJB><<<dim3(kblocks, splits), 512, lds, st>>>((const f4 *)x_tm, KB, (const f4 *)g_tm, G, K, N, dw, db,
+    wgrad_dense_cm<NJB><<<dim3(kblocks, splits), 512, lds, st>>>((const f4 *)x_tm, KB, (const f4 *)g_tm, G, 0,
                                                                  (f4 *)m->wg_part);
     const int64_t per = (int64_t)KB * NJB * 64;
     wgrad_dense_reduce<<<nblk(per + NJB * 16, 256), 256, 0, st>>>((const f4 *)m->wg_part, splits, KB, NJB, K, N, dw, db);
@@ -1777,6 +1792,84 @@ int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_tm, const float *
     }
     if (is_full(a)) return dense_wgrad_launch<11>(m, x_tm, s.nb4, g_tm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9], st);
     return dense_wgrad_launch<2>(m, x_tm, s.nb4, g_tm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9], st);
+}
+
+// heads: dW16[k][j] = sum_c X[c][k] g[c][j] for the 16 head outputs j at once (wgrad_dense_cm with the natural
+// gradient array), then this pass sums the splits in order and scatters the columns [j_lo, j_hi) into the head
+// matrices: column j belongs to head q with offset j0[q] and width N[q]; bias sums likewise.
+struct head_cols { float *dw[4], *db[4]; int j0[4], N[4]; };
+
+__global__ void wgrad_heads_reduce(const f4 *__restrict__ part, int splits, int KB, int K, int j_lo, int j_hi,
+                                   head_cols hc)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = (int64_t)KB * 64;
+    const bool bias = t >= per;
+    const int j = bias ? (int)(t - per) : (int)(t & 15);
+    if (j >= 16 || j < j_lo || j >= j_hi) return;
+    int q = 0;
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if (j >= hc.j0[i]) q = i;
+    const int col = j - hc.j0[q], N = hc.N[q];
+    if (bias) {
+        const float *bpart = (const float *)(part + (size_t)splits * per);
+        float b = bpart[j];
+        int sidx = 1;
+        for (; sidx + 8 <= splits; sidx += 8) {
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) w[u] = bpart[(size_t)(sidx + u) * 16 + j];
+#pragma unroll
+            for (int u = 0; u < 8; u++) b += w[u];
+        }
+        for (; sidx < splits; sidx++) b += bpart[(size_t)sidx * 16 + j];
+        hc.db[q][col] += b;
+        return;
+    }
+    f4 v = part[t];
+    int sidx = 1;
+    for (; sidx + 4 <= splits; sidx += 4) {
+        f4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) w[u] = part[(size_t)(sidx + u) * per + t];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v += w[u];
+    }
+    for (; sidx < splits; sidx++) v += part[(size_t)sidx * per + t];
+    const int lane = (int)(t & 63), kb = (int)(t >> 6), qq = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int k = 16 * kb + 4 * qq + r;
+        if (k < K) hc.dw[q][(size_t)k * N + col] += v[r];
+    }
+}
+
+// x_tm = dropped-out fc4 output (heads 0) or fc5 output (heads 1..3); g16 = [n][16] head gradients
+int cv_tile_heads_wgrad(cv_model *m, const float *d4_tm, const float *h5_tm, const float *g16, int64_t n, hipStream_t st)
+{
+    const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
+    const int G = (int)((n + 15) / 16);
+    if (G <= 0) return 0;
+    float *Gd = m->grads; const int64_t *o = m->poff;
+    head_cols hc;
+    const int j0[4] = {0, 4, 6, 10}, N[4] = {4, 2, 4, 6};
+    for (int q = 0; q < 4; q++) { hc.dw[q] = Gd + o[10 + 2 * q]; hc.db[q] = Gd + o[11 + 2 * q]; hc.j0[q] = j0[q]; hc.N[q] = N[q]; }
+    const size_t lds = (size_t)2 * (1 + 16) * 1024;
+    for (int pass = 0; pass < 2; pass++) {
+        const float *x_tm = pass == 0 ? d4_tm : h5_tm;
+        const int KB = pass == 0 ? s.nb4 : s.nb5, K = pass == 0 ? a.fc4 : a.fc5;
+        const int kblocks = (KB + 15) / 16;
+        int splits = 64 / kblocks;               // little work per group: few, longer ranges keep the second pass short
+        if (splits > G) splits = G;
+        if (wg_part_reserve(m, (size_t)splits * (KB * 256 + 16) * sizeof(float), st)) return 1;
+        wgrad_dense_cm<1, true><<<dim3(kblocks, splits), 512, lds, st>>>((const f4 *)x_tm, KB, (const f4 *)g16, G, n,
+                                                                          (f4 *)m->wg_part);
+        wgrad_heads_reduce<<<nblk((int64_t)KB * 64 + 16, 256), 256, 0, st>>>((const f4 *)m->wg_part, splits, KB, K,
+                                                                             pass == 0 ? 0 : 4, pass == 0 ? 4 : 16, hc);
+    }
+    CV_HIP(hipGetLastError());
+    return 0;
 }
 
 // layer 1 = conv2 (in = pool1 TM), 2 = conv3 (in = pool2 TM); g = pre-activation gradient TM.

@@ -535,58 +535,6 @@ __global__ __launch_bounds__(256) void t_heads_loss(float *__restrict__ pre, con
     if (threadIdx.x < 4) atomicAdd(&loss[threadIdx.x], part[threadIdx.x]);
 }
 
-// heads: weight / bias gradients of the four heads in one launch, layer inputs read from TM buffers
-// dW[k][j] += sum_n X[n][k] g[n][j0 + j] ; row k == K is the bias.  grid.y = candidate-range slices; every
-// slice leaves its partial sums in `part` and b_head_wgrad_sum adds them in slice order (no float atomics).
-struct head_wg { const float *xtm; float *dw, *db; int KB, K, N, j0, t0; };
-struct head_wg4 { head_wg h[4]; int total; };
-
-__global__ void b_head_wgrad_tm(head_wg4 a, const float *__restrict__ g, int64_t n, float *__restrict__ part)
-{
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.total) return;
-    float *out = part + (size_t)blockIdx.y * a.total + t;
-    int q = t >= a.h[2].t0 ? (t >= a.h[3].t0 ? 3 : 2) : (t >= a.h[1].t0 ? 1 : 0);
-    const head_wg h = a.h[q];
-    t -= h.t0;
-    int j = t % h.N;
-    int k = t / h.N;
-    int64_t per = (n + gridDim.y - 1) / gridDim.y;
-    int64_t n0 = per * blockIdx.y, n1 = n0 + per < n ? n0 + per : n;
-    float acc = 0.0f;
-    if (k < h.K) {
-#pragma unroll 8
-        for (int64_t i = n0; i < n1; i++) acc = __builtin_fmaf(h.xtm[cv_tm_index(i, k, h.KB)], g[(size_t)i * 16 + h.j0 + j], acc);
-    } else {
-#pragma unroll 8
-        for (int64_t i = n0; i < n1; i++) acc += g[(size_t)i * 16 + h.j0 + j];
-    }
-    *out = acc;
-}
-
-__global__ void b_head_wgrad_sum(head_wg4 a, const float *__restrict__ part, int slices)
-{
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.total) return;
-    float v = 0.0f;
-    int sl = 0;
-    for (; sl + 8 <= slices; sl += 8) {          // eight loads in flight, added in slice order
-        float w[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) w[u] = part[(size_t)(sl + u) * a.total + t];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v += w[u];
-    }
-    for (; sl < slices; sl++) v += part[(size_t)sl * a.total + t];
-    int q = t >= a.h[2].t0 ? (t >= a.h[3].t0 ? 3 : 2) : (t >= a.h[1].t0 ? 1 : 0);
-    const head_wg h = a.h[q];
-    t -= h.t0;
-    int j = t % h.N;
-    int k = t / h.N;
-    if (k < h.K) h.dw[(size_t)k * h.N + j] += v;
-    else h.db[j] += v;
-}
-
 // heads: data gradients written into TM buffers.  mode 0: gh5_tm = sum over the three fc5-side
 // heads (all entries written, padding = 0); mode 1: gd4_tm += base-head contribution.
 __global__ void b_head_dgrad_tm(const float *__restrict__ ghpre, const float *__restrict__ wb,
@@ -750,24 +698,9 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     for (int l = 0; l < 3; l++) { tgpre[l] = sb.take(np * fa[l]); tgin[l] = sb.take(np * fp[l]); }
     if (!tgin[2]) { cv_set_error("training workspace too small"); return 1; }
     if (cv_pack_train_weights(m, st)) return 1;
-    const int NS = 128;     // candidate-range slices of the head weight gradients (short serial loops)
-    // heads: weight gradients (inputs read from TM), data gradients written to TM
-    {
-        head_wg4 hw;
-        const int hN[4] = {4, 2, 4, 6}, hj0[4] = {0, 4, 6, 10};
-        int t0 = 0;
-        for (int q = 0; q < 4; q++) {
-            head_wg &h = hw.h[q];
-            h.xtm = q == 0 ? td4 : th5; h.KB = q == 0 ? s.nb4 : s.nb5; h.K = q == 0 ? a.fc4 : a.fc5;
-            h.N = hN[q]; h.j0 = hj0[q]; h.dw = G + o[10 + 2 * q]; h.db = G + o[11 + 2 * q]; h.t0 = t0;
-            t0 += (h.K + 1) * h.N;
-        }
-        hw.total = t0;
-        float *hpart = sb.take((size_t)NS * t0);
-        if (!hpart) { cv_set_error("training workspace too small"); return 1; }
-        b_head_wgrad_tm<<<dim3(nblk(t0, 256), NS), 256, 0, st>>>(hw, ghpre, n, hpart);
-        b_head_wgrad_sum<<<nblk(t0, 256), 256, 0, st>>>(hw, hpart, NS);
-    }
+    // heads: weight gradients on the matrix cores (inputs tile-major, the 16 gradients as they lie), data
+    // gradients written to TM
+    if (cv_tile_heads_wgrad(m, td4, th5, ghpre, n, st)) return 1;
     b_head_dgrad_tm<<<nblk(Gn * s.nb5 * 256, 256), 256, 0, st>>>(ghpre, P + o[10], P + o[12], P + o[14], P + o[16], a.fc5,
                                                                s.nb5, n, Gn, 0, tg5);
     // fc5
@@ -813,7 +746,7 @@ static int train_pass(cv_model *m, const float *x, const float *y, int64_t n, bo
     CV_HIP(hipSetDevice(m->device));
     const int64_t slice = 16384;        // one pass for train.py's batch of 10 000
     const size_t need = (train_floats_per_cand(m) * (size_t)((n < slice ? (n > 0 ? n : 1) : slice) + 16)
-                         + (size_t)128 * 4096 /* per-slice head gradients */) * sizeof(float);
+                         ) * sizeof(float);
     if (m->t_bytes < need) {
         if (m->t_buf) CV_HIP(hipFree(m->t_buf));
         m->t_buf = nullptr; m->t_bytes = 0;
