@@ -98,9 +98,8 @@ def pileup_region(args, subtract=False, device=None):
     pl = Pileup(device=device, minMQ=args.minMQ, dcov=args.dcov, considerleftedge=args.considerleftedge)
     pl.set_reference(ref_seq, shift)
     pl.set_candidates(centers)
-    from .ExtractVariantCandidates import view_chunks
-    for chunk in view_chunks(args, ctgStart, ctgEnd):
-        pl.add_sam(chunk)
+    from .ExtractVariantCandidates import stream_alignments
+    stream_alignments(args, pl, ctgStart, ctgEnd)
     t, depth, touched = pl.finish(subtract=subtract)
     inside = torch.from_numpy((pl.centers - shift - (FLANK + 1)) >= 0).to(t.device)
     keep = touched & inside & (depth >= args.minCoverage)

@@ -88,6 +88,14 @@ def view_chunks(args, ctgStart, ctgEnd):
 def stream_alignments(args, pl, ctgStart, ctgEnd, source=None):
     """feed the alignments of the region to the pileup; `source`: already fetched text pieces (a prefetching
     caller), default: spawn samtools now"""
+    if source is None and args.samtools == "native":    # BAM records go to the pileup as they are: no SAM text
+        from .bam import BamFile
+        bf = BamFile(args.bam_fn)
+        try:
+            pl.add_bam(bf, args.ctgName, ctgStart, ctgEnd)
+        finally:
+            bf.close()
+        return
     for chunk in (view_chunks(args, ctgStart, ctgEnd) if source is None else source):
         pl.add_sam(chunk)
 

@@ -53,6 +53,7 @@ struct cv_bam {
     size_t data_pos = 0;
     bool eof = false;
     std::vector<uint8_t> comp;               // scratch: compressed blocks of one batch
+    std::vector<uint32_t> rec_offs;          // cv_bam_view_records: starts of the selected records in `data`
 };
 
 namespace {
@@ -73,20 +74,18 @@ int bgzf_block_size(const uint8_t *p, size_t n)
     return bsize;
 }
 
-bool inflate_block(const uint8_t *blk, int bsize, uint8_t *dst, int *dlen)
+// zs: a raw-deflate inflater of the calling thread (inflateInit2(-15) once, reset per block)
+bool inflate_block(z_stream &zs, const uint8_t *blk, int bsize, uint8_t *dst, int *dlen)
 {
     const int xlen = rd_u16(blk + 10);
     const uint8_t *cdata = blk + 12 + xlen;
     const int clen = bsize - 12 - xlen - 8;
     const uint32_t isize = rd_u32(blk + bsize - 4);
     if (clen < 0 || isize > 65536) return false;
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    if (inflateReset(&zs) != Z_OK) return false;
     zs.next_in = const_cast<uint8_t *>(cdata); zs.avail_in = (uInt)clen;
-    zs.next_out = dst; zs.avail_out = 65536;
+    zs.next_out = dst; zs.avail_out = isize;             // never past the block's own place in the stream
     const int rc = inflate(&zs, Z_FINISH);
-    inflateEnd(&zs);
     if (rc != Z_STREAM_END || zs.total_out != isize) return false;
     if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, isize) != rd_u32(blk + bsize - 8)) return false;
     *dlen = (int)isize;
@@ -121,14 +120,27 @@ int fill(cv_bam *b, int max_blocks)
     }
     const size_t nb = boff.size();
     const size_t base = b->data.size();
-    b->data.resize(base + nb * 65536);
+    // every block states its inflated size in its trailer: the blocks go straight to their final places
+    std::vector<size_t> dst(nb + 1, 0);
+    for (size_t i = 0; i < nb; i++) {
+        const uint32_t isize = rd_u32(b->comp.data() + boff[i] + (size_t)bsz[i] - 4);
+        if (isize > 65536) { cv_set_error("bam: corrupt BGZF block at offset %lld", (long long)(b->next_coff + (int64_t)boff[i])); return 1; }
+        dst[i + 1] = dst[i] + isize;
+    }
+    b->data.resize(base + dst[nb]);
     std::vector<int> dlen(nb, 0);
     std::vector<char> ok(nb, 0);
     int T = b->threads < 1 ? 1 : b->threads;
     if ((size_t)T > nb) T = (int)nb;
     auto work = [&](int t) {
-        for (size_t i = (size_t)t; i < nb; i += (size_t)T)
-            ok[i] = inflate_block(b->comp.data() + boff[i], bsz[i], b->data.data() + base + i * 65536, &dlen[i]);
+        const size_t i0 = nb * (size_t)t / (size_t)T, i1 = nb * ((size_t)t + 1) / (size_t)T;
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -15) != Z_OK) return;          // ok[] stays 0: reported as a corrupt block
+        for (size_t i = i0; i < i1; i++)
+            ok[i] = inflate_block(zs, b->comp.data() + boff[i], bsz[i], b->data.data() + base + dst[i], &dlen[i]) &&
+                    (size_t)dlen[i] == dst[i + 1] - dst[i];
+        inflateEnd(&zs);
     };
     if (T == 1) work(0);
     else {
@@ -136,13 +148,8 @@ int fill(cv_bam *b, int max_blocks)
         for (int t = 0; t < T; t++) th.emplace_back(work, t);
         for (auto &x : th) x.join();
     }
-    size_t w = base;                                        // close the gaps between the 64 KiB slots
-    for (size_t i = 0; i < nb; i++) {
+    for (size_t i = 0; i < nb; i++)
         if (!ok[i]) { cv_set_error("bam: corrupt BGZF block at offset %lld", (long long)(b->next_coff + (int64_t)boff[i])); return 1; }
-        if (w != base + i * 65536) memmove(b->data.data() + w, b->data.data() + base + i * 65536, (size_t)dlen[i]);
-        w += (size_t)dlen[i];
-    }
-    b->data.resize(w);
     b->next_coff += (int64_t)off;
     return 0;
 }
@@ -307,6 +314,78 @@ extern "C" int cv_bam_view_begin(cv_bam *b, const char *ref, int64_t beg1, int64
         b->data_pos = (size_t)(voff & 0xffff);
     }
     return 0;
+}
+
+// The same selection as cv_bam_view_read, without the text: gathers the next run of selected records -- about
+// max_bytes of inflated BAM -- and returns their count; *base + (*offs)[i] is record i at its refID field (the
+// int32 block_size precedes it), laid out as in the SAM/BAM specification section 4.2.  The pointers stay
+// valid until the next call on this handle.  0 with *done = 1 at the end of the view, -1 on error.
+extern "C" int64_t cv_bam_view_records(cv_bam *b, int64_t max_bytes, const uint8_t **base, const uint32_t **offs,
+                                       int *done)
+{
+    if (!b || !base || !offs || max_bytes < 65536) { cv_set_error("cv_bam_view_records: bad argument"); return -1; }
+    b->rec_offs.clear();
+    *base = nullptr; *offs = nullptr;
+    if (max_bytes > ((int64_t)1 << 31)) max_bytes = (int64_t)1 << 31;
+    while (!b->done) {
+        // buffer the window first (fill() may move the data), then walk it
+        while (!b->eof && (int64_t)(b->data.size() - b->data_pos) < max_bytes)
+            if (fill(b, 64 * (b->threads > 1 ? b->threads : 1))) return -1;
+        size_t pos = b->data_pos;
+        const size_t lim = b->data.size();
+        const uint8_t *d = b->data.data();
+        bool partial = false;
+        while (true) {
+            if (lim - pos < 4) { partial = lim != pos; break; }
+            const int64_t bs = rd_i32(d + pos);
+            if (bs < 32) { cv_set_error("bam: corrupt record (block_size %lld)", (long long)bs); return -1; }
+            if ((int64_t)(lim - pos) < 4 + bs) { partial = true; break; }
+            const uint8_t *r = d + pos + 4;
+            const int32_t tid = rd_i32(r), rpos = rd_i32(r + 4);
+            const int l_name = r[8];
+            const int n_cig = rd_u16(r + 12), flag = rd_u16(r + 14);
+            const int64_t l_seq = rd_i32(r + 16);
+            if (32 + (int64_t)l_name + 4 * (int64_t)n_cig + (l_seq + 1) / 2 + l_seq > bs) {
+                cv_set_error("bam: corrupt record layout");
+                return -1;
+            }
+            if (tid < 0 || tid > b->tid || (tid == b->tid && (int64_t)rpos >= b->end0)) { b->done = true; break; }
+            const uint8_t *cig = r + 32 + l_name;
+            bool take = tid == b->tid && !(flag & b->exclude);
+            if (take) {
+                int64_t span = 0;
+                for (int k = 0; k < n_cig; k++) {
+                    const uint32_t c = rd_u32(cig + 4 * k);
+                    const int op = (int)(c & 15);
+                    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += c >> 4;
+                }
+                if (span < 1) span = 1;
+                if ((int64_t)rpos + span <= b->beg0) take = false;
+                if (take && n_cig == 2 && (rd_u32(cig) & 15) == 4 && (int64_t)(rd_u32(cig) >> 4) == l_seq &&
+                    (rd_u32(cig + 4) & 15) == 3) {
+                    cv_set_error("bam: a record keeps its CIGAR in a CG tag (more than 65535 operations): not supported");
+                    return -1;
+                }
+            }
+            if (take) b->rec_offs.push_back((uint32_t)(pos + 4));
+            pos += (size_t)(4 + bs);
+            if ((int64_t)(pos - b->data_pos) >= max_bytes) break;
+        }
+        const bool advanced = pos != b->data_pos;
+        b->data_pos = pos;
+        if (b->done) break;
+        if (partial && b->eof) { b->done = true; cv_set_error("bam: truncated record"); return -1; }
+        if (!partial && b->eof && pos == lim) { b->done = true; break; }
+        if (!b->rec_offs.empty()) break;       // hand out what this window held
+        if (partial && !advanced) {            // one record larger than the window: widen it
+            max_bytes *= 2;
+            if (max_bytes > ((int64_t)1 << 31)) { cv_set_error("bam: record larger than 2 GiB"); return -1; }
+        }
+    }
+    if (done) *done = b->done ? 1 : 0;
+    *base = b->data.data();
+    *offs = b->rec_offs.data();
+    return (int64_t)b->rec_offs.size();
 }
 
 // Appends whole SAM lines to buf (cap bytes); returns the bytes written (0 with *done = 1 at the end of the view), -1 on error.

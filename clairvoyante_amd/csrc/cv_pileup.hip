@@ -669,6 +669,88 @@ static void parse_range(const cv_pileup *p, sam_part *out, const char *cur, cons
     }
 }
 
+// ---- the same reads straight from BAM records (SAM/BAM specification 4.2; no text in between) -------------------
+// rec points at refID; fields: refID pos | l_read_name mapq bin | n_cigar_op flag | l_seq | next_refID next_pos tlen
+// | read_name | cigar (uint32: len << 4 | op, ops "MIDNSHP=X") | seq (4 bits per base, "=ACMGRSVTWYHKDBN") | qual.
+// Everything follows parse_record on the line `samtools view` would print for the record: SEQ "*" for l_seq 0,
+// CIGAR "*" for no operations, RNAME = the contig of the view.
+static inline int32_t le32(const uint8_t *q) { int32_t v; memcpy(&v, q, 4); return v; }
+
+static bool parse_bam_record(const cv_pileup *p, sam_part &out, const uint8_t *rec, bool contig_ok)
+{
+    static const char NT[] = "=ACMGRSVTWYHKDBN";
+    const int64_t pos = le32(rec + 4);
+    const int l_name = rec[8];
+    const int64_t mq = rec[9];
+    const int n_cig = (int)(rec[12] | (rec[13] << 8));
+    const int64_t l_seq = le32(rec + 16);
+    const uint8_t *cg = rec + 32 + l_name;
+    const uint8_t *sq = cg + 4 * (size_t)n_cig;
+    const int64_t seqlen = l_seq > 0 ? l_seq : 1;          // "*"
+    int64_t need = 0, total = 0, clipped = 0;
+    for (int k = 0; k < n_cig; k++) {
+        const uint32_t c = (uint32_t)le32(cg + 4 * k);
+        const int op = (int)(c & 15);
+        const int64_t v = c >> 4;
+        if (op > 8) continue;                               // printed as '?': not an operation for the parser
+        if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) need += v;
+        total += v;
+        if (op == 4) clipped += v;
+    }
+    const bool ct_ok = mq >= p->min_mq;
+    bool evc_ok = p->evc != 0 && mq >= p->evc_min_mq && (p->contig.empty() || contig_ok);
+    if (evc_ok && 1.0 - (double)clipped / (double)(total + 1) < 0.55) evc_ok = false;
+    if (!ct_ok && !evc_ok) return true;
+    if (pos < -(1LL << 30) || pos > (1LL << 31) - (1 << 24)) {
+        char msg[96];
+        snprintf(msg, sizeof(msg), "cv_pileup_add_bam: POS %lld out of range", (long long)pos + 1);
+        out.err = msg;
+        return false;
+    }
+    const int rf = (ct_ok ? F_CT : 0) | (evc_ok ? F_EVC : 0);
+    const uint64_t base = out.seq.size();
+    if (l_seq > 0) {
+        out.seq.resize(base + (size_t)l_seq);
+        uint8_t *w = out.seq.data() + base;
+        int64_t k = 0;
+        for (; k + 1 < l_seq; k += 2) { const uint8_t b = sq[k >> 1]; w[k] = (uint8_t)NT[b >> 4]; w[k + 1] = (uint8_t)NT[b & 15]; }
+        if (k < l_seq) w[k] = (uint8_t)NT[sq[k >> 1] >> 4];
+    } else {
+        out.seq.push_back((uint8_t)'*');
+    }
+    if (need > seqlen) out.seq.insert(out.seq.end(), (size_t)(need - seqlen), (uint8_t)'?');
+    read_rec rr;
+    rr.pos = pos; rr.seg0 = (uint32_t)out.segs.size(); rr.ct = ct_ok; rr.evc = evc_ok; rr.leading = 0;
+    int64_t r = pos, q = 0;
+    for (int k = 0; k < n_cig; k++) {
+        const uint32_t c = (uint32_t)le32(cg + 4 * k);
+        const int op = (int)(c & 15);
+        const int64_t v = c >> 4;
+        const int lf = rf | ((evc_ok && r == pos) ? F_LATE : 0);
+        if (op == 4) q += v;
+        else if (op == 0 || op == 7 || op == 8) { emit(out, T_MATCH, rf, r, base + q, v, pos, true); r += v; q += v; }
+        else if (op == 1) { if (lf & F_LATE) rr.leading = 1; emit(out, T_INS, lf, r, base + q, v, pos, false); q += v; }
+        else if (op == 2) { if (lf & F_LATE) rr.leading = 1; emit(out, T_DEL, lf, r, 0, v, pos, true); r += v; }
+    }
+    rr.nseg = (uint32_t)out.segs.size() - rr.seg0;
+    out.reads.push_back(rr);
+    return true;
+}
+
+static void parse_bam_range(const cv_pileup *p, sam_part *out, const uint8_t *base, const uint32_t *offs, int64_t i0,
+                            int64_t i1, bool contig_ok)
+{
+    if (i1 > i0) {
+        const size_t bytes = (size_t)(offs[i1 - 1] - offs[i0]) + 512;
+        out->segs.reserve(bytes / 40);
+        out->seq.reserve(bytes);
+    }
+    for (int64_t i = i0; i < i1; i++)
+        if (!parse_bam_record(p, *out, base + offs[i], contig_ok)) return;
+}
+
+static int absorb_parts(cv_pileup *p, std::vector<sam_part> &parts, int64_t *kept);
+
 extern "C" int cv_pileup_add_sam(cv_pileup *p, const char *text, int64_t nbytes, int final, int64_t *consumed,
                                  int64_t *kept)
 {
@@ -699,9 +781,14 @@ extern "C" int cv_pileup_add_sam(cv_pileup *p, const char *text, int64_t nbytes,
         for (int t = 0; t < T; ++t) th.emplace_back(parse_range, p, &parts[(size_t)t], cut[(size_t)t], cut[(size_t)t + 1]);
         for (auto &x : th) x.join();
     }
+    return absorb_parts(p, parts, kept);
+}
+
+// (2) running state over the reads of the parser slices (in order), then append them to the queue
+static int absorb_parts(cv_pileup *p, std::vector<sam_part> &parts, int64_t *kept)
+{
     for (auto &part : parts)
         if (!part.err.empty()) { cv_set_error("%s", part.err.c_str()); return 1; }
-    // (2) running state over the reads, then append to the queue
     int64_t k = 0;
     for (auto &part : parts) {
         for (const read_rec &rr : part.reads) {
@@ -740,6 +827,35 @@ extern "C" int cv_pileup_add_sam(cv_pileup *p, const char *text, int64_t nbytes,
     }
     if (kept) *kept = k;
     return 0;
+}
+
+// base/offs/n: a run of BAM records as cv_bam_view_records hands them out (record i at base + offs[i], refID
+// first); contig_ok: the records' reference is the contig given to cv_pileup_set_contig (candidate pass).
+extern "C" int cv_pileup_add_bam(cv_pileup *p, const uint8_t *base, const uint32_t *offs, int64_t n, int contig_ok,
+                                 int64_t *kept)
+{
+    if (!p || n < 0 || (n > 0 && (!base || !offs))) { cv_set_error("cv_pileup_add_bam: bad argument"); return 1; }
+    if (kept) *kept = 0;
+    if (n == 0) return 0;
+    int T = p->threads > 1 && n >= 4096 ? p->threads : 1;
+    std::vector<sam_part> parts((size_t)T);
+    if (T == 1) {
+        parse_bam_range(p, &parts[0], base, offs, 0, n, contig_ok != 0);
+    } else {
+        // slices of about equal bytes (records differ in length): cut where the byte offset crosses t/T of the span
+        std::vector<int64_t> cut((size_t)T + 1);
+        cut[0] = 0; cut[(size_t)T] = n;
+        const uint64_t span = (uint64_t)(offs[n - 1] - offs[0]) + 1;
+        for (int t = 1; t < T; ++t) {
+            const uint32_t want = offs[0] + (uint32_t)(span * (uint64_t)t / (uint64_t)T);
+            cut[(size_t)t] = std::lower_bound(offs, offs + n, want) - offs;
+        }
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back(parse_bam_range, p, &parts[(size_t)t], base, offs, cut[(size_t)t], cut[(size_t)t + 1], contig_ok != 0);
+        for (auto &x : th) x.join();
+    }
+    return absorb_parts(p, parts, kept);
 }
 
 extern "C" int64_t cv_pileup_pending(const cv_pileup *p) { return p ? p->pending_cols : 0; }

@@ -96,6 +96,27 @@ class Pileup(object):
             _lib.check(self.lib.cv_pileup_flush(self.h, self._stream()))
         return self._kept_now
 
+    def add_bam(self, bam, ref, start=None, end=None, exclude_flags=2308, contig_ok=True, window=64 << 20):
+        """feed the records `samtools view -F exclude_flags BAM ref[:start-end]` would print, straight from the
+        BAM (bam: clairvoyante_amd.bam.BamFile) -- no SAM text in between; same result as add_sam on that text"""
+        self._kept_now = 0
+        if self._tail:
+            self.add_sam(b"", final=True)
+        _lib.check(self.lib.cv_bam_view_begin(bam.h, ref.encode(), int(start or 0), int(end or 0), int(exclude_flags), 0))
+        base = ctypes.c_void_p(); offs = ctypes.c_void_p(); done = ctypes.c_int(0); kept = ctypes.c_int64(0)
+        total = 0
+        while not done.value:
+            n = self.lib.cv_bam_view_records(bam.h, int(window), ctypes.byref(base), ctypes.byref(offs), ctypes.byref(done))
+            if n < 0:
+                _lib.check(1)
+            if n:
+                _lib.check(self.lib.cv_pileup_add_bam(self.h, base, offs, n, int(bool(contig_ok)), ctypes.byref(kept)))
+                self.reads_kept += kept.value
+                total += kept.value
+                if self.lib.cv_pileup_pending(self.h) >= FLUSH_COLUMNS:
+                    _lib.check(self.lib.cv_pileup_flush(self.h, self._stream()))
+        return total
+
     def finish(self, subtract=False, want_tensors=True):
         """-> (tensors [n,33,4,4] fp32 on the device, depth [n] int32, touched [n] bool)"""
         import torch

@@ -209,6 +209,13 @@ int cv_pileup_set_candidates(cv_pileup *p, const int64_t *centers, int64_t n);
 int cv_pileup_add_sam(cv_pileup *p, const char *text, int64_t nbytes, int final, int64_t *consumed,
                       int64_t *kept);
 
+/* The same reads straight from BAM records (cv_bam_view_records): every record is taken as the line
+ * `samtools view` prints for it (SEQ "*" for an absent sequence, no CIGAR operations for "*"; the RNAME test
+ * of the candidate pass is the flag contig_ok: the view's contig is the one of cv_pileup_set_contig).
+ * Same filters, same running state, same result as cv_pileup_add_sam on that text.                 */
+int cv_pileup_add_bam(cv_pileup *p, const uint8_t *base, const uint32_t *offs, int64_t n, int contig_ok,
+                      int64_t *kept);
+
 /* Bases queued on the host and not yet scattered (callers flush when this gets large).          */
 int64_t cv_pileup_pending(const cv_pileup *p);
 
@@ -288,6 +295,11 @@ int cv_bam_has_index(const cv_bam *b);
 int cv_bam_view_begin(cv_bam *b, const char *ref, int64_t beg1, int64_t end1, int exclude_flags, int with_qual);
 /* Whole SAM lines into buf[0, cap); returns bytes written (0 and *done = 1 at the end), -1 on error.   */
 int64_t cv_bam_view_read(cv_bam *b, char *buf, int64_t cap, int *done);
+/* The same selection without the text: the next run of selected records (about max_bytes of inflated BAM);
+ * returns their count, record i starts at *base + (*offs)[i] with its refID field (SAM/BAM specification 4.2).
+ * The pointers stay valid until the next call on the handle; 0 and *done = 1 at the end, -1 on error.
+ * Feeds cv_pileup_add_bam.                                                                             */
+int64_t cv_bam_view_records(cv_bam *b, int64_t max_bytes, const uint8_t **base, const uint32_t **offs, int *done);
 
 #ifdef __cplusplus
 }

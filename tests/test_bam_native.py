@@ -123,3 +123,48 @@ def test_errors_are_reported(tmp_path):
     os.remove(bam + ".bai")
     with pytest.raises(_lib.CvError):
         view_text(bam, "ctgA")
+
+
+def view_records(path, ctg, start=None, end=None, window=65536, threads=3, mask=2308):
+    """(QNAME, FLAG, POS, CIGAR, SEQ) of the records cv_bam_view_records selects, decoded here from the raw records"""
+    import ctypes
+    import struct
+    from clairvoyante_amd import _lib
+    from clairvoyante_amd.bam import BamFile
+    bf = BamFile(path, threads=threads)
+    lib = bf.lib
+    _lib.check(lib.cv_bam_view_begin(bf.h, ctg.encode(), int(start or 0), int(end or 0), mask, 0))
+    base = ctypes.c_void_p(); offs = ctypes.c_void_p(); done = ctypes.c_int(0)
+    out = []
+    while not done.value:
+        n = lib.cv_bam_view_records(bf.h, window, ctypes.byref(base), ctypes.byref(offs), ctypes.byref(done))
+        assert n >= 0, _lib.last_error() if hasattr(_lib, "last_error") else "error"
+        if n == 0:
+            continue
+        o = np.ctypeslib.as_array(ctypes.cast(offs, ctypes.POINTER(ctypes.c_uint32)), shape=(n,)).copy()
+        for off in o:
+            bs = struct.unpack("<i", ctypes.string_at(base.value + int(off) - 4, 4))[0]
+            r = ctypes.string_at(base.value + int(off), bs)
+            _tid, pos, l_name, _mq, _bin, n_cig, flag, l_seq = struct.unpack("<iiBBHHHi", r[:20])
+            name = r[32:32 + l_name - 1].decode()
+            cig = struct.unpack("<%dI" % n_cig, r[32 + l_name:32 + l_name + 4 * n_cig])
+            cigar = "".join("%d%s" % (c >> 4, "MIDNSHP=X"[c & 15]) for c in cig) or "*"
+            sq = r[32 + l_name + 4 * n_cig:32 + l_name + 4 * n_cig + (l_seq + 1) // 2]
+            seq = "".join("=ACMGRSVTWYHKDBN"[(sq[k >> 1] >> (4 if k % 2 == 0 else 0)) & 15] for k in range(l_seq)) or "*"
+            out.append((name, flag, pos + 1, cigar, seq))
+    bf.close()
+    return out
+
+
+@pytest.mark.parametrize("case", ["plain", "noisy", "eqx", "handmade"])
+@pytest.mark.parametrize("payload,window", [(60000, 65536), (777, 65536), (4093, 1 << 20)])
+def test_raw_record_view_selects_what_the_text_view_prints(case, payload, window, tmp_path):
+    """cv_bam_view_records (the feed of cv_pileup_add_bam) hands out exactly the records of the text view, in order"""
+    recs = sam_records(case)
+    L = 3000 if case != "handmade" else 320
+    bam = str(tmp_path / "a.bam")
+    write_bam(bam, recs, [("ctgA", max(L, 4000)), ("other", 10)], block_payload=payload, index=True)
+    for start, end in ((None, None), (1, 50), (601, 2900), (1500, 1500), (2990, 100000)):
+        want = [(f[0], int(f[1]), int(f[3]), f[5], f[9]) for f in (l.split("\t") for l in expected(recs, "ctgA", start, end))]
+        assert view_records(bam, "ctgA", start, end, window=window) == want
+    assert view_records(bam, "nope") == [] and view_records(bam, "other") == []

@@ -501,3 +501,84 @@ def test_pileup_counts_are_additive_over_the_reads_at_scale():
         pl.close()
     assert np.array_equal(cands[0][0], cands[1][0]) and np.array_equal(cands[0][1], cands[1][1])
     assert cands[0][2] == 300000 and len(cands[0][0]) > 1000
+
+
+def _both_feeds(tmp_path, ref, recs, centers, region=(None, None), payload=60000, **kw):
+    """the same alignments through the SAM text and straight from BAM records -> two tuples of results"""
+    from bam_writer import write_bam
+    from clairvoyante_amd.bam import BamFile
+    from clairvoyante_amd.pileup import Pileup
+    bam = str(tmp_path / ("f%d.bam" % payload))
+    write_bam(bam, recs, [("ctgA", len(ref)), ("zzz", 50)], block_payload=payload, index=True)
+    outs = []
+    for feed in ("text", "bam"):
+        pl = Pileup(contig="ctgA", **kw)
+        pl.set_reference(ref, 0)
+        if centers is not None:
+            pl.set_candidates(centers)
+        bf = BamFile(bam, threads=3)
+        if feed == "text":
+            for chunk in bf.view("ctgA", region[0], region[1], chunk=1 << 20):
+                pl.add_sam(chunk)
+        else:
+            pl.add_bam(bf, "ctgA", region[0], region[1], window=1 << 20)
+        bf.close()
+        res = None
+        if kw.get("evc"):
+            res = pl.extract_candidates(0.1, 3)
+            if kw.get("retain"):
+                pl.adopt_candidates()
+        t, d, u = pl.finish()
+        outs.append((pl.centers.copy(), t.cpu().numpy(), d.cpu().numpy(), u.cpu().numpy(), pl.reads_kept,
+                     None if res is None else (res["pos0"], res["late"], res["counts"], res["reads"])))
+        pl.close()
+    return outs
+
+
+def _same(a, b):
+    for x, y in zip(a[:5], b[:5]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    if a[5] is not None:
+        for x, y in zip(a[5], b[5]):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
+def test_bam_records_feed_equals_the_sam_text_feed_on_corner_cases(tmp_path):
+    """cv_pileup_add_bam takes every record as the line `samtools view` prints for it: SEQ '*', CIGAR '*', '='/'X',
+    padding, clips, an insertion-only read, runs longer than 64 columns, the per-POS depth cap"""
+    ref = ("ACGTTGCA" * 40)
+    recs = [
+        "a\t0\tctgA\t1\t60\t20M\t*\t0\t0\t" + ref[0:20] + "\t*",
+        "b\t0\tctgA\t1\t60\t10M5I10M\t*\t0\t0\t" + ref[0:10] + "GGGGG" + ref[10:20] + "\t*",
+        "c\t0\tctgA\t3\t60\t30M\t*\t0\t0\t*\t*",
+        "c2\t0\tctgA\t4\t60\t*\t*\t0\t0\tACGT\t*",
+        "d\t0\tctgA\t5\t60\t70I1M\t*\t0\t0\t" + "A" * 70 + "C\t*",
+        "d2\t0\tctgA\t5\t7\t2I6=1X3D4M\t*\t0\t0\tTT" + ref[4:10] + "G" + ref[14:18] + "\t*",
+        "e\t0\tctgA\t9\t60\t5S100M20D50M3H\t*\t0\t0\t" + "T" * 5 + ref[8:108] + ref[128:178] + "\t*",
+        "f\t0\tctgA\t9\t60\t8S\t*\t0\t0\tACGTACGT\t*",
+        "g\t0\tctgA\t40\t60\t3M2P4M\t*\t0\t0\t" + ref[39:46] + "\t*",
+        "g2\t0\tctgA\t40\t60\t3M5N4M\t*\t0\t0\t" + ref[39:42] + ref[47:51] + "\t*",
+        "g3\t1024\tctgA\t41\t60\t9M\t*\t0\t0\t" + ref[40:49] + "\t*",            # duplicate: -F 2308 drops it
+        "h\t0\tctgA\t300\t60\t12M\t*\t0\t0\t" + ref[299:311].lower() + "\t*",
+    ]
+    centers = np.asarray([1, 2, 5, 6, 17, 18, 19, 25, 40, 44, 60, 100, 129, 150, 300, 310, len(ref)], dtype=np.int64)
+    for kw in (dict(dcov=1), dict(dcov=250, considerleftedge=False), dict(dcov=250, minMQ=10)):
+        a, b = _both_feeds(tmp_path, ref, recs, centers, **kw)
+        _same(a, b)
+        assert a[4] > 0 and a[3].any()
+    a, b = _both_feeds(tmp_path, ref, recs, None, evc=True, retain=True, evc_minMQ=5, dcov=2)
+    _same(a, b)
+    a, b = _both_feeds(tmp_path, ref, recs, centers, region=(10, 45), payload=311)
+    _same(a, b)
+
+
+@pytest.mark.parametrize("threads,region", [(1, (None, None)), (7, (None, None)), (5, (9000, 21000))])
+def test_bam_records_feed_equals_the_sam_text_feed_on_random_alignments(tmp_path, threads, region):
+    """24 000 noisy reads, candidate extraction + retained tensor pass, depth cap 3: identical candidates, late marks,
+    counters, tensors, depths and read counts whether the alignments arrive as text or as BAM records"""
+    from clairvoyante_amd import synth_pileup as sp
+    ref, lines = sp.make_alignments(seed=902, ref_len=40000, n_reads=24000, profile=sp.NOISY_PROFILE, stack=9, read_len=(40, 120))
+    a, b = _both_feeds(tmp_path, ref, lines, None, region=region, evc=True, retain=True, dcov=3, minMQ=3, evc_minMQ=5,
+                       threads=threads)
+    _same(a, b)
+    assert len(a[0]) > 300 and a[5][1].sum() > 0

@@ -30,6 +30,39 @@ def main():
         bf.close()
         print("threads %2d: %.2f s -> %.0f MB/s of SAM text, %.0f MB/s of BAM, %.2f M reads/s" % (
             threads, dt, nbytes / dt / 1e6, os.path.getsize(bam) / dt / 1e6, n_reads / dt / 1e6))
+    if "--feed" in sys.argv:
+        import ctypes
+        from clairvoyante_amd import _lib
+        for threads in (4, 16):                   # inflate + record walk alone
+            bf = BamFile(bam, threads=threads)
+            _lib.check(bf.lib.cv_bam_view_begin(bf.h, b"ctgA", 0, 0, 2308, 0))
+            base = ctypes.c_void_p(); offs = ctypes.c_void_p(); done = ctypes.c_int(0)
+            t0 = time.time(); k = 0
+            while not done.value:
+                k += bf.lib.cv_bam_view_records(bf.h, 64 << 20, ctypes.byref(base), ctypes.byref(offs), ctypes.byref(done))
+            dt = time.time() - t0
+            bf.close()
+            print("records only threads %2d: %.3f s -> %.2f M reads/s (%d records)" % (threads, dt, n_reads / dt / 1e6, k))
+        # host side of the front end: BAM -> segments queued for the GPU, through the SAM text and straight from the records
+        from clairvoyante_amd.pileup import Pileup
+        for feed in ("text", "records"):
+            for threads in (4, 16):
+                pl = Pileup(evc=True, retain=True, contig="ctgA", threads=threads)
+                pl.set_reference(ref, 0)
+                bf = BamFile(bam, threads=threads)
+                t0 = time.time()
+                if feed == "text":
+                    for c in bf.view("ctgA"):
+                        pl.add_sam(c)
+                else:
+                    pl.add_bam(bf, "ctgA")
+                import torch
+                torch.cuda.synchronize()
+                dt = time.time() - t0
+                bf.close()
+                print("feed %-7s threads %2d: %.2f s -> %.2f M reads/s, %.0f MB/s of BAM (%d reads kept)" % (
+                    feed, threads, dt, n_reads / dt / 1e6, os.path.getsize(bam) / dt / 1e6, pl.reads_kept))
+                pl.close()
     if "--e2e" in sys.argv:
         import common
         from oracle import cv_oracle as O
