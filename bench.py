@@ -224,6 +224,12 @@ def train_main(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
+        # whole step against the matrix-core roof: forward + data gradients + weight gradients = 3 x the forward
+        # FLOPs per candidate; the step is a chain of ~45 kernels, no single one dominates
+        tf = steps * gb / dt / ws * 3 * FLOP_EXACT[args.arch] / 1e12
+        roof = {"bound": "mfma", "kernel": "whole step (forward, data gradients, weight gradients, Adam)",
+                "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
+                "traffic": None}
         print(json.dumps({"metric": "training candidate tensors/sec", "value": steps * gb / dt, "unit": "candidates/s",
                           "n_gpus": ws, "steps": steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
@@ -231,7 +237,7 @@ def train_main(args):
                           "config": {"workload": "v3 %s training, Adam step on a global batch of %d synthetic labelled "
                                                  "[33,4,4] tensors, dropout 0.5, lambda 1e-3" % (args.arch, gb),
                                      "arch": args.arch, "global_batch": gb, "parallelism": "dp%d" % ws},
-                          "final_loss": float(loss)}), flush=True)
+                          "roofline": roof, "final_loss": float(loss)}), flush=True)
     m.close()
     if use_dist:
         dist.barrier()
