@@ -1,4 +1,4 @@
-// cv_train.hip -- loss, backward and dropout of the training step (plain kernels).
+// cv_train.hip -- loss, backward and dropout of the training step.
 //
 // Replaces the session.run((loss, training_op, ...)) of train / trainNoRT and
 // session.run(loss) of getLoss / getLossNoRT
@@ -8,12 +8,13 @@
 //   alpha-dropout on fc4 (selu.py:34-69): keep mask from a counter-based hash of
 //   (seed, step, candidate, unit) -- the reference's stream is unseeded TF state, so
 //   only the distribution can match.
-// The forward pass and the data-gradient GEMMs (fc4, conv3, conv2) run on the MFMA tile
-// kernels (cv_kernels_mfma.hip: conv_tm MODE 1/2, dense_tm EPI 1); the element-wise steps
-// (SELU', pool routing, dropout) and the weight-gradient reductions are plain kernels on
-// natural-layout copies for now.  Gradients accumulate into the flat buffer
-// (cv_grad_buffer) with float atomics across batch slices.  Architectures the tile kernels
-// do not cover fall back to the all-plain path (train_slice_plain).
+// Forward pass, data gradients and weight gradients all run on the MFMA tile kernels
+// (cv_kernels_mfma.hip: conv_tm MODE 1/2, dense_tm EPI 1, wgrad_*_cm); this file holds the
+// element-wise steps on tile-major buffers (SELU', max-pool routing, dropout, loss, head data
+// gradients) and the sequence of the step.  Gradients accumulate into the flat buffer
+// (cv_grad_buffer) slice by slice in stream order; every weight gradient is reduced in a
+// fixed order (no float atomics), so a step is reproducible bit for bit.  Architectures the
+// tile kernels do not cover fall back to the all-plain path (train_slice_plain, atomics).
 #include "cv_internal.hpp"
 #include "cv_math.hpp"
 
@@ -629,7 +630,7 @@ static int train_slice_plain(cv_model *m, const float *x, const float *y, int64_
     CV_HIP(hipGetLastError());
     if (!backward) return 0;
     // ---- backward
-    const int NS = 128;     // candidate-range splits of the head weight gradients (short serial loops, few atomics)   // batch slices for the weight-gradient reductions
+    const int NS = 128;     // candidate-range slices of the weight-gradient reductions (short serial loops, few atomics)
     // heads: columns of ghpre: 0..3 base (input d4), 4..5 / 6..9 / 10..15 (input h5)
     b_dense_wgrad<<<dim3(nblk((a.fc4 + 1) * 4, 256), NS), 256, 0, st>>>(d4, a.fc4, ghpre + 0, 16, n, a.fc4, 4, G + o[10], G + o[11]);
     b_dense_wgrad<<<dim3(nblk((a.fc5 + 1) * 2, 256), NS), 256, 0, st>>>(h5, a.fc5, ghpre + 4, 16, n, a.fc5, 2, G + o[12], G + o[13]);
