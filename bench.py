@@ -201,7 +201,7 @@ def train_main(args):
     m._seed_rng.seed(1234)
     m.init()
     parallel.broadcast_parameters(m)
-    gb = param.trainBatchSize
+    gb = param.trainBatchSize if args.batch == BATCH else args.batch      # --batch: another global batch (default: the reference's)
     lo, hi = parallel.shard_range(gb, rank, ws)
     xt, cls, rf, alt, il = synth.make_candidates(gb, seed=synth.BASE_SEED, device=dev, return_class=True)
     y = synth.make_labels(cls, rf, alt, il)[lo:hi].contiguous(); x = xt[lo:hi].contiguous()

@@ -745,9 +745,12 @@ static int train_pass(cv_model *m, const float *x, const float *y, int64_t n, bo
     if (n > 0 && (!x || !y)) { cv_set_error("null buffer"); return 1; }
     if (drop4 < 0.0f || drop4 >= 1.0f) { cv_set_error("dropout rate must be in [0,1)"); return 1; }
     CV_HIP(hipSetDevice(m->device));
-    const int64_t slice = 16384;        // one pass for train.py's batch of 10 000
-    const size_t need = (train_floats_per_cand(m) * (size_t)((n < slice ? (n > 0 ? n : 1) : slice) + 16)
-                         ) * sizeof(float);
+    // one pass for train.py's batch of 10 000; larger batches go in equal slices of at most 65 536 candidates
+    // (the kernels are at their best on thousands of groups, and HBM has room: ~0.4 MB of workspace per candidate)
+    const int64_t max_slice = 65536;
+    const int64_t nslice = n > 0 ? (n + max_slice - 1) / max_slice : 1;
+    const int64_t slice = n > 0 ? ((n + nslice - 1) / nslice + 15) / 16 * 16 : 16;
+    const size_t need = train_floats_per_cand(m) * (size_t)(slice + 16) * sizeof(float);
     if (m->t_bytes < need) {
         if (m->t_buf) CV_HIP(hipFree(m->t_buf));
         m->t_buf = nullptr; m->t_bytes = 0;
