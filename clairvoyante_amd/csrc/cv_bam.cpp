@@ -34,6 +34,34 @@ inline uint64_t rd_u64(const uint8_t *p) { return (uint64_t)rd_u32(p) | ((uint64
 
 struct ref_t { std::string name; int64_t len; };
 
+// growable byte buffer without value-initialisation (std::vector<uint8_t>::resize zero-fills every inflated
+// byte before the decoder overwrites it, and re-copies everything when it grows: that cost as much as inflating)
+struct bytebuf {
+    uint8_t *p = nullptr;
+    size_t n = 0, cap = 0;
+    ~bytebuf() { free(p); }
+    bytebuf() = default;
+    bytebuf(const bytebuf &) = delete;
+    bytebuf &operator=(const bytebuf &) = delete;
+    uint8_t *data() { return p; }
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+    void clear() { n = 0; }
+    bool resize(size_t want)                                   // new bytes are uninitialised; false = out of memory
+    {
+        if (want > cap) {
+            size_t c = cap ? cap : (size_t)1 << 20;
+            while (c < want) c += c / 2 + ((size_t)1 << 20);
+            uint8_t *q = (uint8_t *)realloc(p, c);
+            if (!q) return false;
+            p = q; cap = c;
+        }
+        n = want;
+        return true;
+    }
+    void drop_front(size_t k) { memmove(p, p + k, n - k); n -= k; }
+};
+
 }  // namespace
 
 struct cv_bam {
@@ -49,10 +77,10 @@ struct cv_bam {
     int exclude = 0, with_qual = 0, threads = 1;
     bool done = true;
     int64_t next_coff = 0;                   // file offset of the next BGZF block to read
-    std::vector<uint8_t> data;               // inflated bytes not yet consumed
+    bytebuf data;                            // inflated bytes not yet consumed
     size_t data_pos = 0;
     bool eof = false;
-    std::vector<uint8_t> comp;               // scratch: compressed blocks of one batch
+    bytebuf comp;                            // scratch: compressed blocks of one batch
     std::vector<uint32_t> rec_offs;          // cv_bam_view_records: starts of the selected records in `data`
 };
 
@@ -82,12 +110,21 @@ bool inflate_block(z_stream &zs, const uint8_t *blk, int bsize, uint8_t *dst, in
     const int clen = bsize - 12 - xlen - 8;
     const uint32_t isize = rd_u32(blk + bsize - 4);
     if (clen < 0 || isize > 65536) return false;
+    const uint32_t want = rd_u32(blk + bsize - 8);
+    // the block decoder of cv_inflate.cpp first (the 8 bytes of trailer behind the stream are its read slack);
+    // anything it rejects, or gets past its own checks but not past the CRC, goes to zlib
+#ifndef CV_BAM_ZLIB_ONLY                                   /* development: A/B against zlib alone */
+    if (cv_inflate_raw(cdata, clen, dst, (int64_t)isize) == (int64_t)isize && cv_crc32_ieee(0, dst, (int64_t)isize) == want) {
+        *dlen = (int)isize;
+        return true;
+    }
+#endif
     if (inflateReset(&zs) != Z_OK) return false;
     zs.next_in = const_cast<uint8_t *>(cdata); zs.avail_in = (uInt)clen;
     zs.next_out = dst; zs.avail_out = isize;             // never past the block's own place in the stream
     const int rc = inflate(&zs, Z_FINISH);
     if (rc != Z_STREAM_END || zs.total_out != isize) return false;
-    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, isize) != rd_u32(blk + bsize - 8)) return false;
+    if (cv_crc32_ieee(0, dst, (int64_t)isize) != want) return false;
     *dlen = (int)isize;
     return true;
 }
@@ -97,9 +134,9 @@ int fill(cv_bam *b, int max_blocks)
 {
     if (b->eof) return 0;
     if (b->data_pos > 0 && b->data_pos == b->data.size()) { b->data.clear(); b->data_pos = 0; }
-    else if (b->data_pos > (1u << 22)) { b->data.erase(b->data.begin(), b->data.begin() + (long)b->data_pos); b->data_pos = 0; }
+    else if (b->data_pos > (1u << 22)) { b->data.drop_front(b->data_pos); b->data_pos = 0; }
     const size_t want = (size_t)max_blocks * 65536 + 65536;
-    b->comp.resize(want);
+    if (!b->comp.resize(want)) { cv_set_error("bam: out of memory"); return 1; }
     if (fseeko(b->fp, (off_t)b->next_coff, SEEK_SET)) { cv_set_error("bam: seek failed"); return 1; }
     const size_t got = fread(b->comp.data(), 1, want, b->fp);
     if (got == 0) { b->eof = true; return 0; }
@@ -127,7 +164,7 @@ int fill(cv_bam *b, int max_blocks)
         if (isize > 65536) { cv_set_error("bam: corrupt BGZF block at offset %lld", (long long)(b->next_coff + (int64_t)boff[i])); return 1; }
         dst[i + 1] = dst[i] + isize;
     }
-    b->data.resize(base + dst[nb]);
+    if (!b->data.resize(base + dst[nb])) { cv_set_error("bam: out of memory"); return 1; }
     std::vector<int> dlen(nb, 0);
     std::vector<char> ok(nb, 0);
     int T = b->threads < 1 ? 1 : b->threads;

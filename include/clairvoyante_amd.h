@@ -300,6 +300,11 @@ int64_t cv_bam_view_read(cv_bam *b, char *buf, int64_t cap, int *done);
  * The pointers stay valid until the next call on the handle; 0 and *done = 1 at the end, -1 on error.
  * Feeds cv_pileup_add_bam.                                                                             */
 int64_t cv_bam_view_records(cv_bam *b, int64_t max_bytes, const uint8_t **base, const uint32_t **offs, int *done);
+/* The block decoder behind the BGZF reader (raw DEFLATE, RFC 1951, whole block in memory): src[0, n) must be
+ * followed by 8 readable bytes, the stream must produce exactly cap bytes; returns cap or -1.  And the CRC-32 of
+ * the gzip trailer (start with crc = 0).                                                                 */
+int64_t cv_inflate_raw(const uint8_t *src, int64_t n, uint8_t *dst, int64_t cap);
+uint32_t cv_crc32_ieee(uint32_t crc, const uint8_t *p, int64_t n);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,112 @@
+"""Host only: the block DEFLATE decoder of the native BAM reader (csrc/cv_inflate.cpp) against zlib -- every
+compression level and strategy (stored, fixed and dynamic codes, long and short distances, several DEFLATE blocks per
+stream, empty and 64 KiB outputs), and malformed input: truncated, bit-flipped and random streams must be rejected or
+at worst decode to something else -- never write outside the output buffer."""
+import ctypes
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from clairvoyante_amd import _lib
+    L = _lib.load()
+    L.cv_inflate_raw.restype = ctypes.c_int64
+    L.cv_inflate_raw.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+    return L
+
+
+def inflate(lib, comp, size, guard=64):
+    """-> (return code, output bytes, guard intact)"""
+    src = np.frombuffer(comp + b"\xa5" * 8, dtype=np.uint8).copy()          # 8 readable bytes behind the stream
+    dst = np.full(size + guard, 0x5A, dtype=np.uint8)
+    rc = lib.cv_inflate_raw(src.ctypes.data_as(ctypes.c_void_p), len(comp), dst.ctypes.data_as(ctypes.c_void_p), size)
+    return rc, dst[:size].tobytes(), bool((dst[size:] == 0x5A).all())
+
+
+def raw_deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, flush_every=None):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    if flush_every is None:
+        return co.compress(data) + co.flush()
+    out = b""
+    for s in range(0, len(data), flush_every):
+        out += co.compress(data[s:s + flush_every]) + co.flush(zlib.Z_FULL_FLUSH if (s // flush_every) % 2 else zlib.Z_SYNC_FLUSH)
+    return out + co.flush()
+
+
+def corpora():
+    rng = np.random.RandomState(5)
+    bam_like = b"".join(rng.bytes(4) + b"\x00" * 3 + bytes([rng.randint(60)]) + b"readname%05d\x00" % i
+                        + rng.choice(np.frombuffer(b"\x11\x12\x14\x18\x21\x22\x24\x28\x41\x42\x44\x48\x81\x82\x84\x88", np.uint8), 75).tobytes()
+                        + b"\xff" * 150 for i in range(260))
+    return {
+        "empty": b"", "one": b"x", "two": b"ab", "zeros": b"\0" * 65536, "run": b"abcabcabc" * 5000,
+        "random": rng.bytes(65536), "random_small": rng.bytes(300),
+        "text": (b"the quick brown fox jumps over the lazy dog. " * 1500)[:65536],
+        "skewed": rng.choice(np.frombuffer(b"ACGTN\n", np.uint8), 65536, p=[.3, .2, .2, .28, .01, .01]).tobytes(),
+        "bam_like": bam_like[:65536],
+        "far_matches": (rng.bytes(30000) + rng.bytes(2000) * 3 + rng.bytes(100))[:65536] + b"",
+        "all_bytes": bytes(range(256)) * 200,
+    }
+
+
+@pytest.mark.parametrize("name", sorted(corpora()))
+def test_decoder_equals_zlib(lib, name):
+    data = corpora()[name]
+    streams = [raw_deflate(data, lvl) for lvl in range(0, 10)]
+    streams += [raw_deflate(data, 6, st) for st in (zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED)]
+    streams += [raw_deflate(data, 5, flush_every=f) for f in (1000, 7777)] if len(data) > 2000 else []
+    for comp in streams:
+        assert zlib.decompress(comp, -15) == data
+        rc, out, intact = inflate(lib, comp, len(data))
+        assert intact
+        assert rc == len(data) and out == data
+
+
+def test_wrong_sizes_and_truncation_are_rejected(lib):
+    data = corpora()["text"]
+    comp = raw_deflate(data, 6)
+    for size in (len(data) - 1, len(data) + 1, 0, 10):
+        rc, _out, intact = inflate(lib, comp, size)
+        assert rc == -1 and intact
+    for cut in (1, 2, 5, len(comp) // 2, len(comp) - 1):
+        rc, _out, intact = inflate(lib, comp[:cut], len(data))
+        assert intact and rc == -1
+
+
+def test_garbage_never_writes_outside_the_buffer(lib):
+    rng = np.random.RandomState(9)
+    data = corpora()["bam_like"]
+    comp = bytearray(raw_deflate(data, 6))
+    ok = 0
+    for trial in range(3000):
+        c = bytearray(comp)
+        for _ in range(rng.randint(1, 4)):
+            c[rng.randint(len(c))] ^= 1 << rng.randint(8)
+        rc, out, intact = inflate(lib, bytes(c), len(data))
+        assert intact
+        ok += rc == len(data) and out == data
+    assert ok < 3000                                        # most flips break the stream or change the bytes
+    for trial in range(2000):
+        c = rng.bytes(rng.randint(1, 400))
+        rc, _out, intact = inflate(lib, c, rng.randint(0, 70000))
+        assert intact
+
+
+def test_crc32_equals_zlib(lib):
+    rng = np.random.RandomState(3)
+    for n in (0, 1, 7, 15, 16, 17, 31, 33, 1000, 65536):
+        d = rng.bytes(n)
+        a = np.frombuffer(d + b"\0", dtype=np.uint8).copy()
+        assert lib.cv_crc32_ieee(0, a.ctypes.data_as(ctypes.c_void_p), n) == (zlib.crc32(d) & 0xffffffff)
+    d = rng.bytes(5000)                                      # running value over pieces
+    a = np.frombuffer(d, dtype=np.uint8).copy()
+    c = lib.cv_crc32_ieee(0, a.ctypes.data_as(ctypes.c_void_p), 1234)
+    c = lib.cv_crc32_ieee(c, ctypes.c_void_p(a.ctypes.data + 1234), 5000 - 1234)
+    assert c == (zlib.crc32(d) & 0xffffffff)
