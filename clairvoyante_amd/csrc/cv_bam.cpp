@@ -9,8 +9,8 @@
 // tests/bam_writer.py from the same SAM text -- "parity unpinned" against htslib itself.
 //
 // Printed per record (what the consumers read): QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL, QUAL as '*'
-// unless asked for; auxiliary tags are not printed.  Records with more than 65535 CIGAR operations (stored in a CG tag)
-// are reported as an error.
+// unless asked for; auxiliary tags are not printed.  A record with more than 65535 CIGAR operations keeps the
+// placeholder <l_seq>S<span>N inline and the real operations in its CG:B,I tag (SAMv1 4.2.2): the real ones are used.
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -311,6 +311,46 @@ extern "C" int cv_bam_ref(const cv_bam *b, int i, const char **name, int64_t *le
 
 extern "C" int cv_bam_has_index(const cv_bam *b) { return b && b->has_index ? 1 : 0; }
 
+// The CIGAR words of a record (rec at refID, its int32 block_size right before it): the inline ones, or the
+// CG:B,I array when the inline CIGAR is the long-read placeholder.  0 ok, 1 = placeholder without a usable tag.
+extern "C" int cv_bam_record_cigar(const uint8_t *rec, const uint8_t **ops, int64_t *n)
+{
+    const int64_t bs = rd_i32(rec - 4);
+    const int l_name = rec[8];
+    const int n_cig = rd_u16(rec + 12);
+    const int64_t l_seq = rd_i32(rec + 16);
+    const uint8_t *cig = rec + 32 + l_name;
+    *ops = cig; *n = n_cig;
+    if (!(n_cig == 2 && (rd_u32(cig) & 15) == 4 && (int64_t)(rd_u32(cig) >> 4) == l_seq && (rd_u32(cig + 4) & 15) == 3))
+        return 0;
+    const uint8_t *a = cig + 8 + (l_seq + 1) / 2 + l_seq, *const end = rec + bs;
+    while (a + 3 <= end) {
+        const char t0 = (char)a[0], t1 = (char)a[1], ty = (char)a[2];
+        a += 3;
+        int64_t sz;
+        switch (ty) {
+        case 'A': case 'c': case 'C': sz = 1; break;
+        case 's': case 'S': sz = 2; break;
+        case 'i': case 'I': case 'f': sz = 4; break;
+        case 'Z': case 'H': { const void *z = memchr(a, 0, (size_t)(end - a)); if (!z) return 1; sz = (const uint8_t *)z - a + 1; break; }
+        case 'B': {
+            if (a + 5 > end) return 1;
+            const char sub = (char)a[0];
+            const int64_t cnt = rd_i32(a + 1);
+            const int64_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : 0;
+            if (!es || cnt < 0 || a + 5 + cnt * es > end) return 1;
+            if (t0 == 'C' && t1 == 'G' && sub == 'I') { *ops = a + 5; *n = cnt; return 0; }
+            sz = 5 + cnt * es;
+            break;
+        }
+        default: return 1;
+        }
+        if (a + sz > end) return 1;
+        a += sz;
+    }
+    return 1;
+}
+
 extern "C" int cv_bam_view_begin(cv_bam *b, const char *ref, int64_t beg1, int64_t end1, int exclude_flags, int with_qual)
 {
     if (!b || !ref) { cv_set_error("cv_bam_view_begin: null argument"); return 1; }
@@ -398,10 +438,9 @@ extern "C" int64_t cv_bam_view_records(cv_bam *b, int64_t max_bytes, const uint8
                 }
                 if (span < 1) span = 1;
                 if ((int64_t)rpos + span <= b->beg0) take = false;
-                if (take && n_cig == 2 && (rd_u32(cig) & 15) == 4 && (int64_t)(rd_u32(cig) >> 4) == l_seq &&
-                    (rd_u32(cig + 4) & 15) == 3) {
-                    cv_set_error("bam: a record keeps its CIGAR in a CG tag (more than 65535 operations): not supported");
-                    return -1;
+                if (take) {                      // the long-read placeholder must come with its CG tag
+                    const uint8_t *ops; int64_t nops;
+                    if (cv_bam_record_cigar(r, &ops, &nops)) { cv_set_error("bam: placeholder CIGAR without a CG:B,I tag"); return -1; }
                 }
             }
             if (take) b->rec_offs.push_back((uint32_t)(pos + 4));
@@ -459,13 +498,12 @@ extern "C" int64_t cv_bam_view_read(cv_bam *b, char *buf, int64_t cap, int *done
             }
             if (span < 1) span = 1;
             if ((int64_t)pos + span <= b->beg0) take = false;
-            if (take && n_cig == 2 && (rd_u32(cig) & 15) == 4 && (int64_t)(rd_u32(cig) >> 4) == l_seq && (rd_u32(cig + 4) & 15) == 3) {
-                cv_set_error("bam: a record keeps its CIGAR in a CG tag (more than 65535 operations): not supported");
-                return -1;
-            }
         }
+        const uint8_t *rcig = cig;
+        int64_t rn = n_cig;
+        if (take && cv_bam_record_cigar(r, &rcig, &rn)) { cv_set_error("bam: placeholder CIGAR without a CG:B,I tag"); return -1; }
         if (take) {
-            const int64_t worst = l_name + 16 + (int64_t)b->refs[(size_t)tid].name.size() * 2 + 12 * 6 + 11 * (int64_t)n_cig + 2 * l_seq + 16;
+            const int64_t worst = l_name + 16 + (int64_t)b->refs[(size_t)tid].name.size() * 2 + 12 * 6 + 11 * rn + 2 * l_seq + 16;
             if (wend - w < worst) {
                 if (w == buf) { cv_set_error("cv_bam_view_read: buffer of %lld bytes is too small for one record", (long long)cap); return -1; }
                 break;                                  // the caller comes back for this record
@@ -476,9 +514,9 @@ extern "C" int64_t cv_bam_view_read(cv_bam *b, char *buf, int64_t cap, int *done
             *w++ = '\t'; w = put_int(w, (int64_t)pos + 1);
             *w++ = '\t'; w = put_int(w, mapq);
             *w++ = '\t';
-            if (n_cig == 0) *w++ = '*';
-            for (int k = 0; k < n_cig; k++) {
-                const uint32_t c = rd_u32(cig + 4 * k);
+            if (rn == 0) *w++ = '*';
+            for (int64_t k = 0; k < rn; k++) {
+                const uint32_t c = rd_u32(rcig + 4 * k);
                 w = put_int(w, c >> 4);
                 *w++ = (c & 15) < 9 ? OPS[c & 15] : '?';
             }

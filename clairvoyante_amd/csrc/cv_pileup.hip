@@ -675,6 +675,7 @@ static void parse_range(const cv_pileup *p, sam_part *out, const char *cur, cons
 // Everything follows parse_record on the line `samtools view` would print for the record: SEQ "*" for l_seq 0,
 // CIGAR "*" for no operations, RNAME = the contig of the view.
 static inline int32_t le32(const uint8_t *q) { int32_t v; memcpy(&v, q, 4); return v; }
+extern "C" int cv_bam_record_cigar(const uint8_t *rec, const uint8_t **ops, int64_t *n);      // cv_bam.cpp
 
 static bool parse_bam_record(const cv_pileup *p, sam_part &out, const uint8_t *rec, bool contig_ok)
 {
@@ -682,13 +683,15 @@ static bool parse_bam_record(const cv_pileup *p, sam_part &out, const uint8_t *r
     const int64_t pos = le32(rec + 4);
     const int l_name = rec[8];
     const int64_t mq = rec[9];
-    const int n_cig = (int)(rec[12] | (rec[13] << 8));
+    const int n_inline = (int)(rec[12] | (rec[13] << 8));
     const int64_t l_seq = le32(rec + 16);
+    const uint8_t *sq = rec + 32 + l_name + 4 * (size_t)n_inline;
     const uint8_t *cg = rec + 32 + l_name;
-    const uint8_t *sq = cg + 4 * (size_t)n_cig;
+    int64_t n_cig = n_inline;
+    if (cv_bam_record_cigar(rec, &cg, &n_cig)) { out.err = "cv_pileup_add_bam: placeholder CIGAR without a CG:B,I tag"; return false; }
     const int64_t seqlen = l_seq > 0 ? l_seq : 1;          // "*"
     int64_t need = 0, total = 0, clipped = 0;
-    for (int k = 0; k < n_cig; k++) {
+    for (int64_t k = 0; k < n_cig; k++) {
         const uint32_t c = (uint32_t)le32(cg + 4 * k);
         const int op = (int)(c & 15);
         const int64_t v = c >> 4;
@@ -722,7 +725,7 @@ static bool parse_bam_record(const cv_pileup *p, sam_part &out, const uint8_t *r
     read_rec rr;
     rr.pos = pos; rr.seg0 = (uint32_t)out.segs.size(); rr.ct = ct_ok; rr.evc = evc_ok; rr.leading = 0;
     int64_t r = pos, q = 0;
-    for (int k = 0; k < n_cig; k++) {
+    for (int64_t k = 0; k < n_cig; k++) {
         const uint32_t c = (uint32_t)le32(cg + 4 * k);
         const int op = (int)(c & 15);
         const int64_t v = c >> 4;

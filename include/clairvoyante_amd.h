@@ -300,6 +300,9 @@ int64_t cv_bam_view_read(cv_bam *b, char *buf, int64_t cap, int *done);
  * The pointers stay valid until the next call on the handle; 0 and *done = 1 at the end, -1 on error.
  * Feeds cv_pileup_add_bam.                                                                             */
 int64_t cv_bam_view_records(cv_bam *b, int64_t max_bytes, const uint8_t **base, const uint32_t **offs, int *done);
+/* CIGAR words of a record handed out by cv_bam_view_records (rec at refID): the inline ones, or the CG:B,I array
+ * behind the long-read placeholder <l_seq>S<span>N (more than 65535 operations, SAMv1 4.2.2).  0 ok.      */
+int cv_bam_record_cigar(const uint8_t *rec, const uint8_t **ops, int64_t *n);
 /* The block decoder behind the BGZF reader (raw DEFLATE, RFC 1951, whole block in memory): src[0, n) must be
  * followed by 8 readable bytes, the stream must produce exactly cap bytes; returns cap or -1.  And the CRC-32 of
  * the gzip trailer (start with crc = 0).                                                                 */

@@ -41,8 +41,14 @@ def encode_record(fields, tid_of):
     span = sum(n for n, o in ops if o in (0, 2, 3, 7, 8)) or 1
     l_seq = 0 if seq == "*" else len(seq)
     name = qname.encode() + b"\0"
-    out = struct.pack("<iiBBHHHiiii", tid, pos, len(name), mapq, reg2bin(pos, pos + span), len(ops), flag, l_seq, ntid, pnext, tlen)
-    out += name + b"".join(struct.pack("<I", (n << 4) | o) for n, o in ops)
+    aux = b""
+    inline = ops
+    if len(ops) > 65535:                 # SAMv1 4.2.2: placeholder <l_seq>S<span>N inline, the real CIGAR in CG:B,I
+        inline = [(l_seq, 4), (span, 3)]
+        aux = b"NMi" + struct.pack("<i", 7) + b"XZZhello\0" + b"CGBI" + struct.pack("<i", len(ops)) + \
+            b"".join(struct.pack("<I", (n << 4) | o) for n, o in ops) + b"XBBs" + struct.pack("<ihh", 2, -1, 5)
+    out = struct.pack("<iiBBHHHiiii", tid, pos, len(name), mapq, reg2bin(pos, pos + span), len(inline), flag, l_seq, ntid, pnext, tlen)
+    out += name + b"".join(struct.pack("<I", (n << 4) | o) for n, o in inline)
     sq = bytearray((l_seq + 1) // 2)
     for i in range(l_seq):
         c = seq[i].upper()
@@ -50,6 +56,7 @@ def encode_record(fields, tid_of):
         sq[i >> 1] |= v << (4 if i % 2 == 0 else 0)
     out += bytes(sq)
     out += (b"\xff" * l_seq) if qual == "*" or len(qual) != l_seq else bytes(ord(c) - 33 for c in qual)
+    out += aux
     return struct.pack("<i", len(out)) + out, tid, pos, pos + span
 
 

@@ -168,3 +168,67 @@ def test_raw_record_view_selects_what_the_text_view_prints(case, payload, window
         want = [(f[0], int(f[1]), int(f[3]), f[5], f[9]) for f in (l.split("\t") for l in expected(recs, "ctgA", start, end))]
         assert view_records(bam, "ctgA", start, end, window=window) == want
     assert view_records(bam, "nope") == [] and view_records(bam, "other") == []
+
+
+def long_cigar_records(n_ops=70001, start=100):
+    """a read whose CIGAR has more than 65535 operations (1M 1I 1M 1D ...), between two ordinary reads"""
+    rng = np.random.RandomState(4)
+    ops = []
+    while len(ops) < n_ops:
+        ops += ["1M", "1I", "2M", "1D"]
+    ops = ops[:n_ops]
+    qlen = sum(int(o[:-1]) for o in ops if o[-1] in "MI")
+    seq = "".join("ACGT"[i] for i in rng.randint(0, 4, qlen))
+    return ["r0\t0\tctgA\t%d\t60\t30M\t*\t0\t0\t%s\t*" % (start - 20, seq[:30]),
+            "long\t0\tctgA\t%d\t60\t%s\t*\t0\t0\t%s\t*" % (start, "".join(ops), seq),
+            "r2\t0\tctgA\t%d\t60\t12M3S\t*\t0\t0\t%s\t*" % (start + 500, seq[:15])]
+
+
+def test_long_cigar_comes_from_the_cg_tag(tmp_path):
+    """more than 65535 operations: the record holds <l_seq>S<span>N inline and the real CIGAR in CG:B,I (SAMv1 4.2.2);
+    text and record views give the real one; a placeholder without the tag is an error"""
+    import ctypes
+    from clairvoyante_amd import _lib
+    from clairvoyante_amd.bam import BamFile
+    recs = long_cigar_records()
+    bam = str(tmp_path / "long.bam")
+    write_bam(bam, recs, [("ctgA", 200000)], block_payload=60000, index=True)
+    assert view_text(bam, "ctgA") == expected(recs, "ctgA", None, None)
+    assert view_text(bam, "ctgA", 50000, 50010) == expected(recs, "ctgA", 50000, 50010) and len(view_text(bam, "ctgA", 50000, 50010)) == 1
+    got = view_records(bam, "ctgA", window=1 << 20)
+    assert [g[0] for g in got] == ["r0", "long", "r2"] and got[1][3].endswith("N")      # raw view: the placeholder
+    # the helper resolves it
+    bf = BamFile(bam)
+    lib = bf.lib
+    lib.cv_bam_record_cigar.restype = ctypes.c_int
+    lib.cv_bam_record_cigar.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]
+    _lib.check(lib.cv_bam_view_begin(bf.h, b"ctgA", 0, 0, 2308, 0))
+    base = ctypes.c_void_p(); offs = ctypes.c_void_p(); done = ctypes.c_int(0)
+    n = lib.cv_bam_view_records(bf.h, 1 << 22, ctypes.byref(base), ctypes.byref(offs), ctypes.byref(done))
+    assert n == 3
+    o = np.ctypeslib.as_array(ctypes.cast(offs, ctypes.POINTER(ctypes.c_uint32)), shape=(n,))
+    ops = ctypes.c_void_p(); cnt = ctypes.c_int64()
+    assert lib.cv_bam_record_cigar(ctypes.c_void_p(base.value + int(o[1])), ctypes.byref(ops), ctypes.byref(cnt)) == 0
+    words = np.ctypeslib.as_array(ctypes.cast(ops, ctypes.POINTER(ctypes.c_uint32)), shape=(cnt.value,))
+    assert "".join("%d%s" % (w >> 4, "MIDNSHP=X"[w & 15]) for w in words) == recs[1].split("\t")[5]
+    bf.close()
+    # strip the tags: block_size shrinks by the aux length, the placeholder stays -> rejected
+    import struct
+    from bam_writer import encode_record
+    blob, _t, _b, _e = encode_record(recs[1].split("\t"), {"ctgA": 0})
+    bs = struct.unpack("<i", blob[:4])[0]
+    l_seq = struct.unpack("<i", blob[4 + 16:4 + 20])[0]
+    core = 32 + blob[4 + 8] + 8 + (l_seq + 1) // 2 + l_seq
+    assert core < bs
+    bad = struct.pack("<i", core) + blob[4:4 + core]
+    import bam_writer
+    orig = bam_writer.encode_record
+    try:
+        bam_writer.encode_record = lambda f, t: (bad, 0, int(f[3]) - 1, int(f[3]) + 10) if f[0] == "long" else orig(f, t)
+        write_bam(str(tmp_path / "bad.bam"), recs, [("ctgA", 200000)], index=False)
+    finally:
+        bam_writer.encode_record = orig
+    bf = BamFile(str(tmp_path / "bad.bam"))
+    with pytest.raises(Exception):
+        b"".join(bf.view("ctgA"))
+    bf.close()

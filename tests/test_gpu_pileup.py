@@ -582,3 +582,19 @@ def test_bam_records_feed_equals_the_sam_text_feed_on_random_alignments(tmp_path
                        threads=threads)
     _same(a, b)
     assert len(a[0]) > 300 and a[5][1].sum() > 0
+
+
+def test_bam_records_feed_takes_long_cigars_from_the_cg_tag(tmp_path):
+    """a read with 70 001 CIGAR operations (placeholder inline, real CIGAR in CG:B,I): same counts from the text view
+    (which prints the real CIGAR) and from the raw records"""
+    from test_bam_native import long_cigar_records
+    recs = long_cigar_records()
+    rng = np.random.RandomState(8)
+    ref = "".join("ACGT"[i] for i in rng.randint(0, 4, 200000))
+    centers = np.asarray([90, 100, 101, 117, 5000, 50000, 52600, 52700, 60000, 199990], dtype=np.int64)
+    a, b = _both_feeds(tmp_path, ref, recs, centers, dcov=250)
+    _same(a, b)
+    assert a[3][:7].all() and a[1].sum() > 0
+    a, b = _both_feeds(tmp_path, ref, recs, None, evc=True, retain=True, evc_minMQ=5)
+    _same(a, b)
+    assert len(a[0]) > 5          # minCoverage 3: only where the three reads overlap
