@@ -430,15 +430,17 @@ extern "C" int64_t cv_bam_view_records(cv_bam *b, int64_t max_bytes, const uint8
             const uint8_t *cig = r + 32 + l_name;
             bool take = tid == b->tid && !(flag & b->exclude);
             if (take) {
-                int64_t span = 0;
-                for (int k = 0; k < n_cig; k++) {
-                    const uint32_t c = rd_u32(cig + 4 * k);
-                    const int op = (int)(c & 15);
-                    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += c >> 4;
+                if ((int64_t)rpos < b->beg0) {   // starts left of the region: does it reach in?  (else it overlaps anyway)
+                    int64_t span = 0;
+                    for (int k = 0; k < n_cig; k++) {
+                        const uint32_t c = rd_u32(cig + 4 * k);
+                        const int op = (int)(c & 15);
+                        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += c >> 4;
+                    }
+                    if (span < 1) span = 1;
+                    if ((int64_t)rpos + span <= b->beg0) take = false;
                 }
-                if (span < 1) span = 1;
-                if ((int64_t)rpos + span <= b->beg0) take = false;
-                if (take) {                      // the long-read placeholder must come with its CG tag
+                if (take && n_cig == 2) {        // the long-read placeholder must come with its CG tag
                     const uint8_t *ops; int64_t nops;
                     if (cv_bam_record_cigar(r, &ops, &nops)) { cv_set_error("bam: placeholder CIGAR without a CG:B,I tag"); return -1; }
                 }
