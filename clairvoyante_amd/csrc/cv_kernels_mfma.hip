@@ -1247,6 +1247,8 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
         f4 X0 = S.read(buf * NSLOT + NJB + 2 * wid), X1 = S.read(buf * NSLOT + NJB + 2 * wid + 1);
         if (!v0) X0 = zero;
         if (!v1) X1 = zero;
+        f4 Bnext = zero;                     // gradient fragment jb + 1, read while fragment jb is multiplied
+        if constexpr (!GNAT) Bnext = S.read(buf * NSLOT);
 #pragma unroll
         for (int jb = 0; jb < NJB; jb++) {
             f4 B;
@@ -1258,7 +1260,8 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
                         if ((int64_t)g * 16 + 4 * (lane >> 4) + t >= n) B[t] = 0.0f;
                 }
             } else {
-                B = S.read(buf * NSLOT + jb);
+                B = Bnext;
+                if (jb + 1 < NJB) Bnext = S.read(buf * NSLOT + jb + 1);
             }
 #pragma unroll
             for (int t = 0; t < 4; t++) {
