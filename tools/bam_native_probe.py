@@ -80,6 +80,13 @@ def main():
         t0 = time.time()
         res = callVarBam.Run(a)
         print("callVarBam --samtools native: %.2f s, %d reads -> %d candidates" % (time.time() - t0, res["reads"], res["candidates"]))
+        if "--profile" in sys.argv:
+            import cProfile
+            import pstats
+            pr = cProfile.Profile(); pr.enable()
+            callVarBam.Run(a)
+            pr.disable()
+            pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
 
 
 if __name__ == "__main__":
