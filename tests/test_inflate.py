@@ -110,3 +110,39 @@ def test_crc32_equals_zlib(lib):
     c = lib.cv_crc32_ieee(0, a.ctypes.data_as(ctypes.c_void_p), 1234)
     c = lib.cv_crc32_ieee(c, ctypes.c_void_p(a.ctypes.data + 1234), 5000 - 1234)
     assert c == (zlib.crc32(d) & 0xffffffff)
+
+
+def test_decoder_equals_zlib_on_generated_inputs(lib):
+    """property test: byte strings built from random literals, repeats at random distances and runs, compressed with
+    a random level / strategy / flush pattern"""
+    from hypothesis import given, settings, strategies as st
+
+    piece = st.one_of(
+        st.binary(min_size=0, max_size=300),
+        st.tuples(st.integers(1, 40000), st.integers(3, 600)),          # (distance, length) copy from what is there
+        st.tuples(st.integers(0, 255), st.integers(1, 3000)).map(lambda t: bytes([t[0]]) * t[1]),
+    )
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(piece, min_size=0, max_size=40), st.integers(0, 9),
+           st.sampled_from([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED]),
+           st.sampled_from([None, 97, 4000]))
+    def check(pieces, level, strategy, flush):
+        buf = bytearray()
+        for p in pieces:
+            if isinstance(p, tuple):
+                d, n = p
+                if len(buf) == 0:
+                    continue
+                d = min(d, len(buf))
+                for _ in range(n):
+                    buf.append(buf[-d])
+            else:
+                buf += p
+            if len(buf) > 65536:
+                break
+        data = bytes(buf[:65536])
+        comp = raw_deflate(data, level, strategy, flush_every=flush if len(data) > 0 else None)
+        rc, out, intact = inflate(lib, comp, len(data))
+        assert intact and rc == len(data) and out == data
+    check()
