@@ -2,9 +2,9 @@
 //
 // The native BAM reader (cv_bam.cpp) spends three quarters of its time in zlib's inflate() on 64 KiB BGZF blocks.
 // This is the usual table-driven decoder for that case -- the whole compressed block and the exact output size
-// are known, so there is no streaming state: a 64-bit bit buffer refilled with one unaligned load, a 10-bit
+// are known, so there is no streaming state: a 64-bit bit buffer refilled with one unaligned load, an 11-bit
 // first-level table for the literal/length code and an 8-bit one for the distance code (longer codes go through
-// 32- / 128-entry second-level tables), literals and matches written straight into the caller's buffer with
+// 16- / 128-entry second-level tables), literals and matches written straight into the caller's buffer with
 // 8-byte copies where the distance allows.  Every BGZF block carries a CRC-32 of its inflated bytes, which the
 // caller checks; a block this decoder rejects (or gets wrong) is simply handed to zlib.
 //
@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int LBITS = 10, DBITS = 8, MAXBITS = 15;
+constexpr int LBITS = 11, DBITS = 8, MAXBITS = 15;
 constexpr int LSUB = 1 << (MAXBITS - LBITS), DSUB = 1 << (MAXBITS - DBITS);
 
 // table entry: bits 0..7 total code length (0 = invalid), bits 8..12 extra bits, bits 13..15 kind,
