@@ -19,6 +19,11 @@ import sys
 
 import numpy as np
 
+if __package__ in (None, ""):      # run as `python <dir>/ExtractVariantCandidates.py` (the reference's way): make the package importable
+    import os as _os, sys as _sys
+    _sys.path[0] = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    import clairvoyante_amd  # noqa: F401
+    __package__ = "clairvoyante_amd"
 from . import param
 from .CreateTensor import READ_CHUNK, load_reference, region_of
 from .pileup import Pileup

@@ -22,6 +22,11 @@ import time
 
 import numpy as np
 
+if __package__ in (None, ""):      # run as `python <dir>/callVarBam.py` (the reference's way): make the package importable
+    import os as _os, sys as _sys
+    _sys.path[0] = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    import clairvoyante_amd  # noqa: F401
+    __package__ = "clairvoyante_amd"
 from . import param
 from .CreateTensor import load_reference, read_candidates, region_of
 from .ExtractVariantCandidates import read_bed, stream_alignments

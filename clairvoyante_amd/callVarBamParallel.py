@@ -12,6 +12,11 @@ import shlex
 import subprocess
 import sys
 
+if __package__ in (None, ""):      # run as `python <dir>/callVarBamParallel.py` (the reference's way): make the package importable
+    import os as _os, sys as _sys
+    _sys.path[0] = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    import clairvoyante_amd  # noqa: F401
+    __package__ = "clairvoyante_amd"
 from . import param
 
 _nums = [str(a) for a in list(range(0, 23)) + ["X", "Y"]]

@@ -86,6 +86,9 @@ struct cv_bam {
 
 namespace {
 
+// upper bound on a record's block_size (SAMv1 4.2 gives none; the longest reads in practice are a few Mbp)
+const int64_t kMaxRecord = (int64_t)1 << 30;
+
 // one BGZF block at p (n bytes available): total size, or 0 if incomplete, or -1 if not a BGZF block
 int bgzf_block_size(const uint8_t *p, size_t n)
 {
@@ -96,9 +99,13 @@ int bgzf_block_size(const uint8_t *p, size_t n)
     int off = 12, bsize = -1;
     while (off + 4 <= 12 + xlen) {
         const int slen = rd_u16(p + off + 2);
-        if (p[off] == 'B' && p[off + 1] == 'C' && slen == 2) bsize = rd_u16(p + off + 4) + 1;
+        if (p[off] == 'B' && p[off + 1] == 'C' && slen == 2) {
+            if (off + 6 > 12 + xlen) return -1;            // BC payload would lie behind the extra field
+            bsize = rd_u16(p + off + 4) + 1;
+        }
         off += 4 + slen;
     }
+    if (bsize >= 0 && bsize < 12 + xlen + 8) return -1;    // no room for the header and the CRC / ISIZE trailer
     return bsize;
 }
 
@@ -422,7 +429,7 @@ extern "C" int64_t cv_bam_view_records(cv_bam *b, int64_t max_bytes, const uint8
             const int l_name = r[8];
             const int n_cig = rd_u16(r + 12), flag = rd_u16(r + 14);
             const int64_t l_seq = rd_i32(r + 16);
-            if (32 + (int64_t)l_name + 4 * (int64_t)n_cig + (l_seq + 1) / 2 + l_seq > bs) {
+            if (l_seq < 0 || bs > kMaxRecord || 32 + (int64_t)l_name + 4 * (int64_t)n_cig + (l_seq + 1) / 2 + l_seq > bs) {
                 cv_set_error("bam: corrupt record layout");
                 return -1;
             }
@@ -486,7 +493,7 @@ extern "C" int64_t cv_bam_view_read(cv_bam *b, char *buf, int64_t cap, int *done
         const int64_t l_seq = rd_i32(r + 16);
         const int32_t ntid = rd_i32(r + 20), npos = rd_i32(r + 24), tlen = rd_i32(r + 28);
         const int64_t fixed = 32 + (int64_t)l_name + 4 * (int64_t)n_cig + (l_seq + 1) / 2 + l_seq;
-        if (fixed > bs) { cv_set_error("bam: corrupt record layout"); return -1; }
+        if (l_seq < 0 || bs > kMaxRecord || fixed > bs) { cv_set_error("bam: corrupt record layout"); return -1; }
         // sorted file: stop at the first record past the region; unmapped reads (tid -1) sit at the end
         if (tid < 0 || tid > b->tid || (tid == b->tid && (int64_t)pos >= b->end0)) { b->done = true; break; }
         const uint8_t *cig = r + 32 + l_name;

@@ -9,6 +9,11 @@ import logging
 import pickle
 import sys
 
+if __package__ in (None, ""):      # run as `python <dir>/tensor2Bin.py` (the reference's way): make the package importable
+    import os as _os, sys as _sys
+    _sys.path[0] = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    import clairvoyante_amd  # noqa: F401
+    __package__ = "clairvoyante_amd"
 from . import param
 
 logging.basicConfig(format='%(message)s', level=logging.INFO)

@@ -304,8 +304,9 @@ def save_model(model, fn):
         tensors[n + "/Adam_1"] = flat[2][off:off + sz].reshape(shapes[n])
         off += sz
     # TF keeps beta^(t+1) after t steps (initial value beta, multiplied once per step)
-    tensors["beta1_power"] = np.array(0.9 ** (model._adam_t + 1), dtype=np.float32)
-    tensors["beta2_power"] = np.array(0.999 ** (model._adam_t + 1), dtype=np.float32)
+    # (fp32 accumulators of the fp32 constants: the powers are taken of float32(0.9) / float32(0.999))
+    tensors["beta1_power"] = np.array(_B1 ** (model._adam_t + 1), dtype=np.float32)
+    tensors["beta2_power"] = np.array(_B2 ** (model._adam_t + 1), dtype=np.float32)
     d = os.path.dirname(os.path.abspath(fn))
     os.makedirs(d, exist_ok=True)
     write_bundle(fn, tensors)
@@ -316,6 +317,29 @@ def save_model(model, fn):
     base = os.path.basename(fn)
     with open(os.path.join(d, "checkpoint"), "w") as f:
         f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (base, base))
+
+
+_B1 = float(np.float32(0.9))       # the constants as TF holds them (fp32)
+_B2 = float(np.float32(0.999))
+
+
+def _adam_steps(beta1_power, beta2_power):
+    """Optimizer step count t from the two fp32 accumulators TF keeps (beta^(t+1) after t steps).
+    beta2_power = 0.999^(t+1) is the one to read: it stays a normal fp32 number until t ~ 87 000, whereas
+    beta1_power = 0.9^(t+1) is denormal from t ~ 830 and exactly 0 from t ~ 985 (a resumed run would restart its
+    bias correction with lr_t ~ 0.316 lr).  Once beta2_power has underflowed too, both corrections are 1 in TF as
+    well, so any large t reproduces it."""
+    b1 = float(beta1_power) if beta1_power is not None else None
+    b2 = float(beta2_power) if beta2_power is not None else None
+    if b2 is not None and 0.0 < b2 < 1.0:
+        return max(0, int(round(np.log(b2) / np.log(_B2))) - 1)
+    if b2 is not None and b2 == 0.0:
+        return 100000
+    if b1 is not None and 1e-30 < b1 < 1.0:
+        return max(0, int(round(np.log(b1) / np.log(_B1))) - 1)
+    if b1 is not None and 0.0 <= b1 <= 1e-30:
+        return 100000 if b1 == 0.0 else max(0, int(round(np.log(b1) / np.log(_B1))) - 1)
+    return 0
 
 
 def restore_model(model, fn):
@@ -335,8 +359,7 @@ def restore_model(model, fn):
     if all((n + "/Adam") in t and (n + "/Adam_1") in t for n in PARAM_NAMES):
         _host_to_flat(model, 2, np.concatenate([t[n + "/Adam"].ravel() for n in PARAM_NAMES]))
         _host_to_flat(model, 3, np.concatenate([t[n + "/Adam_1"].ravel() for n in PARAM_NAMES]))
-        b1 = float(t.get("beta1_power", np.float32(0.9)))
-        model._adam_t = max(0, int(round(np.log(b1) / np.log(0.9))) - 1) if 0 < b1 < 1 else 0
+        model._adam_t = _adam_steps(t.get("beta1_power"), t.get("beta2_power"))
     else:
         _host_to_flat(model, 2, np.zeros_like(w)); _host_to_flat(model, 3, np.zeros_like(w))
         model._adam_t = 0

@@ -31,6 +31,11 @@ from threading import Thread
 
 import numpy as np
 
+if __package__ in (None, ""):      # run as `python <dir>/train.py` (the reference's way): make the package importable
+    import os as _os, sys as _sys
+    _sys.path[0] = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    import clairvoyante_amd  # noqa: F401
+    __package__ = "clairvoyante_amd"
 from . import param
 
 logging.basicConfig(format='%(message)s', level=logging.INFO)

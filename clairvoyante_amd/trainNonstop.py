@@ -20,6 +20,11 @@ import os
 import sys
 import time
 
+if __package__ in (None, ""):      # run as `python <dir>/trainNonstop.py` (the reference's way): make the package importable
+    import os as _os, sys as _sys
+    _sys.path[0] = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    import clairvoyante_amd  # noqa: F401
+    __package__ = "clairvoyante_amd"
 from . import param
 from .train import _BatchStream, _Job, build_parser, load_dataset, pick_model, run_epoch
 

@@ -4,6 +4,11 @@ The loop lives in trainNonstop.TrainAll(validate=False).
 
     python -m clairvoyante_amd.trainWithoutValidationNonstop --bin_fn TENSORS.bin --ochk_prefix OUT/model
 """
+if __package__ in (None, ""):      # run as `python <dir>/trainWithoutValidationNonstop.py` (the reference's way): make the package importable
+    import os as _os, sys as _sys
+    _sys.path[0] = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    import clairvoyante_amd  # noqa: F401
+    __package__ = "clairvoyante_amd"
 from . import trainNonstop
 
 

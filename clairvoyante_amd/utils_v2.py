@@ -371,7 +371,10 @@ def _unpack_into_one(blocks, key):
         if len(_block_layout) > 64:
             _block_layout.clear()
         a0 = unpack_array(blocks[0]) if len(blocks) else None
-        if not isinstance(a0, np.ndarray) or a0.ndim < 1 or not a0.flags.c_contiguous or a0.dtype.hasobject \
+        # numeric arrays only (X fp32, Y f8): their item size is the same in every block, whereas numpy sizes a
+        # string array ('<U8' vs '<U10' position keys) per block, so a narrower last block could pass the length check
+        # and be reinterpreted with the first block's item size
+        if not isinstance(a0, np.ndarray) or a0.ndim < 1 or not a0.flags.c_contiguous or a0.dtype.kind not in "fiub" \
                 or len(a0) != param.bloscBlockSize:
             return None
         lay = (a0.dtype, a0.shape[1:])

@@ -180,6 +180,38 @@ def test_callvarbamparallel_prints_the_reference_command_list(tag, extra, tmp_pa
     assert got == open(os.path.join(P, "cmds_%s.txt" % tag)).read()
 
 
+def test_printed_parallel_commands_are_runnable(tmp_path, capsys):
+    """the printed `python <pkg>/callVarBam.py ...` lines must start (package-relative imports
+    used to fail when the driver was run as a script); executed here from a foreign directory up to the argument
+    check, plus every other driver with --help"""
+    import shlex
+    import shutil
+    import subprocess
+    from clairvoyante_amd import callVarBamParallel as par
+    P = os.path.join(G, "parallel")
+    work = str(tmp_path)
+    for f in ("model.meta", "in.bam", "ref.fa"):
+        open(os.path.join(work, f), "w").write("x")
+    shutil.copy(os.path.join(P, "ref.fa.fai"), os.path.join(work, "ref.fa.fai"))
+    args = par.build_parser().parse_args(
+        ["--chkpnt_fn", os.path.join(work, "model"), "--bam_fn", os.path.join(work, "in.bam"), "--ref_fn",
+         os.path.join(work, "ref.fa"), "--output_prefix", "out/calls", "--pypy", "python3", "--samtools", "gzip",
+         "--sampleName", "NA1", "--includingAllContigs"])
+    par.Run(args)
+    line = capsys.readouterr().out.splitlines()[0]
+    argv = shlex.split(line)
+    assert argv[0] == "python" and argv[1].endswith("callVarBam.py")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable] + argv[1:] + ["--help"], cwd=work, env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and "--chkpnt_fn" in r.stdout, r.stderr
+    pkg = os.path.dirname(os.path.abspath(par.__file__))
+    for drv in ("callVar.py", "train.py", "evaluate.py", "tensor2Bin.py", "CreateTensor.py", "callVarBamParallel.py",
+                "trainNonstop.py", "trainWithoutValidationNonstop.py", "calTrainDevDiff.py", "evaluateListOfModels.py",
+                "ExtractVariantCandidates.py", "GetTruth.py"):
+        r = subprocess.run([sys.executable, os.path.join(pkg, drv), "--help"], cwd=work, env=env, capture_output=True, text=True)
+        assert r.returncode == 0 and "usage" in r.stdout.lower(), (drv, r.stderr)
+
+
 @pytest.mark.parametrize("tag,region", [("all", (None, None)), ("region", (400, 1500))])
 def test_gettruth_rows_equal_reference_rows(tag, region, tmp_path, capfd):
     """golden: tests/golden/truth/rows_*.txt, printed by the reference's GetTruth.py (make_golden_truth.py)"""

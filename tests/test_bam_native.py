@@ -232,3 +232,73 @@ def test_long_cigar_comes_from_the_cg_tag(tmp_path):
     with pytest.raises(Exception):
         b"".join(bf.view("ctgA"))
     bf.close()
+
+
+def _rewrite_with_patched_stream(src_bam, dst_bam, patch):
+    """inflate every BGZF block of src, let `patch(bytearray stream)` edit the BAM stream, write it back as valid
+    (CRC-correct) BGZF blocks: corrupt RECORDS behind intact block checksums"""
+    import struct
+    import zlib
+    from bam_writer import _bgzf_block, _EOF
+    blob = open(src_bam, "rb").read()
+    stream = bytearray()
+    off = 0
+    while off < len(blob):
+        xlen = struct.unpack("<H", blob[off + 10:off + 12])[0]
+        bsize = struct.unpack("<H", blob[off + 16:off + 18])[0] + 1
+        stream += zlib.decompress(blob[off + 12 + xlen:off + bsize - 8], -15)
+        off += bsize
+    patch(stream)
+    out = bytearray()
+    for o in range(0, len(stream), 60000):
+        out += _bgzf_block(bytes(stream[o:o + 60000]))
+    open(dst_bam, "wb").write(bytes(out + _EOF))
+
+
+def _first_record_offset(stream):
+    import struct
+    l_text = struct.unpack("<i", stream[4:8])[0]
+    n_ref = struct.unpack("<i", stream[8 + l_text:12 + l_text])[0]
+    pos = 12 + l_text
+    for _ in range(n_ref):
+        l_name = struct.unpack("<i", stream[pos:pos + 4])[0]
+        pos += 8 + l_name
+    return pos
+
+
+@pytest.mark.parametrize("l_seq", [-1, -2 ** 31, -2])
+def test_negative_l_seq_is_rejected_not_written_past_the_buffer(l_seq, tmp_path):
+    """a record whose l_seq is negative passed the layout check, made the `worst` size estimate of
+    the text view negative and let name / CIGAR text run past the caller's buffer"""
+    import struct
+    from clairvoyante_amd import _lib
+    recs = sam_records("plain")
+    # give the first record a CIGAR of many operations so that its text is long
+    f = recs[0].split("\t")
+    f[5] = "1M1I" * 20000 + "1M"; f[9] = "A" * 40001; f[10] = "*"
+    recs = ["\t".join(f)] + recs[1:]
+    good = str(tmp_path / "good.bam"); bad = str(tmp_path / "bad.bam")
+    write_bam(good, recs, [("ctgA", 50000)], index=False)
+
+    def patch(stream):
+        p = _first_record_offset(stream)
+        stream[p + 4 + 16:p + 4 + 20] = struct.pack("<i", l_seq)
+    _rewrite_with_patched_stream(good, bad, patch)
+    with pytest.raises(_lib.CvError, match="corrupt record"):
+        view_text(bad, "ctgA")
+    with pytest.raises((_lib.CvError, AssertionError)):
+        view_records(bad, "ctgA")
+
+
+def test_bsize_smaller_than_its_own_header_is_rejected(tmp_path):
+    """BSIZE < header + trailer made the trailer reads land before the block"""
+    import struct
+    from clairvoyante_amd import _lib
+    from clairvoyante_amd.bam import BamFile
+    bam = str(tmp_path / "t.bam")
+    write_bam(bam, sam_records("plain"), [("ctgA", 4000)], index=False)
+    blob = bytearray(open(bam, "rb").read())
+    blob[16:18] = struct.pack("<H", 2)                   # BSIZE = 3 bytes in total
+    open(bam, "wb").write(bytes(blob))
+    with pytest.raises(_lib.CvError):
+        BamFile(bam)

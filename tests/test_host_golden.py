@@ -228,3 +228,19 @@ def test_decompressarray_fast_path_equals_unpickling():
                 assert got.dtype == arr.dtype and np.array_equal(got, want)
                 slow = np.concatenate([utils_v2.unpack_array(b) for b in blocks[st // 500:(st + k - 1) // 500 + 1]])
                 assert np.array_equal(slow[st % 500:st % 500 + k], got)
+
+
+def test_string_blocks_of_varying_width_take_the_generic_path():
+    """position keys are '<U..' arrays whose item size differs per block; the one-array fast path
+    must not reinterpret a narrower last block with the first block's item size"""
+    import numpy as np
+    from clairvoyante_amd import param, utils_v2
+    bs = param.bloscBlockSize
+    wide = np.array(["chr10:%08d" % i for i in range(bs)])                    # '<U14': 56 bytes per item
+    narrow = np.array(["c:%d" % (i % 10) for i in range(14 * 10)])            # '<U3': 140 * 12 bytes = 30 * 56
+    assert wide.dtype.itemsize == 56 and (narrow.nbytes % 56) == 0
+    blocks = [utils_v2.pack_array(wide), utils_v2.pack_array(narrow)]
+    total = bs + len(narrow)
+    out, num, end = utils_v2.DecompressArray(blocks, 0, total, total)
+    assert num == total and end == 1
+    assert list(out) == list(wide) + list(narrow)

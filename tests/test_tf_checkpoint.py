@@ -51,3 +51,25 @@ def test_corruption_is_detected(tmp_path):
     with pytest.raises(ValueError):
         open(prefix + ".index", "wb").write(b"not a table" * 10)
         ck.read_table(prefix + ".index")
+
+
+@pytest.mark.parametrize("t", [0, 1, 7, 829, 985, 1500, 20000, 60000])
+def test_adam_step_count_survives_the_fp32_accumulators(t):
+    """beta1_power = 0.9^(t+1) underflows in fp32 near t = 985; the step count is read from
+    beta2_power, as stored by TF (fp32, multiplied once per step)"""
+    from clairvoyante_amd import tf_checkpoint
+    b1 = np.float32(0.9); b2 = np.float32(0.999)
+    p1 = np.float32(0.9); p2 = np.float32(0.999)
+    for _ in range(t):
+        p1 = np.float32(p1 * b1); p2 = np.float32(p2 * b2)        # TF's own running products
+    assert tf_checkpoint._adam_steps(p1, p2) == t
+    # and from the closed form the codec writes itself
+    assert tf_checkpoint._adam_steps(np.float32(tf_checkpoint._B1 ** (t + 1)), np.float32(tf_checkpoint._B2 ** (t + 1))) == t
+    # an older bundle without beta2_power still works while beta1_power is a normal number
+    if t < 600:
+        assert tf_checkpoint._adam_steps(p1, None) == t
+
+
+def test_adam_step_count_after_both_accumulators_underflowed():
+    from clairvoyante_amd import tf_checkpoint
+    assert tf_checkpoint._adam_steps(np.float32(0.0), np.float32(0.0)) >= 90000
