@@ -207,14 +207,19 @@ def train_main(args):
     y = synth.make_labels(cls, rf, alt, il)[lo:hi].contiguous(); x = xt[lo:hi].contiguous()
     use_dist = dist.is_initialized()
     steps = args.steps if args.steps != 64 else 20
+    if args.overlap is not None:
+        m.setOption("train_overlap", args.overlap)
+    step = m.train if args.sync_loss else m.trainDeferred     # deferred: no host round trip per step (train.run_epoch's way)
     for _ in range(args.warmup):
-        m.train(x, y)
+        step(x, y)
+    m.readLosses()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss, _s = m.train(x, y)
+        r = step(x, y)
+    loss = r[0] if args.sync_loss else m.readLosses()[0][5] / steps       # one read for the whole run, inside the timed region
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -236,7 +241,9 @@ def train_main(args):
                           "data": "synthetic",
                           "config": {"workload": "v3 %s training, Adam step on a global batch of %d synthetic labelled "
                                                  "[33,4,4] tensors, dropout 0.5, lambda 1e-3" % (args.arch, gb),
-                                     "arch": args.arch, "global_batch": gb, "parallelism": "dp%d" % ws},
+                                     "arch": args.arch, "global_batch": gb, "parallelism": "dp%d" % ws,
+                                     "losses": "read every step" if args.sync_loss else "accumulated on the device, read once",
+                                     "weight_gradients": "side stream" if (args.overlap is None or args.overlap) else "stream order"},
                           "roofline": roof, "final_loss": float(loss)}), flush=True)
     m.close()
     if use_dist:
@@ -252,6 +259,8 @@ def main():
     ap.add_argument("--arch", default="full", choices=["full", "slim"])
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--sync-loss", action="store_true", help="train mode: read the losses back after every step (m.train)")
+    ap.add_argument("--overlap", type=int, default=None, help="train mode: option train_overlap (A/B)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "pileup"],
                     help="infer (default, the headline metric) or train: Adam steps on the reference's global "
                          "batch of 10 000 split over the ranks, one RCCL gradient all-reduce per step "

@@ -53,6 +53,17 @@ _SIGS = {
                                ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]),
     "cv_grad_buffer": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
                                       ctypes.POINTER(ctypes.c_int64)]),
+    "cv_grad_bucket_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
+                                           ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "cv_bind_grad_bucket": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
+    "cv_grad_async": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                     ctypes.c_float, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64,
+                                     ctypes.c_void_p, ctypes.c_void_p]),
+    "cv_loss_accumulate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "cv_loss_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                                    ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_void_p]),
+    "cv_selu_sweep": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32,
+                                     ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "cv_apply_adam": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_int64,
                                      ctypes.c_void_p]),
     "cv_flat_copy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,

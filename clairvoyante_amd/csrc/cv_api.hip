@@ -112,7 +112,9 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
         if (e == hipSuccess) e = hipMalloc(p, sizeof(float) * nfloat);
         if (e == hipSuccess) e = hipMemset(*p, 0, sizeof(float) * nfloat);
     };
-    alloc(&m->params, np); alloc(&m->grads, np); alloc(&m->adam_m, np); alloc(&m->adam_v, np);
+    alloc(&m->params, np); alloc(&m->grads_own, np + CV_GRAD_HEADER); alloc(&m->adam_m, np); alloc(&m->adam_v, np);
+    if (m->grads_own) m->grads = m->grads_own + CV_GRAD_HEADER;
+    m->train_overlap = 1;
     alloc(&m->wp_conv1, 4 * 64);
     for (int l = 1; l < 3; l++) alloc(&m->wp_conv[l], (size_t)s.ntile[l] * arch->kh[l] * 4 * s.cinb[l] * 256);
     alloc(&m->wp_fc4, (size_t)s.kb4 * ((s.nb4 + 3) / 4 * 4) * 256);   // fragments padded to the wave count
@@ -125,6 +127,8 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     alloc(&m->wp_heads1, (size_t)s.nb5 * 256);
     m->variant = 47;
     if (e == hipSuccess) e = hipMalloc(&m->loss_dev, sizeof(double) * 8);
+    if (e == hipSuccess) e = hipMalloc(&m->loss_acc, sizeof(double) * 8);
+    if (e == hipSuccess) e = hipMemset(m->loss_acc, 0, sizeof(double) * 8);
     if (e != hipSuccess) {
         cv_set_error("cv_create: device allocation failed: %s", hipGetErrorString(e));
         cv_destroy(m);
@@ -139,12 +143,19 @@ extern "C" int cv_destroy(cv_model *m)
 {
     if (!m) return 0;
     hipSetDevice(m->device);
-    float *bufs[] = {m->params, m->grads, m->adam_m, m->adam_v, m->wp_conv1, m->wp_conv[1], m->wp_conv[2],
+    float *bufs[] = {m->params, m->grads_own, m->adam_m, m->adam_v, m->wp_conv1, m->wp_conv[1], m->wp_conv[2],
                      m->wp_fc4, m->wp_fc5, m->wp_heads0, m->wp_heads1, m->wpd_conv[1], m->wpd_conv[2], m->wpd_fc4, m->wpd_fc5, m->wps_fc4, m->wg_part, m->tm_p1, m->tm_p2, m->tm_p3, m->tm_h4, m->tm_h5, m->r_a[0],
                      m->r_a[1], m->r_a[2], m->r_p[0], m->r_p[1], m->r_p[2], m->r_h4, m->r_h5, m->t_buf};
     for (float *b : bufs)
         if (b) hipFree(b);
     if (m->loss_dev) hipFree(m->loss_dev);
+    if (m->loss_acc) hipFree(m->loss_acc);
+    if (m->tr_side) {
+        (void)hipStreamSynchronize(m->tr_side);
+        (void)hipStreamDestroy(m->tr_side);
+        for (int i = 0; i < CV_TR_EVENTS; i++) (void)hipEventDestroy(m->tr_ev[i]);
+        (void)hipEventDestroy(m->tr_dense_ready);
+    }
     cv_prof_free(m);
     delete m;
     return 0;
@@ -219,6 +230,7 @@ extern "C" int cv_set_option(cv_model *m, const char *key, int64_t value)
         return 0;
     }
     if (!strcmp(key, "profile")) { m->profile = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "train_overlap")) { m->train_overlap = value ? 1 : 0; return 0; }
     if (!strcmp(key, "variant")) { m->variant = (int)value; return 0; }
     if (!strcmp(key, "chunk")) {
         if (value < 16 || value > (1 << 22)) { cv_set_error("chunk must be in [16, 4194304]"); return 1; }
@@ -235,6 +247,7 @@ extern "C" int cv_get_option(const cv_model *m, const char *key, int64_t *value)
     if (!strcmp(key, "impl")) { *value = m->impl; return 0; }
     if (!strcmp(key, "chunk")) { *value = m->chunk; return 0; }
     if (!strcmp(key, "profile")) { *value = m->profile; return 0; }
+    if (!strcmp(key, "train_overlap")) { *value = m->train_overlap; return 0; }
     if (!strcmp(key, "variant")) { *value = m->variant; return 0; }
     cv_set_error("unknown option '%s'", key);
     return 1;
@@ -262,7 +275,19 @@ extern "C" int cv_forward(cv_model *m, const float *x_dev, int64_t n, float *out
 extern "C" int cv_get_activation(cv_model *m, int layer, float *dst_dev, int64_t n, void *stream)
 {
     if (!m || !dst_dev) { cv_set_error("cv_get_activation: null argument"); return 1; }
-    if (layer < 1 || layer > 5) { cv_set_error("cv_get_activation: layer %d not in 1..5", layer); return 1; }
+    if (layer < 1 || layer > 7) { cv_set_error("cv_get_activation: layer %d not in 1..7", layer); return 1; }
+    if (layer >= 6) {        // training-pass tensors: 6 = keep mask scaled by a (0 where dropped), 7 = dropout output
+        if (n <= 0 || n > m->last_tr_n || !m->last_tr_d4) {
+            cv_set_error("cv_get_activation: n=%lld but the last training slice held %lld candidates", (long long)n,
+                         (long long)m->last_tr_n);
+            return 1;
+        }
+        CV_HIP(hipSetDevice(m->device));
+        const float *src = layer == 6 ? m->last_tr_mask : m->last_tr_d4;
+        if (m->last_tr_tile) return cv_tm_to_natural(src, m->sh.nb4, m->sh.nb4 * 16, m->arch.fc4, 1, n, dst_dev, (hipStream_t)stream);
+        CV_HIP(hipMemcpyAsync(dst_dev, src, sizeof(float) * (size_t)m->arch.fc4 * n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return 0;
+    }
     if (n <= 0 || n > m->last_n) {
         cv_set_error("cv_get_activation: n=%lld but the last pass held %lld candidates", (long long)n,
                      (long long)m->last_n);

@@ -82,7 +82,19 @@ struct cv_model {
     int64_t tr_cap;
     float *t_buf;        // one slab, carved by the training code
     size_t t_bytes;
-    double *loss_dev;    // 8 doubles
+    double *loss_dev;    // 8 doubles: losses of the current pass
+    double *loss_acc;    // 8 doubles: losses accumulated over steps (cv_loss_accumulate / cv_loss_read)
+    float *grads_own;    // the library's own gradient bucket (CV_GRAD_HEADER + count floats); `grads` points
+                         // CV_GRAD_HEADER floats into it, or into the caller's bucket (cv_bind_grad_bucket)
+    // training step: side stream of the weight-gradient kernels, fork / join events, "dense gradients final"
+    hipStream_t tr_side;
+    hipEvent_t tr_ev[16];
+    hipEvent_t tr_dense_ready;
+    int train_overlap;   // option: weight gradients on the side stream (default 1)
+    // fc4 dropout output / keep mask (a*keep) of the LAST training slice, for cv_get_activation 6 / 7
+    const float *last_tr_d4, *last_tr_mask;
+    int64_t last_tr_n;
+    int last_tr_tile;    // 1: tile-major buffers, 0: natural [n, fc4]
     // optional per-kernel timing (option "profile")
     int profile;
     void *prof;          // cv_prof*, owned
@@ -94,6 +106,9 @@ void cv_prof_end(cv_model *m, int stage, hipStream_t st);
 void cv_prof_free(cv_model *m);
 
 void cv_set_error(const char *fmt, ...);
+
+#define CV_TR_EVENTS 16
+#define CV_GRAD_HEADER 16     // floats in front of the flat gradient: the loss header (cv_train.hip)
 
 #define CV_HIP(expr)                                                                     \
     do {                                                                                 \
@@ -121,6 +136,7 @@ int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm,
 int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_tm, const float *g_tm, int64_t n, hipStream_t st);
 int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_tm, const float *g_tm, int64_t n, hipStream_t st);
 int cv_tile_conv1_wgrad(cv_model *m, const float *x, const float *g_tm, int64_t n, hipStream_t st);
+int cv_wgrad_scratch_reserve(cv_model *m);      // scratch of the weight-gradient kernels at its upper bound
 int cv_tile_heads_wgrad(cv_model *m, const float *d4_tm, const float *h5_tm, const float *g16, int64_t n, hipStream_t st);
 int cv_tile_heads_pre(cv_model *m, const float *d4_tm, const float *h5_tm, int64_t n, float *pre16, hipStream_t st);
 int cv_dropout_tm(cv_model *m, const float *h4, float *d4, float *amask, int64_t n, float rate, uint64_t seed,

@@ -1765,6 +1765,33 @@ static int wg_part_reserve(cv_model *m, size_t need, hipStream_t st)
     return 0;
 }
 
+// Upper bound of the scratch over the weight-gradient launches of one step (their split counts are capped, so it
+// does not depend on the batch): reserved before a step is enqueued, so that nothing inside the step
+// synchronises or reallocates -- the kernels of the step run on two streams.
+int cv_wgrad_scratch_reserve(cv_model *m)
+{
+    const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
+    size_t need = 0;
+    auto upd = [&](size_t b) { if (b > need) need = b; };
+    const int njb4 = s.nb4, njb5 = s.nb5;
+    upd((size_t)(256 / ((s.kb4 + 15) / 16) + 1) * ((size_t)s.kb4 * njb4 * 256 + njb4 * 16));
+    upd((size_t)(256 / ((s.nb4 + 15) / 16) + 1) * ((size_t)s.nb4 * njb5 * 256 + njb5 * 16));
+    upd((size_t)65 * ((size_t)s.nb4 * 256 + 16));
+    for (int l = 1; l < 3; l++) {
+        const size_t NT = s.ntile[l], TILES = (size_t)a.kh[l] * 4 * s.cinb[l];
+        upd(((2048 + NT - 1) / NT) * NT * (TILES + 1) * 256);
+    }
+    upd((size_t)1024 * 5 * 256);
+    need *= sizeof(float);
+    if (m->wg_part_bytes >= need) return 0;
+    CV_HIP(hipDeviceSynchronize());
+    if (m->wg_part) CV_HIP(hipFree(m->wg_part));
+    m->wg_part = nullptr; m->wg_part_bytes = 0;
+    CV_HIP(hipMalloc(&m->wg_part, need));
+    m->wg_part_bytes = need;
+    return 0;
+}
+
 template <int NJB>
 static int dense_wgrad_launch(cv_model *m, const float *x_tm, int KB, const float *g_tm, int G, int K, int N, float *dw,
                               float *db, hipStream_t st)

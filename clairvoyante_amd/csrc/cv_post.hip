@@ -1,5 +1,6 @@
 // cv_post.hip -- device side of callVar.Output, optimizer step and flat-buffer plumbing.
 #include "cv_internal.hpp"
+#include "cv_math.hpp"
 
 namespace {
 
@@ -72,7 +73,48 @@ __global__ void adam_kernel(float *__restrict__ w, float *__restrict__ mm, float
     w[i] = wi - (m1 * lr_t) / (sqrtf(v1) + 1e-8f);
 }
 
+// Exhaustive monotonicity sweep of the canonical SELU over the negative floats (bit patterns 0x80000000 .. -inf):
+// each thread walks RUN consecutive patterns (magnitude ascending = value descending) plus the first one of the next
+// run and counts pairs with selu(next) > selu(prev); chk accumulates a checksum of the outputs so that the same
+// sweep on the oracle can be compared.
+__global__ void selu_sweep(uint32_t lo, uint32_t hi, uint32_t run, unsigned long long *__restrict__ out)
+{
+    const uint64_t first = (uint64_t)lo + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * run;
+    if (first > hi) return;
+    uint64_t last = first + run;
+    if (last > hi) last = hi;
+    float prev = cvm::selu(cvm::bits2f((uint32_t)first));
+    unsigned long long viol = 0, chk = 0;
+    for (uint64_t u = first + 1; u <= last; u++) {
+        const float cur = cvm::selu(cvm::bits2f((uint32_t)u));
+        viol += cur > prev ? 1ull : 0ull;
+        chk += (unsigned long long)__builtin_bit_cast(uint32_t, cur);
+        prev = cur;
+    }
+    if (viol) atomicAdd(&out[0], viol);
+    atomicAdd(&out[1], chk);
+}
+
 }  // namespace
+
+extern "C" int cv_selu_sweep(int device, uint32_t lo_bits, uint32_t hi_bits, uint64_t *violations, uint64_t *checksum)
+{
+    if (lo_bits > hi_bits || !violations) { cv_set_error("cv_selu_sweep: bad range"); return 1; }
+    CV_HIP(hipSetDevice(device));
+    unsigned long long *d = nullptr, h[2] = {0, 0};
+    CV_HIP(hipMalloc(&d, sizeof(h)));
+    CV_HIP(hipMemset(d, 0, sizeof(h)));
+    const uint32_t run = 4096;
+    const uint64_t threads = ((uint64_t)hi_bits - lo_bits) / run + 1;
+    selu_sweep<<<(unsigned)((threads + 255) / 256), 256>>>(lo_bits, hi_bits, run, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) { cv_set_error("cv_selu_sweep: %s", hipGetErrorString(e)); return 1; }
+    *violations = h[0];
+    if (checksum) *checksum = h[1];
+    return 0;
+}
 
 extern "C" int cv_call_postproc(cv_model *m, const float *x_dev, const float *out16_dev, int64_t n,
                                 int32_t *call_dev, float *qual_dev, void *stream)
@@ -92,6 +134,29 @@ extern "C" int cv_grad_buffer(cv_model *m, float **flat_dev, int64_t *count)
     if (!m) { cv_set_error("null model"); return 1; }
     if (flat_dev) *flat_dev = m->grads;
     if (count) *count = m->poff[CV_NUM_PARAMS];
+    return 0;
+}
+
+extern "C" int cv_grad_bucket_info(const cv_model *m, int64_t *count, int64_t *header, int64_t *dense_begin)
+{
+    if (!m) { cv_set_error("null model"); return 1; }
+    if (count) *count = CV_GRAD_HEADER + m->poff[CV_NUM_PARAMS];
+    if (header) *header = CV_GRAD_HEADER;
+    if (dense_begin) *dense_begin = CV_GRAD_HEADER + m->poff[6];
+    return 0;
+}
+
+extern "C" int cv_bind_grad_bucket(cv_model *m, float *bucket_dev, int64_t count)
+{
+    if (!m) { cv_set_error("null model"); return 1; }
+    if (!bucket_dev) { m->grads = m->grads_own + CV_GRAD_HEADER; return 0; }
+    if (count != CV_GRAD_HEADER + m->poff[CV_NUM_PARAMS]) {
+        cv_set_error("cv_bind_grad_bucket: %lld floats, the bucket holds %lld", (long long)count,
+                     (long long)(CV_GRAD_HEADER + m->poff[CV_NUM_PARAMS]));
+        return 1;
+    }
+    if (((uintptr_t)bucket_dev & 15) != 0) { cv_set_error("cv_bind_grad_bucket: the bucket must be 16-byte aligned"); return 1; }
+    m->grads = bucket_dev + CV_GRAD_HEADER;
     return 0;
 }
 

@@ -622,6 +622,7 @@ static int train_slice_plain(cv_model *m, const float *x, const float *y, int64_
     t_dense_pre<<<nblk(n * a.fc4, 256), 256, 0, st>>>(pool[2], P + o[6], P + o[7], fc4pre, n, s.flat, a.fc4);
     t_fc4_act<<<nblk(n * a.fc4, 256), 256, 0, st>>>(fc4pre, d4, amask, n, a.fc4, backward ? drop4 : 0.0f, seed,
                                                     step, cand0);
+    m->last_tr_d4 = d4; m->last_tr_mask = amask; m->last_tr_n = n; m->last_tr_tile = 0;
     t_dense_pre<<<nblk(n * a.fc5, 256), 256, 0, st>>>(d4, P + o[8], P + o[9], fc5pre, n, a.fc4, a.fc5);
     t_selu_act<<<nblk(n * a.fc5, 256), 256, 0, st>>>(fc5pre, h5, n * a.fc5);
     t_heads<<<nblk(n, 16), 256, 0, st>>>(d4, h5, a.fc4, a.fc5, P + o[10], P + o[11], P + o[12], P + o[13],
@@ -667,11 +668,43 @@ static int train_slice_plain(cv_model *m, const float *x, const float *y, int64_
 // forward (+ optional backward) of one slice of the batch on the tile kernels; every
 // intermediate stays tile-major, the only natural-layout tensors are X, Y and the 16 head
 // gradients per candidate
+// Weight gradients leave the critical path: the data-gradient chain (heads -> fc5 -> fc4 -> conv3 -> conv2 -> conv1)
+// runs on `st`, every weight-gradient kernel pair on the model's side stream `sw` behind an event recorded after
+// the kernel that produces its gradient operand.  All weight gradients share one scratch buffer and one stream, so
+// they stay in a fixed order (bit-reproducible); at train.py's batch and below the grids do not fill the chip and
+// the two chains overlap.  sw == st: everything in stream order (option "train_overlap" = 0).
+struct tr_fork {
+    cv_model *m; hipStream_t st, sw; int k;
+    int to_side()                 // sw continues behind everything enqueued on st so far
+    {
+        if (sw == st) return 0;
+        hipEvent_t e = m->tr_ev[k++ % CV_TR_EVENTS];
+        CV_HIP(hipEventRecord(e, st));
+        CV_HIP(hipStreamWaitEvent(sw, e, 0));
+        return 0;
+    }
+    int join()                    // st continues behind everything enqueued on sw so far
+    {
+        if (sw == st) return 0;
+        hipEvent_t e = m->tr_ev[k++ % CV_TR_EVENTS];
+        CV_HIP(hipEventRecord(e, sw));
+        CV_HIP(hipStreamWaitEvent(st, e, 0));
+        return 0;
+    }
+};
+
+// forward (+ optional backward) of one slice of the batch on the tile kernels; every
+// intermediate stays tile-major, the only natural-layout tensors are X, Y and the 16 head
+// gradients per candidate.  dense_ready (last slice of a backward pass): recorded once the
+// gradients of fc4, fc5 and the heads -- the contiguous tail of the flat gradient buffer, 95 %
+// of its bytes -- are final, so that the caller's exchange of that part runs under the conv
+// backward pass.
 static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t n, int64_t cand0, bool backward,
-                            float drop4, uint64_t seed, uint64_t step, hipStream_t st)
+                            float drop4, uint64_t seed, uint64_t step, hipStream_t st, hipStream_t sw,
+                            hipEvent_t dense_ready)
 {
     const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
-    const float *P = m->params; float *G = m->grads; const int64_t *o = m->poff;
+    const float *P = m->params; const int64_t *o = m->poff;
     const int64_t np = (n + 15) / 16 * 16;             // TM buffers hold whole groups
     const int64_t Gn = np / 16;
     slab sb{m->t_buf, 0, m->t_bytes / sizeof(float)};
@@ -688,6 +721,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     if (cv_tile_train_convs(m, x, n, tp[0], ta[0], tp[1], ta[1], tp[2], ta[2], st)) return 1;
     if (cv_tile_dense_fwd(m, 4, tp[2], th4, n, st)) return 1;
     if (cv_dropout_tm(m, th4, td4, tmask, n, backward ? drop4 : 0.0f, seed, step, cand0, st)) return 1;
+    m->last_tr_d4 = td4; m->last_tr_mask = tmask; m->last_tr_n = n; m->last_tr_tile = 1;
     if (cv_tile_dense_fwd(m, 5, td4, th5, n, st)) return 1;
     if (cv_tile_heads_pre(m, td4, th5, n, ghpre, st)) return 1;
     t_heads_loss<<<nblk(n, 64), 256, 0, st>>>(ghpre, y, n, backward ? 1 : 0, m->loss_dev);
@@ -699,52 +733,84 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     for (int l = 0; l < 3; l++) { tgpre[l] = sb.take(np * fa[l]); tgin[l] = sb.take(np * fp[l]); }
     if (!tgin[2]) { cv_set_error("training workspace too small"); return 1; }
     if (cv_pack_train_weights(m, st)) return 1;
+    tr_fork f{m, st, sw, 0};
     // heads: weight gradients on the matrix cores (inputs tile-major, the 16 gradients as they lie), data
     // gradients written to TM
-    if (cv_tile_heads_wgrad(m, td4, th5, ghpre, n, st)) return 1;
+    if (f.to_side()) return 1;
+    if (cv_tile_heads_wgrad(m, td4, th5, ghpre, n, sw)) return 1;
     b_head_dgrad_tm<<<nblk(Gn * s.nb5 * 256, 256), 256, 0, st>>>(ghpre, P + o[10], P + o[12], P + o[14], P + o[16], a.fc5,
                                                                s.nb5, n, Gn, 0, tg5);
     // fc5
     b_selu_tm<<<nblk(np * f5u / 4, 256), 256, 0, st>>>((const tf4 *)tg5, (const tf4 *)th5, nullptr, (tf4 *)tg5pre, np * f5u / 4);
-    if (cv_tile_dense_wgrad(m, 5, td4, tg5pre, n, st)) return 1;
+    if (f.to_side()) return 1;
+    if (cv_tile_dense_wgrad(m, 5, td4, tg5pre, n, sw)) return 1;
     if (cv_tile_fc5_dgrad(m, tg5pre, tgd4, n, st)) return 1;
     b_head_dgrad_tm<<<nblk(Gn * s.nb4 * 256, 256), 256, 0, st>>>(ghpre, P + o[10], P + o[12], P + o[14], P + o[16], a.fc4,
                                                                s.nb4, n, Gn, 1, tgd4);
     // dropout4 + selu' (h4 is the SELU output before dropout)
     b_selu_tm<<<nblk(np * f4u / 4, 256), 256, 0, st>>>((const tf4 *)tgd4, (const tf4 *)th4, (const tf4 *)tmask, (tf4 *)tg4pre, np * f4u / 4);
     // fc4
-    if (cv_tile_dense_wgrad(m, 4, tp[2], tg4pre, n, st)) return 1;
+    if (f.to_side()) return 1;
+    if (cv_tile_dense_wgrad(m, 4, tp[2], tg4pre, n, sw)) return 1;
+    if (dense_ready) CV_HIP(hipEventRecord(dense_ready, sw));
     if (cv_tile_fc4_dgrad(m, tg4pre, tgin[2], n, st)) return 1;
     // conv stack
     for (int l = 2; l >= 0; l--) {
         const int H = s.hc[l], NT = s.ntile[l];
         if (launch_pool_selu(tgin[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st)) return 1;
+        if (f.to_side()) return 1;
         if (l == 0) {        // first layer: X viewed as [33][16] fragments, read in place
-            if (cv_tile_conv1_wgrad(m, x, tgpre[0], n, st)) return 1;
+            if (cv_tile_conv1_wgrad(m, x, tgpre[0], n, sw)) return 1;
         } else {
-            if (cv_tile_conv_wgrad(m, l, tp[l - 1], tgpre[l], n, st)) return 1;
+            if (cv_tile_conv_wgrad(m, l, tp[l - 1], tgpre[l], n, sw)) return 1;
             if (cv_tile_conv_dgrad(m, l, tgpre[l], tgin[l - 1], n, st)) return 1;
         }
     }
+    if (f.join()) return 1;
     CV_HIP(hipGetLastError());
     return 0;
 }
 
 static int train_slice(cv_model *m, const float *x, const float *y, int64_t n, int64_t cand0, bool backward,
-                       float drop4, uint64_t seed, uint64_t step, hipStream_t st)
+                       float drop4, uint64_t seed, uint64_t step, hipStream_t st, hipStream_t sw, hipEvent_t dense_ready)
 {
-    if (m->impl == 1 && cv_tile_supported(m)) return train_slice_tile(m, x, y, n, cand0, backward, drop4, seed, step, st);
-    return train_slice_plain(m, x, y, n, cand0, backward, drop4, seed, step, st);
+    if (m->impl == 1 && cv_tile_supported(m))
+        return train_slice_tile(m, x, y, n, cand0, backward, drop4, seed, step, st, sw, dense_ready);
+    if (train_slice_plain(m, x, y, n, cand0, backward, drop4, seed, step, st)) return 1;
+    if (dense_ready) CV_HIP(hipEventRecord(dense_ready, st));
+    return 0;
 }
 
-static int train_pass(cv_model *m, const float *x, const float *y, int64_t n, bool backward, float drop4,
-                      float lambda, uint64_t seed, uint64_t step, double *losses_host, hipStream_t st)
+// Loss header of the gradient bucket (cv_grad_bucket): 16 floats in front of the flat gradient.  Slots 2k, 2k+1 =
+// loss k (k = 0..3: base, zygosity, type, length) of this pass as a (hi, lo) pair of floats whose sum is the
+// double the kernels accumulated; slots 8, 9 = lambda * sum(w^2)/2 likewise; slot 10 = 1 (counts the ranks when
+// the bucket is all-reduced); the rest 0.  A SUM all-reduce of the header therefore keeps ~48 bits of every loss.
+__global__ void t_loss_header(const double *__restrict__ loss, double lambda, float *__restrict__ hdr)
 {
-    if (!m) { cv_set_error("null model"); return 1; }
-    if (n < 0) { cv_set_error("negative batch"); return 1; }
-    if (n > 0 && (!x || !y)) { cv_set_error("null buffer"); return 1; }
-    if (drop4 < 0.0f || drop4 >= 1.0f) { cv_set_error("dropout rate must be in [0,1)"); return 1; }
-    CV_HIP(hipSetDevice(m->device));
+    const int t = threadIdx.x;
+    if (t >= 16) return;
+    float v = 0.0f;
+    if (t < 10) {
+        const int k = t >> 1;
+        const double d = k < 4 ? loss[k] : loss[4] * lambda;
+        const float hi = (float)d;
+        v = (t & 1) ? (float)(d - (double)hi) : hi;
+    } else if (t == 10) v = 1.0f;
+    hdr[t] = v;
+}
+
+// acc[0..3] += data losses of the header, acc[4] += L2 term (divided by the rank count: it is identical on all
+// ranks), acc[6] += 1 (steps accumulated)
+__global__ void t_loss_accumulate(const float *__restrict__ hdr, double *__restrict__ acc)
+{
+    const int t = threadIdx.x;
+    if (t < 4) acc[t] += (double)hdr[2 * t] + (double)hdr[2 * t + 1];
+    else if (t == 4) acc[4] += ((double)hdr[8] + (double)hdr[9]) / (double)(hdr[10] > 0.5f ? hdr[10] : 1.0f);
+    else if (t == 6) acc[6] += 1.0;
+}
+
+static int train_workspace(cv_model *m, int64_t n, int64_t *slice_out)
+{
     // one pass for train.py's batch of 10 000; larger batches go in equal slices of at most 65 536 candidates
     // (the kernels are at their best on thousands of groups, and HBM has room: ~0.4 MB of workspace per candidate)
     const int64_t max_slice = 65536;
@@ -752,24 +818,62 @@ static int train_pass(cv_model *m, const float *x, const float *y, int64_t n, bo
     const int64_t slice = n > 0 ? ((n + nslice - 1) / nslice + 15) / 16 * 16 : 16;
     const size_t need = train_floats_per_cand(m) * (size_t)(slice + 16) * sizeof(float);
     if (m->t_bytes < need) {
+        CV_HIP(hipDeviceSynchronize());
         if (m->t_buf) CV_HIP(hipFree(m->t_buf));
-        m->t_buf = nullptr; m->t_bytes = 0;
+        m->t_buf = nullptr; m->t_bytes = 0; m->last_tr_n = 0;
         CV_HIP(hipMalloc(&m->t_buf, need));
         m->t_bytes = need;
     }
+    if (!m->tr_side) {
+        CV_HIP(hipStreamCreateWithFlags(&m->tr_side, hipStreamNonBlocking));
+        for (int i = 0; i < CV_TR_EVENTS; i++) CV_HIP(hipEventCreateWithFlags(&m->tr_ev[i], hipEventDisableTiming));
+        CV_HIP(hipEventCreateWithFlags(&m->tr_dense_ready, hipEventDisableTiming));
+    }
+    *slice_out = slice;
+    return 0;
+}
+
+// enqueue forward (+ backward) of the whole batch; no host synchronisation
+static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n, bool backward, float drop4,
+                         float lambda, uint64_t seed, uint64_t step, hipStream_t st, hipStream_t comm)
+{
+    if (!m) { cv_set_error("null model"); return 1; }
+    if (n < 0) { cv_set_error("negative batch"); return 1; }
+    if (n > 0 && (!x || !y)) { cv_set_error("null buffer"); return 1; }
+    if (drop4 < 0.0f || drop4 >= 1.0f) { cv_set_error("dropout rate must be in [0,1)"); return 1; }
+    CV_HIP(hipSetDevice(m->device));
+    int64_t slice = 16;
+    if (train_workspace(m, n, &slice)) return 1;
+    if (backward && cv_wgrad_scratch_reserve(m)) return 1;
+    hipStream_t sw = (backward && m->train_overlap) ? m->tr_side : st;
     CV_HIP(hipMemsetAsync(m->loss_dev, 0, sizeof(double) * 8, st));
     if (backward) CV_HIP(hipMemsetAsync(m->grads, 0, sizeof(float) * m->poff[CV_NUM_PARAMS], st));
+    bool recorded = false;
     for (int64_t off = 0; off < n; off += slice) {
         int64_t cn = n - off < slice ? n - off : slice;
+        const bool last = off + slice >= n;
+        hipEvent_t ev = (backward && last) ? m->tr_dense_ready : nullptr;
         if (train_slice(m, x + (size_t)off * (CV_INPUT_H * 16), y + (size_t)off * 16, cn, off, backward, drop4,
-                        seed, step, st))
+                        seed, step, st, sw, ev))
             return 1;
+        recorded = recorded || ev != nullptr;
     }
+    if (backward && !recorded) CV_HIP(hipEventRecord(m->tr_dense_ready, st));      // empty batch
+    if (backward && comm) CV_HIP(hipStreamWaitEvent(comm, m->tr_dense_ready, 0));
     if (lambda != 0.0f) {
         l2_args la;
         for (int p = 0; p < CV_NUM_PARAMS; p += 2) { la.w[p / 2] = m->params + m->poff[p]; la.count[p / 2] = m->psize[p]; }
         t_l2<<<dim3(256, CV_NUM_PARAMS / 2), 256, 0, st>>>(la, m->loss_dev + 4);
     }
+    if (backward) t_loss_header<<<1, 64, 0, st>>>(m->loss_dev, (double)lambda, m->grads - CV_GRAD_HEADER);
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
+static int train_pass(cv_model *m, const float *x, const float *y, int64_t n, bool backward, float drop4,
+                      float lambda, uint64_t seed, uint64_t step, double *losses_host, hipStream_t st)
+{
+    if (train_enqueue(m, x, y, n, backward, drop4, lambda, seed, step, st, nullptr)) return 1;
     double h[8];
     CV_HIP(hipMemcpyAsync(h, m->loss_dev, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
     CV_HIP(hipStreamSynchronize(st));
@@ -791,4 +895,35 @@ extern "C" int cv_grad(cv_model *m, const float *x_dev, const float *y_dev, int6
                        float lambda, uint64_t seed, uint64_t step, double *losses_host, void *stream)
 {
     return train_pass(m, x_dev, y_dev, n, true, drop4, lambda, seed, step, losses_host, (hipStream_t)stream);
+}
+
+extern "C" int cv_grad_async(cv_model *m, const float *x_dev, const float *y_dev, int64_t n, float drop4,
+                             float lambda, uint64_t seed, uint64_t step, void *stream, void *comm_stream)
+{
+    return train_enqueue(m, x_dev, y_dev, n, true, drop4, lambda, seed, step, (hipStream_t)stream,
+                         (hipStream_t)comm_stream);
+}
+
+extern "C" int cv_loss_accumulate(cv_model *m, void *stream)
+{
+    if (!m) { cv_set_error("null model"); return 1; }
+    CV_HIP(hipSetDevice(m->device));
+    t_loss_accumulate<<<1, 64, 0, (hipStream_t)stream>>>(m->grads - CV_GRAD_HEADER, m->loss_acc);
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int cv_loss_read(cv_model *m, double losses_host[6], int64_t *steps, int reset, void *stream)
+{
+    if (!m || !losses_host) { cv_set_error("cv_loss_read: null argument"); return 1; }
+    CV_HIP(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    double h[8];
+    CV_HIP(hipMemcpyAsync(h, m->loss_acc, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
+    if (reset) CV_HIP(hipMemsetAsync(m->loss_acc, 0, sizeof(double) * 8, st));
+    CV_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < 5; k++) losses_host[k] = h[k];
+    losses_host[5] = h[0] + h[1] + h[2] + h[3] + h[4];
+    if (steps) *steps = (int64_t)(h[6] + 0.5);
+    return 0;
 }

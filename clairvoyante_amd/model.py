@@ -97,6 +97,9 @@ class Clairvoyante(object):
         self._train_step = 0       # counter for the dropout stream
         self._dropout_seed = int.from_bytes(os.urandom(8), "little")   # reference is unseeded (selu.py:55)
         self._seed_rng = np.random.RandomState()
+        self._bucket = None        # gradient bucket (torch tensor), bound on the first training step
+        self._carry = ([0.0] * 6, 0)   # losses of deferred steps already read from the device accumulator
+        self._keep = None
 
     # ---- helpers --------------------------------------------------------------
     def _stream(self):
@@ -203,25 +206,28 @@ class Clairvoyante(object):
          self.predictVarTypeRTVal, self.predictIndelLengthRTVal) = self._predict_host(XArray)
 
     def getActivation(self, layer, n):
-        """Intermediate of the last pass in the reference's layout (debug / parity)."""
+        """Intermediate of the last pass in the reference's layout (debug / parity); layers 6 / 7 are the
+        alpha-dropout keep mask (times its factor a) and output of the last train / getLoss slice."""
         a = self._arch
         hp = [33 - (a.pool[0] - 1)]
         hp.append(hp[0] - (a.pool[1] - 1)); hp.append(hp[1] - (a.pool[2] - 1))
         shp = {1: (n, hp[0], 4, a.cout[0]), 2: (n, hp[1], 4, a.cout[1]), 3: (n, hp[2], 4, a.cout[2]),
-               4: (n, a.fc4), 5: (n, a.fc5)}[layer]
+               4: (n, a.fc4), 5: (n, a.fc5),
+               6: (n, a.fc4), 7: (n, a.fc4)}[layer]     # last TRAINING slice: a*keep mask of fc4, dropout4 output
         dst = torch.empty(shp, dtype=torch.float32, device=self.device)
         _lib.check(self._lib.cv_get_activation(self._h, layer, ctypes.c_void_p(dst.data_ptr()), n,
                                                self._stream()))
         return dst
 
     # ---- training ---------------------------------------------------------------
-    def _flat(self, which):
-        """Copy of a flat device buffer as a torch tensor view-able by torch.distributed."""
-        raise NotImplementedError
-
     def _zero_adam(self):
-        mp = ctypes.c_void_p(); vp = ctypes.c_void_p(); cnt = ctypes.c_int64()
-        _lib.check(self._lib.cv_adam_buffers(self._h, ctypes.byref(mp), ctypes.byref(vp), ctypes.byref(cnt)))
+        """Adam slots m / v and the step count back to their initial state (what
+        tf.global_variables_initializer does to "<var>/Adam", "<var>/Adam_1", beta*_power; v3.py:177)."""
+        with torch.cuda.device(self.device):
+            z = torch.zeros(self.numParameters, dtype=torch.float32, device=self.device)
+            for which in (2, 3):
+                _lib.check(self._lib.cv_flat_copy(self._h, which, ctypes.c_void_p(z.data_ptr()), 1, self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()
         self._adam_t = 0
 
     def _losses(self, fn, *args):
@@ -236,22 +242,69 @@ class Clairvoyante(object):
                              ctypes.c_void_p(y.data_ptr()), x.shape[0])
         return np.float32(l[5])
 
-    def _train_step_impl(self, batchX, batchY):
+    def _ensure_bucket(self):
+        """The gradient bucket (loss header + flat gradient, include/clairvoyante_amd.h) lives in a torch tensor
+        so that torch.distributed reduces it in place; the library writes into it (cv_bind_grad_bucket)."""
+        if getattr(self, "_bucket", None) is None:
+            cnt = ctypes.c_int64(); hdr = ctypes.c_int64(); dense = ctypes.c_int64()
+            _lib.check(self._lib.cv_grad_bucket_info(self._h, ctypes.byref(cnt), ctypes.byref(hdr), ctypes.byref(dense)))
+            self._bucket = torch.zeros(cnt.value, dtype=torch.float32, device=self.device)
+            self._bucket_header, self._bucket_dense = int(hdr.value), int(dense.value)
+            _lib.check(self._lib.cv_bind_grad_bucket(self._h, ctypes.c_void_p(self._bucket.data_ptr()), cnt.value))
+        return self._bucket
+
+    def gradients(self):
+        """flat gradient of the last step (a view of the bucket behind its loss header)"""
+        return self._ensure_bucket()[self._bucket_header:]
+
+    def _enqueue_step(self, batchX, batchY):
+        """One optimizer step enqueued on the current stream, no host synchronisation: forward + backward
+        (cv_grad_async), gradient / loss exchange over the ranks (parallel.exchange_bucket: the dense 95 % of the
+        bucket while the convolution backward pass still runs), Adam, losses added to the device accumulator."""
         from . import parallel
+        x = self._to_dev(batchX, (33, 4, 4)); y = self._to_dev(batchY, (16,))
+        self._train_step += 1
+        self._ensure_bucket()
+        comm = parallel.comm_stream(self)
+        _lib.check(self._lib.cv_grad_async(self._h, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+                                           x.shape[0], ctypes.c_float(self.dropoutRateFC4Val),
+                                           ctypes.c_float(self.l2RegularizationLambdaVal),
+                                           ctypes.c_uint64(self._dropout_seed & 0xFFFFFFFFFFFFFFFF),
+                                           ctypes.c_uint64(self._train_step), self._stream(),
+                                           ctypes.c_void_p(comm.cuda_stream) if comm is not None else None))
+        parallel.exchange_bucket(self, comm)
+        self._adam_t += 1
+        _lib.check(self._lib.cv_apply_adam(self._h, ctypes.c_float(self.learningRateVal),
+                                           ctypes.c_float(self.l2RegularizationLambdaVal),
+                                           self._adam_t, self._stream()))
+        _lib.check(self._lib.cv_loss_accumulate(self._h, self._stream()))
+        self._keep = (x, y)          # the step is still running: the batch stays referenced until the next one
+
+    def _read_acc(self):
+        losses = (ctypes.c_double * 6)(); steps = ctypes.c_int64()
+        _lib.check(self._lib.cv_loss_read(self._h, losses, ctypes.byref(steps), 1, self._stream()))
+        return list(losses), int(steps.value)
+
+    def readLosses(self, reset=True):
+        """-> ([loss1..loss4, lossL2, total] summed over the trainDeferred steps since the last reset, number of
+        steps); synchronises.  Global-batch values under data parallelism."""
         with torch.cuda.device(self.device):
-            x = self._to_dev(batchX, (33, 4, 4)); y = self._to_dev(batchY, (16,))
-            self._train_step += 1
-            l = self._losses(self._lib.cv_grad, self._h, ctypes.c_void_p(x.data_ptr()),
-                             ctypes.c_void_p(y.data_ptr()), x.shape[0],
-                             ctypes.c_float(self.dropoutRateFC4Val),
-                             ctypes.c_float(self.l2RegularizationLambdaVal),
-                             ctypes.c_uint64(self._dropout_seed & 0xFFFFFFFFFFFFFFFF),
-                             ctypes.c_uint64(self._train_step))
-            l = parallel.allreduce_gradients(self, l)
-            self._adam_t += 1
-            _lib.check(self._lib.cv_apply_adam(self._h, ctypes.c_float(self.learningRateVal),
-                                               ctypes.c_float(self.l2RegularizationLambdaVal),
-                                               self._adam_t, self._stream()))
+            l, n = self._read_acc()
+        l = [u + v for u, v in zip(l, self._carry[0])]; n += self._carry[1]
+        self._carry = ([0.0] * 6, 0) if reset else (l, n)
+        return l, n
+
+    def trainDeferred(self, batchX, batchY):
+        """trainNoRT without the host round trip: the step is enqueued and its losses are added to the device
+        accumulator (readLosses); what train.run_epoch uses -- train.py:113-114 only needs the epoch's sum."""
+        with torch.cuda.device(self.device):
+            self._enqueue_step(batchX, batchY)
+
+    def _train_step_impl(self, batchX, batchY):
+        with torch.cuda.device(self.device):
+            self.readLosses(reset=False)          # park what trainDeferred steps have accumulated so far
+            self._enqueue_step(batchX, batchY)
+            l, _n = self._read_acc()
         summary = {"learning_rate": self.learningRateVal, "l2Lambda": self.l2RegularizationLambdaVal,
                    "loss1": l[0], "loss2": l[1], "loss3": l[2], "loss4": l[3], "lossL2": l[4], "loss": l[5]}
         return np.float32(l[5]), summary

@@ -62,30 +62,79 @@ def allreduce_sum_(flat, losses=None):
     """In-place SUM all-reduce of a flat tensor (+ optional list of python floats)."""
     if not _active():
         return losses
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    _all_reduce(flat)
     if losses is not None:
         t = torch.tensor(losses, dtype=torch.float64, device=flat.device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _all_reduce(t)
         losses = t.tolist()
     return losses
 
 
-def allreduce_gradients(model, losses):
-    """Gradient exchange of one optimizer step.  losses = [l1,l2,l3,l4,lL2,total] of this
-    rank's shard; returns the global-batch values (lL2 is identical on all ranks)."""
+_host_staged = [None]      # gloo without device support: collectives of device tensors go through the host
+
+
+def _all_reduce(t, async_op=False):
+    """all-reduce(SUM) in place; RCCL ("nccl") reduces device tensors directly.  The gloo backend (CPU tests, and
+    the two-ranks-on-one-GPU tests: RCCL refuses two ranks on one device) may lack device support, in which case
+    the tensor is staged through the host -- decided once, identically on every rank."""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        if _host_staged[0] is None:
+            try:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                _host_staged[0] = False
+                return None
+            except RuntimeError:
+                _host_staged[0] = True
+        if _host_staged[0]:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+            return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
+def _broadcast(t, src):
+    if t.is_cuda and dist.get_backend() == "gloo" and _host_staged[0] is not False:
+        h = t.cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+        return
+    dist.broadcast(t, src=src)
+
+
+def comm_stream(model):
+    """The stream the early part of the gradient exchange is enqueued on (one per model), or None when there
+    is nothing to exchange.  cv_grad_async makes it wait for the event "fc4 / fc5 / head gradients are final"."""
+    if not _active() or torch.device(model.device).type != "cuda":
+        return None
+    st = getattr(model, "_comm_stream", None)
+    if st is None:
+        st = model._comm_stream = torch.cuda.Stream(device=model.device)
+    return st
+
+
+def exchange_bucket(model, comm=None):
+    """Gradient + loss exchange of one optimizer step, in place on the model's bucket (no staging copies, no
+    host synchronisation): all-reduce(SUM) of the dense part [dense_begin, end) -- 95 % of the bytes, final before
+    the convolution backward pass -- on `comm`, so that it runs under the rest of the backward pass, then
+    all-reduce(SUM) of [0, dense_begin) = loss header + convolution gradients in stream order.  The current
+    stream continues behind both (Adam follows).  The loss header sums to the global-batch losses; its L2 slot is
+    identical on every rank and is divided by the rank count when read (cv_loss_accumulate)."""
     if not _active():
-        return losses
-    from . import _lib
-    n = model.numParameters
-    if getattr(model, "_grad_bucket", None) is None:
-        model._grad_bucket = torch.empty(n, dtype=torch.float32, device=model.device)
-    b = model._grad_bucket
-    st = model._stream()
-    _lib.check(model._lib.cv_flat_copy(model._h, 1, ctypes.c_void_p(b.data_ptr()), 0, st))
-    data = allreduce_sum_(b, losses[0:4])
-    _lib.check(model._lib.cv_flat_copy(model._h, 1, ctypes.c_void_p(b.data_ptr()), 1, st))
-    l2 = losses[4]
-    return data + [l2, sum(data) + l2]
+        return
+    b = model._bucket
+    d = model._bucket_dense
+    if comm is not None:
+        with torch.cuda.stream(comm):
+            w1 = _all_reduce(b[d:], async_op=True)
+    else:
+        w1 = _all_reduce(b[d:], async_op=True)
+    w2 = _all_reduce(b[:d], async_op=True)
+    for w in (w1, w2):
+        if w is not None:
+            w.wait()
+    if comm is not None:
+        torch.cuda.current_stream(model.device).wait_stream(comm)
 
 
 def broadcast_parameters(model, src=0):
@@ -98,7 +147,7 @@ def broadcast_parameters(model, src=0):
     st = model._stream()
     for which in (0, 2, 3):
         _lib.check(model._lib.cv_flat_copy(model._h, which, ctypes.c_void_p(b.data_ptr()), 0, st))
-        dist.broadcast(b, src=src)
+        _broadcast(b, src)
         _lib.check(model._lib.cv_flat_copy(model._h, which, ctypes.c_void_p(b.data_ptr()), 1, st))
 
 
@@ -107,6 +156,6 @@ def allreduce_scalar(value, model=None):
     if not _active():
         return value
     dev = model.device if model is not None else "cpu"
-    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())

@@ -94,11 +94,24 @@ int cv_call_postproc(cv_model *m, const float *x_dev, const float *out16_dev, in
 /* debug / parity: copy one intermediate of the LAST cv_forward chunk to
  * dst_dev in the reference's natural layout ([n,h,4,c] NHWC or [n,units]).
  * layer: 1..3 = pool1..pool3 outputs (for slim: conv outputs), 4 = fc4, 5 = fc5.
- * Serves what getTensorAndLayerPNG.py:30-37 reaches into m.conv1.. for.         */
+ * Serves what getTensorAndLayerPNG.py:30-37 reaches into m.conv1.. for.
+ * layer 6 / 7 refer to the last cv_grad / cv_loss slice instead: 6 = the alpha-dropout
+ * keep mask of fc4 times its affine factor a (selu.py:53-62; 0 where a unit was
+ * dropped, a where kept, 1 everywhere at rate 0), 7 = dropout4, the layer's output
+ * [n, fc4] -- what the parity tests feed to / compare with the oracle.            */
 int cv_get_activation(cv_model *m, int layer, float *dst_dev, int64_t n, void *stream);
 
+/* debug / parity: the device's SELU (csrc/cv_math.hpp, selu.py:21-25) evaluated on every fp32 bit pattern in
+ * [lo_bits, hi_bits] in ascending pattern order; *violations = adjacent pairs, taken as NEGATIVE floats (pattern
+ * ascending = value descending), where the output increases; *checksum = wrapping sum of the output bit patterns of
+ * all but the first input (the oracle's sweep must give the same).  0x80000000 .. 0xff800000 is the whole negative
+ * axis: zero violations there prove SELU monotone, which is what lets the convolution kernels apply max-pooling
+ * to the raw accumulators and the activation once per pooled row (max and a monotone map commute).  Synchronous. */
+int cv_selu_sweep(int device, uint32_t lo_bits, uint32_t hi_bits, uint64_t *violations, uint64_t *checksum);
+
 /* knobs: "impl" (0 = plain one-thread-per-output kernels, 1 = MFMA tile kernels),
- * "chunk" (candidates per internal pass), "profile" (0/1, see cv_kernel_times),
+ * "chunk" (candidates per internal pass), "profile" (0/1, see cv_kernel_times), "train_overlap" (0/1: weight
+ * gradients of the training step on a side stream next to the data-gradient chain; default 1, same bits),
  * "variant" (bit 0: first layer fused into the conv2 kernel, bit 1: MFMA heads kernel,
  * bit 2: 8-wave fc4 workgroups, bit 3: rotating-window conv3 kernel, bit 5: fc4 with two groups of
  * 16 candidates per wave; default 47; the alternatives give bit-identical results and exist for A/B
@@ -129,6 +142,32 @@ int cv_grad(cv_model *m, const float *x_dev, const float *y_dev, int64_t n, floa
             float lambda, uint64_t seed, uint64_t step, double *losses_host, void *stream);
 /* flat gradient buffer, same order/size as cv_param_buffer (for RCCL all-reduce) */
 int cv_grad_buffer(cv_model *m, float **flat_dev, int64_t *count);
+
+/* ---- the optimizer step without host round trips (what train.py's loop and a data-parallel host use) ----
+ * The gradient BUCKET is `header` (= 16) floats followed by the flat gradient.  The header carries the losses of
+ * the step so that ONE all-reduce(SUM) of the bucket exchanges gradients and losses together: floats 2k, 2k+1 =
+ * loss k (base, zygosity, type, length; v3.py:140-148) as a (hi, lo) float pair whose sum is the double the
+ * kernels accumulated, floats 8, 9 = lambda * sum(w^2)/2, float 10 = 1 per contributing rank, rest 0.
+ * dense_begin = first float of the fc4 / fc5 / head gradients: [dense_begin, count) is 95 % of the bucket and is
+ * final early (before the convolution backward pass), [0, dense_begin) at the end of the step.
+ * cv_bind_grad_bucket makes the step write into a caller-owned device buffer of `count` floats (16-byte aligned;
+ * e.g. a torch tensor that torch.distributed reduces in place -- no staging copies); NULL returns to the
+ * library's own.  The caller keeps the buffer alive while it is bound.                                          */
+int cv_grad_bucket_info(const cv_model *m, int64_t *count, int64_t *header, int64_t *dense_begin);
+int cv_bind_grad_bucket(cv_model *m, float *bucket_dev, int64_t count);
+/* cv_grad without the host synchronisation: enqueues forward + backward on `stream` (the weight-gradient kernels
+ * on an internal side stream that forks from / joins `stream`; option "train_overlap" = 0 keeps one stream) and
+ * the loss header.  comm_stream (may be NULL): made to wait, through an event, for the moment the dense part of
+ * the bucket is final, so that an exchange enqueued on it overlaps the rest of the backward pass; the part
+ * before dense_begin is final in `stream` order.  The caller orders cv_apply_adam behind its exchange.         */
+int cv_grad_async(cv_model *m, const float *x_dev, const float *y_dev, int64_t n, float drop4, float lambda,
+                  uint64_t seed, uint64_t step, void *stream, void *comm_stream);
+/* add the (exchanged) loss header of the bucket to a device-side accumulator (the L2 term divided by the rank
+ * count of float 10) -- train.py only needs the SUM of the batch losses of an epoch (train.py:113-114,123).     */
+int cv_loss_accumulate(cv_model *m, void *stream);
+/* read the accumulator: losses_host[6] = loss1..loss4, lossL2, total summed over the accumulated steps, *steps =
+ * how many (may be NULL); reset != 0 zeroes it.  Synchronises `stream`.                                         */
+int cv_loss_read(cv_model *m, double losses_host[6], int64_t *steps, int reset, void *stream);
 /* TF1 Adam (beta1 .9, beta2 .999, eps 1e-8, lr_t = lr*sqrt(1-b2^t)/(1-b1^t)) on
  * grad + lambda*w for non-bias variables (l2 term of v3.py:150); t = 1,2,...     */
 int cv_apply_adam(cv_model *m, float lr, float lambda, int64_t t, void *stream);

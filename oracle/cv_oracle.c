@@ -611,3 +611,27 @@ void cvo_adam_step(float *w, float *m, float *v, const float *g, int64_t n, floa
         w[i] = w[i] - lr_t * m[i] / (sqrtf(v[i]) + 1e-8f);
     }
 }
+
+/* Sweep of cvo_selu over the bit patterns [lo, hi] taken as negative floats (ascending pattern = descending value):
+ * returns the number of adjacent pairs whose output INCREASES (0 over 0x80000000..0xff800000 = SELU is monotone
+ * on the whole negative axis) and the wrapping sum of the output patterns of all but the first input -- the same
+ * quantities the device reports through cv_selu_sweep. */
+uint64_t cvo_selu_sweep(uint32_t lo, uint32_t hi, uint64_t *checksum)
+{
+    uint64_t viol = 0, chk = 0;
+    const uint64_t chunk = 1u << 20;
+#pragma omp parallel for schedule(dynamic) reduction(+ : viol, chk)
+    for (uint64_t c = lo; c < (uint64_t)hi; c += chunk) {
+        const uint64_t end = c + chunk < (uint64_t)hi ? c + chunk : (uint64_t)hi;
+        float prev = cvo_selu(as_float((uint32_t)c));
+        for (uint64_t u = c + 1; u <= end; u++) {
+            const float cur = cvo_selu(as_float((uint32_t)u));
+            uint32_t b; memcpy(&b, &cur, 4);
+            viol += cur > prev;
+            chk += b;
+            prev = cur;
+        }
+    }
+    if (checksum) *checksum = chk;
+    return viol;
+}

@@ -1,0 +1,324 @@
+"""GPU tests of the training step as the data-parallel host drives it:
+
+* alpha-dropout (selu.py:34-69 applied at clairvoyante_v3.py:111): the keep mask the device drew is
+  exported (cv_get_activation layer 6) and fed to the oracle -- forward values, loss parts and all 18 gradients of
+  the DEFAULT training configuration (rate 0.5) are compared, full + slim;
+* init() really resets the optimizer (v3.py:177);
+* the step on two streams (weight gradients on the side stream) gives the same bits as on one;
+* deferred losses (no host round trip per step) sum to the per-step values;
+* the real data-parallel step with TWO ranks on the one GPU of the box (backend gloo: RCCL refuses two ranks on
+  one device): broadcast from deliberately different weights, model.train on each rank's shard_range of a global
+  batch through parallel.exchange_bucket, compared with one process on the whole batch; then train.run_epoch.
+"""
+import ctypes
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(arch):
+    from clairvoyante_amd import clairvoyante_v3, clairvoyante_v3_slim
+    return clairvoyante_v3.Clairvoyante() if arch == "full" else clairvoyante_v3_slim.Clairvoyante()
+
+
+def _flat(m, which):
+    import torch
+    from clairvoyante_amd import _lib
+    t = torch.empty(m.numParameters, device="cuda")
+    _lib.check(m._lib.cv_flat_copy(m._h, which, ctypes.c_void_p(t.data_ptr()), 0, None))
+    torch.cuda.synchronize()
+    return t.cpu().numpy().copy()
+
+
+def _data(n, seed):
+    from clairvoyante_amd import synth
+    xt, cls, rf, alt, il = synth.make_candidates(n, seed=seed, return_class=True)
+    return xt.numpy(), synth.make_labels(cls, rf, alt, il).numpy()
+
+
+ALPHA_P = np.float32(-1.7580993408473766)
+
+
+def _affine(rate):
+    q = np.float32(1.0) - np.float32(rate)
+    a = np.float32(np.sqrt(np.float32(1.0) / (q * ((np.float32(1.0) - q) * (ALPHA_P * ALPHA_P) + np.float32(1.0)))))
+    return a
+
+
+@pytest.mark.parametrize("arch", ["full", "slim"])
+@pytest.mark.parametrize("n", [17, 80, 1000])
+def test_alpha_dropout_forward_and_backward_match_oracle(oracle, arch, n):
+    rate, lam = 0.5, 0.01
+    x, y = _data(n, seed=9)
+    P = common.bench_params(oracle, arch)
+    m = _model(arch); m.setParameters(P)
+    m.dropoutRateFC4Val = rate; m.setL2RegularizationLambda(lam); m.setLearningRate(1e-3)
+    m._dropout_seed = 777
+    loss, summ = m.train(x, y)
+    amask = m.getActivation(6, n).cpu().numpy()
+    d4 = m.getActivation(7, n).cpu().numpy()
+    a = _affine(rate)
+    assert set(np.unique(amask)).issubset({np.float32(0.0), a}), np.unique(amask)[:5]
+    keep = (amask != 0).astype(np.float32)
+    # the mask is a fair coin per (candidate, unit)
+    N = keep.size
+    assert abs(keep.mean() - 0.5) <= 4 * 0.5 / np.sqrt(N)
+    if n > 1:
+        assert len({r.tobytes() for r in keep}) == n                # no two candidates share a mask
+    # forward: dropout4 of the oracle under the device's mask
+    fa = oracle.forward_all(arch, P, x, mask4=keep, rate4=rate)
+    assert np.abs(d4 - fa["d4"]).max() <= 1e-6
+    # loss parts and gradients
+    l_or, parts, g_or = oracle.loss_grad(arch, P, x, y, lam=lam, mask4=keep, rate4=rate)
+    assert abs(loss - l_or) <= 1e-5 * abs(l_or)
+    for k, ref in zip(("loss1", "loss2", "loss3", "loss4", "lossL2"), parts):
+        assert abs(summ[k] - ref) <= 1e-5 * max(1.0, abs(ref)), k
+    gb = _flat(m, 1)
+    off = 0
+    for name in oracle.PARAM_NAMES:
+        sz = g_or[name].size
+        g = gb[off:off + sz].reshape(g_or[name].shape); off += sz
+        gref = g_or[name] - (lam * P[name] if "bias" not in name else 0)     # data terms only
+        assert np.abs(g - gref).max() <= 2e-5 * np.abs(gref).max() + 1e-7, name
+    # the mask changes with the step and with the seed (each rank draws its own seed from os.urandom)
+    m.train(x, y)
+    keep2 = (m.getActivation(6, n).cpu().numpy() != 0)
+    assert 0.35 < (keep2 == (keep != 0)).mean() < 0.65
+    m2 = _model(arch); m2.setParameters(P); m2.dropoutRateFC4Val = rate; m2._dropout_seed = 778
+    m2.train(x, y)
+    keep3 = (m2.getActivation(6, n).cpu().numpy() != 0)
+    assert 0.35 < (keep3 == (keep != 0)).mean() < 0.65
+    f1 = _model(arch); f2 = _model(arch)
+    assert f1._dropout_seed != f2._dropout_seed                        # fresh models (ranks): fresh seeds
+    f1.close(); f2.close()
+    # rate 0: identity, mask of ones
+    m2.dropoutRateFC4Val = 0.0
+    m2.train(x, y)
+    assert np.array_equal(m2.getActivation(6, n).cpu().numpy(), np.ones((n, amask.shape[1]), np.float32))
+    m.close(); m2.close()
+
+
+@pytest.mark.parametrize("arch", ["full", "slim"])
+def test_init_after_training_resets_the_optimizer(oracle, arch):
+    """tf.global_variables_initializer also re-initialises "<var>/Adam", "<var>/Adam_1" and the beta powers
+    (v3.py:177): a model that has trained and is initialised again takes the same first step as a fresh one"""
+    x, y = _data(300, seed=3)
+    P = common.bench_params(oracle, arch)
+    P2 = common.bench_params(oracle, arch, seed=2)
+
+    def first_step(m):
+        m.setParameters(P); m._dropout_seed = 5; m._train_step = 0
+        m.setLearningRate(1e-3)
+        loss, _ = m.train(x, y)
+        return float(loss), _flat(m, 0), _flat(m, 2), _flat(m, 3)
+    fresh = _model(arch)
+    want = first_step(fresh)
+    used = _model(arch); used.setParameters(P2); used.setLearningRate(1e-3)
+    for _ in range(3):
+        used.train(x, y)
+    assert used._adam_t == 3 and np.abs(_flat(used, 2)).max() > 0
+    used.init()
+    assert used._adam_t == 0 and not _flat(used, 2).any() and not _flat(used, 3).any()
+    got = first_step(used)
+    assert got[0] == want[0]
+    for u, v in zip(got[1:], want[1:]):
+        assert np.array_equal(u.view(np.uint32), v.view(np.uint32))
+    fresh.close(); used.close()
+
+
+@pytest.mark.parametrize("arch,n", [("full", 10000), ("slim", 10000), ("full", 1250), ("full", 70000)])
+def test_side_stream_weight_gradients_give_the_same_bits(oracle, arch, n):
+    """option train_overlap: the weight-gradient kernels on the side stream next to the data-gradient chain, or
+    everything in stream order -- same kernels, same operands, same order among the weight gradients"""
+    import torch
+    from clairvoyante_amd import synth
+    xt, cls, rf, alt, il = synth.make_candidates(n, seed=41, device="cuda", return_class=True)
+    y = synth.make_labels(cls, rf, alt, il)
+    P = common.bench_params(oracle, arch)
+
+    def run(overlap):
+        m = _model(arch); m.setParameters(P); m.setOption("train_overlap", overlap)
+        m._dropout_seed = 99; m.setLearningRate(1e-3)
+        losses = [float(m.train(xt, y)[0]) for _ in range(3)]
+        out = (losses, _flat(m, 0), _flat(m, 1))
+        m.close()
+        return out
+    a = run(1); b = run(0)
+    assert np.allclose(a[0], b[0], rtol=1e-12, atol=0)
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+    assert np.isfinite(a[1]).all()
+
+
+def test_deferred_losses_sum_to_the_per_step_losses(oracle):
+    x, y = _data(2000, seed=13)
+    P = common.bench_params(oracle, "slim")
+    a = _model("slim"); b = _model("slim")
+    for m in (a, b):
+        m.setParameters(P); m._dropout_seed = 4; m.setLearningRate(1e-3); m.setL2RegularizationLambda(1e-3)
+    per_step = [a.train(x, y)[1] for _ in range(5)]
+    for _ in range(5):
+        b.trainDeferred(x, y)
+    l, steps = b.readLosses()
+    assert steps == 5
+    for i, k in enumerate(("loss1", "loss2", "loss3", "loss4", "lossL2", "loss")):
+        want = sum(s[k] for s in per_step)
+        assert abs(l[i] - want) <= 1e-9 * abs(want), k
+    assert b.readLosses() == ([0.0] * 6, 0)
+    # mixing: a synchronous step in between does not lose what the deferred ones accumulated
+    b.trainDeferred(x, y)
+    one = b.train(x, y)[1]["loss"]
+    l2, s2 = b.readLosses()
+    assert s2 == 1 and abs(l2[5] - a.train(x, y)[1]["loss"]) <= 1e-9 * abs(l2[5])
+    assert abs(one - a.train(x, y)[1]["loss"]) <= 1e-9 * abs(one)
+    assert np.array_equal(_flat(a, 0).view(np.uint32), _flat(b, 0).view(np.uint32))
+    a.close(); b.close()
+
+
+# ---- two ranks on one GPU ---------------------------------------------------------------------------------
+
+def _dp_worker(rank, ws, port, tmp, arch, n, steps, rate):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws),
+                      LOCAL_RANK="0")
+    import torch
+    from clairvoyante_amd import parallel
+    from oracle import cv_oracle as O
+    import common as C
+    torch.cuda.set_device(0)
+    r, w, _ = parallel.init_from_env(backend="gloo")
+    assert (r, w) == (rank, ws)
+    m = _model(arch)
+    # deliberately different weights and optimizer state per rank: the broadcast must replace them
+    m.setParameters(C.bench_params(O, arch, seed=1 + rank))
+    m.train(*_data(64, seed=50))                # a (collective) step: non-zero Adam slots everywhere
+    m.setParameters(C.bench_params(O, arch, seed=1 + rank))
+    if rank == 0:
+        m._zero_adam()                          # rank 0 holds the state every rank must end up with
+    else:
+        assert _flat(m, 2).any()
+    parallel.broadcast_parameters(m)
+    assert np.array_equal(_flat(m, 0), np.concatenate([C.bench_params(O, arch, seed=1)[k].ravel() for k in O.PARAM_NAMES]))
+    assert not _flat(m, 2).any() and not _flat(m, 3).any()
+    m._adam_t = 0
+    m.dropoutRateFC4Val = rate; m.setLearningRate(1e-3); m.setL2RegularizationLambda(0.01)
+    x, y = _data(n, seed=60)
+    lo, hi = parallel.shard_range(n, rank, ws)
+    losses = []
+    for s in range(steps):
+        loss, summ = m.train(x[lo:hi], y[lo:hi])
+        losses.append([summ[k] for k in ("loss1", "loss2", "loss3", "loss4", "lossL2", "loss")])
+    g = _flat(m, 1)
+    np.savez(os.path.join(tmp, "rank%d.npz" % rank), w=_flat(m, 0), am=_flat(m, 2), av=_flat(m, 3), g=g,
+             losses=np.asarray(losses))
+    torch.distributed.barrier()
+    m.close()
+    torch.distributed.destroy_process_group()
+
+
+def _spawn(fn, args, nprocs=2):
+    import torch.multiprocessing as mp
+    port = 29900 + os.getpid() % 500
+    mp.spawn(fn, args=(nprocs, port) + tuple(args), nprocs=nprocs, join=True)
+
+
+@pytest.mark.parametrize("arch,n", [("full", 10000), ("slim", 4001)])
+def test_two_rank_data_parallel_step_equals_the_single_process_step(oracle, arch, n, tmp_path):
+    steps = 3
+    _spawn(_dp_worker, (str(tmp_path), arch, n, steps, 0.0))
+    r0 = np.load(str(tmp_path / "rank0.npz")); r1 = np.load(str(tmp_path / "rank1.npz"))
+    # identical replicas: every rank applied the same update to the same weights
+    for k in ("w", "am", "av", "g"):
+        assert np.array_equal(r0[k].view(np.uint32), r1[k].view(np.uint32)), k
+    assert np.array_equal(r0["losses"], r1["losses"])
+    # one process on the whole batch
+    m = _model(arch); m.setParameters(common.bench_params(oracle, arch, seed=1))
+    m.dropoutRateFC4Val = 0.0; m.setLearningRate(1e-3); m.setL2RegularizationLambda(0.01)
+    x, y = _data(n, seed=60)
+    losses = []
+    for s in range(steps):
+        loss, summ = m.train(x, y)
+        losses.append([summ[k] for k in ("loss1", "loss2", "loss3", "loss4", "lossL2", "loss")])
+    assert np.allclose(r0["losses"], np.asarray(losses), rtol=2e-6)
+    g = _flat(m, 1); w = _flat(m, 0); am = _flat(m, 2); av = _flat(m, 3)
+    off = 0
+    P = common.bench_params(oracle, arch, seed=1)
+    for name in oracle.PARAM_NAMES:
+        sz = P[name].size
+        sl = slice(off, off + sz); off += sz
+        assert np.abs(r0["g"][sl] - g[sl]).max() <= 2e-5 * np.abs(g[sl]).max() + 1e-7, name
+        assert np.abs(r0["am"][sl] - am[sl]).max() <= 2e-5 * np.abs(am[sl]).max() + 1e-9, name
+        assert np.abs(r0["av"][sl] - av[sl]).max() <= 4e-5 * np.abs(av[sl]).max() + 1e-12, name
+    # weights: Adam divides by sqrt(v), so an element whose gradient is pure rounding noise may move differently;
+    # all but a vanishing fraction agree to 1e-6, none differs by more than the three steps can move it
+    dw = np.abs(r0["w"] - w)
+    assert (dw <= 1e-6).mean() >= 0.999, (dw <= 1e-6).mean()
+    assert dw.max() <= 2 * steps * 1e-3
+    assert np.abs(w - np.concatenate([P[k].ravel() for k in oracle.PARAM_NAMES])).max() > 1e-4     # it did train
+    m.close()
+
+
+def test_two_rank_replicas_stay_identical_with_dropout(oracle, tmp_path):
+    """each rank draws its own dropout stream; the exchanged gradient is what both apply"""
+    _spawn(_dp_worker, (str(tmp_path), "slim", 3000, 4, 0.5))
+    r0 = np.load(str(tmp_path / "rank0.npz")); r1 = np.load(str(tmp_path / "rank1.npz"))
+    for k in ("w", "am", "av", "g"):
+        assert np.array_equal(r0[k].view(np.uint32), r1[k].view(np.uint32)), k
+    assert np.isfinite(r0["w"]).all() and np.array_equal(r0["losses"], r1["losses"])
+
+
+def _epoch_worker(rank, ws, port, tmp, binfn, n):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws),
+                      LOCAL_RANK="0")
+    import torch
+    from clairvoyante_amd import param, parallel, train, utils_v2
+    from oracle import cv_oracle as O
+    import common as C
+    torch.cuda.set_device(0)
+    parallel.init_from_env(backend="gloo")
+    with open(binfn, "rb") as fh:
+        total = pickle.load(fh); XC = pickle.load(fh); YC = pickle.load(fh)
+    m = _model("slim"); m.setParameters(C.bench_params(O, "slim", seed=1 + rank))
+    parallel.broadcast_parameters(m)
+    m.dropoutRateFC4Val = 0.0; m.setLearningRate(1e-3); m.setL2RegularizationLambda(1e-3)
+    vstart = int(total * param.trainingDatasetPercentage) + 1
+    stream = train._BatchStream(utils_v2, XC, YC, total, vstart, rank, ws)
+    sums = [train.run_epoch(stream, m, rank, ws, None, e, vstart) for e in (1, 2)]
+    np.savez(os.path.join(tmp, "epoch%d.npz" % rank), sums=np.asarray(sums, dtype=np.float64), w=_flat(m, 0))
+    torch.distributed.barrier()
+    m.close()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_epoch_equals_the_single_process_epoch(oracle, tmp_path, monkeypatch):
+    """train.run_epoch under two ranks: every rank walks the same schedule on its slice of each batch; training sums
+    come out of the exchanged loss header, validation sums through parallel.allreduce_scalar (train.py:113-123)"""
+    from clairvoyante_amd import param, train, utils_v2
+    n = 26000
+    x, y = _data(n, seed=71)
+    y = y.astype(np.float64)
+    XC = [utils_v2.pack_array(x[s:s + 500]) for s in range(0, n + 1, 500)]
+    YC = [utils_v2.pack_array(y[s:s + 500]) for s in range(0, n + 1, 500)]
+    binfn = str(tmp_path / "dp.bin")
+    with open(binfn, "wb") as fh:
+        pickle.dump(n, fh); pickle.dump(XC, fh); pickle.dump(YC, fh); pickle.dump([], fh)
+    _spawn(_epoch_worker, (str(tmp_path), binfn, n))
+    e0 = np.load(str(tmp_path / "epoch0.npz")); e1 = np.load(str(tmp_path / "epoch1.npz"))
+    assert np.array_equal(e0["sums"], e1["sums"]) and np.array_equal(e0["w"].view(np.uint32), e1["w"].view(np.uint32))
+    m = _model("slim"); m.setParameters(common.bench_params(oracle, "slim", seed=1))
+    m.dropoutRateFC4Val = 0.0; m.setLearningRate(1e-3); m.setL2RegularizationLambda(1e-3)
+    vstart = int(n * param.trainingDatasetPercentage) + 1
+    stream = train._BatchStream(utils_v2, XC, YC, n, vstart)
+    sums = np.asarray([train.run_epoch(stream, m, 0, 1, None, e, vstart) for e in (1, 2)], dtype=np.float64)
+    assert np.allclose(e0["sums"], sums, rtol=1e-4), (e0["sums"], sums)
+    assert sums[1, 0] < sums[0, 0]                     # the second epoch starts from trained weights
+    m.close()

@@ -137,3 +137,20 @@ def test_candidates_are_independent_at_scale(setup):
     assert np.isfinite(o).all() and (o >= 0).all() and (o <= 1).all()
     for lo, hi in ((4, 6), (6, 10), (10, 16)):
         assert np.abs(o[:, lo:hi].sum(axis=1) - 1).max() <= 2e-6
+
+
+@pytest.mark.gpu
+def test_device_selu_sweep_equals_the_oracle_sweep_and_is_monotone(oracle):
+    """all 2 139 095 041 negative floats through the shipped binary's SELU: no monotonicity violation, and the same
+    checksum of output bits as the oracle's sweep (i.e. device and oracle SELU agree on EVERY negative input)"""
+    import ctypes
+    from clairvoyante_amd import _lib
+    lib = _lib.load()
+    viol = ctypes.c_uint64(); chk = ctypes.c_uint64()
+    _lib.check(lib.cv_selu_sweep(0, 0x80000000, 0xff800000, ctypes.byref(viol), ctypes.byref(chk)))
+    o_viol, o_chk = oracle.selu_sweep()
+    assert viol.value == 0 and o_viol == 0
+    assert chk.value == o_chk
+    # a small window too (different split of the range into runs)
+    _lib.check(lib.cv_selu_sweep(0, 0xbe000000, 0xbe100000, ctypes.byref(viol), ctypes.byref(chk)))
+    assert (viol.value, chk.value) == oracle.selu_sweep(0xbe000000, 0xbe100000)

@@ -115,3 +115,18 @@ def test_adam_step_matches_tf_formula(oracle):
         m64 = 0.9 * m64 + 0.1 * g; v64 = 0.999 * v64 + 0.001 * g.astype(np.float64) ** 2
         w64 -= lr_t * m64 / (np.sqrt(v64) + 1e-8)
     assert np.abs(w - w64).max() < 1e-6
+
+
+def test_selu_is_monotone_over_every_negative_float(oracle):
+    """exhaustive: no pair of adjacent negative floats where the canonical SELU increases as x decreases
+    (x >= 0 is a rounded multiplication by a positive constant).  Max-pooling therefore commutes with the
+    activation bit for bit, max_j selu(a_j + b) == selu(max_j a_j + b), which the convolution kernels use to apply
+    the activation once per POOLED row (tools/selu_monotone.c is the stand-alone form of this sweep)."""
+    viol, chk = oracle.selu_sweep()
+    assert viol == 0 and chk != 0
+    # the seam between the two branches
+    assert oracle.lib().cvo_selu_scalar(np.float32(-1e-45)) <= oracle.lib().cvo_selu_scalar(np.float32(0.0))
+    x = -np.abs(np.random.RandomState(0).standard_normal(4000).astype(np.float32) * 20)
+    x.sort()
+    y = np.array([oracle.lib().cvo_selu_scalar(v) for v in x], dtype=np.float32)
+    assert (np.diff(y) >= 0).all()

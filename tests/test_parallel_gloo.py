@@ -48,11 +48,33 @@ def _worker(rank, ws, port, tmp):
     lam = 0.01
     l_sh, parts, g_sh = O.loss_grad(arch, P, x[lo:hi], y[lo:hi], lam=0.0)
     flat = torch.from_numpy(np.concatenate([g_sh[k].ravel() for k in O.PARAM_NAMES]))
+    keep = flat.clone()
     losses = parallel.allreduce_sum_(flat, parts[0:4])
     l_all, parts_all, g_all = O.loss_grad(arch, P, x, y, lam=lam)
     ref = np.concatenate([(g_all[k] - (lam * P[k] if "bias" not in k else 0)).ravel() for k in O.PARAM_NAMES])
     assert np.abs(flat.numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
     assert np.allclose(losses, parts_all[0:4], rtol=1e-6)
+    # the product's exchange (parallel.exchange_bucket) on a bucket laid out as cv_grad_async leaves it
+    # (include/clairvoyante_amd.h: 16-float loss header of (hi, lo) pairs + flat gradient), two collectives
+    l2 = lam * sum(float(np.sum(P[k].astype(np.float64) ** 2)) / 2 for k in O.PARAM_NAMES if "bias" not in k)
+    hdr = np.zeros(16, dtype=np.float32)
+    for k, d in enumerate(list(parts[0:4]) + [l2]):
+        hdr[2 * k] = np.float32(d); hdr[2 * k + 1] = np.float32(d - float(hdr[2 * k]))
+    hdr[10] = 1.0
+
+    class Stub(object):
+        device = torch.device("cpu")
+    m = Stub()
+    m._bucket = torch.cat([torch.from_numpy(hdr), keep])
+    m._bucket_header = 16
+    m._bucket_dense = 16 + sum(P[k].size for k in O.PARAM_NAMES[:6])
+    assert parallel.comm_stream(m) is None
+    parallel.exchange_bucket(m, None)
+    got = m._bucket.numpy()
+    assert np.array_equal(got[16:], flat.numpy())            # same sums as the single collective
+    dec = [float(got[2 * k]) + float(got[2 * k + 1]) for k in range(5)]
+    assert np.allclose(dec[0:4], parts_all[0:4], rtol=1e-7)
+    assert got[10] == ws and abs(dec[4] / got[10] - l2) <= 1e-7 * l2
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
