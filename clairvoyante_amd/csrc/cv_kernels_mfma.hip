@@ -32,15 +32,35 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c)
 
 __device__ __forceinline__ f4 selu4(f4 v)
 {
+#ifdef CV_SCALAR_SELU                       /* development: A/B against the scalar sequence */
     f4 r;
     r[0] = cvm::selu(v[0]); r[1] = cvm::selu(v[1]); r[2] = cvm::selu(v[2]); r[3] = cvm::selu(v[3]);
     return r;
+#else
+    const cvm::f2v a = cvm::selu2((cvm::f2v){v[0], v[1]}), b = cvm::selu2((cvm::f2v){v[2], v[3]});
+    return (f4){a[0], a[1], b[0], b[1]};
+#endif
+}
+
+// One v_max_f32.  fmaxf() costs two when the compiler cannot prove an operand canonical (a loop-carried running
+// maximum, an MFMA result): in IEEE mode it first quiets signalling NaNs with v_max_f32 x, x, x.  The instruction
+// itself already returns the non-NaN operand, which is all max-pooling needs.  Operands and results only travel
+// between ordinary VALU instructions (no MFMA / memory hazard windows around the asm).
+__device__ __forceinline__ float vmaxf(float a, float b)
+{
+#ifdef CV_LIBM_MAX                          /* development: A/B against fmaxf */
+    return fmaxf(a, b);
+#else
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
 }
 
 __device__ __forceinline__ f4 max4(f4 a, f4 b)
 {
     f4 r;
-    r[0] = fmaxf(a[0], b[0]); r[1] = fmaxf(a[1], b[1]); r[2] = fmaxf(a[2], b[2]); r[3] = fmaxf(a[3], b[3]);
+    r[0] = vmaxf(a[0], b[0]); r[1] = vmaxf(a[1], b[1]); r[2] = vmaxf(a[2], b[2]); r[3] = vmaxf(a[3], b[3]);
     return r;
 }
 
@@ -250,6 +270,23 @@ __global__ __launch_bounds__(256) void conv1_tm(const float *__restrict__ x, int
                 if (wi < 0 || wi > 3) continue;
                 acc[wo] = mfma4(A[kw], xw[wi], acc[wo]);
             }
+        if constexpr (!SAVE && POOL > 1) {
+            // inference: max-pool the PRE-activations (running maxima pw[j] = max of the last j+1 rows) and apply
+            // SELU once per pooled row: SELU is monotone over all of fp32 (cv_selu_sweep), hence
+            // max_j selu(a_j + b) == selu(max_j (a_j + b)) bit for bit
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const f4 t = acc[w] + b4;      // (the sum, unlike a raw MFMA result, needs no canonicalising v_max x, x, x)
+                const f4 o = max4(pw[POOL - 2][w], t);
+#pragma unroll
+                for (int j = POOL - 2; j > 0; j--) pw[j][w] = max4(pw[j - 1][w], t);
+                pw[0][w] = t;
+                if (h - r0 >= POOL - 1) op[(size_t)((h - (POOL - 1)) * 4 + w) * 64] = selu4(o);
+            }
+#pragma unroll
+            for (int w = 0; w < 4; w++) xw[w] = xn[w];
+            continue;
+        }
         f4 v[4];
 #pragma unroll
         for (int w = 0; w < 4; w++) v[w] = selu4(acc[w] + b4);
@@ -326,8 +363,9 @@ struct front_source {
                 if (wi < 0 || wi > 3) continue;
                 acc[wo] = mfma4(A[kw], xc[wi], acc[wo]);
             }
+        // pre-activations: SELU is applied to the pooled row (next()), see conv1_tm
 #pragma unroll
-        for (int w = 0; w < 4; w++) v[w] = selu4(acc[w] + b4);
+        for (int w = 0; w < 4; w++) v[w] = acc[w] + b4;
 #pragma unroll
         for (int w = 0; w < 4; w++) xc[w] = xn[w];
         hx++;
@@ -344,11 +382,22 @@ struct front_source {
         load_x(xc, 0);
         load_x(xn, 1);
         if constexpr (FRONT > 1) {
+            // cw[j] = running maximum of the last j+1 pre-activation rows
 #pragma unroll
-            for (int j = 0; j < FRONT - 1; j++) conv1_row(cw[j]);
+            for (int r = 0; r < FRONT - 1; r++) {
+                f4 v[4];
+                conv1_row(v);
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+#pragma unroll
+                    for (int j = FRONT - 2; j > 0; j--) cw[j][w] = r == 0 ? v[w] : max4(cw[j - 1][w], v[w]);
+                    cw[0][w] = v[w];
+                }
+            }
         }
     }
-    // next pooled conv1 row (rows are requested in ascending order)
+    // next pooled conv1 row (rows are requested in ascending order): max over the window of pre-activation rows,
+    // then SELU once (monotone: same bits as pooling the activated rows)
     __device__ __forceinline__ void next(f4 (&row)[4][1])
     {
         f4 v[4];
@@ -356,20 +405,15 @@ struct front_source {
         if constexpr (FRONT > 1) {
 #pragma unroll
             for (int w = 0; w < 4; w++) {
-                f4 o = v[w];
+                const f4 o = max4(cw[FRONT - 2][w], v[w]);
 #pragma unroll
-                for (int j = 0; j < FRONT - 1; j++) o = max4(o, cw[j][w]);
-                row[w][0] = o;
+                for (int j = FRONT - 2; j > 0; j--) cw[j][w] = max4(cw[j - 1][w], v[w]);
+                cw[0][w] = v[w];
+                row[w][0] = selu4(o);
             }
-#pragma unroll
-            for (int j = 0; j + 1 < FRONT - 1; j++)
-#pragma unroll
-                for (int w = 0; w < 4; w++) cw[j][w] = cw[j + 1][w];
-#pragma unroll
-            for (int w = 0; w < 4; w++) cw[FRONT - 2][w] = v[w];
         } else {
 #pragma unroll
-            for (int w = 0; w < 4; w++) row[w][0] = v[w];
+            for (int w = 0; w < 4; w++) row[w][0] = selu4(v[w]);
         }
     }
 };
@@ -496,6 +540,33 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
 #ifdef CV_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
+        if constexpr (MODE == 0 && POOL > 1) {
+            // inference: pool the PRE-activations (pw[j] = running maximum of the last j+1 rows), SELU once per
+            // pooled row (monotone activation: bit-identical, see conv1_tm); the first POOL-1 positions of a
+            // candidate produce no pooled row and skip the activation altogether
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const f4 t = acc[w] + b4;
+                const f4 o = max4(pw[POOL - 2][w], t);
+#pragma unroll
+                for (int j = POOL - 2; j > 0; j--) pw[j][w] = max4(pw[j - 1][w], t);
+                pw[0][w] = t;
+                if (h >= POOL - 1) {
+#if defined(CV_ABL) && (CV_ABL & 1)
+                    op[(size_t)((h - (POOL - 1)) * 4 + w) * (NT * 64)] = o;
+#else
+                    op[(size_t)((h - (POOL - 1)) * 4 + w) * (NT * 64)] = selu4(o);
+#endif
+                }
+            }
+#pragma unroll
+            for (int j = 0; j + 1 < KH; j++)
+#pragma unroll
+                for (int w = 0; w < 4; w++)
+#pragma unroll
+                    for (int cb = 0; cb < CINB; cb++) win[j][w][cb] = win[j + 1][w][cb];
+            continue;
+        }
         f4 v[4];
         if constexpr (MODE == 2) {
 #pragma unroll
@@ -576,7 +647,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
     f4 *op = out_tm + (size_t)g * (HOUT * 4 * NT * 64) + (size_t)nt * 64 + lane;
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
     f4 win[3][4][CINB];          // slot (r + 1) % 3 holds input row r
-    f4 m1[4], m2[4];             // SELU outputs of the previous row / max of the previous two
+    f4 m1[4], m2[4];             // pre-activations of the previous row / max of the previous two
 #pragma unroll
     for (int w = 0; w < 4; w++) { m1[w] = zero; m2[w] = zero; }
     auto load_row = [&](int hr, f4 (&row)[4][CINB]) {
@@ -614,13 +685,16 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
                     }
             }
         }
+        // max-pool on the PRE-activations, SELU once per pooled row (SELU is monotone over all of fp32 --
+        // cv_selu_sweep -- so max_j selu(a_j + b) == selu(max_j (a_j + b)) bit for bit): 24 activated rows per
+        // candidate instead of 26
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            const f4 v = selu4(acc[w] + b4);
-            const f4 o = max4(m2[w], v);             // max(v[h-2], v[h-1], v[h]); exact, order-free
-            m2[w] = max4(m1[w], v);
-            m1[w] = v;
-            if (h >= POOL - 1) op[(size_t)((h - (POOL - 1)) * 4 + w) * (NT * 64)] = o;
+            const f4 t = acc[w] + b4;                // (a sum needs no canonicalising v_max x, x, x; a raw MFMA result would)
+            const f4 o = max4(m2[w], t);             // max(t[h-2], t[h-1], t[h]); exact, order-free
+            m2[w] = max4(m1[w], t);
+            m1[w] = t;
+            if (h >= POOL - 1) op[(size_t)((h - (POOL - 1)) * 4 + w) * (NT * 64)] = selu4(o);
         }
     };
 #pragma unroll 1

@@ -74,6 +74,42 @@ __device__ __forceinline__ float selu(float x)
     return x < 0.0f ? neg : pos;
 }
 
+// Two SELUs at once on the packed fp32 pipe (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two IEEE operations per
+// instruction).  The operation sequence per element is selu()'s, each packed instruction rounds its two lanes
+// exactly like the scalar one, so the results are bit-identical; the multiplications, the ten fused
+// multiply-adds and the additions -- 15 of the 21 instructions -- cost half an issue slot per element
+// (tools/mfma_coissue.hip: 2.4 ns per packed instruction against 2.0 ns per scalar one next to the MFMAs).
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2v selu2(f2v x)
+{
+    f2v xc;
+    xc[0] = __builtin_amdgcn_fmed3f(x[0], -87.33654475055310f, 0.0f);
+    xc[1] = __builtin_amdgcn_fmed3f(x[1], -87.33654475055310f, 0.0f);
+    const f2v t = xc * 1.44269504088896341f;
+    f2v z;
+    z[0] = __builtin_rintf(t[0]); z[1] = __builtin_rintf(t[1]);
+    f2v r = __builtin_elementwise_fma(z, (f2v)(-0.693359375f), xc);
+    r = __builtin_elementwise_fma(z, (f2v)(2.12194440e-4f), r);
+    const f2v r2 = r * r;
+    f2v p = (f2v)(1.9875691500e-4f);
+    p = __builtin_elementwise_fma(p, r, (f2v)(1.3981999507e-3f));
+    p = __builtin_elementwise_fma(p, r, (f2v)(8.3334519073e-3f));
+    p = __builtin_elementwise_fma(p, r, (f2v)(4.1665795894e-2f));
+    p = __builtin_elementwise_fma(p, r, (f2v)(1.6666665459e-1f));
+    p = __builtin_elementwise_fma(p, r, (f2v)(5.0000001201e-1f));
+    f2v y = __builtin_elementwise_fma(p, r2, r);
+    y = y + 1.0f;
+    y[0] = __builtin_ldexpf(y[0], (int)z[0]);
+    y[1] = __builtin_ldexpf(y[1], (int)z[1]);
+    const f2v neg = SELU_SCALE * (SELU_ALPHA * (y - 1.0f));
+    const f2v pos = SELU_SCALE * x;
+    f2v o;
+    o[0] = x[0] < 0.0f ? neg[0] : pos[0];
+    o[1] = x[1] < 0.0f ? neg[1] : pos[1];
+    return o;
+}
+
 // d selu / d pre-activation
 __device__ __forceinline__ float selu_grad(float pre)
 {
