@@ -209,6 +209,10 @@ def train_main(args):
     steps = args.steps if args.steps != 64 else 20
     if args.overlap is not None:
         m.setOption("train_overlap", args.overlap)
+    if args.tiny is not None:
+        m.setOption("train_tiny_groups", args.tiny)
+    if args.ksplit is not None:
+        m.setOption("train_ksplit", args.ksplit)
     step = m.train if args.sync_loss else m.trainDeferred     # deferred: no host round trip per step (train.run_epoch's way)
     for _ in range(args.warmup):
         step(x, y)
@@ -261,6 +265,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--sync-loss", action="store_true", help="train mode: read the losses back after every step (m.train)")
     ap.add_argument("--overlap", type=int, default=None, help="train mode: option train_overlap (A/B)")
+    ap.add_argument("--tiny", type=int, default=None, help="train mode: option train_tiny_groups (A/B)")
+    ap.add_argument("--ksplit", type=int, default=None, help="train mode: option train_ksplit (A/B)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "pileup"],
                     help="infer (default, the headline metric) or train: Adam steps on the reference's global "
                          "batch of 10 000 split over the ranks, one RCCL gradient all-reduce per step "

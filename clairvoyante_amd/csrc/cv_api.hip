@@ -115,6 +115,8 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     alloc(&m->params, np); alloc(&m->grads_own, np + CV_GRAD_HEADER); alloc(&m->adam_m, np); alloc(&m->adam_v, np);
     if (m->grads_own) m->grads = m->grads_own + CV_GRAD_HEADER;
     m->train_overlap = 1;
+    m->train_ksplit = 1;
+    m->tiny_g = 160;
     alloc(&m->wp_conv1, 4 * 64);
     for (int l = 1; l < 3; l++) alloc(&m->wp_conv[l], (size_t)s.ntile[l] * arch->kh[l] * 4 * s.cinb[l] * 256);
     alloc(&m->wp_fc4, (size_t)s.kb4 * ((s.nb4 + 3) / 4 * 4) * 256);   // fragments padded to the wave count
@@ -134,7 +136,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
         cv_destroy(m);
         return 1;
     }
-    m->packed_dirty = true;
+    m->packed_dirty = true; m->packed_train_dirty = true;
     *out = m;
     return 0;
 }
@@ -193,7 +195,7 @@ extern "C" int cv_set_param(cv_model *m, const char *tf_name, const float *src, 
     hipStream_t st = (hipStream_t)stream;
     CV_HIP(hipMemcpyAsync(m->params + m->poff[i], src, sizeof(float) * count, hipMemcpyHostToDevice, st));
     CV_HIP(hipStreamSynchronize(st));
-    m->packed_dirty = true;
+    m->packed_dirty = true; m->packed_train_dirty = true;
     return 0;
 }
 
@@ -217,7 +219,7 @@ extern "C" int cv_get_param(cv_model *m, const char *tf_name, float *dst, int64_
 extern "C" int cv_params_changed(cv_model *m)
 {
     if (!m) { cv_set_error("null model"); return 1; }
-    m->packed_dirty = true;
+    m->packed_dirty = true; m->packed_train_dirty = true;
     return 0;
 }
 
@@ -231,6 +233,8 @@ extern "C" int cv_set_option(cv_model *m, const char *key, int64_t value)
     }
     if (!strcmp(key, "profile")) { m->profile = value ? 1 : 0; return 0; }
     if (!strcmp(key, "train_overlap")) { m->train_overlap = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "train_ksplit")) { m->train_ksplit = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "train_tiny_groups")) { m->tiny_g = value < 0 ? 0 : (value > 160 ? 160 : (int)value); return 0; }
     if (!strcmp(key, "variant")) { m->variant = (int)value; return 0; }
     if (!strcmp(key, "chunk")) {
         if (value < 16 || value > (1 << 22)) { cv_set_error("chunk must be in [16, 4194304]"); return 1; }
@@ -248,6 +252,8 @@ extern "C" int cv_get_option(const cv_model *m, const char *key, int64_t *value)
     if (!strcmp(key, "chunk")) { *value = m->chunk; return 0; }
     if (!strcmp(key, "profile")) { *value = m->profile; return 0; }
     if (!strcmp(key, "train_overlap")) { *value = m->train_overlap; return 0; }
+    if (!strcmp(key, "train_ksplit")) { *value = m->train_ksplit; return 0; }
+    if (!strcmp(key, "train_tiny_groups")) { *value = m->tiny_g; return 0; }
     if (!strcmp(key, "variant")) { *value = m->variant; return 0; }
     cv_set_error("unknown option '%s'", key);
     return 1;

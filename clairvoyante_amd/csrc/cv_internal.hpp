@@ -69,7 +69,8 @@ struct cv_model {
     float *wp_heads0;    // [nb4][64][4]  base head (rows 0..3)
     float *wp_heads1;    // [nb5][64][4]  zygosity / type / length heads
     int variant;         // bit 0: first layer fused into conv2; bit 1: MFMA heads kernel; bit 2: 8-wave fc4 workgroups; bit 3: rotating-window conv3
-    bool packed_dirty;
+    bool packed_dirty;         // forward fragments are stale
+    bool packed_train_dirty;   // data-gradient fragments are stale
     // workspaces (allocated lazily for `ws_cap` candidates)
     int64_t ws_cap;      // MFMA path capacity (multiple of 16)
     float *tm_p1, *tm_p2, *tm_p3, *tm_h4, *tm_h5;
@@ -91,6 +92,9 @@ struct cv_model {
     hipEvent_t tr_ev[16];
     hipEvent_t tr_dense_ready;
     int train_overlap;   // option: weight gradients on the side stream (default 1)
+    int train_ksplit;    // option: k-split fc4 forward at tiny batches (default 1)
+    int tiny_g;          // option "train_tiny_groups": batches of up to this many groups take the latency-oriented
+                         // kernel variants of the training step (default 160; 0 = never)
     // fc4 dropout output / keep mask (a*keep) of the LAST training slice, for cv_get_activation 6 / 7
     const float *last_tr_d4, *last_tr_mask;
     int64_t last_tr_n;
@@ -127,9 +131,13 @@ int cv_launch_heads(cv_model *m, const float *h4, const float *h5, int tm, int64
                     hipStream_t st);
 bool cv_tile_supported(const cv_model *m);
 int cv_pack_train_weights(cv_model *m, hipStream_t st);
+int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward);   // whatever is stale, in one launch
 int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float *a1, float *p2, float *a2,
                         float *p3, float *a3, hipStream_t st);
-int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm, int64_t n, hipStream_t st);
+#define CV_DENSE_KSPLIT 8      // k ranges of the fc4 training forward at tiny batches (cv_tile_dense_fwd)
+// part: scratch of CV_DENSE_KSPLIT * groups * nb4 fragments, or NULL = always the single ascending-k chain
+int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm, int64_t n, hipStream_t st,
+                      float *part = nullptr);
 int cv_tile_fc5_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
 int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
 int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);

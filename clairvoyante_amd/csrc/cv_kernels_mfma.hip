@@ -80,9 +80,8 @@ __device__ __forceinline__ f4 load_bias4(const float *__restrict__ bias, int ob,
 // ---------------------------------------------------------------------------
 // weight packing (runs once per parameter change)
 // ---------------------------------------------------------------------------
-__global__ void pack_conv1(const float *__restrict__ w, float *__restrict__ wp, int cout)
+__device__ __forceinline__ void pack_conv1(int64_t t, const float *__restrict__ w, float *__restrict__ wp, int cout)
 {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;   // [kw][lane]
     if (t >= 4 * 64) return;
     int lane = t & 63, kw = t >> 6;
     int i = lane & 15, kq = lane >> 4;
@@ -90,10 +89,9 @@ __global__ void pack_conv1(const float *__restrict__ w, float *__restrict__ wp, 
     wp[t] = co < cout ? w[((size_t)kw * 4 + kq) * cout + co] : 0.0f;
 }
 
-__global__ void pack_conv(const float *__restrict__ w, float *__restrict__ wp, int KH, int cin, int cout,
+__device__ __forceinline__ void pack_conv(int64_t t, const float *__restrict__ w, float *__restrict__ wp, int KH, int cin, int cout,
                           int CINB, int NT)
 {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = (int64_t)NT * KH * 4 * CINB * 256;
     if (t >= total) return;
     int s = (int)(t & 3), lane = (int)((t >> 2) & 63);
@@ -109,9 +107,8 @@ __global__ void pack_conv(const float *__restrict__ w, float *__restrict__ wp, i
 
 // dense [K][N] -> [kb][ob][lane][s];  input feature k = 16*kb + 4*s + kq.  NBP >= ceil(N/16)
 // fragments per k step (pad fragments are zero: see dense_tm)
-__global__ void pack_dense(const float *__restrict__ w, float *__restrict__ wp, int K, int N, int KB, int NBP)
+__device__ __forceinline__ void pack_dense(int64_t t, const float *__restrict__ w, float *__restrict__ wp, int K, int N, int KB, int NBP)
 {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = (int64_t)KB * NBP * 256;
     if (t >= total) return;
     int s = (int)(t & 3), lane = (int)((t >> 2) & 63);
@@ -126,10 +123,9 @@ __global__ void pack_dense(const float *__restrict__ w, float *__restrict__ wp, 
 // forward weights of a dense layer in NSLAB slabs of NBS output fragments (padded to NBSP per k step):
 // [slab][kb][NBSP][lane][s] -- small batches run one workgroup per (group block, slab), so that a layer
 // with few groups still fills the chip
-__global__ void pack_dense_slabs(const float *__restrict__ w, float *__restrict__ wp, int K, int N, int KB, int NBS,
+__device__ __forceinline__ void pack_dense_slabs(int64_t t, const float *__restrict__ w, float *__restrict__ wp, int K, int N, int KB, int NBS,
                                  int NBSP, int NSLAB)
 {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = (int64_t)NSLAB * KB * NBSP * 256;
     if (t >= total) return;
     int s = (int)(t & 3), lane = (int)((t >> 2) & 63);
@@ -144,10 +140,9 @@ __global__ void pack_dense_slabs(const float *__restrict__ w, float *__restrict_
 
 // data-gradient weights of a dense layer: out feature = original input k, in feature =
 // original output j; fragments [slab][jb][ob_in_slab][lane][s] (slabs of NBS output fragments)
-__global__ void pack_dense_dgrad(const float *__restrict__ w, float *__restrict__ wp, int K, int N, int JB,
+__device__ __forceinline__ void pack_dense_dgrad(int64_t t, const float *__restrict__ w, float *__restrict__ wp, int K, int N, int JB,
                                  int NBS, int NSLAB)
 {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = (int64_t)NSLAB * JB * NBS * 256;
     if (t >= total) return;
     int s = (int)(t & 3), lane = (int)((t >> 2) & 63);
@@ -163,10 +158,9 @@ __global__ void pack_dense_dgrad(const float *__restrict__ w, float *__restrict_
 
 // data-gradient weights of a conv layer (see conv_tm MODE 2): flipped taps, channels swapped
 //   Wd[nt'][kh'][kw'][cb'][lane][s] = W[KH-1-kh'][3-kw'][ci = 16 nt' + sigma(i)][co = 16 cb' + 4 s + kq]
-__global__ void pack_conv_dgrad(const float *__restrict__ w, float *__restrict__ wp, int KH, int cin, int cout,
+__device__ __forceinline__ void pack_conv_dgrad(int64_t t, const float *__restrict__ w, float *__restrict__ wp, int KH, int cin, int cout,
                                 int COB, int CIT)
 {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = (int64_t)CIT * KH * 4 * COB * 256;
     if (t >= total) return;
     int s = (int)(t & 3), lane = (int)((t >> 2) & 63);
@@ -424,8 +418,8 @@ struct front_source {
 // convolution  gIn[h][w][ci] = sum g[h-kh+pt][w-kw+1][co] W[kh][kw][ci][co]  on flipped,
 // in/out-swapped packed weights (pack_conv_dgrad): padding 2 left / 1 right and
 // KH-1-(KH-1)/2 on top, no bias, no activation, no pooling.
-// HSPLIT > 1 (no pooling, no fused first layer): HSPLIT waves share a (group, tile), each producing a
-// contiguous range of positions -- more waves in flight when a batch has few groups.
+// HSPLIT > 1 (no fused first layer): HSPLIT waves share a (group, tile), each producing a contiguous range of
+// (pooled) positions -- more waves in flight when a batch has few groups.
 template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT, int MODE, int HSPLIT = 1>
 __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, const float *__restrict__ x,
                                                    int64_t n, const float *__restrict__ wp1,
@@ -435,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
 {
     static_assert(FRONT == 0 || CINB == 1, "the fused first layer feeds one 16-channel fragment");
     static_assert(MODE != 2 || (POOL == 1 && FRONT == 0), "the data-gradient pass has no pooling / first layer");
-    static_assert(HSPLIT == 1 || (POOL == 1 && FRONT == 0), "position ranges need independent output rows");
+    static_assert(HSPLIT == 1 || FRONT == 0, "position ranges read their rows from a TM buffer");
     extern __shared__ __attribute__((aligned(16))) f4 ldsw[];
     constexpr int PADT = MODE == 2 ? KH - 1 - (KH - 1) / 2 : (KH - 1) / 2;
     constexpr int PADL = MODE == 2 ? 2 : 1;
@@ -448,7 +442,10 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
     const int hs = wv % HSPLIT, gt = wv / HSPLIT;
     const int g = gt / NT, nt = gt % NT;
     if (g >= G) return;
-    const int hbeg = HIN * hs / HSPLIT, hend = HIN * (hs + 1) / HSPLIT;      // positions [hbeg, hend)
+    // positions [hbeg, hend): with pooling a part owns the pooled rows [HOUT*hs/HSPLIT, HOUT*(hs+1)/HSPLIT) and
+    // computes the POOL-1 convolution rows behind them as well (recomputed by its neighbour: same values)
+    const int hbeg = POOL > 1 ? HOUT * hs / HSPLIT : HIN * hs / HSPLIT;
+    const int hend = POOL > 1 ? HOUT * (hs + 1) / HSPLIT + POOL - 1 : HIN * (hs + 1) / HSPLIT;
     const int q = lane >> 4;
     const f4 b4 = MODE == 2 ? (f4){0.f, 0.f, 0.f, 0.f} : load_bias4(bias, nt, q, cout);
     const f4 *inp = in_tm + (size_t)g * (HIN * 4 * CINB * 64) + lane;
@@ -551,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
 #pragma unroll
                 for (int j = POOL - 2; j > 0; j--) pw[j][w] = max4(pw[j - 1][w], t);
                 pw[0][w] = t;
-                if (h >= POOL - 1) {
+                if (h - hbeg >= POOL - 1) {
 #if defined(CV_ABL) && (CV_ABL & 1)
                     op[(size_t)((h - (POOL - 1)) * 4 + w) * (NT * 64)] = o;
 #else
@@ -599,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
                 for (int w = 0; w < 4; w++) pw[j][w] = pw[j + 1][w];
 #pragma unroll
             for (int w = 0; w < 4; w++) pw[POOL - 2][w] = v[w];
-            if (h >= POOL - 1) {
+            if (h - hbeg >= POOL - 1) {
 #pragma unroll
                 for (int w = 0; w < 4; w++) op[(size_t)((h - (POOL - 1)) * 4 + w) * (NT * 64)] = o[w];
             }
@@ -718,11 +715,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
 // The 6-way softmax spans lanes c+32 / c+48; its sum is formed in index order
 // ((((e0+e1)+e2)+e3)+e4)+e5 by passing the partial sum across.
 // ---------------------------------------------------------------------------
-__global__ void pack_heads(const float *__restrict__ wb, const float *__restrict__ wz,
+__device__ __forceinline__ void pack_heads(int64_t t, const float *__restrict__ wb, const float *__restrict__ wz,
                            const float *__restrict__ wt, const float *__restrict__ wl, int K4, int K5,
                            int NB4, int NB5, float *__restrict__ wp0, float *__restrict__ wp1)
 {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
     int tot0 = NB4 * 256, tot1 = NB5 * 256;
     if (t < tot0) {
         int s = t & 3, lane = (t >> 2) & 63, kb = t >> 8;
@@ -844,7 +840,15 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
     constexpr int NBP = (NB + WAVES - 1) / WAVES * WAVES;
     constexpr int STAGE = NBP * 64;              // f4 per stage
     constexpr int PER = NBP / WAVES;             // fragments each wave stages per k step
-    const f4 *wp = wp_all + (size_t)blockIdx.y * KB * STAGE;
+    // gridDim.z > 1 (training forward of tiny batches): the contraction is split into gridDim.z ranges of k
+    // fragments, each workgroup leaves the raw partial accumulators of its range in out_tm ([z][g][NBT] fragments)
+    // and dense_ksum adds the ranges in ascending order, + bias, SELU.  A fixed order (reproducible), but not the
+    // single ascending-k chain of the inference path -- used where the step is latency-bound (288 dependent k
+    // steps for fc4) and parity is a tolerance, never for cv_forward.
+    const int KS = gridDim.z, kz = blockIdx.z;
+    const int kb0 = KS > 1 ? KB * kz / KS : 0, KBA = KB;
+    if (KS > 1) KB = KBA * (kz + 1) / KS - kb0;
+    const f4 *wp = wp_all + ((size_t)blockIdx.y * KBA + kb0) * STAGE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = (blockIdx.x * WAVES + wid) * GR;
@@ -852,7 +856,7 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
 #pragma unroll
     for (int r = 0; r < GR; r++) {
         const int gl = g + r < G ? g + r : G - 1;
-        bp[r] = in_tm + (size_t)gl * KB * 64 + lane;
+        bp[r] = in_tm + ((size_t)gl * KBA + kb0) * 64 + lane;
     }
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
     f4 acc[GR][NB];
@@ -938,7 +942,12 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
 #pragma unroll
     for (int r = 0; r < GR; r++) {
         if (g + r >= G) break;
-        f4 *op = out_tm + ((size_t)(g + r) * NBT + (size_t)blockIdx.y * NB) * 64 + lane;
+        f4 *op = out_tm + (((size_t)kz * G + (size_t)(g + r)) * NBT + (size_t)blockIdx.y * NB) * 64 + lane;
+        if (KS > 1) {
+#pragma unroll
+            for (int ob = 0; ob < NB; ob++) op[ob * 64] = acc[r][ob];
+            continue;
+        }
 #pragma unroll
         for (int ob = 0; ob < NB; ob++) {
             if constexpr (EPI == 0) {
@@ -949,6 +958,19 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
             }
         }
     }
+}
+
+// second pass of a k-split dense layer: out = selu(sum_z part[z] + bias), ranges added in ascending z
+__global__ void dense_ksum(const f4 *__restrict__ part, int KS, int G, int NBT, const float *__restrict__ bias, int nout,
+                           f4 *__restrict__ out_tm)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = (int64_t)G * NBT * 64;
+    if (t >= per) return;
+    f4 v = part[t];
+    for (int z = 1; z < KS; z++) v += part[(size_t)z * per + t];
+    const int lane = (int)(t & 63), ob = (int)((t >> 6) % NBT);
+    out_tm[t] = selu4(v + load_bias4(bias, ob, lane >> 4, nout));
 }
 
 // training: the same two tile products, stored as pre-activations (+ bias) in candidate-major [n][16] order
@@ -1000,6 +1022,9 @@ __global__ __launch_bounds__(256) void heads_pre_tm(const f4 *__restrict__ h4, c
 // up to this many groups (16 candidates each) fc4 runs as 3 output slabs per group block: 8-wave workgroups
 // x 3 slabs fill the 256 CUs from ~700 groups on; above the threshold one workgroup keeps all 21 tiles
 constexpr int CV_FC4_SLAB_MAX_G = 2048;
+// "tiny" batches of the training step (cv_model::tiny_g, option "train_tiny_groups", default 160 groups = 2 560
+// candidates): the step is a chain of latency-bound kernels on a fraction of the chip; the layers then split their
+// serial loops over more waves
 
 inline unsigned nblk(int64_t total, int bs) { return (unsigned)((total + bs - 1) / bs); }
 
@@ -1039,11 +1064,20 @@ int launch_conv3_rot(const float *in, const float *wp, const float *bias, int co
 
 template <int NB, int WAVES, int EPI = 0, int GR = 1>
 int launch_dense(const float *in, int KB, const float *wp, const float *bias, int nout, float *out, int G,
-                 hipStream_t st, int slabs = 1)
+                 hipStream_t st, int slabs = 1, int ksplit = 1, float *part = nullptr)
 {
     auto k = dense_tm<NB, WAVES, EPI, GR>;
     size_t lds = (size_t)3 * ((NB + WAVES - 1) / WAVES * WAVES) * 1024;
     if (set_lds(k, lds)) return 1;
+    if (ksplit > 1) {       // partial sums per k range, then dense_ksum (EPI 0 layers only)
+        static_assert(EPI == 0 || true, "");
+        k<<<dim3(nblk(G, WAVES * GR), slabs, ksplit), WAVES * 64, lds, st>>>((const f4 *)in, KB, (const f4 *)wp, bias, nout,
+                                                                        (f4 *)part, G, NB * slabs);
+        dense_ksum<<<nblk((int64_t)G * NB * slabs * 64, 256), 256, 0, st>>>((const f4 *)part, ksplit, G, NB * slabs, bias, nout,
+                                                                          (f4 *)out);
+        CV_HIP(hipGetLastError());
+        return 0;
+    }
     k<<<dim3(nblk(G, WAVES * GR), slabs), WAVES * 64, lds, st>>>((const f4 *)in, KB, (const f4 *)wp, bias, nout,
                                                             (f4 *)out, G, NB * slabs);
     CV_HIP(hipGetLastError());
@@ -1060,33 +1094,117 @@ bool arch_is(const cv_arch &a, int k0, int k1, int k2, int c0, int c1, int c2, i
 
 }  // namespace
 
-int cv_pack_weights(cv_model *m, hipStream_t st)
+// ---- all weight packing of a parameter change in ONE launch ------------------------------------------------
+// A training step re-packs every layer after its Adam update (forward fragments, slabs, transposed data-gradient
+// fragments: 14 small jobs).  As separate launches they are 14 x ~5 us of dependent-launch latency at the head of
+// the step -- 6 % of the step at config 4's per-rank batch; here the jobs share one grid (a block finds its job
+// from the table) and cost one launch.
+static bool is_full(const cv_arch &a);
+
+struct pack_job {
+    int kind;                      // 0 conv1, 1 conv, 2 dense, 3 dense slabs, 4 dense dgrad, 5 conv dgrad, 6 heads
+    const float *src[4];
+    float *dst[2];
+    int i[8];
+    unsigned first;                // first block of the job
+};
+struct pack_tab { pack_job j[14]; int n; };
+
+__global__ __launch_bounds__(256) void pack_all(pack_tab tab)
+{
+    const unsigned b = blockIdx.x;
+    int k = 0;
+    while (k + 1 < tab.n && b >= tab.j[k + 1].first) k++;
+    const pack_job &J = tab.j[k];
+    const int64_t t = (int64_t)(b - J.first) * 256 + threadIdx.x;
+    switch (J.kind) {
+    case 0: pack_conv1(t, J.src[0], J.dst[0], J.i[0]); break;
+    case 1: pack_conv(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4]); break;
+    case 2: pack_dense(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3]); break;
+    case 3: pack_dense_slabs(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4], J.i[5]); break;
+    case 4: pack_dense_dgrad(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4]); break;
+    case 5: pack_conv_dgrad(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4]); break;
+    default: pack_heads(t, J.src[0], J.src[1], J.src[2], J.src[3], J.i[0], J.i[1], J.i[2], J.i[3], J.dst[0], J.dst[1]); break;
+    }
+}
+
+struct pack_builder {
+    pack_tab tab; unsigned blocks;
+    pack_builder() : blocks(0) { tab.n = 0; }
+    pack_job &add(int kind, int64_t threads)
+    {
+        pack_job &J = tab.j[tab.n++];
+        J = pack_job();
+        J.kind = kind; J.first = blocks;
+        blocks += (unsigned)((threads + 255) / 256);
+        return J;
+    }
+};
+
+// forward fragments (inference and training); with_train: also the transposed / flipped fragments of the
+// data-gradient kernels
+static int pack_launch(cv_model *m, hipStream_t st, bool fwd, bool with_train)
 {
     const float *P = m->params;
     const int64_t *o = m->poff;
     const cv_shapes &s = m->sh;
-    pack_conv1<<<1, 256, 0, st>>>(P + o[0], m->wp_conv1, m->arch.cout[0]);
-    for (int l = 1; l < 3; l++) {
-        int64_t tot = (int64_t)s.ntile[l] * m->arch.kh[l] * 4 * s.cinb[l] * 256;
-        pack_conv<<<nblk(tot, 256), 256, 0, st>>>(P + o[2 * l], m->wp_conv[l], m->arch.kh[l], s.cin[l],
-                                                  m->arch.cout[l], s.cinb[l], s.ntile[l]);
-    }
-    {
+    const cv_arch &a = m->arch;
+    pack_builder pb;
+    if (fwd) {
+        { pack_job &J = pb.add(0, 256); J.src[0] = P + o[0]; J.dst[0] = m->wp_conv1; J.i[0] = a.cout[0]; }
+        for (int l = 1; l < 3; l++) {
+            pack_job &J = pb.add(1, (int64_t)s.ntile[l] * a.kh[l] * 4 * s.cinb[l] * 256);
+            J.src[0] = P + o[2 * l]; J.dst[0] = m->wp_conv[l];
+            J.i[0] = a.kh[l]; J.i[1] = s.cin[l]; J.i[2] = a.cout[l]; J.i[3] = s.cinb[l]; J.i[4] = s.ntile[l];
+        }
         const int nbp4 = (s.nb4 + 3) / 4 * 4, nbp5 = (s.nb5 + 3) / 4 * 4;   // launch_dense: WAVES = 4
-        int64_t tot = (int64_t)s.kb4 * nbp4 * 256;
-        pack_dense<<<nblk(tot, 256), 256, 0, st>>>(P + o[6], m->wp_fc4, s.flat, m->arch.fc4, s.kb4, nbp4);
-        tot = (int64_t)s.nb4 * nbp5 * 256;
-        pack_dense<<<nblk(tot, 256), 256, 0, st>>>(P + o[8], m->wp_fc5, m->arch.fc4, m->arch.fc5, s.nb4, nbp5);
+        { pack_job &J = pb.add(2, (int64_t)s.kb4 * nbp4 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wp_fc4;
+          J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = nbp4; }
+        { pack_job &J = pb.add(2, (int64_t)s.nb4 * nbp5 * 256); J.src[0] = P + o[8]; J.dst[0] = m->wp_fc5;
+          J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb4; J.i[3] = nbp5; }
         if (m->wps_fc4) {       // full topology: fc4 in 3 slabs of 7 fragments for small batches
-            tot = (int64_t)3 * s.kb4 * 8 * 256;
-            pack_dense_slabs<<<nblk(tot, 256), 256, 0, st>>>(P + o[6], m->wps_fc4, s.flat, m->arch.fc4, s.kb4, 7, 8, 3);
+            pack_job &J = pb.add(3, (int64_t)3 * s.kb4 * 8 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wps_fc4;
+            J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = 7; J.i[4] = 8; J.i[5] = 3;
+        }
+        { pack_job &J = pb.add(6, (int64_t)(s.nb4 + s.nb5) * 256);
+          J.src[0] = P + o[10]; J.src[1] = P + o[12]; J.src[2] = P + o[14]; J.src[3] = P + o[16];
+          J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb4; J.i[3] = s.nb5; J.dst[0] = m->wp_heads0; J.dst[1] = m->wp_heads1; }
+    }
+    if (with_train) {
+        for (int l = 1; l < 3; l++) {
+            pack_job &J = pb.add(5, (int64_t)s.cinb[l] * a.kh[l] * 4 * s.ntile[l] * 256);
+            J.src[0] = P + o[2 * l]; J.dst[0] = m->wpd_conv[l];
+            J.i[0] = a.kh[l]; J.i[1] = s.cin[l]; J.i[2] = a.cout[l]; J.i[3] = s.ntile[l]; J.i[4] = s.cinb[l];
+        }
+        { pack_job &J = pb.add(4, (int64_t)(s.kb4 / 24) * s.nb4 * 24 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wpd_fc4;
+          J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.nb4; J.i[3] = 24; J.i[4] = s.kb4 / 24; }
+        {   // fc5: one slab; fragment stride = dense_tm's padded count (full: 21 -> 24 with 8 waves, slim: 3 -> 4)
+            const int nbp = is_full(a) ? 24 : 4;
+            pack_job &J = pb.add(4, (int64_t)s.nb5 * nbp * 256); J.src[0] = P + o[8]; J.dst[0] = m->wpd_fc5;
+            J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb5; J.i[3] = nbp; J.i[4] = 1;
         }
     }
-    pack_heads<<<nblk((int64_t)(s.nb4 + s.nb5) * 256, 256), 256, 0, st>>>(P + o[10], P + o[12], P + o[14], P + o[16],
-                                                                          m->arch.fc4, m->arch.fc5, s.nb4, s.nb5,
-                                                                          m->wp_heads0, m->wp_heads1);
+    if (pb.blocks == 0) return 0;
+    pack_all<<<pb.blocks, 256, 0, st>>>(pb.tab);
     CV_HIP(hipGetLastError());
+    return 0;
+}
+
+int cv_pack_weights(cv_model *m, hipStream_t st)
+{
+    if (pack_launch(m, st, true, false)) return 1;
     m->packed_dirty = false;
+    return 0;
+}
+
+// training step: whatever is stale in one launch
+int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward)
+{
+    const bool fwd = m->packed_dirty, tr = backward && m->packed_train_dirty;
+    if (!fwd && !tr) return 0;
+    if (pack_launch(m, st, fwd, tr)) return 1;
+    if (fwd) m->packed_dirty = false;
+    if (tr) m->packed_train_dirty = false;
     return 0;
 }
 
@@ -1701,23 +1819,8 @@ bool cv_tile_supported(const cv_model *m) { return is_full(m->arch) || is_slim(m
 
 int cv_pack_train_weights(cv_model *m, hipStream_t st)
 {
-    const float *P = m->params;
-    const int64_t *o = m->poff;
-    const cv_shapes &s = m->sh;
-    const cv_arch &a = m->arch;
-    for (int l = 1; l < 3; l++) {
-        int64_t tot = (int64_t)s.cinb[l] * a.kh[l] * 4 * s.ntile[l] * 256;
-        pack_conv_dgrad<<<nblk(tot, 256), 256, 0, st>>>(P + o[2 * l], m->wpd_conv[l], a.kh[l], s.cin[l], a.cout[l],
-                                                        s.ntile[l], s.cinb[l]);
-    }
-    int64_t tot = (int64_t)(s.kb4 / 24) * s.nb4 * 24 * 256;
-    pack_dense_dgrad<<<nblk(tot, 256), 256, 0, st>>>(P + o[6], m->wpd_fc4, s.flat, a.fc4, s.nb4, 24, s.kb4 / 24);
-    {   // fc5: one slab; fragment stride = dense_tm's padded count (full: 21 -> 24 with 8 waves, slim: 3 -> 4)
-        const int nbp = is_full(a) ? 24 : 4;
-        tot = (int64_t)s.nb5 * nbp * 256;
-        pack_dense_dgrad<<<nblk(tot, 256), 256, 0, st>>>(P + o[8], m->wpd_fc5, a.fc4, a.fc5, s.nb5, nbp, 1);
-    }
-    CV_HIP(hipGetLastError());
+    if (pack_launch(m, st, false, true)) return 1;
+    m->packed_train_dirty = false;
     return 0;
 }
 
@@ -1730,20 +1833,33 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
     const int64_t *o = m->poff;
     const int G = (int)((n + 15) / 16);
     int rc = 0;
+    // few groups (config 4's per-rank batch of 1 250 is 79): the positions of a (group, tile) are split over several
+    // waves so that the layer is not one long serial loop on a quarter of the SIMDs; same values, row for row
+    const bool tiny = G <= m->tiny_g;
     if (is_full(a)) {
         conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (f4 *)a1);
-        rc |= launch_conv<2, 1, 2, 4, 29, 0, 1>(p1, x, n, nullptr, nullptr, 0, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
-        rc |= launch_conv<3, 2, 3, 3, 26, 0, 1>(p2, x, n, nullptr, nullptr, 0, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
+        if (tiny) {
+            rc |= launch_conv<2, 1, 2, 4, 29, 0, 1, 4>(p1, x, n, nullptr, nullptr, 0, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
+            rc |= launch_conv<3, 2, 3, 3, 26, 0, 1, 4>(p2, x, n, nullptr, nullptr, 0, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
+        } else {
+            rc |= launch_conv<2, 1, 2, 4, 29, 0, 1>(p1, x, n, nullptr, nullptr, 0, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
+            rc |= launch_conv<3, 2, 3, 3, 26, 0, 1>(p2, x, n, nullptr, nullptr, 0, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
+        }
     } else {
         conv1_tm<1, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (f4 *)a1);
-        rc |= launch_conv<3, 1, 1, 1, 33, 0, 1>(p1, x, n, nullptr, nullptr, 0, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
-        rc |= launch_conv<5, 1, 2, 1, 33, 0, 1>(p2, x, n, nullptr, nullptr, 0, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
+        if (tiny) {
+            rc |= launch_conv<3, 1, 1, 1, 33, 0, 1, 4>(p1, x, n, nullptr, nullptr, 0, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
+            rc |= launch_conv<5, 1, 2, 1, 33, 0, 1, 4>(p2, x, n, nullptr, nullptr, 0, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
+        } else {
+            rc |= launch_conv<3, 1, 1, 1, 33, 0, 1>(p1, x, n, nullptr, nullptr, 0, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
+            rc |= launch_conv<5, 1, 2, 1, 33, 0, 1>(p2, x, n, nullptr, nullptr, 0, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
+        }
     }
     CV_HIP(hipGetLastError());
     return rc;
 }
 
-int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm, int64_t n, hipStream_t st)
+int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm, int64_t n, hipStream_t st, float *part)
 {
     const cv_arch &a = m->arch;
     const float *P = m->params;
@@ -1752,6 +1868,11 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
     const int G = (int)((n + 15) / 16);
     if (is_full(a)) {
         if (layer == 4) {
+            // tiny batches: 288 dependent k steps at ~0.9 us each are the longest kernel of the step; eight k ranges
+            // (CV_DENSE_KSPLIT) run side by side instead and a second pass adds them up in order
+            if (part && G <= m->tiny_g)
+                return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3, CV_DENSE_KSPLIT, part);
+            // (two k ranges at train.py's batch of 10 000 -- 237 workgroups otherwise -- measured: no gain)
             if (G <= CV_FC4_SLAB_MAX_G) return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3);
             return launch_dense<21, 8>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);
         }
@@ -1785,18 +1906,23 @@ int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm,
     const int G = (int)((n + 15) / 16);
     const float *W = m->wpd_conv[layer];
     const bool few = G <= 1024;        // train.py's batch of 10 000 is 625 groups: split the positions over more waves
+    const bool tiny = G <= m->tiny_g;  // a rank's share of it: more still
     if (is_full(a)) {
         if (layer == 2) {
+            if (tiny) return launch_conv<3, 3, 2, 1, 26, 0, 2, 6>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
             if (few) return launch_conv<3, 3, 2, 1, 26, 0, 2, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
             return launch_conv<3, 3, 2, 1, 26, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
         }
+        if (tiny) return launch_conv<2, 2, 1, 1, 29, 0, 2, 8>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
         if (few) return launch_conv<2, 2, 1, 1, 29, 0, 2, 4>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
         return launch_conv<2, 2, 1, 1, 29, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
     }
     if (layer == 2) {
+        if (tiny) return launch_conv<5, 2, 1, 1, 33, 0, 2, 8>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
         if (few) return launch_conv<5, 2, 1, 1, 33, 0, 2, 4>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
         return launch_conv<5, 2, 1, 1, 33, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
     }
+    if (tiny) return launch_conv<3, 1, 1, 1, 33, 0, 2, 8>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
     if (few) return launch_conv<3, 1, 1, 1, 33, 0, 2, 4>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
     return launch_conv<3, 1, 1, 1, 33, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
 }

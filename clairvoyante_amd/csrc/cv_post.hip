@@ -178,7 +178,7 @@ extern "C" int cv_flat_copy(cv_model *m, int which, float *caller_dev, int to_mo
     size_t bytes = sizeof(float) * m->poff[CV_NUM_PARAMS];
     if (to_model) {
         CV_HIP(hipMemcpyAsync(bufs[which], caller_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-        if (which == 0) m->packed_dirty = true;
+        if (which == 0) m->packed_dirty = true; m->packed_train_dirty = true;
     } else {
         CV_HIP(hipMemcpyAsync(caller_dev, bufs[which], bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
@@ -197,6 +197,6 @@ extern "C" int cv_apply_adam(cv_model *m, float lr, float lambda, int64_t t, voi
     adam_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(m->params, m->adam_m, m->adam_v,
                                                                              m->grads, offs, (float)lr_t, lambda);
     CV_HIP(hipGetLastError());
-    m->packed_dirty = true;
+    m->packed_dirty = true; m->packed_train_dirty = true;
     return 0;
 }

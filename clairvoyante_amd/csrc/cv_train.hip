@@ -476,9 +476,65 @@ __global__ void b_pool_selu_tm(const tf4 *__restrict__ gpool, const tf4 *__restr
     }
 }
 
-static int launch_pool_selu(const float *gpool, const float *act, float *gpre, int64_t G, int H, int NT, int p,
-                            hipStream_t st)
+// The same result with one thread per (group, column, ROW): row h collects the gradients of the <= P windows that
+// hold it (ascending window order, first maximum wins: the order and the rule of the streaming kernel, so the bits
+// are the same) -- P*P cached reads per thread instead of a serial walk over the H rows.  For batches of few
+// groups, where the streaming kernel is a handful of waves each waiting on H dependent steps.
+template <int P>
+__global__ void b_pool_selu_rows(const tf4 *__restrict__ gpool, const tf4 *__restrict__ act, tf4 *__restrict__ gpre,
+                                 int64_t G, int H, int NT)
 {
+    const int cols = 4 * NT * 64;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= G * H * cols) return;
+    const int col = (int)(t % cols);
+    const int h = (int)((t / cols) % H);
+    const int64_t g = t / ((int64_t)cols * H);
+    const int Ho = H - P + 1;
+    const tf4 *a = act + (size_t)g * H * cols + col;
+    const tf4 *gp = gpool + (size_t)g * Ho * cols + col;
+    tf4 acc = (tf4){0.f, 0.f, 0.f, 0.f};
+    const int lo = h - (P - 1) > 0 ? h - (P - 1) : 0, hi = h < Ho - 1 ? h : Ho - 1;
+    for (int ho = lo; ho <= hi; ho++) {
+        tf4 w[P];
+#pragma unroll
+        for (int d = 0; d < P; d++) w[d] = a[(size_t)(ho + d) * cols];
+        const tf4 gv = gp[(size_t)ho * cols];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float mx = w[0][k];
+            int idx = 0;
+#pragma unroll
+            for (int d = 1; d < P; d++) {
+                const bool gt = w[d][k] > mx;
+                mx = gt ? w[d][k] : mx;
+                idx = gt ? d : idx;
+            }
+            acc[k] += ho + idx == h ? gv[k] : 0.0f;
+        }
+    }
+    const tf4 me = a[(size_t)h * cols];
+    tf4 r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k] = acc[k] * selu_grad_from_out(me[k]);
+    gpre[(size_t)(g * H + h) * cols + col] = r;
+}
+
+static int launch_pool_selu(const float *gpool, const float *act, float *gpre, int64_t G, int H, int NT, int p,
+                            hipStream_t st, int tiny_g)
+{
+    if (G <= tiny_g && p > 1) {       // tiny batches (cv_model::tiny_g)
+        const unsigned grid = (unsigned)((G * H * 4 * NT * 64 + 255) / 256);
+        const tf4 *gi = (const tf4 *)gpool, *ai = (const tf4 *)act;
+        tf4 *go = (tf4 *)gpre;
+        switch (p) {
+        case 2: b_pool_selu_rows<2><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); return 0;
+        case 3: b_pool_selu_rows<3><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); return 0;
+        case 4: b_pool_selu_rows<4><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); return 0;
+        case 5: b_pool_selu_rows<5><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); return 0;
+        default: break;
+        }
+    }
     const unsigned grid = (unsigned)((G * 4 * NT * 64 + 255) / 256);
     const tf4 *gi = (const tf4 *)gpool, *ai = (const tf4 *)act;
     tf4 *go = (tf4 *)gpre;
@@ -586,7 +642,7 @@ static size_t train_floats_per_cand(const cv_model *m)
     // tile path: TM copies of activations, pre-pool activations and three gradient maps,
     // padded channel counts, plus the dense TM buffers
     for (int l = 0; l < 3; l++) f += (size_t)(2 * s.hc[l] + 2 * s.hp[l]) * 4 * s.ntile[l] * 16;
-    f += 6 * (size_t)s.nb4 * 16 + 2 * (size_t)s.nb5 * 16;
+    f += (6 + CV_DENSE_KSPLIT) * (size_t)s.nb4 * 16 + 2 * (size_t)s.nb5 * 16;
     return f + 64 * 80;
 }
 
@@ -678,7 +734,7 @@ struct tr_fork {
     int to_side()                 // sw continues behind everything enqueued on st so far
     {
         if (sw == st) return 0;
-        hipEvent_t e = m->tr_ev[k++ % CV_TR_EVENTS];
+        hipEvent_t e = m->tr_ev[k++ % (CV_TR_EVENTS - 1)];
         CV_HIP(hipEventRecord(e, st));
         CV_HIP(hipStreamWaitEvent(sw, e, 0));
         return 0;
@@ -686,7 +742,7 @@ struct tr_fork {
     int join()                    // st continues behind everything enqueued on sw so far
     {
         if (sw == st) return 0;
-        hipEvent_t e = m->tr_ev[k++ % CV_TR_EVENTS];
+        hipEvent_t e = m->tr_ev[k++ % (CV_TR_EVENTS - 1)];
         CV_HIP(hipEventRecord(e, sw));
         CV_HIP(hipStreamWaitEvent(st, e, 0));
         return 0;
@@ -715,11 +771,12 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     for (int l = 0; l < 3; l++) { tp[l] = sb.take(np * fp[l]); ta[l] = sb.take(np * fa[l]); }
     float *th4 = sb.take(np * f4u), *td4 = sb.take(np * f4u), *tmask = sb.take(np * f4u), *th5 = sb.take(np * f5u);
     float *ghpre = sb.take((size_t)n * 16);
-    if (!ghpre) { cv_set_error("training workspace too small"); return 1; }
+    float *kpart = sb.take((size_t)CV_DENSE_KSPLIT * np * f4u);      // partial sums of the k-split fc4 forward
+    if (!ghpre || !kpart) { cv_set_error("training workspace too small"); return 1; }
     // ---- forward
-    if (m->packed_dirty && cv_pack_weights(m, st)) return 1;
+    if (cv_pack_for_training(m, st, backward)) return 1;
     if (cv_tile_train_convs(m, x, n, tp[0], ta[0], tp[1], ta[1], tp[2], ta[2], st)) return 1;
-    if (cv_tile_dense_fwd(m, 4, tp[2], th4, n, st)) return 1;
+    if (cv_tile_dense_fwd(m, 4, tp[2], th4, n, st, m->train_ksplit ? kpart : nullptr)) return 1;
     if (cv_dropout_tm(m, th4, td4, tmask, n, backward ? drop4 : 0.0f, seed, step, cand0, st)) return 1;
     m->last_tr_d4 = td4; m->last_tr_mask = tmask; m->last_tr_n = n; m->last_tr_tile = 1;
     if (cv_tile_dense_fwd(m, 5, td4, th5, n, st)) return 1;
@@ -732,7 +789,6 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     float *tgpre[3], *tgin[3];
     for (int l = 0; l < 3; l++) { tgpre[l] = sb.take(np * fa[l]); tgin[l] = sb.take(np * fp[l]); }
     if (!tgin[2]) { cv_set_error("training workspace too small"); return 1; }
-    if (cv_pack_train_weights(m, st)) return 1;
     tr_fork f{m, st, sw, 0};
     // heads: weight gradients on the matrix cores (inputs tile-major, the 16 gradients as they lie), data
     // gradients written to TM
@@ -757,7 +813,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     // conv stack
     for (int l = 2; l >= 0; l--) {
         const int H = s.hc[l], NT = s.ntile[l];
-        if (launch_pool_selu(tgin[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st)) return 1;
+        if (launch_pool_selu(tgin[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st, m->tiny_g)) return 1;
         if (f.to_side()) return 1;
         if (l == 0) {        // first layer: X viewed as [33][16] fragments, read in place
             if (cv_tile_conv1_wgrad(m, x, tgpre[0], n, sw)) return 1;
@@ -848,6 +904,17 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
     hipStream_t sw = (backward && m->train_overlap) ? m->tr_side : st;
     CV_HIP(hipMemsetAsync(m->loss_dev, 0, sizeof(double) * 8, st));
     if (backward) CV_HIP(hipMemsetAsync(m->grads, 0, sizeof(float) * m->poff[CV_NUM_PARAMS], st));
+    // lambda * sum(w^2)/2 depends on the weights alone: with a side stream it runs there, next to the forward pass
+    // (the slices join the side stream before they return), instead of at the tail of the step
+    bool l2_done = false;
+    if (lambda != 0.0f && sw != st && n > 0) {
+        CV_HIP(hipEventRecord(m->tr_ev[CV_TR_EVENTS - 1], st));
+        CV_HIP(hipStreamWaitEvent(sw, m->tr_ev[CV_TR_EVENTS - 1], 0));
+        l2_args la;
+        for (int p = 0; p < CV_NUM_PARAMS; p += 2) { la.w[p / 2] = m->params + m->poff[p]; la.count[p / 2] = m->psize[p]; }
+        t_l2<<<dim3(256, CV_NUM_PARAMS / 2), 256, 0, sw>>>(la, m->loss_dev + 4);
+        l2_done = true;
+    }
     bool recorded = false;
     for (int64_t off = 0; off < n; off += slice) {
         int64_t cn = n - off < slice ? n - off : slice;
@@ -860,7 +927,7 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
     }
     if (backward && !recorded) CV_HIP(hipEventRecord(m->tr_dense_ready, st));      // empty batch
     if (backward && comm) CV_HIP(hipStreamWaitEvent(comm, m->tr_dense_ready, 0));
-    if (lambda != 0.0f) {
+    if (lambda != 0.0f && !l2_done) {
         l2_args la;
         for (int p = 0; p < CV_NUM_PARAMS; p += 2) { la.w[p / 2] = m->params + m->poff[p]; la.count[p / 2] = m->psize[p]; }
         t_l2<<<dim3(256, CV_NUM_PARAMS / 2), 256, 0, st>>>(la, m->loss_dev + 4);
