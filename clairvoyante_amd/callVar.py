@@ -243,10 +243,110 @@ def Run(args):
             param.NUM_THREADS = 4
     else:
         param.NUM_THREADS = args.threads
+    from . import parallel
+    rank, ws, _local = parallel.init_from_env(os.environ.get("CV_DIST_BACKEND"))   # torchrun: one process per GPU
     m = cv.Clairvoyante()
     m.init()
     m.restoreParameters(os.path.abspath(args.chkpnt_fn))
-    Test(args, m, utils)
+    if ws > 1:
+        TestSharded(args, m, utils, rank, ws)
+    else:
+        Test(args, m, utils)
+
+
+# input lines per block of the multi-rank split (block k -> rank k % N); CV_SHARD_BLOCK_LINES overrides (tests)
+SHARD_BLOCK_LINES = int(os.environ.get("CV_SHARD_BLOCK_LINES", "16384"))
+
+
+def merge_fragments(call_fn, ws, out_fh):
+    """Rank 0: append the per-rank record fragments to the VCF in input order.  Rank r wrote CALL.rank<r> (its
+    records, block after block) and CALL.rank<r>.idx (one line per block it owns: "<block> <bytes>"); block k
+    belongs to rank k % ws, so walking k = 0, 1, 2, ... and taking the next <bytes> of that rank's fragment
+    reproduces the single-process file -- the reference's own multi-process recipe is per-chunk VCFs joined by
+    `vcfcat` (README.md:184-202)."""
+    frags = [open("%s.rank%d" % (call_fn, r), "rb") for r in range(ws)]
+    idx = []
+    for r in range(ws):
+        with open("%s.rank%d.idx" % (call_fn, r)) as f:
+            idx.append([tuple(int(v) for v in line.split()) for line in f if line.strip()])
+    nblocks = sum(len(i) for i in idx)
+    for k in range(nblocks):
+        r = k % ws
+        if k // ws >= len(idx[r]) or idx[r][k // ws][0] != k:
+            raise RuntimeError("fragment index of rank %d does not hold block %d" % (r, k))
+        nbytes = idx[r][k // ws][1]
+        if nbytes:
+            data = frags[r].read(nbytes)
+            if len(data) != nbytes:
+                raise RuntimeError("fragment of rank %d is short at block %d" % (r, k))
+            out_fh.write(data.decode("ascii"))
+    for f in frags:
+        f.close()
+    for r in range(ws):
+        os.remove("%s.rank%d" % (call_fn, r)); os.remove("%s.rank%d.idx" % (call_fn, r))
+
+
+def TestSharded(args, m, utils, rank, ws):
+    """Test() under torchrun (BASELINE configs[2]: candidates sharded over the GPUs of a node): candidates are
+    independent (v3.py:54-138 has no cross-candidate state), so the ranks split the INPUT LINES block-cyclically,
+    every rank calls its blocks with its own replica of the weights -- no collective on the data path -- and
+    rank 0 joins the per-rank record fragments in input order: the VCF is byte-identical to the single-process
+    one."""
+    import io
+    import torch
+    import torch.distributed as dist
+    logging.info("Calling variants (rank %d of %d) ..." % (rank, ws))
+    predictStart = time.time()
+    frag_fn = "%s.rank%d" % (args.call_fn, rank)
+    frag = open(frag_fn, "w")
+    index = []
+    q_in = Queue(maxsize=4)
+
+    def reader():
+        try:
+            for item in utils.GetTensorBlocks(args.tensor_fn, SHARD_BLOCK_LINES, rank, ws):
+                q_in.put(item)
+        except BaseException as e:
+            q_in.put(e)
+        q_in.put(None)
+
+    rt = Thread(target=reader, daemon=True)
+    rt.start()
+    pending = None
+    with torch.cuda.device(m.device):
+        while True:
+            item = q_in.get()
+            if isinstance(item, BaseException):
+                raise item
+            nxt = None
+            if item is not None:
+                block, num, X, pos = item
+                call = qual = None
+                if num > 0:
+                    xd = torch.from_numpy(X).to(m.device, non_blocking=True)
+                    call, qual = predict_and_reduce(m, xd)
+                nxt = (block, num, X, pos, call, qual)
+            if pending is not None:
+                pblock, pnum, pX, ppos, pcall, pqual = pending
+                buf = io.StringIO()
+                if pnum > 0:
+                    OutputFromDevice(args, buf, pnum, pX, ppos, pcall.cpu().numpy(), pqual.cpu().numpy())
+                text = buf.getvalue()
+                frag.write(text)
+                index.append((pblock, len(text.encode("ascii"))))
+            pending = nxt
+            if item is None:
+                break
+    frag.close()
+    with open(frag_fn + ".idx", "w") as f:
+        f.write("".join("%d %d\n" % e for e in index))
+    dist.barrier()
+    if rank == 0:
+        with open(args.call_fn, "w") as call_fh:
+            PrintVCFHeader(args, call_fh)
+            merge_fragments(args.call_fn, ws, call_fh)
+        logging.info("Total time elapsed: %.2f s" % (time.time() - predictStart))
+    dist.barrier()
 
 
 def Test(args, m, utils):

@@ -59,6 +59,70 @@ def _open_tensor_stream(tensor_fn):
     return None, sys.stdin.buffer
 
 
+def owned_line_blocks(fo, rank, ws, block_lines):
+    """Split a text stream into blocks of `block_lines` lines and yield (block index, bytes) for the blocks
+    rank `rank` of `ws` owns (block k belongs to rank k % ws): the sharding of callVar under torchrun.  Every rank
+    reads (decompresses) the whole stream but only parses its own blocks; a last line without newline gets one."""
+    block, have = 0, 0                      # current block index, lines of it seen so far
+    parts = []                              # pieces of the current block if it is ours
+    while True:
+        chunk = fo.read(1 << 24)
+        if not chunk:
+            break
+        nl = np.flatnonzero(np.frombuffer(chunk, dtype=np.uint8) == 10)
+        start, used = 0, 0                  # byte offset / newlines of the chunk consumed
+        while used < len(nl):
+            need = block_lines - have
+            if len(nl) - used >= need:      # the block ends inside this chunk
+                end = int(nl[used + need - 1]) + 1
+                if block % ws == rank:
+                    parts.append(chunk[start:end])
+                    yield block, b"".join(parts)
+                parts = []
+                block += 1; have = 0
+                start = end; used += need
+            else:
+                have += len(nl) - used
+                used = len(nl)
+        if start < len(chunk) and block % ws == rank:
+            parts.append(chunk[start:])
+    if parts or have:
+        tail = b"".join(parts)
+        if block % ws == rank and tail:
+            yield block, tail if tail.endswith(b"\n") else tail + b"\n"
+
+
+def GetTensorBlocks(tensor_fn, block_lines, rank, ws):
+    """Sharded form of GetTensor (callVar under torchrun): yields (block index, c, X, pos) for every block of
+    `block_lines` input lines this rank owns -- one batch per block, rows as GetTensor makes them."""
+    if tensor_fn == "PIPE":
+        raise ValueError("--tensor_fn PIPE cannot be sharded over ranks: give the tensor file")
+    lib = _lib.load()
+    proc, fo = _open_tensor_stream(tensor_fn)
+    consumed = ctypes.c_int64(); nrows = ctypes.c_int64(); nbad = ctypes.c_int64()
+    for block, data in owned_line_blocks(fo, rank, ws, block_lines):
+        rows = _pinned.empty((block_lines, _NV), np.float32)
+        meta = np.empty((block_lines, 6), dtype=np.int64)
+        c, off, bufs = 0, 0, []
+        while off < len(data):
+            view = data[off:] if off else data
+            _lib.check(lib.cv_parse_tensor_text(view, len(view), block_lines - c,
+                                                rows[c:].ctypes.data_as(ctypes.c_void_p),
+                                                meta[c:].ctypes.data_as(ctypes.c_void_p),
+                                                ctypes.byref(consumed), ctypes.byref(nrows), ctypes.byref(nbad)))
+            if nbad.value:
+                print("UnpackATensorRecord Failure (%d malformed rows skipped)" % nbad.value, file=sys.stderr)
+            if nrows.value:
+                bufs.append((view, meta[c:c + nrows.value].copy()))
+            c += nrows.value
+            off += consumed.value
+            if consumed.value == 0:
+                break
+        yield block, c, rows[:c].reshape((c, 2 * param.flankingBaseNum + 1, 4, param.matrixNum)), _join_pos(bufs) if bufs else []
+    fo.close()
+    proc.wait()
+
+
 def GetTensor(tensor_fn, num, log=True):
     """Generator over batches of `num` candidates: yields (endFlag, c, X, pos) exactly like
     utils_v2.py:23-59 -- X [c,33,4,4] fp32 with matrices 1..3 minus matrix 0, rows whose

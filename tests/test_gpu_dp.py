@@ -359,3 +359,35 @@ def test_two_rank_epoch_equals_the_single_process_epoch(oracle, tmp_path, monkey
     assert np.allclose(e0["sums"], sums, rtol=1e-4), (e0["sums"], sums)
     assert sums[1, 0] < sums[0, 0]                     # the second epoch starts from trained weights
     m.close()
+
+
+@pytest.mark.parametrize("arch,flags", [("full", []), ("slim", ["--slim"])])
+def test_callvar_command_line_under_two_ranks_writes_the_single_rank_vcf(oracle, arch, flags, tmp_path):
+    """BASELINE configs[2] through the CLI: `torchrun ... -m clairvoyante_amd.callVar` shards the input lines over
+    the ranks (here: two processes on the one GPU, backend gloo) and rank 0 joins the record fragments; the VCF must
+    be byte-identical to the single-process run of the same command"""
+    import subprocess
+    import test_gpu_pipeline as tp
+    P = common.bench_params(oracle, arch)
+    m = _model(arch); m.setParameters(P)
+    prefix = str(tmp_path / "model")
+    m.saveParameters(prefix); m.close()
+    x = common.inputs(3000, seed=17)
+    tfn = str(tmp_path / "tensors.gz")
+    tp._write_text_tensors(tfn, x)
+    base = [sys.executable, "-m", "clairvoyante_amd.callVar", "--chkpnt_fn", prefix, "--tensor_fn", tfn,
+            "--sampleName", "NA12878", "--qual", "30"] + flags
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    one = str(tmp_path / "one.vcf")
+    subprocess.check_call(base + ["--call_fn", one], env=env, cwd=ROOT)
+    two = str(tmp_path / "two.vcf")
+    port = 29400 + os.getpid() % 500
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                 CV_DIST_BACKEND="gloo", CV_SHARD_BLOCK_LINES="256")
+        procs.append(subprocess.Popen(base + ["--call_fn", two], env=e, cwd=ROOT))
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    a, b = open(one).read(), open(two).read()
+    assert a == b and a.count("\n") > 200
+    assert not [f for f in os.listdir(str(tmp_path)) if ".rank" in f]

@@ -84,3 +84,84 @@ def test_two_rank_gloo_shards_and_gradient_allreduce(tmp_path, oracle):
     port = 29600 + os.getpid() % 300
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+# ---- callVar under two ranks: block-cyclic split of the input lines, per-rank record fragments, merge -------------
+
+def _write_tensor_text(path, x, seed=3, bad_every=97):
+    import gzip
+    rng = np.random.RandomState(seed)
+    raw = x.copy()
+    for i in range(1, 4):
+        raw[:, :, :, i] += raw[:, :, :, 0]
+    with gzip.open(path, "wt") as f:
+        for j in range(raw.shape[0]):
+            seq = "".join(rng.choice(list("ACGT"), 33))
+            if j % bad_every == 5:
+                seq = seq[:16] + "N" + seq[17:]          # dropped by GetTensor (utils_v2.py:38-40)
+            f.write("%s %d %s %s\n" % ("chr%d" % (1 + j % 4), 10000 + 7 * j, seq,
+                                       " ".join("%0.1f" % v for v in raw[j].reshape(-1))))
+
+
+def _callvar_worker(rank, ws, port, tmp, tfn, block_lines):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws),
+                      LOCAL_RANK=str(rank))
+    import io
+    import types
+    from clairvoyante_amd import callVar, parallel, utils_v2
+    from oracle import cv_oracle as O
+    import common
+    parallel.init_from_env(backend="gloo")
+    P = common.bench_params(O, "slim")
+    args = types.SimpleNamespace(v2=False, v3=True, showRef=False, qual=30, ref_fn=None, sampleName="S")
+    call_fn = os.path.join(tmp, "calls.vcf")
+    frag = open("%s.rank%d" % (call_fn, rank), "w")
+    index = []
+    for block, c, X, pos in utils_v2.GetTensorBlocks(tfn, block_lines, rank, ws):
+        assert block % ws == rank
+        buf = io.StringIO()
+        if c:
+            o = O.predict("slim", P, X)
+            callVar.Output(args, buf, c, X, pos, o[:, 0:4], o[:, 4:6], o[:, 6:10], o[:, 10:16])
+        frag.write(buf.getvalue())
+        index.append((block, len(buf.getvalue().encode("ascii"))))
+    frag.close()
+    with open("%s.rank%d.idx" % (call_fn, rank), "w") as f:
+        f.write("".join("%d %d\n" % e for e in index))
+    dist.barrier()
+    if rank == 0:
+        with open(call_fn, "w") as fh:
+            callVar.PrintVCFHeader(args, fh)
+            callVar.merge_fragments(call_fn, ws, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,block_lines", [(700, 64), (130, 64), (64, 64), (5, 64), (300, 1000)])
+def test_two_rank_callvar_split_and_merge_equals_one_process(oracle, tmp_path, n, block_lines):
+    """the sharding / merge logic of callVar.TestSharded with the oracle in the model's place (no GPU here): every
+    rank parses only its blocks of input lines, formats its records, rank 0 joins the fragments in input order --
+    the file must equal the single-process VCF byte for byte, whatever the number of blocks (fewer blocks than
+    ranks, a ragged last block, rows dropped for a non-ACGT centre base)"""
+    import io
+    import types
+    import common
+    from clairvoyante_amd import callVar, utils_v2
+    x = common.inputs(n, seed=23)
+    tfn = str(tmp_path / "t.gz")
+    _write_tensor_text(tfn, x)
+    port = 29700 + (os.getpid() + n) % 200
+    mp.spawn(_callvar_worker, args=(2, port, str(tmp_path), tfn, block_lines), nprocs=2, join=True)
+    got = open(str(tmp_path / "calls.vcf")).read()
+    args = types.SimpleNamespace(v2=False, v3=True, showRef=False, qual=30, ref_fn=None, sampleName="S")
+    P = common.bench_params(oracle, "slim")
+    fh = io.StringIO()
+    callVar.PrintVCFHeader(args, fh)
+    for end, c, X, pos in utils_v2.GetTensor(tfn, 100, log=False):
+        if c:
+            o = oracle.predict("slim", P, X)
+            callVar.Output(args, fh, c, X, pos, o[:, 0:4], o[:, 4:6], o[:, 6:10], o[:, 10:16])
+    assert got == fh.getvalue()
+    assert got.count("\n") > 10 or n < 20
+    assert not [f for f in os.listdir(str(tmp_path)) if ".rank" in f]          # fragments are removed
