@@ -338,21 +338,38 @@ def main():
             avg_ms = ms[s] / cnt[s]
             flop = STAGE_FLOP[args.arch][s] + (STAGE_FLOP[args.arch][0] if (s == 1 and cnt[0] == 0) else 0)
             tf = flop * per_launch / (avg_ms * 1e-3) / 1e12
-            stages.append({"kernel": STAGE_NAMES[s], "avg_ms": avg_ms, "launches": int(cnt[s]), "tflops": tf,
+            kn = ctypes.c_char_p()
+            _lib.check(m._lib.cv_kernel_name(m._h, s, ctypes.byref(kn)))
+            stages.append({"kernel": STAGE_NAMES[s], "kernel_name": kn.value.decode() if kn.value else None,
+                           "avg_ms": avg_ms, "launches": int(cnt[s]), "tflops": tf,
                            "share": ms[s] / max(sum(ms), 1e-12)})
         dom = max(stages, key=lambda r: r["avg_ms"]) if stages else None
-        traffic = None
-        try:   # HBM bytes per launch of that kernel from the separate rocprofv3 --pmc passes (profiles/)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            ent = tj.get(args.arch, {}).get(dom["kernel"]) if dom else None
-            if ent and ent.get("candidates_per_launch") == per_launch:
-                traffic = ent["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_traffic.py -> profiles/): a counter
+        # run cannot share a process with the timed run, so the file is matched against the kernels THIS binary ran --
+        # an entry counts only if its template instance is the one the stage launched and the launch size is the same
+        traffic, traffic_path, traffic_note = None, None, "profiles/pmc_traffic.json has no entry for the kernels of this run"
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.arch, {})
+
+            def entry(st):
+                ent = tj.get(st["kernel"])
+                ok = ent and ent.get("kernel_name") == st["kernel_name"] and ent.get("candidates_per_launch") == per_launch
+                return ent if ok else None
+            if dom and entry(dom):
+                traffic = entry(dom)["hbm_bytes_per_launch"]
+                traffic_note = "rocprofv3 --pmc passes at git %s, kernel %s" % (tj.get("_git_head"), dom["kernel_name"])
+            if stages and all(entry(st) for st in stages):
+                tot = sum(entry(st)["hbm_bytes_per_launch"] for st in stages)
+                traffic_path = {"hbm_bytes_per_launch": tot, "compulsory_bytes_per_launch": 2176 * per_launch,
+                                "ratio_to_compulsory": tot / (2176.0 * per_launch),
+                                "per_kernel": {st["kernel"]: entry(st)["hbm_bytes_per_launch"] for st in stages}}
+        except Exception as e:
+            traffic_note = "profiles/pmc_traffic.json unreadable: %s" % e
         roof = None
         if dom:
             roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                    "traffic_source": traffic_note, "traffic_whole_path": traffic_path,
                     "avg_launch_ms": dom["avg_ms"], "candidates_per_launch": per_launch,
                     "whole_path_tflops": value / ws * FLOP_EXACT[args.arch] / 1e12,
                     "whole_path_frac": value / ws * FLOP_EXACT[args.arch] / 1e12 / PEAK_FP32_MFMA_TFLOPS,

@@ -62,6 +62,7 @@ _SIGS = {
     "cv_loss_accumulate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "cv_loss_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                     ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_void_p]),
+    "cv_kernel_name": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]),
     "cv_selu_sweep": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32,
                                      ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "cv_apply_adam": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_int64,

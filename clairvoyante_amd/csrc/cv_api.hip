@@ -373,6 +373,13 @@ void cv_prof_free(cv_model *m)
     m->prof = nullptr;
 }
 
+extern "C" int cv_kernel_name(const cv_model *m, int stage, const char **name)
+{
+    if (!m || !name || stage < 0 || stage >= CV_NUM_STAGES) { cv_set_error("cv_kernel_name: bad argument"); return 1; }
+    *name = m->last_impl == 1 ? m->stage_kernel[stage] : nullptr;
+    return 0;
+}
+
 extern "C" int cv_kernel_times(cv_model *m, double ms[CV_NUM_STAGES], int64_t launches[CV_NUM_STAGES])
 {
     if (!m || !ms || !launches) { cv_set_error("cv_kernel_times: null argument"); return 1; }

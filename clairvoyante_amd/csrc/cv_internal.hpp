@@ -102,6 +102,7 @@ struct cv_model {
     // optional per-kernel timing (option "profile")
     int profile;
     void *prof;          // cv_prof*, owned
+    const char *stage_kernel[CV_NUM_STAGES];   // kernel (template instance) each stage of the last cv_forward chunk ran
 };
 
 // brackets one kernel launch with events when profiling is on (no-ops otherwise)

@@ -1235,6 +1235,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         return 1;
     }
     if (mfma_alloc(m, n)) return 1;
+    for (int i = 0; i < CV_NUM_STAGES; i++) m->stage_kernel[i] = nullptr;
     if (m->packed_dirty && cv_pack_weights(m, st)) return 1;
     const float *P = m->params;
     const int64_t *o = m->poff;
@@ -1246,49 +1247,59 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
     if (full) {
         if (fuse_front) {
             cv_prof_begin(m, 1, st);
+            m->stage_kernel[1] = "conv_tm<2, 1, 2, 4, 29, 5, 0, 1>";
             rc |= launch_conv<2, 1, 2, 4, 29, 5>(nullptr, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
             cv_prof_end(m, 1, st);
         } else {
             cv_prof_begin(m, 0, st);
+            m->stage_kernel[0] = "conv1_tm<5, false>";
             conv1_tm<5><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, W1, B1, a.cout[0], (f4 *)m->tm_p1, G);
             cv_prof_end(m, 0, st);
             cv_prof_begin(m, 1, st);
+            m->stage_kernel[1] = "conv_tm<2, 1, 2, 4, 29, 0, 0, 1>";
             rc |= launch_conv<2, 1, 2, 4, 29, 0>(m->tm_p1, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
             cv_prof_end(m, 1, st);
         }
         cv_prof_begin(m, 2, st);
-        if (m->variant & 8) rc |= launch_conv3_rot<2, 3, 26, 4, 2>(m->tm_p2, m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st);
-        else rc |= launch_conv<3, 2, 3, 3, 26, 0>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st);
+        if (m->variant & 8) { m->stage_kernel[2] = "conv3_rot<2, 3, 26, 4, 2>"; rc |= launch_conv3_rot<2, 3, 26, 4, 2>(m->tm_p2, m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st); }
+        else { m->stage_kernel[2] = "conv_tm<3, 2, 3, 3, 26, 0, 0, 1>"; rc |= launch_conv<3, 2, 3, 3, 26, 0>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st); }
         cv_prof_end(m, 2, st);
         cv_prof_begin(m, 3, st);
-        if (G <= CV_FC4_SLAB_MAX_G) rc |= launch_dense<7, 8>(m->tm_p3, s.kb4, m->wps_fc4, P + o[7], a.fc4, m->tm_h4, G, st, 3);
-        else if (m->variant & 32) rc |= launch_dense<21, 8, 0, 2>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
-        else if (m->variant & 4) rc |= launch_dense<21, 8>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
-        else rc |= launch_dense<21, 4>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
+        if (G <= CV_FC4_SLAB_MAX_G) { m->stage_kernel[3] = "dense_tm<7, 8, 0, 1>"; rc |= launch_dense<7, 8>(m->tm_p3, s.kb4, m->wps_fc4, P + o[7], a.fc4, m->tm_h4, G, st, 3); }
+        else if (m->variant & 32) { m->stage_kernel[3] = "dense_tm<21, 8, 0, 2>"; rc |= launch_dense<21, 8, 0, 2>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st); }
+        else if (m->variant & 4) { m->stage_kernel[3] = "dense_tm<21, 8, 0, 1>"; rc |= launch_dense<21, 8>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st); }
+        else { m->stage_kernel[3] = "dense_tm<21, 4, 0, 1>"; rc |= launch_dense<21, 4>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st); }
         cv_prof_end(m, 3, st);
         cv_prof_begin(m, 4, st);
+        m->stage_kernel[4] = "dense_tm<11, 4, 0, 1>";
         rc |= launch_dense<11, 4>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st);
         cv_prof_end(m, 4, st);
     } else {
         if (fuse_front) {
             cv_prof_begin(m, 1, st);
+            m->stage_kernel[1] = "conv_tm<3, 1, 1, 1, 33, 1, 0, 1>";
             rc |= launch_conv<3, 1, 1, 1, 33, 1>(nullptr, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
             cv_prof_end(m, 1, st);
         } else {
             cv_prof_begin(m, 0, st);
+            m->stage_kernel[0] = "conv1_tm<1, false>";
             conv1_tm<1><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, W1, B1, a.cout[0], (f4 *)m->tm_p1, G);
             cv_prof_end(m, 0, st);
             cv_prof_begin(m, 1, st);
+            m->stage_kernel[1] = "conv_tm<3, 1, 1, 1, 33, 0, 0, 1>";
             rc |= launch_conv<3, 1, 1, 1, 33, 0>(m->tm_p1, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
             cv_prof_end(m, 1, st);
         }
         cv_prof_begin(m, 2, st);
+        m->stage_kernel[2] = "conv_tm<5, 1, 2, 1, 33, 0, 0, 1>";
         rc |= launch_conv<5, 1, 2, 1, 33, 0>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st);
         cv_prof_end(m, 2, st);
         cv_prof_begin(m, 3, st);
+        m->stage_kernel[3] = "dense_tm<3, 4, 0, 1>";
         rc |= launch_dense<3, 4>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st);
         cv_prof_end(m, 3, st);
         cv_prof_begin(m, 4, st);
+        m->stage_kernel[4] = "dense_tm<2, 4, 0, 1>";
         rc |= launch_dense<2, 4>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st);
         cv_prof_end(m, 4, st);
     }
@@ -1299,11 +1310,13 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
     m->last_variant = m->variant;
     cv_prof_begin(m, 5, st);
     if (m->variant & 2) {
+        m->stage_kernel[5] = "heads_tm";
         heads_tm<<<nblk(G, 4), 256, 0, st>>>((const f4 *)m->tm_h4, (const f4 *)m->tm_h5, s.nb4, s.nb5,
                                             (const f4 *)m->wp_heads0, (const f4 *)m->wp_heads1, P + o[11], P + o[13],
                                             P + o[15], P + o[17], n, out16, G);
         rc = 0;
     } else {
+        m->stage_kernel[5] = "heads_kernel";
         rc = cv_launch_heads(m, m->tm_h4, m->tm_h5, 1, n, out16, st);
     }
     cv_prof_end(m, 5, st);

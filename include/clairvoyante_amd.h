@@ -129,6 +129,10 @@ int cv_get_option(const cv_model *m, const char *key, int64_t *value);
  * the summed milliseconds and launch counts since the last call, and resets them.  */
 #define CV_NUM_STAGES 6
 int cv_kernel_times(cv_model *m, double ms[CV_NUM_STAGES], int64_t launches[CV_NUM_STAGES]);
+/* The kernel (template instance as rocprofv3 prints it, without the argument list) stage s of the last cv_forward
+ * chunk ran, or NULL if the stage was fused away / the plain kernels ran: lets a measurement taken in another
+ * process (rocprofv3 --pmc passes, profiles/pmc_traffic.json) be matched to the binary that is running.          */
+int cv_kernel_name(const cv_model *m, int stage, const char **name);
 
 /* ---- training (replaces the session.run calls of train / trainNoRT /
  * getLoss / getLossNoRT, v3.py:183-227, and AdamOptimizer, v3.py:174) ---------- */
