@@ -264,6 +264,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--sync-loss", action="store_true", help="train mode: read the losses back after every step (m.train)")
+    ap.add_argument("--variant", type=int, default=None, help="infer mode: option variant (kernel selection, A/B)")
     ap.add_argument("--overlap", type=int, default=None, help="train mode: option train_overlap (A/B)")
     ap.add_argument("--tiny", type=int, default=None, help="train mode: option train_tiny_groups (A/B)")
     ap.add_argument("--ksplit", type=int, default=None, help="train mode: option train_ksplit (A/B)")
@@ -295,6 +296,8 @@ def main():
     m = clairvoyante_v3.Clairvoyante() if args.arch == "full" else clairvoyante_v3_slim.Clairvoyante()
     P = common.bench_params(O, args.arch)          # identical seeded weights on every rank
     m.setParameters(P)
+    if args.variant is not None:
+        m.setOption("variant", args.variant)
 
     # synthetic pileup tensors, generated straight into HBM (seed = 20260927 + rank)
     nbuf = max(1, min(args.steps, 64))

@@ -127,7 +127,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     if (s.nb4 == 21) alloc(&m->wps_fc4, (size_t)3 * s.kb4 * 8 * 256);
     alloc(&m->wp_heads0, (size_t)s.nb4 * 256);
     alloc(&m->wp_heads1, (size_t)s.nb5 * 256);
-    m->variant = 47;
+    m->variant = 111;
     if (e == hipSuccess) e = hipMalloc(&m->loss_dev, sizeof(double) * 8);
     if (e == hipSuccess) e = hipMalloc(&m->loss_acc, sizeof(double) * 8);
     if (e == hipSuccess) e = hipMemset(m->loss_acc, 0, sizeof(double) * 8);

@@ -420,7 +420,9 @@ struct front_source {
 // KH-1-(KH-1)/2 on top, no bias, no activation, no pooling.
 // HSPLIT > 1 (no fused first layer): HSPLIT waves share a (group, tile), each producing a contiguous range of
 // (pooled) positions -- more waves in flight when a batch has few groups.
-template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT, int MODE, int HSPLIT = 1>
+// KS4: MFMA steps per 16-channel input fragment (4 channels each); a layer whose last fragment holds fewer than 16
+// real channels (slim conv2: 8) skips the steps that would multiply the zero padding -- they add an exact +0.
+template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT, int MODE, int HSPLIT = 1, int KS4 = 4>
 __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, const float *__restrict__ x,
                                                    int64_t n, const float *__restrict__ wp1,
                                                    const float *__restrict__ bias1, int cout1,
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
                     for (int cb = 0; cb < CINB; cb++) {
                         const f4 A = wl[(size_t)((kh * 4 + kw) * CINB + cb) * 64];
 #pragma unroll
-                        for (int s = 0; s < 4; s++)
+                        for (int s = 0; s < KS4; s++)
 #pragma unroll
                             for (int wo = 0; wo < 4; wo++) {
                                 const int wi = wo + kw - PADL;
@@ -611,6 +613,162 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
 #pragma unroll
                 for (int cb = 0; cb < CINB; cb++) win[j][w][cb] = win[j + 1][w][cb];
     }
+}
+
+// ---------------------------------------------------------------------------
+// conv1 k(1,4) + pool(5) + conv2 k(2,4) + pool(4) of the full topology with the FIRST LAYER SHARED between the two
+// waves of a group (variant bit 6).  conv_tm<2,1,2,4,29,5> gives each of the two output tiles of conv2 its own wave,
+// and both waves push the whole first layer through their registers: its 33 MFMA rows, pooling windows and -- the
+// expensive part -- 29 rows of SELU are computed twice.  Here a workgroup (4 waves = 2 groups x 2 tiles) walks the 29
+// pooled first-layer rows in chunks of CH: in phase A the two waves of a group each produce HALF of the chunk's rows
+// (pre-activations of CH/2 + 4 input rows, running maxima, one SELU per pooled row) into an LDS row buffer laid out
+// as B fragments; after a barrier both waves run conv2 over the chunk from LDS (phase B: 96 MFMA steps per
+// position, kh-row and pooling state kept in registers across chunks), second barrier, next chunk.  Per position a
+// wave now evaluates 8 + 16 SELU'd values x lanes instead of 16 + 16.  Arithmetic and order per output value are
+// those of conv_tm: bit-identical.  LDS: 16 KB conv2 weights + 2 groups x CH x 4 KB rows (CH = 6: 64 KB, two
+// workgroups per CU).
+// ---------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(256, 2) void front2_tm(const float *__restrict__ x, int64_t n,
+                                                     const float *__restrict__ wp1, const float *__restrict__ bias1,
+                                                     int cout1, const f4 *__restrict__ wp,
+                                                     const float *__restrict__ bias, int cout,
+                                                     f4 *__restrict__ out_tm, int G)
+{
+    constexpr int P1 = 5, H1 = CV_INPUT_H - P1 + 1;      // 29 pooled first-layer rows
+    constexpr int NT = 2, P2 = 4, H2 = H1 - P2 + 1;      // conv2: 29 rows -> 26 pooled rows
+    constexpr int NW = NT * 2 * 4 * 64;                  // f4 of packed conv2 weights [nt][kh][kw][64]
+    extern __shared__ __attribute__((aligned(16))) f4 lds[];
+    f4 *rows = lds + NW;                                 // [group in workgroup][CH][w][64]
+    for (int i = threadIdx.x; i < NW; i += 256) lds[i] = wp[i];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int gl = wid >> 1, nt = wid & 1;
+    const int gq = blockIdx.x * 2 + gl;
+    const bool live = gq < G;                            // a spare half workgroup still takes part in the barriers
+    const int g = live ? gq : G - 1;
+    const int q = lane >> 4;
+    int64_t cand = (int64_t)g * 16 + (lane & 15);
+    if (cand >= n) cand = n - 1;
+    const float *xp = x + (size_t)cand * (CV_INPUT_H * 16) + q;      // lane (c, ci = q)
+    float A1[4];
+#pragma unroll
+    for (int kw = 0; kw < 4; kw++) A1[kw] = wp1[kw * 64 + lane];
+    const f4 b1 = load_bias4(bias1, 0, q, cout1);
+    const f4 b2 = load_bias4(bias, nt, q, cout);
+    const f4 *wl = lds + (size_t)nt * (2 * 4 * 64) + lane;
+    f4 *myrows = rows + (size_t)gl * (CH * 4 * 64) + lane;
+    f4 *op = out_tm + (size_t)g * (H2 * 4 * NT * 64) + (size_t)nt * 64 + lane;
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 prev[4], m1[4], m2[4], m3[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) { prev[w] = zero; m1[w] = zero; m2[w] = zero; m3[w] = zero; }
+
+    // conv2 output row h from input rows h (prev) and h + 1 (cur; absent below the last row), pooled over 4 rows
+    auto out_row = [&](int h, const f4 (&cur)[4], bool has_cur) {
+        f4 acc[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) acc[w] = zero;
+#pragma unroll
+        for (int kw = 0; kw < 4; kw++) {
+            const f4 A = wl[(size_t)(0 * 4 + kw) * 64];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+                for (int wo = 0; wo < 4; wo++) {
+                    const int wi = wo + kw - 1;
+                    if (wi < 0 || wi > 3) continue;
+                    acc[wo] = mfma4(A[s4], prev[wi][s4], acc[wo]);
+                }
+        }
+        if (has_cur) {
+#pragma unroll
+            for (int kw = 0; kw < 4; kw++) {
+                const f4 A = wl[(size_t)(1 * 4 + kw) * 64];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+                    for (int wo = 0; wo < 4; wo++) {
+                        const int wi = wo + kw - 1;
+                        if (wi < 0 || wi > 3) continue;
+                        acc[wo] = mfma4(A[s4], cur[wi][s4], acc[wo]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const f4 t = acc[w] + b2;
+            const f4 o = max4(m3[w], t);
+            m3[w] = max4(m2[w], t);
+            m2[w] = max4(m1[w], t);
+            m1[w] = t;
+            if (h >= P2 - 1 && live) op[(size_t)((h - (P2 - 1)) * 4 + w) * (NT * 64)] = selu4(o);
+        }
+    };
+
+    __syncthreads();                                     // conv2 weights are in LDS
+#pragma unroll 1
+    for (int c0 = 0; c0 < H1; c0 += CH) {
+        const int cn = H1 - c0 < CH ? H1 - c0 : CH;
+        // ---- phase A: this wave's half of the chunk's first-layer rows
+        const int half = (cn + 1) >> 1;
+        const int a0 = c0 + nt * half;
+        const int a1 = a0 + half < c0 + cn ? a0 + half : c0 + cn;
+        if (a0 < a1) {
+            f4 rm[4][4];                                 // rm[j] = running maximum of the last j + 1 pre-activation rows
+            float xc[4], xn[4];
+#pragma unroll
+            for (int w = 0; w < 4; w++) xc[w] = xp[a0 * 16 + w * 4];
+#pragma unroll 1
+            for (int r = a0; r < a1 + P1 - 1; r++) {
+                {
+                    const int rn = r + 1 < a1 + P1 - 1 ? r + 1 : r;
+#pragma unroll
+                    for (int w = 0; w < 4; w++) xn[w] = xp[rn * 16 + w * 4];
+                }
+                f4 acc[4];
+#pragma unroll
+                for (int w = 0; w < 4; w++) acc[w] = zero;
+#pragma unroll
+                for (int kw = 0; kw < 4; kw++)
+#pragma unroll
+                    for (int wo = 0; wo < 4; wo++) {
+                        const int wi = wo + kw - 1;
+                        if (wi < 0 || wi > 3) continue;
+                        acc[wo] = mfma4(A1[kw], xc[wi], acc[wo]);
+                    }
+                const int i = r - a0;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const f4 t = acc[w] + b1;
+                    if (i == 0) {
+                        rm[0][w] = t; rm[1][w] = t; rm[2][w] = t; rm[3][w] = t;
+                    } else {
+                        const f4 o = max4(rm[3][w], t);
+                        rm[3][w] = max4(rm[2][w], t);
+                        rm[2][w] = max4(rm[1][w], t);
+                        rm[1][w] = max4(rm[0][w], t);
+                        rm[0][w] = t;
+                        if (i >= P1 - 1) myrows[(size_t)((r - (P1 - 1) - c0) * 4 + w) * 64] = selu4(o);
+                    }
+                }
+#pragma unroll
+                for (int w = 0; w < 4; w++) xc[w] = xn[w];
+            }
+        }
+        __syncthreads();
+        // ---- phase B: conv2 over the chunk's rows
+#pragma unroll 1
+        for (int p = c0; p < c0 + cn; p++) {
+            f4 cur[4];
+#pragma unroll
+            for (int w = 0; w < 4; w++) cur[w] = myrows[(size_t)((p - c0) * 4 + w) * 64];
+            if (p > 0) out_row(p - 1, cur, true);
+#pragma unroll
+            for (int w = 0; w < 4; w++) prev[w] = cur[w];
+        }
+        __syncthreads();
+    }
+    out_row(H1 - 1, prev, false);                        // the row below the last one is SAME padding
 }
 
 // ---------------------------------------------------------------------------
@@ -1036,12 +1194,12 @@ int set_lds(K kernel, size_t bytes)
     return 0;
 }
 
-template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT, int MODE = 0, int HSPLIT = 1>
+template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT, int MODE = 0, int HSPLIT = 1, int KS4 = 4>
 int launch_conv(const float *in, const float *x, int64_t n, const float *wp1, const float *bias1, int cout1,
                 const float *wp, const float *bias, int cout, float *out, int G, hipStream_t st,
                 float *act = nullptr)
 {
-    auto k = conv_tm<KH, CINB, NT, POOL, HIN, FRONT, MODE, HSPLIT>;
+    auto k = conv_tm<KH, CINB, NT, POOL, HIN, FRONT, MODE, HSPLIT, KS4>;
     size_t lds = (size_t)NT * KH * 4 * CINB * 1024;
     if (set_lds(k, lds)) return 1;
     unsigned grid = nblk((int64_t)G * NT * HSPLIT, 4);
@@ -1245,7 +1403,18 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
     const bool fuse_front = (m->variant & 1) != 0;
     const float *W1 = m->wp_conv1, *B1 = P + o[1];
     if (full) {
-        if (fuse_front) {
+        if (fuse_front && (m->variant & 64)) {
+            cv_prof_begin(m, 1, st);
+            m->stage_kernel[1] = "front2_tm<6>";
+            {
+                auto k = front2_tm<6>;
+                const size_t lds = (size_t)(16 + 2 * 6 * 4) * 1024;
+                if (set_lds(k, lds)) return 1;
+                k<<<nblk(G, 2), 256, lds, st>>>(x, n, W1, B1, a.cout[0], (const f4 *)m->wp_conv[1], P + o[3], a.cout[1],
+                                                (f4 *)m->tm_p2, G);
+            }
+            cv_prof_end(m, 1, st);
+        } else if (fuse_front) {
             cv_prof_begin(m, 1, st);
             m->stage_kernel[1] = "conv_tm<2, 1, 2, 4, 29, 5, 0, 1>";
             rc |= launch_conv<2, 1, 2, 4, 29, 5>(nullptr, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
@@ -1277,8 +1446,8 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
     } else {
         if (fuse_front) {
             cv_prof_begin(m, 1, st);
-            m->stage_kernel[1] = "conv_tm<3, 1, 1, 1, 33, 1, 0, 1>";
-            rc |= launch_conv<3, 1, 1, 1, 33, 1>(nullptr, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
+            m->stage_kernel[1] = "conv_tm<3, 1, 1, 1, 33, 1, 0, 1, 2>";
+            rc |= launch_conv<3, 1, 1, 1, 33, 1, 0, 1, 2>(nullptr, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
             cv_prof_end(m, 1, st);
         } else {
             cv_prof_begin(m, 0, st);
@@ -1286,8 +1455,8 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             conv1_tm<1><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, W1, B1, a.cout[0], (f4 *)m->tm_p1, G);
             cv_prof_end(m, 0, st);
             cv_prof_begin(m, 1, st);
-            m->stage_kernel[1] = "conv_tm<3, 1, 1, 1, 33, 0, 0, 1>";
-            rc |= launch_conv<3, 1, 1, 1, 33, 0>(m->tm_p1, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
+            m->stage_kernel[1] = "conv_tm<3, 1, 1, 1, 33, 0, 0, 1, 2>";
+            rc |= launch_conv<3, 1, 1, 1, 33, 0, 0, 1, 2>(m->tm_p1, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
             cv_prof_end(m, 1, st);
         }
         cv_prof_begin(m, 2, st);
@@ -1861,10 +2030,10 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
     } else {
         conv1_tm<1, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (f4 *)a1);
         if (tiny) {
-            rc |= launch_conv<3, 1, 1, 1, 33, 0, 1, 4>(p1, x, n, nullptr, nullptr, 0, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
+            rc |= launch_conv<3, 1, 1, 1, 33, 0, 1, 4, 2>(p1, x, n, nullptr, nullptr, 0, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
             rc |= launch_conv<5, 1, 2, 1, 33, 0, 1, 4>(p2, x, n, nullptr, nullptr, 0, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
         } else {
-            rc |= launch_conv<3, 1, 1, 1, 33, 0, 1>(p1, x, n, nullptr, nullptr, 0, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
+            rc |= launch_conv<3, 1, 1, 1, 33, 0, 1, 1, 2>(p1, x, n, nullptr, nullptr, 0, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
             rc |= launch_conv<5, 1, 2, 1, 33, 0, 1>(p2, x, n, nullptr, nullptr, 0, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
         }
     }

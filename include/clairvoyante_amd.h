@@ -118,7 +118,8 @@ int cv_selu_sweep(int device, uint32_t lo_bits, uint32_t hi_bits, uint64_t *viol
  * order, within the gradient tolerance, never used by cv_forward),
  * "variant" (bit 0: first layer fused into the conv2 kernel, bit 1: MFMA heads kernel,
  * bit 2: 8-wave fc4 workgroups, bit 3: rotating-window conv3 kernel, bit 5: fc4 with two groups of
- * 16 candidates per wave; default 47; the alternatives give bit-identical results and exist for A/B
+ * 16 candidates per wave, bit 6: fused conv1+conv2 kernel whose two waves per group share the first layer through
+ * LDS (full topology); default 111; the alternatives give bit-identical results and exist for A/B
  * timing).                                                                                          */
 int cv_set_option(cv_model *m, const char *key, int64_t value);
 int cv_get_option(const cv_model *m, const char *key, int64_t *value);

@@ -44,7 +44,7 @@ def test_outputs_match_oracle(setup, impl):
     assert common.argmax_match(got, ref["out"]) == [1.0, 1.0, 1.0, 1.0]
 
 
-@pytest.mark.parametrize("impl,variant", [(1, 47), (1, 6), (1, 0), (0, 47)])
+@pytest.mark.parametrize("impl,variant", [(1, 111), (1, 47), (1, 6), (1, 0), (0, 47)])
 def test_intermediates_match_oracle(setup, impl, variant):
     import torch
     arch, P, m, x, ref = setup
@@ -52,7 +52,7 @@ def test_intermediates_match_oracle(setup, impl, variant):
     m.setOption("variant", variant)
     n = x.shape[0]
     m.predict_device(torch.from_numpy(x).cuda())
-    m.setOption("variant", 47)
+    m.setOption("variant", common.DEFAULT_VARIANT)
     for layer, name in ((1, "pool1"), (2, "pool2"), (3, "pool3"), (4, "fc4"), (5, "fc5")):
         if layer == 1 and impl == 1 and (variant & 1):
             continue      # with the first layer fused into the conv2 kernel pool1 never reaches HBM
@@ -89,11 +89,11 @@ def test_plain_and_tile_kernels_agree_bitwise(setup):
     m.setOption("impl", 0)
     a = np.concatenate(m.predict(x), axis=1)
     m.setOption("impl", 1)
-    for variant in (0, 1, 2, 4, 7, 8, 15, 47):       # every kernel variant computes the same bits
+    for variant in (0, 1, 2, 4, 7, 8, 15, 47, 111, 65):       # every kernel variant computes the same bits
         m.setOption("variant", variant)
         b = np.concatenate(m.predict(x), axis=1)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), variant
-    m.setOption("variant", 47)
+    m.setOption("variant", common.DEFAULT_VARIANT)
     assert np.array_equal(a.view(np.uint32), ref["out"].view(np.uint32))     # ... the oracle's bits
 
 
@@ -108,12 +108,12 @@ def test_large_pass_kernels_equal_small_pass_kernels(setup):
     m.setOption("impl", 1)
     m.setOption("chunk", 8192)
     small = m.predict_device(xd).cpu().numpy()
-    for variant in (47, 15, 11):             # two groups per wave / one group per wave with 8 or 4 waves per workgroup
+    for variant in (111, 47, 15, 11):        # two groups per wave / one group per wave with 8 or 4 waves per workgroup
         m.setOption("variant", variant)
         m.setOption("chunk", 65536)
         big = m.predict_device(xd).cpu().numpy()
         assert np.array_equal(small.view(np.uint32), big.view(np.uint32)), variant
-    m.setOption("variant", 47)
+    m.setOption("variant", common.DEFAULT_VARIANT)
     m.setOption("chunk", 65536)
     head = m.predict(xd[:256].cpu().numpy())
     assert np.array_equal(np.concatenate(head, axis=1), small[:256])
@@ -126,7 +126,7 @@ def test_candidates_are_independent_at_scale(setup):
     import torch
     from clairvoyante_amd import synth
     arch, P, m, x, ref = setup
-    m.setOption("impl", 1); m.setOption("variant", 47); m.setOption("chunk", 65536)
+    m.setOption("impl", 1); m.setOption("variant", common.DEFAULT_VARIANT); m.setOption("chunk", 65536)
     n = 300000
     xd = synth.make_candidates(n, seed=123, device="cuda")
     out = m.predict_device(xd)

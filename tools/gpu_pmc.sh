@@ -30,9 +30,9 @@ for r in csv.DictReader(open(sys.argv[1])):
 for k, v in acc.items():
     m = {c: sum(x) / len(x) for c, x in v.items()}
     if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("GRBM_GUI_ACTIVE"):
-        # busy cycles are summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is the kernel's wall in cycles
+        # busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs (wall = GRBM / 8)
         print("%-40s launches %3d  SQ_INSTS_VALU %.4g  MFMA busy %.3f" % (k[:40], len(v["SQ_INSTS_VALU"]), m.get("SQ_INSTS_VALU", 0),
-              m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] * 1024.0)))
+              m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] * 128.0)))
 PY
 rm -rf $OUT/p_sq
 cat $OUT/sq_summary.txt 2>/dev/null
