@@ -115,7 +115,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     alloc(&m->params, np); alloc(&m->grads_own, np + CV_GRAD_HEADER); alloc(&m->adam_m, np); alloc(&m->adam_v, np);
     if (m->grads_own) m->grads = m->grads_own + CV_GRAD_HEADER;
     m->train_overlap = 1;
-    m->train_ksplit = 1;
+    m->train_ksplit = 0;
     m->tiny_g = 160;
     alloc(&m->wp_conv1, 4 * 64);
     for (int l = 1; l < 3; l++) alloc(&m->wp_conv[l], (size_t)s.ntile[l] * arch->kh[l] * 4 * s.cinb[l] * 256);
@@ -125,9 +125,11 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     alloc(&m->wpd_fc4, (size_t)((s.kb4 + 23) / 24) * s.nb4 * 24 * 256);
     alloc(&m->wpd_fc5, (size_t)s.nb5 * 24 * 256);
     if (s.nb4 == 21) alloc(&m->wps_fc4, (size_t)3 * s.kb4 * 8 * 256);
+    if (s.nb4 == 21) alloc(&m->wps7_fc4, (size_t)7 * s.kb4 * 3 * 256);
+    if (s.nb4 == 21 && s.nb5 == 11) alloc(&m->wps3_fc5, (size_t)3 * s.nb4 * 4 * 256);
     alloc(&m->wp_heads0, (size_t)s.nb4 * 256);
     alloc(&m->wp_heads1, (size_t)s.nb5 * 256);
-    m->variant = 111;
+    m->variant = 239;
     if (e == hipSuccess) e = hipMalloc(&m->loss_dev, sizeof(double) * 8);
     if (e == hipSuccess) e = hipMalloc(&m->loss_acc, sizeof(double) * 8);
     if (e == hipSuccess) e = hipMemset(m->loss_acc, 0, sizeof(double) * 8);
@@ -146,7 +148,7 @@ extern "C" int cv_destroy(cv_model *m)
     if (!m) return 0;
     hipSetDevice(m->device);
     float *bufs[] = {m->params, m->grads_own, m->adam_m, m->adam_v, m->wp_conv1, m->wp_conv[1], m->wp_conv[2],
-                     m->wp_fc4, m->wp_fc5, m->wp_heads0, m->wp_heads1, m->wpd_conv[1], m->wpd_conv[2], m->wpd_fc4, m->wpd_fc5, m->wps_fc4, m->wg_part, m->tm_p1, m->tm_p2, m->tm_p3, m->tm_h4, m->tm_h5, m->r_a[0],
+                     m->wp_fc4, m->wp_fc5, m->wp_heads0, m->wp_heads1, m->wpd_conv[1], m->wpd_conv[2], m->wpd_fc4, m->wpd_fc5, m->wps_fc4, m->wps7_fc4, m->wps3_fc5, m->wg_part, m->tm_p1, m->tm_p2, m->tm_p3, m->tm_h4, m->tm_h5, m->r_a[0],
                      m->r_a[1], m->r_a[2], m->r_p[0], m->r_p[1], m->r_p[2], m->r_h4, m->r_h5, m->t_buf};
     for (float *b : bufs)
         if (b) hipFree(b);
@@ -311,7 +313,7 @@ extern "C" int cv_get_activation(cv_model *m, int layer, float *dst_dev, int64_t
         CV_HIP(hipMemcpyAsync(dst_dev, src, sizeof(float) * per * n, hipMemcpyDeviceToDevice, st));
         return 0;
     }
-    if (layer == 1 && m->last_impl == 1 && (m->last_variant & 1)) {
+    if (layer == 1 && m->last_impl == 1 && (m->last_variant & 1) && !m->stage_kernel[0]) {
         cv_set_error("layer 1 is not materialised while the first layer is fused into the conv2 kernel "
                      "(option variant bit 0); clear the bit to inspect it");
         return 1;

@@ -65,6 +65,8 @@ struct cv_model {
     float *wg_part;      // per-split tiles of the dense weight gradients (two-pass combine), owned
     size_t wg_part_bytes;
     float *wps_fc4;      // forward weights of fc4 in 3 slabs [slab][kb][8][64][4] (full topology, small batches)
+    float *wps7_fc4;     // ... and in 7 slabs [slab][kb][3][64][4] (dense_small: one wave per group and slab)
+    float *wps3_fc5;     // fc5 in 3 slabs [slab][kb][4][64][4] (dense_small)
     float *wpd_fc5;      // data-gradient weights of fc5 [jb][24 | 4][64][4]
     float *wp_heads0;    // [nb4][64][4]  base head (rows 0..3)
     float *wp_heads1;    // [nb5][64][4]  zygosity / type / length heads

@@ -1118,6 +1118,68 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
     }
 }
 
+// ---------------------------------------------------------------------------
+// dense layer for FEW groups (a predict() call of the reference's batch of 1 000 is 63 groups): dense_tm streams the
+// weight matrix through an LDS ring with one workgroup barrier per k fragment -- ~0.9 us per step whatever the
+// batch, 254 us for fc4's 288 dependent steps, half of a small call.  Here nothing is shared: ONE WAVE owns a
+// (group, slab of NBW output fragments) pair and reads its operands straight from L2 -- the activation fragment
+// and NBW weight fragments per step, D steps ahead through a register ring (the loop is unrolled by D, so slot
+// indices are constants and the compiler's counted vmcnt waits leave the younger loads in flight).  A step is
+// NBW x 4 MFMAs with no barrier and no LDS round trip.  The contraction is the same single ascending-k chain per
+// output value: bit-identical to dense_tm.  Weights: [slab][kb][NBW][64] fragments (pack_dense_slabs).
+// ---------------------------------------------------------------------------
+template <int NBW, int D, int EPI = 0>
+__global__ __launch_bounds__(256) void dense_small(const f4 *__restrict__ in_tm, int KB, const f4 *__restrict__ wp_all,
+                                                    const float *__restrict__ bias, int nout, f4 *__restrict__ out_tm,
+                                                    int G, int NSLAB, int NBT)
+{
+    // NBT = output fragments per group (<= NBW * NSLAB: the last slab may be padded with zero fragments)
+    const int lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= G * NSLAB) return;
+    const int g = unit / NSLAB, slab = unit % NSLAB;
+    const f4 *bp = in_tm + (size_t)g * KB * 64 + lane;
+    const f4 *wp = wp_all + (size_t)slab * KB * (NBW * 64) + lane;
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 acc[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; j++) acc[j] = zero;
+    f4 A[D][NBW], B[D];
+    // KB is a multiple of D (launcher): the loop body never needs a bounds test, and the operand pointers just advance
+    auto fetch = [&](const f4 *pb, const f4 *pw, int d) {
+        B[d] = pb[(size_t)d * 64];
+#pragma unroll
+        for (int j = 0; j < NBW; j++) A[d][j] = pw[((size_t)d * NBW + j) * 64];
+    };
+    auto step = [&](int d) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+            for (int j = 0; j < NBW; j++) acc[j] = mfma4(A[d][j][s4], B[d][s4], acc[j]);
+    };
+#pragma unroll
+    for (int d = 0; d < D; d++) fetch(bp, wp, d);
+#pragma unroll 1
+    for (int kb0 = D; kb0 < KB; kb0 += D) {
+        bp += (size_t)D * 64; wp += (size_t)D * NBW * 64;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            step(d);
+            fetch(bp, wp, d);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) step(d);
+    const int q = lane >> 4;
+    f4 *op = out_tm + ((size_t)g * NBT + (size_t)slab * NBW) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < NBW; j++) {
+        if (slab * NBW + j >= NBT) break;
+        if constexpr (EPI == 0) op[j * 64] = selu4(acc[j] + load_bias4(bias, slab * NBW + j, q, nout));
+        else op[j * 64] = acc[j];
+    }
+}
+
 // second pass of a k-split dense layer: out = selu(sum_z part[z] + bias), ranges added in ascending z
 __global__ void dense_ksum(const f4 *__restrict__ part, int KS, int G, int NBT, const float *__restrict__ bias, int nout,
                            f4 *__restrict__ out_tm)
@@ -1242,6 +1304,23 @@ int launch_dense(const float *in, int KB, const float *wp, const float *bias, in
     return 0;
 }
 
+template <int NBW, int D, int EPI = 0>
+int launch_dense_small(const float *in, int KB, const float *wp, const float *bias, int nout, float *out, int G, int nslab,
+                       hipStream_t st, int nbt = 0)
+{
+    if (nbt == 0) nbt = NBW * nslab;
+    if (KB % D != 0 || KB < D) { cv_set_error("dense_small: %d k fragments are not a multiple of %d", KB, D); return 1; }
+    dense_small<NBW, D, EPI><<<nblk((int64_t)G * nslab, 4), 256, 0, st>>>((const f4 *)in, KB, (const f4 *)wp, bias, nout,
+                                                                          (f4 *)out, G, nslab, nbt);
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
+// up to this many groups fc4 runs on dense_small (one wave per group and slab of 3 output fragments, no barriers)
+constexpr int CV_FC4_SMALL_MAX_G = 256;
+// up to this many groups the convolutions of an inference pass split their positions over four waves
+constexpr int CV_CONV_SMALL_MAX_G = 160;
+
 bool arch_is(const cv_arch &a, int k0, int k1, int k2, int c0, int c1, int c2, int p0, int p1, int p2,
              int f4_, int f5_)
 {
@@ -1266,7 +1345,7 @@ struct pack_job {
     int i[8];
     unsigned first;                // first block of the job
 };
-struct pack_tab { pack_job j[14]; int n; };
+struct pack_tab { pack_job j[16]; int n; };
 
 __global__ __launch_bounds__(256) void pack_all(pack_tab tab)
 {
@@ -1323,6 +1402,14 @@ static int pack_launch(cv_model *m, hipStream_t st, bool fwd, bool with_train)
         if (m->wps_fc4) {       // full topology: fc4 in 3 slabs of 7 fragments for small batches
             pack_job &J = pb.add(3, (int64_t)3 * s.kb4 * 8 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wps_fc4;
             J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = 7; J.i[4] = 8; J.i[5] = 3;
+        }
+        if (m->wps3_fc5) {      // fc5 in 3 slabs of 4 fragments (11 -> 12, the last one zero) for dense_small
+            pack_job &J = pb.add(3, (int64_t)3 * s.nb4 * 4 * 256); J.src[0] = P + o[8]; J.dst[0] = m->wps3_fc5;
+            J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb4; J.i[3] = 4; J.i[4] = 4; J.i[5] = 3;
+        }
+        if (m->wps7_fc4) {      // ... and in 7 slabs of 3 fragments for the one-wave-per-slab kernel of very small batches
+            pack_job &J = pb.add(3, (int64_t)7 * s.kb4 * 3 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wps7_fc4;
+            J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = 3; J.i[4] = 3; J.i[5] = 7;
         }
         { pack_job &J = pb.add(6, (int64_t)(s.nb4 + s.nb5) * 256);
           J.src[0] = P + o[10]; J.src[1] = P + o[12]; J.src[2] = P + o[14]; J.src[3] = P + o[16];
@@ -1403,7 +1490,20 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
     const bool fuse_front = (m->variant & 1) != 0;
     const float *W1 = m->wp_conv1, *B1 = P + o[1];
     if (full) {
-        if (fuse_front && (m->variant & 64)) {
+        // very small passes (a predict() call of the reference's batch of 1 000 is 63 groups) are latency-bound by the
+        // serial position loop of one (group, tile): the layers are launched unfused with their positions split over
+        // four waves (pooled layers recompute the window overlap) -- the same values row for row
+        const bool small_pass = (m->variant & 128) && G <= CV_CONV_SMALL_MAX_G;
+        if (small_pass) {
+            cv_prof_begin(m, 0, st);
+            m->stage_kernel[0] = "conv1_tm<5, false>";
+            conv1_tm<5><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, W1, B1, a.cout[0], (f4 *)m->tm_p1, G);
+            cv_prof_end(m, 0, st);
+            cv_prof_begin(m, 1, st);
+            m->stage_kernel[1] = "conv_tm<2, 1, 2, 4, 29, 0, 0, 4>";
+            rc |= launch_conv<2, 1, 2, 4, 29, 0, 0, 4>(m->tm_p1, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
+            cv_prof_end(m, 1, st);
+        } else if (fuse_front && (m->variant & 64)) {
             cv_prof_begin(m, 1, st);
             m->stage_kernel[1] = "front2_tm<6>";
             {
@@ -1430,18 +1530,25 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             cv_prof_end(m, 1, st);
         }
         cv_prof_begin(m, 2, st);
-        if (m->variant & 8) { m->stage_kernel[2] = "conv3_rot<2, 3, 26, 4, 2>"; rc |= launch_conv3_rot<2, 3, 26, 4, 2>(m->tm_p2, m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st); }
+        if (small_pass) { m->stage_kernel[2] = "conv_tm<3, 2, 3, 3, 26, 0, 0, 4>"; rc |= launch_conv<3, 2, 3, 3, 26, 0, 0, 4>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st); }
+        else if (m->variant & 8) { m->stage_kernel[2] = "conv3_rot<2, 3, 26, 4, 2>"; rc |= launch_conv3_rot<2, 3, 26, 4, 2>(m->tm_p2, m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st); }
         else { m->stage_kernel[2] = "conv_tm<3, 2, 3, 3, 26, 0, 0, 1>"; rc |= launch_conv<3, 2, 3, 3, 26, 0>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st); }
         cv_prof_end(m, 2, st);
         cv_prof_begin(m, 3, st);
-        if (G <= CV_FC4_SLAB_MAX_G) { m->stage_kernel[3] = "dense_tm<7, 8, 0, 1>"; rc |= launch_dense<7, 8>(m->tm_p3, s.kb4, m->wps_fc4, P + o[7], a.fc4, m->tm_h4, G, st, 3); }
+        if (G <= CV_FC4_SMALL_MAX_G && (m->variant & 128)) { m->stage_kernel[3] = "dense_small<3, 8, 0>"; rc |= launch_dense_small<3, 8>(m->tm_p3, s.kb4, m->wps7_fc4, P + o[7], a.fc4, m->tm_h4, G, 7, st); }
+        else if (G <= CV_FC4_SLAB_MAX_G) { m->stage_kernel[3] = "dense_tm<7, 8, 0, 1>"; rc |= launch_dense<7, 8>(m->tm_p3, s.kb4, m->wps_fc4, P + o[7], a.fc4, m->tm_h4, G, st, 3); }
         else if (m->variant & 32) { m->stage_kernel[3] = "dense_tm<21, 8, 0, 2>"; rc |= launch_dense<21, 8, 0, 2>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st); }
         else if (m->variant & 4) { m->stage_kernel[3] = "dense_tm<21, 8, 0, 1>"; rc |= launch_dense<21, 8>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st); }
         else { m->stage_kernel[3] = "dense_tm<21, 4, 0, 1>"; rc |= launch_dense<21, 4>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st); }
         cv_prof_end(m, 3, st);
         cv_prof_begin(m, 4, st);
-        m->stage_kernel[4] = "dense_tm<11, 4, 0, 1>";
-        rc |= launch_dense<11, 4>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st);
+        if (G <= CV_FC4_SMALL_MAX_G && (m->variant & 128)) {
+            m->stage_kernel[4] = "dense_small<4, 7, 0>";
+            rc |= launch_dense_small<4, 7>(m->tm_h4, s.nb4, m->wps3_fc5, P + o[9], a.fc5, m->tm_h5, G, 3, st, s.nb5);
+        } else {
+            m->stage_kernel[4] = "dense_tm<11, 4, 0, 1>";
+            rc |= launch_dense<11, 4>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st);
+        }
         cv_prof_end(m, 4, st);
     } else {
         if (fuse_front) {
@@ -2054,10 +2161,14 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
             // (CV_DENSE_KSPLIT) run side by side instead and a second pass adds them up in order
             if (part && G <= m->tiny_g)
                 return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3, CV_DENSE_KSPLIT, part);
+            if (G <= m->tiny_g && (m->variant & 128))
+                return launch_dense_small<3, 8>(in_tm, s.kb4, m->wps7_fc4, P + o[7], a.fc4, out_tm, G, 7, st);
             // (two k ranges at train.py's batch of 10 000 -- 237 workgroups otherwise -- measured: no gain)
             if (G <= CV_FC4_SLAB_MAX_G) return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3);
             return launch_dense<21, 8>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);
         }
+        if (G <= m->tiny_g && (m->variant & 128))
+            return launch_dense_small<4, 7>(in_tm, s.nb4, m->wps3_fc5, P + o[9], a.fc5, out_tm, G, 3, st, s.nb5);
         return launch_dense<11, 4>(in_tm, s.nb4, m->wp_fc5, P + o[9], a.fc5, out_tm, G, st);
     }
     if (layer == 4) return launch_dense<3, 4>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);

@@ -56,8 +56,8 @@ def _affine(rate):
 @pytest.mark.parametrize("arch", ["full", "slim"])
 @pytest.mark.parametrize("n,ksplit", [(17, 0), (80, 0), (1000, 0), (1000, 1)])
 def test_alpha_dropout_forward_and_backward_match_oracle(oracle, arch, n, ksplit):
-    """ksplit 0: fc4 of the training pass is the oracle's single ascending-k chain (tight bounds); 1 (the default at
-    these batch sizes): eight partial sums added in order -- the same values up to fp32 summation order"""
+    """ksplit 0 (default): fc4 of the training pass is the oracle's single ascending-k chain (tight bounds); 1 (option
+    train_ksplit): eight partial sums added in order -- the same values up to fp32 summation order"""
     rate, lam = 0.5, 0.01
     x, y = _data(n, seed=9)
     P = common.bench_params(oracle, arch)

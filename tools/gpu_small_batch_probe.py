@@ -15,7 +15,13 @@ m = clairvoyante_v3.Clairvoyante()
 m.setParameters(common.bench_params(O, "full"))
 x = synth.make_candidates(65536, seed=1, device="cuda")
 out = torch.empty((65536, 16), device="cuda")
-for n in (16, 256, 1000, 4096, 16384, 65536):
+import ctypes
+from clairvoyante_amd import _lib
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else None
+if variant is not None:
+    m.setOption("variant", variant)
+print("variant", variant)
+for n in (16, 256, 1000, 2560, 4096, 16384, 65536):
     xs = x[:n].contiguous(); os_ = out[:n]
     for _ in range(20):
         m.predict_device(xs, os_)
@@ -33,3 +39,11 @@ for n in (16, 256, 1000, 4096, 16384, 65536):
     dh = (time.perf_counter() - t0) / 20
     print("n=%6d: device call %8.1f us -> %6.2f M cand/s | predict(numpy) %8.1f us -> %6.2f M cand/s" % (
         n, dt * 1e6, n / dt / 1e6, dh * 1e6, n / dh / 1e6))
+    m.setOption("profile", 1)
+    for _ in range(20):
+        m.predict_device(xs, os_)
+    ms = (ctypes.c_double * 6)(); cnt = (ctypes.c_int64 * 6)()
+    _lib.check(m._lib.cv_kernel_times(m._h, ms, cnt))
+    m.setOption("profile", 0)
+    print("          per kernel (us): " + "  ".join("%s %.1f" % (k, ms[i] / max(cnt[i], 1) * 1e3) for i, k in
+                                                  enumerate(("conv1", "conv2", "conv3", "fc4", "fc5", "heads")) if cnt[i]))
