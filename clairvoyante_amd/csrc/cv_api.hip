@@ -129,7 +129,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     if (s.nb4 == 21 && s.nb5 == 11) alloc(&m->wps3_fc5, (size_t)3 * s.nb4 * 4 * 256);
     alloc(&m->wp_heads0, (size_t)s.nb4 * 256);
     alloc(&m->wp_heads1, (size_t)s.nb5 * 256);
-    m->variant = 239;
+    m->variant = 495;
     if (e == hipSuccess) e = hipMalloc(&m->loss_dev, sizeof(double) * 8);
     if (e == hipSuccess) e = hipMalloc(&m->loss_acc, sizeof(double) * 8);
     if (e == hipSuccess) e = hipMemset(m->loss_acc, 0, sizeof(double) * 8);
@@ -316,6 +316,11 @@ extern "C" int cv_get_activation(cv_model *m, int layer, float *dst_dev, int64_t
     if (layer == 1 && m->last_impl == 1 && (m->last_variant & 1) && !m->stage_kernel[0]) {
         cv_set_error("layer 1 is not materialised while the first layer is fused into the conv2 kernel "
                      "(option variant bit 0); clear the bit to inspect it");
+        return 1;
+    }
+    if (layer == 3 && m->last_impl == 1 && m->stage_kernel[2] && !m->stage_kernel[3]) {
+        cv_set_error("layer 3 is not materialised while conv3 and fc4 run as one kernel (option variant bit 8); "
+                     "clear the bit to inspect it");
         return 1;
     }
     if (layer <= 3) {

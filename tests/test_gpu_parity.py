@@ -44,7 +44,7 @@ def test_outputs_match_oracle(setup, impl):
     assert common.argmax_match(got, ref["out"]) == [1.0, 1.0, 1.0, 1.0]
 
 
-@pytest.mark.parametrize("impl,variant", [(1, 239), (1, 111), (1, 47), (1, 6), (1, 0), (0, 47)])
+@pytest.mark.parametrize("impl,variant", [(1, 495), (1, 239), (1, 111), (1, 47), (1, 6), (1, 0), (0, 47)])
 def test_intermediates_match_oracle(setup, impl, variant):
     import torch
     arch, P, m, x, ref = setup
@@ -54,8 +54,11 @@ def test_intermediates_match_oracle(setup, impl, variant):
     m.predict_device(torch.from_numpy(x).cuda())
     m.setOption("variant", common.DEFAULT_VARIANT)
     for layer, name in ((1, "pool1"), (2, "pool2"), (3, "pool3"), (4, "fc4"), (5, "fc5")):
-        if layer == 1 and impl == 1 and (variant & 1):
-            continue      # with the first layer fused into the conv2 kernel pool1 never reaches HBM
+        if layer == 1 and impl == 1 and (variant & 1) and not ((variant & 128) and arch == "full"):
+            continue      # with the first layer fused into the conv2 kernel pool1 never reaches HBM (small passes of the
+                          # full topology run unfused under variant bit 7)
+        if layer == 3 and impl == 1 and (variant & 256) and arch == "slim":
+            continue      # slim conv3 + fc4 as one kernel: the conv3 map never exists in memory
         a = m.getActivation(layer, n).cpu().numpy().reshape(n, -1)
         b = ref[name].reshape(n, -1)
         scale = max(1.0, float(np.abs(b).max()))
@@ -89,7 +92,7 @@ def test_plain_and_tile_kernels_agree_bitwise(setup):
     m.setOption("impl", 0)
     a = np.concatenate(m.predict(x), axis=1)
     m.setOption("impl", 1)
-    for variant in (0, 1, 2, 4, 7, 8, 15, 47, 111, 65, 239, 128):       # every kernel variant computes the same bits
+    for variant in (0, 1, 2, 4, 7, 8, 15, 47, 111, 65, 239, 128, 495, 256):       # every kernel variant computes the same bits
         m.setOption("variant", variant)
         b = np.concatenate(m.predict(x), axis=1)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), variant
@@ -108,7 +111,7 @@ def test_large_pass_kernels_equal_small_pass_kernels(setup):
     m.setOption("impl", 1)
     m.setOption("chunk", 8192)
     small = m.predict_device(xd).cpu().numpy()
-    for variant in (239, 111, 47, 15, 11):        # two groups per wave / one group per wave with 8 or 4 waves per workgroup
+    for variant in (495, 239, 111, 47, 15, 11):        # two groups per wave / one group per wave with 8 or 4 waves per workgroup
         m.setOption("variant", variant)
         m.setOption("chunk", 65536)
         big = m.predict_device(xd).cpu().numpy()
