@@ -1429,6 +1429,43 @@ int launch_conv(const float *in, const float *x, int64_t n, const float *wp1, co
     return 0;
 }
 
+// How many waves should share the positions of a (group, tile)?  The chip runs 2 048 conv waves at a time (256 CUs x
+// 4 SIMDs x 2); a layer takes rounds x (rows per wave), where a pooled layer's parts recompute `overlap` rows.
+// train.py's batch of 10 000 is 625 groups: conv3's data gradient with 2 tiles x 2 parts = 2 500 waves is two rounds
+// of 13 rows (the second a fifth full), with 3 parts 1.8 rounds of 9.  Ties go to fewer parts (less redundancy).
+static int pick_hsplit(int G, int NT, int rows, int overlap, int max_parts)
+{
+    static const int cand[6] = {1, 2, 3, 4, 6, 8};
+    int best = 1;
+    long best_cost = -1;
+    for (int i = 0; i < 6; i++) {
+        const int hs = cand[i];
+        if (hs > max_parts || hs > rows) break;
+        const long waves = (long)G * NT * hs;
+        const long rounds = (waves + 2047) / 2048;
+        const long cost = rounds * ((rows + hs - 1) / hs + overlap);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = hs; }
+    }
+    return best;
+}
+
+// launch_conv with the number of position parts chosen at run time (MODE 1: 1-4, MODE 2: 1-8)
+template <int KH, int CINB, int NT, int POOL, int HIN, int MODE, int KS4 = 4>
+int launch_conv_parts(int hs, const float *in, const float *x, int64_t n, const float *wp, const float *bias, int cout,
+                      float *out, int G, hipStream_t st, float *act = nullptr)
+{
+#define CV_PARTS(H) return launch_conv<KH, CINB, NT, POOL, HIN, 0, MODE, H, KS4>(in, x, n, nullptr, nullptr, 0, wp, bias, cout, out, G, st, act)
+    switch (hs) {
+    case 2: CV_PARTS(2);
+    case 3: CV_PARTS(3);
+    case 4: CV_PARTS(4);
+    case 6: if constexpr (MODE == 2) { CV_PARTS(6); } else { CV_PARTS(4); }
+    case 8: if constexpr (MODE == 2) { CV_PARTS(8); } else { CV_PARTS(4); }
+    default: CV_PARTS(1);
+    }
+#undef CV_PARTS
+}
+
 template <int CINB, int NT, int HIN, int WAVES, int MINW>
 int launch_conv3_rot(const float *in, const float *wp, const float *bias, int cout, float *out, int G, hipStream_t st)
 {
@@ -2292,27 +2329,18 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
     const int64_t *o = m->poff;
     const int G = (int)((n + 15) / 16);
     int rc = 0;
-    // few groups (config 4's per-rank batch of 1 250 is 79): the positions of a (group, tile) are split over several
-    // waves so that the layer is not one long serial loop on a quarter of the SIMDs; same values, row for row
-    const bool tiny = G <= m->tiny_g;
+    // the positions of a (group, tile) are split over as many waves as fills the chip best for this batch
+    // (pick_hsplit; config 4's per-rank batch of 1 250 is 79 groups -> 4 parts, train.py's 625 groups -> conv2 in 3);
+    // same values row for row.  Option train_tiny_groups = 0 keeps one wave per (group, tile).
+    const bool split = m->tiny_g > 0;
     if (is_full(a)) {
         conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (f4 *)a1);
-        if (tiny) {
-            rc |= launch_conv<2, 1, 2, 4, 29, 0, 1, 4>(p1, x, n, nullptr, nullptr, 0, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
-            rc |= launch_conv<3, 2, 3, 3, 26, 0, 1, 4>(p2, x, n, nullptr, nullptr, 0, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
-        } else {
-            rc |= launch_conv<2, 1, 2, 4, 29, 0, 1>(p1, x, n, nullptr, nullptr, 0, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
-            rc |= launch_conv<3, 2, 3, 3, 26, 0, 1>(p2, x, n, nullptr, nullptr, 0, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
-        }
+        rc |= launch_conv_parts<2, 1, 2, 4, 29, 1>(split ? pick_hsplit(G, 2, 26, 3, 4) : 1, p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
+        rc |= launch_conv_parts<3, 2, 3, 3, 26, 1>(split ? pick_hsplit(G, 3, 24, 2, 4) : 1, p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
     } else {
         conv1_tm<1, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (f4 *)a1);
-        if (tiny) {
-            rc |= launch_conv<3, 1, 1, 1, 33, 0, 1, 4, 2>(p1, x, n, nullptr, nullptr, 0, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
-            rc |= launch_conv<5, 1, 2, 1, 33, 0, 1, 4>(p2, x, n, nullptr, nullptr, 0, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
-        } else {
-            rc |= launch_conv<3, 1, 1, 1, 33, 0, 1, 1, 2>(p1, x, n, nullptr, nullptr, 0, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
-            rc |= launch_conv<5, 1, 2, 1, 33, 0, 1>(p2, x, n, nullptr, nullptr, 0, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
-        }
+        rc |= launch_conv_parts<3, 1, 1, 1, 33, 1, 2>(split ? pick_hsplit(G, 1, 33, 0, 4) : 1, p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
+        rc |= launch_conv_parts<5, 1, 2, 1, 33, 1>(split ? pick_hsplit(G, 2, 33, 0, 4) : 1, p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
     }
     CV_HIP(hipGetLastError());
     return rc;
@@ -2368,26 +2396,15 @@ int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm,
     const cv_arch &a = m->arch;
     const int G = (int)((n + 15) / 16);
     const float *W = m->wpd_conv[layer];
-    const bool few = G <= 1024;        // train.py's batch of 10 000 is 625 groups: split the positions over more waves
-    const bool tiny = G <= m->tiny_g;  // a rank's share of it: more still
+    const bool split = m->tiny_g > 0;      // see cv_tile_train_convs
     if (is_full(a)) {
-        if (layer == 2) {
-            if (tiny) return launch_conv<3, 3, 2, 1, 26, 0, 2, 6>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
-            if (few) return launch_conv<3, 3, 2, 1, 26, 0, 2, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
-            return launch_conv<3, 3, 2, 1, 26, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
-        }
-        if (tiny) return launch_conv<2, 2, 1, 1, 29, 0, 2, 8>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
-        if (few) return launch_conv<2, 2, 1, 1, 29, 0, 2, 4>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
-        return launch_conv<2, 2, 1, 1, 29, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
+        if (layer == 2)
+            return launch_conv_parts<3, 3, 2, 1, 26, 2>(split ? pick_hsplit(G, 2, 26, 0, 8) : 1, g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
+        return launch_conv_parts<2, 2, 1, 1, 29, 2>(split ? pick_hsplit(G, 1, 29, 0, 8) : 1, g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
     }
-    if (layer == 2) {
-        if (tiny) return launch_conv<5, 2, 1, 1, 33, 0, 2, 8>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
-        if (few) return launch_conv<5, 2, 1, 1, 33, 0, 2, 4>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
-        return launch_conv<5, 2, 1, 1, 33, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
-    }
-    if (tiny) return launch_conv<3, 1, 1, 1, 33, 0, 2, 8>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
-    if (few) return launch_conv<3, 1, 1, 1, 33, 0, 2, 4>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
-    return launch_conv<3, 1, 1, 1, 33, 0, 2>(g_tm, nullptr, n, nullptr, nullptr, 0, W, nullptr, 0, gin_tm, G, st);
+    if (layer == 2)
+        return launch_conv_parts<5, 2, 1, 1, 33, 2>(split ? pick_hsplit(G, 1, 33, 0, 8) : 1, g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
+    return launch_conv_parts<3, 1, 1, 1, 33, 2>(split ? pick_hsplit(G, 1, 33, 0, 8) : 1, g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
 }
 
 // heads of the training pass: pre-activations of the 16 outputs from the dropped-out fc4 output and fc5 (tile-major)

@@ -162,7 +162,8 @@ def test_side_stream_weight_gradients_give_the_same_bits(oracle, arch, n):
     assert np.isfinite(a[1]).all()
 
 
-@pytest.mark.parametrize("arch,n", [("full", 1250), ("slim", 1250), ("full", 83), ("full", 2560)])
+@pytest.mark.parametrize("arch,n", [("full", 1250), ("slim", 1250), ("full", 83), ("full", 2560), ("full", 10000),
+                                    ("slim", 10000), ("full", 20000)])
 def test_tiny_batch_kernel_variants_give_the_same_bits(oracle, arch, n):
     """batches of few groups (a rank's share of train.py's batch) split the serial loops of the training step over
     more waves: position ranges in the convolutions (pooled layers recompute the window overlap), one thread per
