@@ -15,8 +15,13 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
+#include <unistd.h>
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
@@ -117,6 +122,79 @@ static const char *parse_lines(const char *buf, const char *p, const char *end, 
 
 static int g_host_threads = 1;
 
+// ---- host thread pool -------------------------------------------------------------------------------------------
+// The data plane is called once per batch (20 blosc blocks of ~1 MB, a few text slices): spawning its threads per
+// call cost as much as the work of a block, and a static split of 20 blocks over 16 threads leaves 12 of them idle
+// for half of the call.  Workers are created once (detached, at most 63), a job is a task count + a function; tasks
+// are handed out through an atomic counter, the calling thread works too.  One job at a time: a second caller (the
+// trainer decompresses X and Y of the next batch from two producer threads) runs its tasks on threads of its own.
+namespace {
+struct HostPool {
+    std::mutex job_mu;                          // owner of the pool for the duration of a job
+    std::mutex mu;
+    std::condition_variable cv_start, cv_done;
+    int nworkers = 0;
+    pid_t pid = 0;                              // workers do not survive a fork
+    const std::function<void(int64_t)> *fn = nullptr;
+    std::atomic<int64_t> next{0};
+    int64_t ntasks = 0;
+    int active = 0, want = 0;
+    uint64_t gen = 0;
+
+    void drain()
+    {
+        for (;;) {
+            const int64_t i = next.fetch_add(1);
+            if (i >= ntasks) break;
+            (*fn)(i);
+        }
+    }
+    void worker(int id, uint64_t seen)
+    {
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_start.wait(lk, [&] { return gen != seen; });
+            seen = gen;
+            const bool part = id < want;
+            lk.unlock();
+            if (part) drain();
+            lk.lock();
+            if (--active == 0) cv_done.notify_one();
+        }
+    }
+    void run(int64_t n, int T, const std::function<void(int64_t)> &f)
+    {
+        if (T > n) T = (int)n;
+        if (T <= 1) { for (int64_t i = 0; i < n; i++) f(i); return; }
+        std::unique_lock<std::mutex> job(job_mu, std::try_to_lock);
+        if (!job.owns_lock()) {                 // pool busy: threads of this call, same dynamic hand-out
+            std::atomic<int64_t> nx{0};
+            auto body = [&]() { for (;;) { const int64_t i = nx.fetch_add(1); if (i >= n) break; f(i); } };
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; t++) th.emplace_back(body);
+            body();
+            for (auto &x : th) x.join();
+            return;
+        }
+        if (pid != getpid()) { pid = getpid(); nworkers = 0; gen = 0; }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            while (nworkers < T - 1 && nworkers < 63) {
+                std::thread(&HostPool::worker, this, nworkers, gen).detach();
+                nworkers++;
+            }
+            fn = &f; ntasks = n; next.store(0); want = T - 1; active = nworkers; gen++;
+        }
+        cv_start.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return active == 0; });
+        fn = nullptr;
+    }
+};
+HostPool &host_pool() { static HostPool *p = new HostPool(); return *p; }   // never destroyed: workers are detached
+}  // namespace
+
 extern "C" int cv_set_host_threads(int n)
 {
     g_host_threads = n < 1 ? 1 : n > 64 ? 64 : n;
@@ -163,16 +241,11 @@ extern "C" int cv_parse_tensor_text(const char *buf, int64_t len, int64_t max_ro
         for (int t = 0; t <= T; t++) { first_line.push_back(lines * t / T); cut.push_back(starts[(size_t)(lines * t / T)]); }
     }
     std::vector<int64_t> got((size_t)T, 0), bads((size_t)T, 0);
-    {
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; t++)
-            th.emplace_back([&, t]() {
-                parse_lines(buf, cut[(size_t)t], cut[(size_t)t + 1], first_line[(size_t)t + 1] - first_line[(size_t)t],
-                            x_out + (size_t)first_line[(size_t)t] * NV, meta_out + first_line[(size_t)t] * 6, &got[(size_t)t],
-                            &bads[(size_t)t]);
-            });
-        for (auto &x : th) x.join();
-    }
+    host_pool().run(T, T, [&](int64_t t) {
+        parse_lines(buf, cut[(size_t)t], cut[(size_t)t + 1], first_line[(size_t)t + 1] - first_line[(size_t)t],
+                    x_out + (size_t)first_line[(size_t)t] * NV, meta_out + first_line[(size_t)t] * 6, &got[(size_t)t],
+                    &bads[(size_t)t]);
+    });
     int64_t rows = 0, bd = 0;
     for (int t = 0; t < T; t++) {                              // close the gaps left by dropped rows
         if (rows != first_line[(size_t)t] && got[(size_t)t]) {
@@ -373,18 +446,7 @@ extern "C" int cv_blosc_decompress_many(const uint8_t *const *chunks, const int6
                                         const int64_t *dstcaps, int64_t n, int32_t *status)
 {
     if ((!chunks || !clens || !dsts || !dstcaps || !status) && n > 0) { cv_set_error("blosc: null argument"); return 1; }
-    int T = g_host_threads;
-    if (T > n) T = (int)n;
-    if (T <= 1) {
-        for (int64_t i = 0; i < n; i++) status[i] = cv_blosc_decompress(chunks[i], clens[i], dsts[i], dstcaps[i]);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; t++)
-            th.emplace_back([=]() {
-                for (int64_t i = t; i < n; i += T) status[i] = cv_blosc_decompress(chunks[i], clens[i], dsts[i], dstcaps[i]);
-            });
-        for (auto &x : th) x.join();
-    }
+    host_pool().run(n, g_host_threads, [=](int64_t i) { status[i] = cv_blosc_decompress(chunks[i], clens[i], dsts[i], dstcaps[i]); });
     for (int64_t i = 0; i < n; i++)
         if (status[i]) { cv_set_error("blosc: chunk %lld is corrupt or unsupported", (long long)i); return 1; }
     return 0;
@@ -422,38 +484,25 @@ extern "C" int cv_blosc_unpack_blocks(const uint8_t *const *chunks, const int64_
                                       int64_t block_bytes, int64_t *lens, int32_t *status)
 {
     if ((!chunks || !clens || !dst || !lens || !status) && n > 0) { cv_set_error("blosc: null argument"); return 1; }
-    int T = g_host_threads;
-    if (T > n) T = (int)n;
-    if (T < 1) T = 1;
-    auto work = [=](int t) {
-        uint8_t *scratch = nullptr;
-        int64_t cap = 0;
-        for (int64_t i = t; i < n; i += T) {
-            const int64_t nb = cv_blosc_nbytes(chunks[i], clens[i]);
-            status[i] = 1; lens[i] = 0;
-            if (nb < 0) continue;
-            if (nb > cap) { free(scratch); scratch = (uint8_t *)malloc((size_t)nb + 16); cap = nb; }
-            if (!scratch || cv_blosc_decompress(chunks[i], clens[i], scratch, nb)) continue;
-            int64_t off = 0, L = 0;
-            status[i] = 2;
-            if (!find_array_payload(scratch, nb, &off, &L)) {
-                // an empty trailing block pickles an array without a data object worth finding: accept a tiny stream
-                if (i == n - 1 && nb < 512) { status[i] = 0; lens[i] = 0; }
-                continue;
-            }
-            if ((i < n - 1 && L != block_bytes) || L > block_bytes) continue;
-            memcpy(dst + (size_t)i * (size_t)block_bytes, scratch + off, (size_t)L);
-            lens[i] = L;
-            status[i] = 0;
+    host_pool().run(n, g_host_threads, [=](int64_t i) {
+        static thread_local std::vector<uint8_t> scratch;       // per worker, kept between calls
+        const int64_t nb = cv_blosc_nbytes(chunks[i], clens[i]);
+        status[i] = 1; lens[i] = 0;
+        if (nb < 0) return;
+        if ((int64_t)scratch.size() < nb + 16) scratch.resize((size_t)nb + 16);
+        if (cv_blosc_decompress(chunks[i], clens[i], scratch.data(), nb)) return;
+        int64_t off = 0, L = 0;
+        status[i] = 2;
+        if (!find_array_payload(scratch.data(), nb, &off, &L)) {
+            // an empty trailing block pickles an array without a data object worth finding: accept a tiny stream
+            if (i == n - 1 && nb < 512) { status[i] = 0; lens[i] = 0; }
+            return;
         }
-        free(scratch);
-    };
-    if (T == 1) work(0);
-    else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; t++) th.emplace_back(work, t);
-        for (auto &x : th) x.join();
-    }
+        if ((i < n - 1 && L != block_bytes) || L > block_bytes) return;
+        memcpy(dst + (size_t)i * (size_t)block_bytes, scratch.data() + off, (size_t)L);
+        lens[i] = L;
+        status[i] = 0;
+    });
     for (int64_t i = 0; i < n; i++)
         if (status[i]) { cv_set_error("blosc: block %lld: status %d", (long long)i, status[i]); return 1; }
     return 0;
