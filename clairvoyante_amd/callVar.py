@@ -313,34 +313,50 @@ def TestSharded(args, m, utils, rank, ws):
     rt = Thread(target=reader, daemon=True)
     rt.start()
     pending = None
-    with torch.cuda.device(m.device):
-        while True:
-            item = q_in.get()
-            if isinstance(item, BaseException):
-                raise item
-            nxt = None
-            if item is not None:
-                block, num, X, pos = item
-                call = qual = None
-                if num > 0:
-                    xd = torch.from_numpy(X).to(m.device, non_blocking=True)
-                    call, qual = predict_and_reduce(m, xd)
-                nxt = (block, num, X, pos, call, qual)
-            if pending is not None:
-                pblock, pnum, pX, ppos, pcall, pqual = pending
-                buf = io.StringIO()
-                if pnum > 0:
-                    OutputFromDevice(args, buf, pnum, pX, ppos, pcall.cpu().numpy(), pqual.cpu().numpy())
-                text = buf.getvalue()
-                frag.write(text)
-                index.append((pblock, len(text.encode("ascii"))))
-            pending = nxt
-            if item is None:
-                break
-    frag.close()
-    with open(frag_fn + ".idx", "w") as f:
-        f.write("".join("%d %d\n" % e for e in index))
-    dist.barrier()
+    failure = None
+    try:
+        with torch.cuda.device(m.device):
+            while True:
+                item = q_in.get()
+                if isinstance(item, BaseException):
+                    raise item
+                nxt = None
+                if item is not None:
+                    block, num, X, pos = item
+                    call = qual = None
+                    if num > 0:
+                        xd = torch.from_numpy(X).to(m.device, non_blocking=True)
+                        call, qual = predict_and_reduce(m, xd)
+                    nxt = (block, num, X, pos, call, qual)
+                if pending is not None:
+                    pblock, pnum, pX, ppos, pcall, pqual = pending
+                    buf = io.StringIO()
+                    if pnum > 0:
+                        OutputFromDevice(args, buf, pnum, pX, ppos, pcall.cpu().numpy(), pqual.cpu().numpy())
+                    text = buf.getvalue()
+                    frag.write(text)
+                    index.append((pblock, len(text.encode("ascii"))))
+                pending = nxt
+                if item is None:
+                    break
+        frag.close()
+        with open(frag_fn + ".idx", "w") as f:
+            f.write("".join("%d %d\n" % e for e in index))
+    except BaseException as e:          # the other ranks must not wait at the barrier for a rank that died
+        failure = e
+    # every rank learns whether all fragments are complete (MAX of a flag) before anyone merges or leaves
+    flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32,
+                        device=m.device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()) != 0:
+        for fn in (frag_fn, frag_fn + ".idx"):
+            try:
+                os.remove(fn)
+            except OSError:
+                pass
+        if failure is not None:
+            raise failure
+        sys.exit("callVar: another rank failed; no VCF written")
     if rank == 0:
         with open(args.call_fn, "w") as call_fh:
             PrintVCFHeader(args, call_fh)
