@@ -9,6 +9,8 @@
 //
 // selu follows /root/reference/clairvoyante/selu.py:21-25
 //   scale * where(x >= 0, x, alpha * elu(x)),  elu(x) = exp(x) - 1
+// (its negative branch is an own fixed sequence, see selu() below; exp() elsewhere -- sigmoid, softmax, selu' -- is
+// expf_fixed)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -45,18 +47,20 @@ __device__ __forceinline__ float expf_fixed(float x)
 constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f;
 constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
 
-// Branch-free form of the same operation sequence (a wave never diverges on the sign of
-// an activation): bitwise identical to `x >= 0 ? SCALE*x : SCALE*(ALPHA*(expf_fixed(x)-1))`
-// for every x.  Notes: (i) the argument is clamped at the flush threshold instead of
-// flushing exp to 0 -- below it exp(x) <= 1.2e-38 and exp(x) - 1 rounds to -1 either way;
-// (ii) the final select is `x < 0 ? neg : pos`, which also routes NaN (and -0) to pos.
+constexpr float SELU_SA = (float)(1.0507009873554804934193349852946 * 1.6732632423543772848170429916717);
+
+// SELU, branch-free (a wave never diverges on the sign of an activation).  The negative branch is its own fixed
+// operation sequence (the CPU checker of the test suite states the same one): clamp at the flush threshold (below it exp(x) - 1
+// rounds to -1 either way), ONE-constant range reduction r = x - z*fl(ln 2) (|z| <= 126), the Cephes polynomial of
+// expf_fixed, y*2^z by one v_ldexp_f32 (the product is a normal number), and scale*alpha*(y - 1) as ONE fused
+// multiply-add with the product constant -- 18 element operations per value where scale*(alpha*(expf_fixed(x)-1))
+// took 21, a little MORE accurate (max |err| 1.2e-7 vs 2.0e-7 over all negative floats) and monotone over every
+// fp32 input (cv_selu_sweep).  The select is `x < 0 ? neg : pos`, which routes NaN (and -0) to pos.
 __device__ __forceinline__ float selu(float x)
 {
-    // clamp to [flush threshold, 0] (one v_med3_f32); for x > 0 the exp branch is unused
     const float xc = __builtin_amdgcn_fmed3f(x, -87.33654475055310f, 0.0f);
     float z = __builtin_rintf(xc * 1.44269504088896341f);
-    float r = __builtin_fmaf(z, -0.693359375f, xc);
-    r = __builtin_fmaf(z, 2.12194440e-4f, r);
+    float r = __builtin_fmaf(z, -0.69314718055994530942f, xc);
     float r2 = r * r;
     float p = 1.9875691500e-4f;
     p = __builtin_fmaf(p, r, 1.3981999507e-3f);
@@ -66,19 +70,17 @@ __device__ __forceinline__ float selu(float x)
     p = __builtin_fmaf(p, r, 5.0000001201e-1f);
     float y = __builtin_fmaf(p, r2, r);
     y = y + 1.0f;
-    // y * 2^n: n in [-126, 0] here and y in [0.70, 1.42), the product is a normal number, so
-    // one v_ldexp_f32 equals expf_fixed's two exact power-of-two multiplications bit for bit
     y = __builtin_ldexpf(y, (int)z);
-    const float neg = SELU_SCALE * (SELU_ALPHA * (y - 1.0f));
+    const float neg = __builtin_fmaf(y, SELU_SA, -SELU_SA);
     const float pos = SELU_SCALE * x;
     return x < 0.0f ? neg : pos;
 }
 
 // Two SELUs at once on the packed fp32 pipe (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two IEEE operations per
-// instruction).  The operation sequence per element is selu()'s, each packed instruction rounds its two lanes
-// exactly like the scalar one, so the results are bit-identical; the multiplications, the ten fused
-// multiply-adds and the additions -- 15 of the 21 instructions -- cost half an issue slot per element
-// (tools/mfma_coissue.hip: 2.4 ns per packed instruction against 2.0 ns per scalar one next to the MFMAs).
+// instruction).  The operation sequence per element is selu()'s and each packed instruction rounds its two lanes
+// exactly like the scalar one: bit-identical.  12 of the 18 instructions per pair are packed; measured, a packed
+// instruction occupies the pipe like the two scalar ones it replaces (slim's kernels did not move when this went
+// in), so what it buys is shorter code, not time -- the cost of exact fp32 VALU work is per element operation.
 typedef float f2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f2v selu2(f2v x)
@@ -89,8 +91,7 @@ __device__ __forceinline__ f2v selu2(f2v x)
     const f2v t = xc * 1.44269504088896341f;
     f2v z;
     z[0] = __builtin_rintf(t[0]); z[1] = __builtin_rintf(t[1]);
-    f2v r = __builtin_elementwise_fma(z, (f2v)(-0.693359375f), xc);
-    r = __builtin_elementwise_fma(z, (f2v)(2.12194440e-4f), r);
+    const f2v r = __builtin_elementwise_fma(z, (f2v)(-0.69314718055994530942f), xc);
     const f2v r2 = r * r;
     f2v p = (f2v)(1.9875691500e-4f);
     p = __builtin_elementwise_fma(p, r, (f2v)(1.3981999507e-3f));
@@ -102,7 +103,7 @@ __device__ __forceinline__ f2v selu2(f2v x)
     y = y + 1.0f;
     y[0] = __builtin_ldexpf(y[0], (int)z[0]);
     y[1] = __builtin_ldexpf(y[1], (int)z[1]);
-    const f2v neg = SELU_SCALE * (SELU_ALPHA * (y - 1.0f));
+    const f2v neg = __builtin_elementwise_fma(y, (f2v)(SELU_SA), (f2v)(-SELU_SA));
     const f2v pos = SELU_SCALE * x;
     f2v o;
     o[0] = x[0] < 0.0f ? neg[0] : pos[0];
