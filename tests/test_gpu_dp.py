@@ -251,11 +251,14 @@ def _dp_worker(rank, ws, port, tmp, arch, n, steps, rate):
     x, y = _data(n, seed=60)
     lo, hi = parallel.shard_range(n, rank, ws)
     losses = []
+    g1 = None
     for s in range(steps):
         loss, summ = m.train(x[lo:hi], y[lo:hi])
         losses.append([summ[k] for k in ("loss1", "loss2", "loss3", "loss4", "lossL2", "loss")])
+        if s == 0:
+            g1 = _flat(m, 1)          # the exchanged gradient of the FIRST step: same weights as the single-process run
     g = _flat(m, 1)
-    np.savez(os.path.join(tmp, "rank%d.npz" % rank), w=_flat(m, 0), am=_flat(m, 2), av=_flat(m, 3), g=g,
+    np.savez(os.path.join(tmp, "rank%d.npz" % rank), w=_flat(m, 0), am=_flat(m, 2), av=_flat(m, 3), g=g, g1=g1,
              losses=np.asarray(losses))
     torch.distributed.barrier()
     m.close()
@@ -282,19 +285,26 @@ def test_two_rank_data_parallel_step_equals_the_single_process_step(oracle, arch
     m.dropoutRateFC4Val = 0.0; m.setLearningRate(1e-3); m.setL2RegularizationLambda(0.01)
     x, y = _data(n, seed=60)
     losses = []
+    g1 = None
     for s in range(steps):
         loss, summ = m.train(x, y)
         losses.append([summ[k] for k in ("loss1", "loss2", "loss3", "loss4", "lossL2", "loss")])
-    assert np.allclose(r0["losses"], np.asarray(losses), rtol=2e-6)
+        if s == 0:
+            g1 = _flat(m, 1)
+    assert np.allclose(r0["losses"][0], np.asarray(losses)[0], rtol=2e-6)       # first step: identical weights
+    assert np.allclose(r0["losses"], np.asarray(losses), rtol=1e-4)             # later steps: weights equal to rounding
     g = _flat(m, 1); w = _flat(m, 0); am = _flat(m, 2); av = _flat(m, 3)
     off = 0
     P = common.bench_params(oracle, arch, seed=1)
     for name in oracle.PARAM_NAMES:
         sz = P[name].size
         sl = slice(off, off + sz); off += sz
-        assert np.abs(r0["g"][sl] - g[sl]).max() <= 2e-5 * np.abs(g[sl]).max() + 1e-7, name
-        assert np.abs(r0["am"][sl] - am[sl]).max() <= 2e-5 * np.abs(am[sl]).max() + 1e-9, name
-        assert np.abs(r0["av"][sl] - av[sl]).max() <= 4e-5 * np.abs(av[sl]).max() + 1e-12, name
+        # the sum of the two shard gradients against the full-batch gradient at the SAME weights: summation order only
+        assert np.abs(r0["g1"][sl] - g1[sl]).max() <= 2e-5 * np.abs(g1[sl]).max() + 1e-7, name
+        # after three updates the weights differ in their last bits (Adam divides by sqrt(v)): looser
+        assert np.abs(r0["g"][sl] - g[sl]).max() <= 1e-3 * np.abs(g[sl]).max() + 1e-6, name
+        assert np.abs(r0["am"][sl] - am[sl]).max() <= 1e-3 * np.abs(am[sl]).max() + 1e-9, name
+        assert np.abs(r0["av"][sl] - av[sl]).max() <= 2e-3 * np.abs(av[sl]).max() + 1e-12, name
     # weights: Adam divides by sqrt(v), so an element whose gradient is pure rounding noise may move differently;
     # all but a vanishing fraction agree to 1e-6, none differs by more than the three steps can move it
     dw = np.abs(r0["w"] - w)
