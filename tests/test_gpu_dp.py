@@ -314,6 +314,45 @@ def test_two_rank_data_parallel_step_equals_the_single_process_step(oracle, arch
     m.close()
 
 
+def test_two_rank_step_with_an_empty_shard(oracle, tmp_path):
+    """a global batch smaller than the rank count leaves a rank without candidates: it still takes part in the
+    exchange (zero gradient, zero losses) and every rank applies the same update"""
+    _spawn(_dp_worker, (str(tmp_path), "slim", 1, 2, 0.0))
+    r0 = np.load(str(tmp_path / "rank0.npz")); r1 = np.load(str(tmp_path / "rank1.npz"))
+    for k in ("w", "am", "av", "g"):
+        assert np.array_equal(r0[k].view(np.uint32), r1[k].view(np.uint32)), k
+    m = _model("slim"); m.setParameters(common.bench_params(oracle, "slim", seed=1))
+    m.dropoutRateFC4Val = 0.0; m.setLearningRate(1e-3); m.setL2RegularizationLambda(0.01)
+    x, y = _data(1, seed=60)
+    loss, summ = m.train(x, y)
+    assert abs(r0["losses"][0][5] - summ["loss"]) <= 1e-6 * abs(summ["loss"])
+    assert np.abs(r0["g1"] - _flat(m, 1)).max() <= 1e-6 * np.abs(r0["g1"]).max()
+    m.close()
+
+
+def test_gradient_bucket_binding_is_checked(oracle):
+    import ctypes
+    import torch
+    from clairvoyante_amd import _lib
+    m = _model("slim")
+    cnt = ctypes.c_int64(); hdr = ctypes.c_int64(); dense = ctypes.c_int64()
+    _lib.check(m._lib.cv_grad_bucket_info(m._h, ctypes.byref(cnt), ctypes.byref(hdr), ctypes.byref(dense)))
+    assert cnt.value == m.numParameters + hdr.value and hdr.value == 16 and hdr.value < dense.value < cnt.value
+    t = torch.zeros(cnt.value + 4, device="cuda")
+    with pytest.raises(_lib.CvError, match="floats"):
+        _lib.check(m._lib.cv_bind_grad_bucket(m._h, ctypes.c_void_p(t.data_ptr()), cnt.value - 1))
+    with pytest.raises(_lib.CvError, match="aligned"):
+        _lib.check(m._lib.cv_bind_grad_bucket(m._h, ctypes.c_void_p(t.data_ptr() + 4), cnt.value))
+    _lib.check(m._lib.cv_bind_grad_bucket(m._h, ctypes.c_void_p(t.data_ptr()), cnt.value))
+    x, y = _data(40, seed=2)
+    m.setParameters(common.bench_params(oracle, "slim"))
+    _lib.check(m._lib.cv_bind_grad_bucket(m._h, None, 0))           # back to the library's own bucket
+    loss, _ = m.train(x, y)                                          # (the model binds its own tensor on first use)
+    assert np.isfinite(loss) and float(m.gradients().abs().max()) > 0
+    assert float(t.abs().max()) == 0.0                               # the unbound tensor was never written
+    m.close()
+
+
 def test_two_rank_replicas_stay_identical_with_dropout(oracle, tmp_path):
     """each rank draws its own dropout stream; the exchanged gradient is what both apply"""
     _spawn(_dp_worker, (str(tmp_path), "slim", 3000, 4, 0.5))
