@@ -342,10 +342,13 @@ def main():
             flop = STAGE_FLOP[args.arch][s] + (STAGE_FLOP[args.arch][0] if (s == 1 and cnt[0] == 0) else 0)
             if s == 2 and cnt[3] == 0:          # conv3 and fc4 as one kernel (slim, variant bit 8)
                 flop += STAGE_FLOP[args.arch][3]
+            if s == 4 and cnt[5] == 0:          # the heads ride on the fc5 kernel (variant bit 9)
+                flop += STAGE_FLOP[args.arch][5]
             tf = flop * per_launch / (avg_ms * 1e-3) / 1e12
             kn = ctypes.c_char_p()
             _lib.check(m._lib.cv_kernel_name(m._h, s, ctypes.byref(kn)))
-            label = STAGE_NAMES[s] + (" + fc4 (fused)" if (s == 2 and cnt[3] == 0) else "")
+            label = STAGE_NAMES[s] + (" + fc4 (fused)" if (s == 2 and cnt[3] == 0) else "") + \
+                (" + heads (fused)" if (s == 4 and cnt[5] == 0) else "")
             stages.append({"kernel": label, "kernel_name": kn.value.decode() if kn.value else None,
                            "avg_ms": avg_ms, "launches": int(cnt[s]), "tflops": tf,
                            "share": ms[s] / max(sum(ms), 1e-12)})

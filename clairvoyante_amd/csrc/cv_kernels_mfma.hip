@@ -1054,34 +1054,14 @@ __device__ __forceinline__ void pack_heads(int64_t t, const float *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void heads_tm(const f4 *__restrict__ h4, const f4 *__restrict__ h5, int NB4,
-                                                 int NB5, const f4 *__restrict__ wp0, const f4 *__restrict__ wp1,
-                                                 const float *__restrict__ bb, const float *__restrict__ bz,
-                                                 const float *__restrict__ bt, const float *__restrict__ bl,
-                                                 int64_t n, float *__restrict__ out16, int G)
+// Epilogue of the heads: a0 = base-head tile (rows 0..3 on q = 0), a1 = zygosity / type / length tile; sigmoid,
+// softmax(selu(.) + 1e-10) per head in registers (the 6-way softmax spans lanes c+32 / c+48), 16 outputs per candidate.
+__device__ __forceinline__ void heads_finish(f4 a0, f4 a1, const float *__restrict__ bb, const float *__restrict__ bz,
+                                             const float *__restrict__ bt, const float *__restrict__ bl, int64_t n,
+                                             float *__restrict__ out16, int g, int lane)
 {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= G) return;
     const int c = lane & 15, q = lane >> 4;
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
-    f4 a0 = zero, a1 = zero;
-    const f4 *p4 = h4 + (size_t)g * NB4 * 64 + lane;
-    const f4 *p5 = h5 + (size_t)g * NB5 * 64 + lane;
-#pragma unroll 3
-    for (int kb = 0; kb < NB4; kb++) {
-        const f4 B = p4[(size_t)kb * 64];
-        const f4 A = wp0[(size_t)kb * 64 + lane];
-#pragma unroll
-        for (int s = 0; s < 4; s++) a0 = mfma4(A[s], B[s], a0);
-    }
-#pragma unroll 3
-    for (int kb = 0; kb < NB5; kb++) {
-        const f4 B = p5[(size_t)kb * 64];
-        const f4 A = wp1[(size_t)kb * 64 + lane];
-#pragma unroll
-        for (int s = 0; s < 4; s++) a1 = mfma4(A[s], B[s], a1);
-    }
     // biases of this lane's rows
     f4 bias1 = zero;
     if (q == 0) { bias1[0] = bz[0]; bias1[1] = bz[1]; }
@@ -1128,8 +1108,46 @@ __global__ __launch_bounds__(256) void heads_tm(const f4 *__restrict__ h4, const
         } else if (q == 3) {
             o[14] = e[0] / tot; o[15] = e[1] / tot;
         }
+    }}
+
+__global__ __launch_bounds__(256) void heads_tm(const f4 *__restrict__ h4, const f4 *__restrict__ h5, int NB4,
+                                                 int NB5, const f4 *__restrict__ wp0, const f4 *__restrict__ wp1,
+                                                 const float *__restrict__ bb, const float *__restrict__ bz,
+                                                 const float *__restrict__ bt, const float *__restrict__ bl,
+                                                 int64_t n, float *__restrict__ out16, int G)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const int c = lane & 15, q = lane >> 4;
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 a0 = zero, a1 = zero;
+    const f4 *p4 = h4 + (size_t)g * NB4 * 64 + lane;
+    const f4 *p5 = h5 + (size_t)g * NB5 * 64 + lane;
+#pragma unroll 3
+    for (int kb = 0; kb < NB4; kb++) {
+        const f4 B = p4[(size_t)kb * 64];
+        const f4 A = wp0[(size_t)kb * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 4; s++) a0 = mfma4(A[s], B[s], a0);
     }
+#pragma unroll 3
+    for (int kb = 0; kb < NB5; kb++) {
+        const f4 B = p5[(size_t)kb * 64];
+        const f4 A = wp1[(size_t)kb * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 4; s++) a1 = mfma4(A[s], B[s], a1);
+    }
+    heads_finish(a0, a1, bb, bz, bt, bl, n, out16, g, lane);
 }
+
+// operands of the heads when they ride on the fc5 kernel (dense_tm EPI 2)
+struct heads_args {
+    const f4 *wp0, *wp1;                 // packed head weights (pack_heads): base head over fc4, the others over fc5
+    const float *bb, *bz, *bt, *bl;      // biases
+    int64_t n;
+    float *out16;
+};
 
 // ---------------------------------------------------------------------------
 // dense (KB*16 -> NB*16) + bias + SELU, TM -> TM.  One wave per group of 16
@@ -1140,14 +1158,20 @@ __global__ __launch_bounds__(256) void heads_tm(const f4 *__restrict__ h4, const
 // EPI 0: + bias, SELU (forward layer).  EPI 1: raw accumulators (data-gradient pass: the same
 // kernel on transposed packed weights; blockIdx.y selects a slab of NB output fragments of a
 // wider result with NBT fragments per group).
+// EPI 2 (fc5 of an inference pass): EPI 0 plus the four heads (v3.py:124-138) on the same wave -- the layer's input
+// fragments (the fc4 output, which the base head contracts over) stream through the wave anyway and its output
+// tiles are, after SELU, the fragments the other three heads contract over: two more accumulator tiles, 4 MFMAs
+// per k step + 4 per output tile, then heads_finish.  No separate heads launch, the fc5 output is not re-read.
 // GR = groups per wave (1 or 2): with 2 a wave keeps two sets of accumulator tiles and every weight fragment read
 // from LDS feeds both -- twice the MFMA work per barrier and per LDS read, at 2 waves per SIMD.
 template <int NB, int WAVES, int EPI = 0, int GR = 1>
 __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_tm(const f4 *__restrict__ in_tm, int KB,
                                                         const f4 *__restrict__ wp_all,
                                                         const float *__restrict__ bias, int nout,
-                                                        f4 *__restrict__ out_tm, int G, int NBT = NB)
+                                                        f4 *__restrict__ out_tm, int G, int NBT = NB,
+                                                        heads_args hd = heads_args())
 {
+    static_assert(EPI != 2 || GR == 1, "the fused heads keep one group per wave");
     // The packed weight matrix holds NBP = roundup(NB, WAVES) fragments per k step (the pad
     // fragments are zero and never multiplied), so every thread stages exactly PER 16-byte
     // pieces per step: no conditional loads in the loop, which lets the waits sit at the
@@ -1207,11 +1231,14 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
     };
     stage_async(0, 0);
     stage_async(KB > 1 ? 1 : 0, 1);
+    f4 hacc0 = zero, hA = zero;                 // EPI 2: base-head tile and its weight fragment of the current k step
+    if constexpr (EPI == 2) hA = load_frag(hd.wp0 + lane);
     f4 B[GR];
 #pragma unroll
     for (int r = 0; r < GR; r++) B[r] = load_frag(bp[r]);
 #pragma unroll
     for (int r = 0; r < GR; r++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(B[r]) : : "memory");
+    if constexpr (EPI == 2) asm volatile("" : "+v"(hA) : : "memory");
     __syncthreads();
     int slot = 0;
 #pragma unroll 1
@@ -1224,6 +1251,8 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
         f4 Bn[GR];
 #pragma unroll
         for (int r = 0; r < GR; r++) Bn[r] = load_frag(bp[r] + (size_t)kn * 64);
+        f4 hAn = zero;
+        if constexpr (EPI == 2) hAn = load_frag(hd.wp0 + (size_t)kn * 64 + lane);      // issued before this step's DMA pieces
         stage_async(ks, wslot);          // slot (kb+2)%3 was last read in step kb-1 (barrier passed)
         const f4 *wl = ring + slot * STAGE + lane;
 #pragma unroll
@@ -1240,6 +1269,10 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
                     for (int r = 0; r < GR; r++)
                         if (ob + j < NB) acc[r][ob + j] = mfma4(A[j][s], B[r][s], acc[r][ob + j]);
         }
+        if constexpr (EPI == 2) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) hacc0 = mfma4(hA[s], B[0][s], hacc0);
+        }
         __builtin_amdgcn_sched_barrier(0);                  // keep the MFMAs above the wait
         // Counted wait: leave THIS step's PER DMA pieces (stage kb+2, first read two steps from
         // now) in flight; everything older -- Bn and the pieces of stage kb+1 issued one step
@@ -1249,6 +1282,7 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
         else if constexpr (PER == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(Bn[0]) : : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(Bn[0]) : : "memory");
         if constexpr (GR == 2) asm volatile("" : "+v"(Bn[1]) : : "memory");      // the same wait covers the second fragment
+        if constexpr (EPI == 2) { asm volatile("" : "+v"(hAn) : : "memory"); hA = hAn; }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < GR; r++) B[r] = Bn[r];
@@ -1262,6 +1296,25 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
         if (KS > 1) {
 #pragma unroll
             for (int ob = 0; ob < NB; ob++) op[ob * 64] = acc[r][ob];
+            continue;
+        }
+        if constexpr (EPI == 2) {
+            // the other three heads: contraction over this layer's output tiles, straight from the registers
+            f4 hW[NB];
+#pragma unroll
+            for (int ob = 0; ob < NB; ob++) hW[ob] = load_frag(hd.wp1 + (size_t)ob * 64 + lane);
+            f4 hacc1 = zero;
+#pragma unroll
+            for (int ob = 0; ob < NB; ob++) {
+                const f4 b4 = load_bias4(bias, ob, q, nout);
+                const f4 h = selu4(acc[r][ob] + b4);
+                op[ob * 64] = h;                             // kept for cv_get_activation
+                if (ob == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hW[0]) : : "memory");
+                asm volatile("" : "+v"(hW[ob]) : : "memory");
+#pragma unroll
+                for (int s = 0; s < 4; s++) hacc1 = mfma4(hW[ob][s], h[s], hacc1);
+            }
+            heads_finish(hacc0, hacc1, hd.bb, hd.bz, hd.bt, hd.bl, hd.n, hd.out16, g + r, lane);
             continue;
         }
 #pragma unroll
@@ -1479,7 +1532,7 @@ int launch_conv3_rot(const float *in, const float *wp, const float *bias, int co
 
 template <int NB, int WAVES, int EPI = 0, int GR = 1>
 int launch_dense(const float *in, int KB, const float *wp, const float *bias, int nout, float *out, int G,
-                 hipStream_t st, int slabs = 1, int ksplit = 1, float *part = nullptr)
+                 hipStream_t st, int slabs = 1, int ksplit = 1, float *part = nullptr, heads_args hd = heads_args())
 {
     auto k = dense_tm<NB, WAVES, EPI, GR>;
     size_t lds = (size_t)3 * ((NB + WAVES - 1) / WAVES * WAVES) * 1024;
@@ -1487,14 +1540,14 @@ int launch_dense(const float *in, int KB, const float *wp, const float *bias, in
     if (ksplit > 1) {       // partial sums per k range, then dense_ksum (EPI 0 layers only)
         static_assert(EPI == 0 || true, "");
         k<<<dim3(nblk(G, WAVES * GR), slabs, ksplit), WAVES * 64, lds, st>>>((const f4 *)in, KB, (const f4 *)wp, bias, nout,
-                                                                        (f4 *)part, G, NB * slabs);
+                                                                        (f4 *)part, G, NB * slabs, heads_args());
         dense_ksum<<<nblk((int64_t)G * NB * slabs * 64, 256), 256, 0, st>>>((const f4 *)part, ksplit, G, NB * slabs, bias, nout,
                                                                           (f4 *)out);
         CV_HIP(hipGetLastError());
         return 0;
     }
     k<<<dim3(nblk(G, WAVES * GR), slabs), WAVES * 64, lds, st>>>((const f4 *)in, KB, (const f4 *)wp, bias, nout,
-                                                            (f4 *)out, G, NB * slabs);
+                                                            (f4 *)out, G, NB * slabs, hd);
     CV_HIP(hipGetLastError());
     return 0;
 }
@@ -1684,6 +1737,11 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
     int rc = 0;
     const bool fuse_front = (m->variant & 1) != 0;
     const float *W1 = m->wp_conv1, *B1 = P + o[1];
+    bool heads_done = false;             // the heads rode on the fc5 kernel (variant bit 9)
+    heads_args hd;
+    hd.wp0 = (const f4 *)m->wp_heads0; hd.wp1 = (const f4 *)m->wp_heads1;
+    hd.bb = P + o[11]; hd.bz = P + o[13]; hd.bt = P + o[15]; hd.bl = P + o[17];
+    hd.n = n; hd.out16 = out16;
     if (full) {
         // very small passes (a predict() call of the reference's batch of 1 000 is 63 groups) are latency-bound by the
         // serial position loop of one (group, tile): the layers are launched unfused with their positions split over
@@ -1740,6 +1798,10 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         if (G <= CV_FC4_SMALL_MAX_G && (m->variant & 128)) {
             m->stage_kernel[4] = "dense_small<4, 7, 0>";
             rc |= launch_dense_small<4, 7>(m->tm_h4, s.nb4, m->wps3_fc5, P + o[9], a.fc5, m->tm_h5, G, 3, st, s.nb5);
+        } else if (m->variant & 512) {      // fc5 + heads as one kernel
+            m->stage_kernel[4] = "dense_tm<11, 4, 2, 1>";
+            rc |= launch_dense<11, 4, 2>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st, 1, 1, nullptr, hd);
+            heads_done = true;
         } else {
             m->stage_kernel[4] = "dense_tm<11, 4, 0, 1>";
             rc |= launch_dense<11, 4>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st);
@@ -1782,8 +1844,14 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         cv_prof_end(m, 3, st);
         }
         cv_prof_begin(m, 4, st);
-        m->stage_kernel[4] = "dense_tm<2, 4, 0, 1>";
-        rc |= launch_dense<2, 4>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st);
+        if (m->variant & 512) {
+            m->stage_kernel[4] = "dense_tm<2, 4, 2, 1>";
+            rc |= launch_dense<2, 4, 2>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st, 1, 1, nullptr, hd);
+            heads_done = true;
+        } else {
+            m->stage_kernel[4] = "dense_tm<2, 4, 0, 1>";
+            rc |= launch_dense<2, 4>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st);
+        }
         cv_prof_end(m, 4, st);
     }
     if (rc) return 1;
@@ -1791,6 +1859,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
     m->last_n = n;
     m->last_impl = 1;
     m->last_variant = m->variant;
+    if (heads_done) return 0;
     cv_prof_begin(m, 5, st);
     if (m->variant & 2) {
         m->stage_kernel[5] = "heads_tm";

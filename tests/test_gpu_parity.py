@@ -44,7 +44,7 @@ def test_outputs_match_oracle(setup, impl):
     assert common.argmax_match(got, ref["out"]) == [1.0, 1.0, 1.0, 1.0]
 
 
-@pytest.mark.parametrize("impl,variant", [(1, 495), (1, 239), (1, 111), (1, 47), (1, 6), (1, 0), (0, 47)])
+@pytest.mark.parametrize("impl,variant", [(1, 1007), (1, 495), (1, 239), (1, 111), (1, 47), (1, 6), (1, 0), (0, 47)])
 def test_intermediates_match_oracle(setup, impl, variant):
     import torch
     arch, P, m, x, ref = setup
@@ -92,7 +92,7 @@ def test_plain_and_tile_kernels_agree_bitwise(setup):
     m.setOption("impl", 0)
     a = np.concatenate(m.predict(x), axis=1)
     m.setOption("impl", 1)
-    for variant in (0, 1, 2, 4, 7, 8, 15, 47, 111, 65, 239, 128, 495, 256):       # every kernel variant computes the same bits
+    for variant in (0, 1, 2, 4, 7, 8, 15, 47, 111, 65, 239, 128, 495, 256, 1007, 512, 879):       # every kernel variant computes the same bits
         m.setOption("variant", variant)
         b = np.concatenate(m.predict(x), axis=1)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), variant
@@ -111,7 +111,7 @@ def test_large_pass_kernels_equal_small_pass_kernels(setup):
     m.setOption("impl", 1)
     m.setOption("chunk", 8192)
     small = m.predict_device(xd).cpu().numpy()
-    for variant in (495, 239, 111, 47, 15, 11):        # two groups per wave / one group per wave with 8 or 4 waves per workgroup
+    for variant in (1007, 495, 239, 111, 47, 15, 11):        # two groups per wave / one group per wave with 8 or 4 waves per workgroup
         m.setOption("variant", variant)
         m.setOption("chunk", 65536)
         big = m.predict_device(xd).cpu().numpy()
