@@ -2428,6 +2428,8 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
             // (CV_DENSE_KSPLIT) run side by side instead and a second pass adds them up in order
             if (part && G <= m->tiny_g)
                 return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3, CV_DENSE_KSPLIT, part);
+            // (dense_small beyond the tiny range loses: at 625 groups its 4 375 waves re-read the weight matrix from L2
+            // 7 x 625 times -- 2.63 against 2.41 ms per step)
             if (G <= m->tiny_g && (m->variant & 128))
                 return launch_dense_small<3, 8>(in_tm, s.kb4, m->wps7_fc4, P + o[7], a.fc4, out_tm, G, 7, st);
             // (two k ranges at train.py's batch of 10 000 -- 237 workgroups otherwise -- measured: no gain)
