@@ -441,3 +441,60 @@ def test_callvar_command_line_under_two_ranks_writes_the_single_rank_vcf(oracle,
     a, b = open(one).read(), open(two).read()
     assert a == b and a.count("\n") > 200
     assert not [f for f in os.listdir(str(tmp_path)) if ".rank" in f]
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys, ctypes
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["CV_ROOT"]); sys.path.insert(0, os.path.join(os.environ["CV_ROOT"], "tests"))
+import common
+from oracle import cv_oracle as O
+from clairvoyante_amd import parallel, clairvoyante_v3, synth, _lib
+rank, ws, local = parallel.init_from_env()
+assert dist.is_initialized() and dist.get_backend() == "nccl" and parallel._active()
+m = clairvoyante_v3.Clairvoyante(); m.setParameters(common.bench_params(O, "full"))
+parallel.broadcast_parameters(m)
+assert parallel.comm_stream(m) is not None
+m._dropout_seed = 99; m.setLearningRate(1e-3); m.setL2RegularizationLambda(1e-3)
+xt, cls, rf, alt, il = synth.make_candidates(3000, seed=41, device="cuda", return_class=True)
+y = synth.make_labels(cls, rf, alt, il)
+losses = [float(m.train(xt, y)[0]) for _ in range(3)]
+for _ in range(2):
+    m.trainDeferred(xt, y)
+acc, steps = m.readLosses()
+t = torch.empty(m.numParameters, device="cuda")
+_lib.check(m._lib.cv_flat_copy(m._h, 0, ctypes.c_void_p(t.data_ptr()), 0, None)); torch.cuda.synchronize()
+np.savez(os.environ["CV_OUT"], w=t.cpu().numpy(), losses=np.asarray(losses), acc=np.asarray(acc), steps=steps,
+         one=parallel.allreduce_scalar(1.5, m))
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_rccl_code_path_with_one_rank_equals_the_plain_step(oracle, tmp_path):
+    """The RCCL branch of the exchange -- communication stream behind the 'dense gradients final' event, two in-place
+    asynchronous all-reduces of the bucket, Adam behind both, the loss header divided by the rank count -- run for
+    real through backend nccl with ONE rank (CV_FORCE_DIST=1; the box has one GPU and RCCL refuses two ranks per
+    device): a sum over one rank is the identity, so weights and losses must equal the non-distributed step bit for
+    bit."""
+    import subprocess
+    import torch
+    from clairvoyante_amd import synth
+    out = str(tmp_path / "rccl.npz")
+    env = dict(os.environ, CV_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29300 + os.getpid() % 500), CV_ROOT=ROOT, CV_OUT=out, PYTHONPATH=ROOT)
+    env.pop("CV_DIST_BACKEND", None)
+    subprocess.check_call([sys.executable, "-c", _RCCL_ONE_RANK], env=env, cwd=ROOT)
+    got = np.load(out)
+    m = _model("full"); m.setParameters(common.bench_params(oracle, "full"))
+    m._dropout_seed = 99; m.setLearningRate(1e-3); m.setL2RegularizationLambda(1e-3)
+    xt, cls, rf, alt, il = synth.make_candidates(3000, seed=41, device="cuda", return_class=True)
+    y = synth.make_labels(cls, rf, alt, il)
+    losses = [float(m.train(xt, y)[0]) for _ in range(3)]
+    for _ in range(2):
+        m.trainDeferred(xt, y)
+    acc, steps = m.readLosses()
+    assert np.array_equal(got["w"].view(np.uint32), _flat(m, 0).view(np.uint32))
+    assert np.allclose(got["losses"], losses, rtol=1e-12, atol=0)
+    assert int(got["steps"]) == steps == 2 and np.allclose(got["acc"], acc, rtol=1e-9, atol=0)
+    assert float(got["one"]) == 1.5
+    m.close()
