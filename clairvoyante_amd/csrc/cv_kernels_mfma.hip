@@ -57,6 +57,23 @@ __device__ __forceinline__ float vmaxf(float a, float b)
 #endif
 }
 
+// max of three in one v_max3_f32 (same reasoning as vmaxf)
+__device__ __forceinline__ f4 max3_4(f4 a, f4 b, f4 c)
+{
+    f4 r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#ifdef CV_LIBM_MAX
+        r[k] = fmaxf(fmaxf(a[k], b[k]), c[k]);
+#else
+        float v;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(v) : "v"(a[k]), "v"(b[k]), "v"(c[k]));
+        r[k] = v;
+#endif
+    }
+    return r;
+}
+
 __device__ __forceinline__ f4 max4(f4 a, f4 b)
 {
     f4 r;
@@ -723,17 +740,21 @@ __global__ __launch_bounds__(256, 2) void front2_tm(const float *__restrict__ x,
         const int a0 = c0 + nt * half;
         const int a1 = a0 + half < c0 + cn ? a0 + half : c0 + cn;
         if (a0 < a1) {
-            f4 rm[4][4];                                 // rm[j] = running maximum of the last j + 1 pre-activation rows
-            float xc[4], xn[4];
+            // HALF pooled rows need HALF + 4 pre-activation rows; all of them are kept in registers so that the 5-row
+            // windows share their middle: c = max3(t2,t3,t4), rows = max3(t0,t1,c), max3(t1,c,t5), max3(c,t5,t6) --
+            // four v_max3 per value for three rows, where a running-maximum walk takes four v_max per value and ROW
+            static_assert(CH == 6, "the block pooling below is written for three rows per wave");
+            constexpr int HALF = CH / 2, NRAW = HALF + P1 - 1;
+            float xr[NRAW][4];
 #pragma unroll
-            for (int w = 0; w < 4; w++) xc[w] = xp[a0 * 16 + w * 4];
-#pragma unroll 1
-            for (int r = a0; r < a1 + P1 - 1; r++) {
-                {
-                    const int rn = r + 1 < a1 + P1 - 1 ? r + 1 : r;
+            for (int r = 0; r < NRAW; r++) {
+                const int rr = a0 + r < CV_INPUT_H ? a0 + r : CV_INPUT_H - 1;   // rows past the input feed unused outputs
 #pragma unroll
-                    for (int w = 0; w < 4; w++) xn[w] = xp[rn * 16 + w * 4];
-                }
+                for (int w = 0; w < 4; w++) xr[r][w] = xp[rr * 16 + w * 4];
+            }
+            f4 t[NRAW][4];
+#pragma unroll
+            for (int r = 0; r < NRAW; r++) {
                 f4 acc[4];
 #pragma unroll
                 for (int w = 0; w < 4; w++) acc[w] = zero;
@@ -743,25 +764,20 @@ __global__ __launch_bounds__(256, 2) void front2_tm(const float *__restrict__ x,
                     for (int wo = 0; wo < 4; wo++) {
                         const int wi = wo + kw - 1;
                         if (wi < 0 || wi > 3) continue;
-                        acc[wo] = mfma4(A1[kw], xc[wi], acc[wo]);
+                        acc[wo] = mfma4(A1[kw], xr[r][wi], acc[wo]);
                     }
-                const int i = r - a0;
 #pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    const f4 t = acc[w] + b1;
-                    if (i == 0) {
-                        rm[0][w] = t; rm[1][w] = t; rm[2][w] = t; rm[3][w] = t;
-                    } else {
-                        const f4 o = max4(rm[3][w], t);
-                        rm[3][w] = max4(rm[2][w], t);
-                        rm[2][w] = max4(rm[1][w], t);
-                        rm[1][w] = max4(rm[0][w], t);
-                        rm[0][w] = t;
-                        if (i >= P1 - 1) myrows[(size_t)((r - (P1 - 1) - c0) * 4 + w) * 64] = selu4(o);
-                    }
-                }
+                for (int w = 0; w < 4; w++) t[r][w] = acc[w] + b1;
+            }
 #pragma unroll
-                for (int w = 0; w < 4; w++) xc[w] = xn[w];
+            for (int w = 0; w < 4; w++) {
+                const f4 c = max3_4(t[2][w], t[3][w], t[4][w]);
+                const f4 o0 = max3_4(t[0][w], t[1][w], c);
+                const f4 o1 = max3_4(t[1][w], c, t[5][w]);
+                const f4 o2 = max3_4(c, t[5][w], t[6][w]);
+                myrows[(size_t)((a0 - c0 + 0) * 4 + w) * 64] = selu4(o0);
+                if (a0 + 1 < a1) myrows[(size_t)((a0 - c0 + 1) * 4 + w) * 64] = selu4(o1);
+                if (a0 + 2 < a1) myrows[(size_t)((a0 - c0 + 2) * 4 + w) * 64] = selu4(o2);
             }
         }
         __syncthreads();
@@ -811,9 +827,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
     f4 *op = out_tm + (size_t)g * (HOUT * 4 * NT * 64) + (size_t)nt * 64 + lane;
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
     f4 win[3][4][CINB];          // slot (r + 1) % 3 holds input row r
-    f4 m1[4], m2[4];             // pre-activations of the previous row / max of the previous two
+    f4 tp[3][4];                 // pre-activation rows h-2, h-1, h of the pooling window (slot h % 3)
 #pragma unroll
-    for (int w = 0; w < 4; w++) { m1[w] = zero; m2[w] = zero; }
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) tp[j][w] = zero;
     auto load_row = [&](int hr, f4 (&row)[4][CINB]) {
 #pragma unroll
         for (int w = 0; w < 4; w++)
@@ -853,12 +871,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
         // cv_selu_sweep -- so max_j selu(a_j + b) == selu(max_j (a_j + b)) bit for bit): 24 activated rows per
         // candidate instead of 26
 #pragma unroll
+        // the three pre-activation rows of the window sit in rotating slots (like the input window): one v_max3 per
+        // value and row
         for (int w = 0; w < 4; w++) {
-            const f4 t = acc[w] + b4;                // (a sum needs no canonicalising v_max x, x, x; a raw MFMA result would)
-            const f4 o = max4(m2[w], t);             // max(t[h-2], t[h-1], t[h]); exact, order-free
-            m2[w] = max4(m1[w], t);
-            m1[w] = t;
-            if (h >= POOL - 1) op[(size_t)((h - (POOL - 1)) * 4 + w) * (NT * 64)] = selu4(o);
+            tp[R][w] = acc[w] + b4;                  // (a sum needs no canonicalising v_max x, x, x; a raw MFMA result would)
+            if (h >= POOL - 1)
+                op[(size_t)((h - (POOL - 1)) * 4 + w) * (NT * 64)] = selu4(max3_4(tp[0][w], tp[1][w], tp[2][w]));
         }
     };
 #pragma unroll 1
@@ -1802,7 +1820,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             m->stage_kernel[4] = "dense_tm<11, 4, 2, 1>";
             rc |= launch_dense<11, 4, 2>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st, 1, 1, nullptr, hd);
             heads_done = true;
-        } else {
+        } else {                            // (two groups per wave, as for fc4, measured: 79.5 -> 75.3 us; not worth a variant)
             m->stage_kernel[4] = "dense_tm<11, 4, 0, 1>";
             rc |= launch_dense<11, 4>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st);
         }

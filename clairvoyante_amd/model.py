@@ -99,6 +99,7 @@ class Clairvoyante(object):
         self._seed_rng = np.random.RandomState()
         self._bucket = None        # gradient bucket (torch tensor), bound on the first training step
         self._carry = ([0.0] * 6, 0)   # losses of deferred steps already read from the device accumulator
+        self._deferred = 0             # trainDeferred steps whose losses still sit in the device accumulator
         self._keep = None
 
     # ---- helpers --------------------------------------------------------------
@@ -292,6 +293,7 @@ class Clairvoyante(object):
             l, n = self._read_acc()
         l = [u + v for u, v in zip(l, self._carry[0])]; n += self._carry[1]
         self._carry = ([0.0] * 6, 0) if reset else (l, n)
+        self._deferred = 0
         return l, n
 
     def trainDeferred(self, batchX, batchY):
@@ -299,10 +301,12 @@ class Clairvoyante(object):
         accumulator (readLosses); what train.run_epoch uses -- train.py:113-114 only needs the epoch's sum."""
         with torch.cuda.device(self.device):
             self._enqueue_step(batchX, batchY)
+            self._deferred += 1
 
     def _train_step_impl(self, batchX, batchY):
         with torch.cuda.device(self.device):
-            self.readLosses(reset=False)          # park what trainDeferred steps have accumulated so far
+            if self._deferred:
+                self.readLosses(reset=False)      # park what trainDeferred steps have accumulated so far
             self._enqueue_step(batchX, batchY)
             l, _n = self._read_acc()
         summary = {"learning_rate": self.learningRateVal, "l2Lambda": self.l2RegularizationLambdaVal,
