@@ -77,6 +77,67 @@ def cpu_torch_line(arch, P, x_sample, ref_out, target_s=6.0):
             "max_abs_dprob_vs_oracle": float(np.abs(got - ref_out[:n]).max())}
 
 
+def relaunch_under_torchrun(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here (one process per GPU,
+    torch.distributed.run on 127.0.0.1) with the same arguments and pass their output and exit code through."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def init_ranks(args):
+    """-> (rank, world size, local rank).  A line whose n_gpus is not --gpus is never printed: mismatch = exit 2."""
+    from clairvoyante_amd import parallel
+    rank, ws, local = parallel.init_from_env()
+    if ws != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but %d rank(s) are running (WORLD_SIZE); refusing to report a line whose "
+                  "n_gpus differs from the request" % (args.gpus, ws), file=sys.stderr)
+        finish_ranks()
+        sys.exit(2)
+    return rank, ws, local
+
+
+def rank_info(ws):
+    """what actually ran: number of ranks of the process group and its backend ("nccl" = RCCL on ROCm)"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
+    return {"rccl_ranks": ws, "backend": None}
+
+
+def finish_ranks():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def dry_main(args):
+    """--dry: no GPU work; the ranks rendezvous, count themselves with one all-reduce and rank 0 prints the line
+    skeleton.  Shows (also on a CPU box with CV_DIST_BACKEND=gloo) that `--gpus N` alone starts N ranks."""
+    import torch
+    import torch.distributed as dist
+    rank, ws, local = init_ranks(args)
+    n = 1
+    if dist.is_available() and dist.is_initialized():
+        dev = "cuda:%d" % local if dist.get_backend() == "nccl" else "cpu"
+        t = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        n = int(t.item())
+    if rank == 0:
+        line = {"dry": True, "mode": args.mode, "n_gpus": ws, "counted_ranks": n}
+        line.update(rank_info(ws))
+        print(json.dumps(line), flush=True)
+    finish_ranks()
+
+
 def pileup_main(args):
     """--mode pileup: a step = one device pass of the BAM front end over alignments already in HBM:
     candidate counters (evc_count) + selection + tensor scatter + finalize; value = alignment columns/s.
@@ -87,7 +148,7 @@ def pileup_main(args):
     import torch.distributed as dist
     from clairvoyante_amd import parallel, synth_pileup
     from clairvoyante_amd.pileup import Pileup
-    rank, ws, local = parallel.init_from_env()
+    rank, ws, local = init_ranks(args)
     torch.cuda.set_device(local)
     n_reads, L, read_len = 2000000, 10000000, 150
     thr, mincov = 0.06, 4
@@ -171,7 +232,8 @@ def pileup_main(args):
             cpu = {"value": len(lines) * read_len / cs, "unit": "alignment columns/s", "cores": 1, "kind": "port",
                    "sample": "first %d reads of the timed set through oracle/extract_candidates.py + oracle/create_tensor.py "
                              "(CPython restatement of the reference scripts), %.1f s" % (len(lines), cs)}
-        print(json.dumps({"metric": "alignment columns/sec (candidates + tensors)", "value": ws * steps * columns / dt,
+        print(json.dumps({"rccl_ranks": rank_info(ws)["rccl_ranks"], "backend": rank_info(ws)["backend"],
+                          "metric": "alignment columns/sec (candidates + tensors)", "value": ws * steps * columns / dt,
                           "unit": "columns/s", "n_gpus": ws, "steps": steps, "warmup": args.warmup,
                           "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "i32", "data": "synthetic",
@@ -183,38 +245,29 @@ def pileup_main(args):
                                              "columns_per_s": columns / host_s},
                           "parity": {"repeat_passes_identical": bool(same)}}), flush=True)
     pl.close()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish_ranks()
 
 
-def train_main(args):
-    """--mode train: a step = one optimizer step (forward, backward, all-reduce, Adam) on a global batch of
-    param.trainBatchSize = 10 000 synthetic labelled tensors (strong scaling: the batch is split)."""
+def run_train(arch, gb, steps, warmup, rank, ws, dev, sync_loss=False, options=None):
+    """`steps` optimizer steps (forward, backward, gradient exchange over the ranks, Adam) on a GLOBAL batch of `gb`
+    synthetic labelled tensors split over the ranks; barrier + synchronize on both sides, MAX over ranks.
+    -> dict(value, ms_per_step, roofline, final_loss, ...)."""
     import torch
     import torch.distributed as dist
-    from clairvoyante_amd import clairvoyante_v3, clairvoyante_v3_slim, parallel, param, synth
-    rank, ws, local = parallel.init_from_env()
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    m = clairvoyante_v3.Clairvoyante() if args.arch == "full" else clairvoyante_v3_slim.Clairvoyante()
+    from clairvoyante_amd import clairvoyante_v3, clairvoyante_v3_slim, parallel, synth
+    m = clairvoyante_v3.Clairvoyante() if arch == "full" else clairvoyante_v3_slim.Clairvoyante()
     m._seed_rng.seed(1234)
     m.init()
     parallel.broadcast_parameters(m)
-    gb = param.trainBatchSize if args.batch == BATCH else args.batch      # --batch: another global batch (default: the reference's)
     lo, hi = parallel.shard_range(gb, rank, ws)
     xt, cls, rf, alt, il = synth.make_candidates(gb, seed=synth.BASE_SEED, device=dev, return_class=True)
     y = synth.make_labels(cls, rf, alt, il)[lo:hi].contiguous(); x = xt[lo:hi].contiguous()
     use_dist = dist.is_initialized()
-    steps = args.steps if args.steps != 64 else 20
-    if args.overlap is not None:
-        m.setOption("train_overlap", args.overlap)
-    if args.tiny is not None:
-        m.setOption("train_tiny_groups", args.tiny)
-    if args.ksplit is not None:
-        m.setOption("train_ksplit", args.ksplit)
-    step = m.train if args.sync_loss else m.trainDeferred     # deferred: no host round trip per step (train.run_epoch's way)
-    for _ in range(args.warmup):
+    for k, v in (options or {}).items():
+        if v is not None:
+            m.setOption(k, v)
+    step = m.train if sync_loss else m.trainDeferred     # deferred: no host round trip per step (train.run_epoch's way)
+    for _ in range(warmup):
         step(x, y)
     m.readLosses()
     torch.cuda.synchronize()
@@ -223,7 +276,7 @@ def train_main(args):
     t0 = time.perf_counter()
     for _ in range(steps):
         r = step(x, y)
-    loss = r[0] if args.sync_loss else m.readLosses()[0][5] / steps       # one read for the whole run, inside the timed region
+    loss = r[0] if sync_loss else m.readLosses()[0][5] / steps       # one read for the whole run, inside the timed region
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -232,92 +285,92 @@ def train_main(args):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if rank == 0:
-        # whole step against the matrix-core roof: forward + data gradients + weight gradients = 3 x the forward
-        # FLOPs per candidate; the step is a chain of ~45 kernels, no single one dominates
-        tf = steps * gb / dt / ws * 3 * FLOP_EXACT[args.arch] / 1e12
-        roof = {"bound": "mfma", "kernel": "whole step (forward, data gradients, weight gradients, Adam)",
-                "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": None}
-        print(json.dumps({"metric": "training candidate tensors/sec", "value": steps * gb / dt, "unit": "candidates/s",
-                          "n_gpus": ws, "steps": steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
-                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-                          "data": "synthetic",
-                          "config": {"workload": "v3 %s training, Adam step on a global batch of %d synthetic labelled "
-                                                 "[33,4,4] tensors, dropout 0.5, lambda 1e-3" % (args.arch, gb),
-                                     "arch": args.arch, "global_batch": gb, "parallelism": "dp%d" % ws,
-                                     "losses": "read every step" if args.sync_loss else "accumulated on the device, read once",
-                                     "weight_gradients": "side stream" if (args.overlap is None or args.overlap) else "stream order"},
-                          "roofline": roof, "final_loss": float(loss)}), flush=True)
     m.close()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    # whole step against the matrix-core roof: forward + data gradients + weight gradients = 3 x the forward
+    # FLOPs per candidate; the step is a chain of ~40 kernels, no single one dominates
+    tf = steps * gb / dt / ws * 3 * FLOP_EXACT[arch] / 1e12
+    traffic, note = train_traffic(arch, hi - lo)
+    roof = {"bound": "mfma", "kernel": "whole step (forward, data gradients, weight gradients, Adam)",
+            "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
+            "traffic": traffic, "traffic_source": note}
+    return {"value": steps * gb / dt, "unit": "candidates/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "global_batch": gb, "per_rank_batch": hi - lo, "roofline": roof, "final_loss": float(loss)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--arch", default="full", choices=["full", "slim"])
-    ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--sync-loss", action="store_true", help="train mode: read the losses back after every step (m.train)")
-    ap.add_argument("--variant", type=int, default=None, help="infer mode: option variant (kernel selection, A/B)")
-    ap.add_argument("--overlap", type=int, default=None, help="train mode: option train_overlap (A/B)")
-    ap.add_argument("--tiny", type=int, default=None, help="train mode: option train_tiny_groups (A/B)")
-    ap.add_argument("--ksplit", type=int, default=None, help="train mode: option train_ksplit (A/B)")
-    ap.add_argument("--mode", default="infer", choices=["infer", "train", "pileup"],
-                    help="infer (default, the headline metric) or train: Adam steps on the reference's global "
-                         "batch of 10 000 split over the ranks, one RCCL gradient all-reduce per step "
-                         "(BASELINE.json configs[3]); pileup: candidate extraction + tensor generation over "
-                         "alignments resident in HBM (SURVEY.md 8f N4)")
-    args = ap.parse_args()
+def train_traffic(arch, per_rank):
+    """HBM bytes of one optimizer step from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, section
+    "train"), keyed by arch and per-rank batch; None when no pass was taken at this size."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("train", {})
+        ent = tj.get("%s_%d" % (arch, per_rank))
+        if ent:
+            return ent["hbm_bytes_per_step"], "rocprofv3 --pmc passes at git %s" % tj.get("_git_head")
+    except Exception as e:
+        return None, "profiles/pmc_traffic.json unreadable: %s" % e
+    return None, "profiles/pmc_traffic.json has no train entry for %s at %d candidates per rank" % (arch, per_rank)
 
-    import numpy as np
+
+def train_main(args):
+    """--mode train: a step = one optimizer step (forward, backward, all-reduce, Adam) on a global batch of
+    param.trainBatchSize = 10 000 synthetic labelled tensors (strong scaling: the batch is split)."""
+    import torch
+    import torch.distributed as dist
+    from clairvoyante_amd import parallel, param
+    rank, ws, local = init_ranks(args)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    gb = param.trainBatchSize if args.batch == BATCH else args.batch      # --batch: another global batch (default: the reference's)
+    steps = args.steps if args.steps != 64 else 20
+    r = run_train(args.arch, gb, steps, args.warmup, rank, ws, dev, sync_loss=args.sync_loss,
+                  options={"train_overlap": args.overlap, "train_tiny_groups": args.tiny, "train_ksplit": args.ksplit})
+    if rank == 0:
+        line = {"metric": "training candidate tensors/sec", "value": r["value"], "unit": "candidates/s",
+                "n_gpus": ws, "steps": steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic",
+                "config": {"workload": "v3 %s training, Adam step on a global batch of %d synthetic labelled "
+                                       "[33,4,4] tensors, dropout 0.5, lambda 1e-3" % (args.arch, gb),
+                           "arch": args.arch, "global_batch": gb, "parallelism": "dp%d" % ws,
+                           "losses": "read every step" if args.sync_loss else "accumulated on the device, read once",
+                           "weight_gradients": "side stream" if (args.overlap is None or args.overlap) else "stream order"},
+                "roofline": r["roofline"], "final_loss": r["final_loss"]}
+        line.update(rank_info(ws))
+        print(json.dumps(line), flush=True)
+    finish_ranks()
+
+
+def run_infer(arch, batch, steps, warmup, rank, ws, dev, variant=None, batches=None):
+    """`steps` passes of the inference hot path over batches resident in HBM; barrier + synchronize on both sides,
+    MAX over ranks.  -> (result dict, model, parameters, batches); the caller closes the model."""
     import torch
     import torch.distributed as dist
     import common
-    from oracle import cv_oracle as O
-    from clairvoyante_amd import clairvoyante_v3, clairvoyante_v3_slim, parallel, synth, _lib
-
-    if args.mode == "train":
-        return train_main(args)
-    if args.mode == "pileup":
-        return pileup_main(args)
-    rank, ws, local = parallel.init_from_env()
-    if ws != args.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, ws), file=sys.stderr)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    m = clairvoyante_v3.Clairvoyante() if args.arch == "full" else clairvoyante_v3_slim.Clairvoyante()
-    P = common.bench_params(O, args.arch)          # identical seeded weights on every rank
+    from oracle import cv_oracle as O          # seeded weights only (common.bench_params); nothing is computed with it here
+    from clairvoyante_amd import clairvoyante_v3, clairvoyante_v3_slim, synth, _lib
+    m = clairvoyante_v3.Clairvoyante() if arch == "full" else clairvoyante_v3_slim.Clairvoyante()
+    P = common.bench_params(O, arch)          # identical seeded weights on every rank
     m.setParameters(P)
-    if args.variant is not None:
-        m.setOption("variant", args.variant)
-
+    if variant is not None:
+        m.setOption("variant", variant)
     # synthetic pileup tensors, generated straight into HBM (seed = 20260927 + rank)
-    nbuf = max(1, min(args.steps, 64))
-    batches = [synth.make_candidates(args.batch, seed=synth.BASE_SEED + rank + 1000 * b, device=dev)
-               for b in range(nbuf)]
-    out = torch.empty((args.batch, 16), dtype=torch.float32, device=dev)
-
+    nbuf = max(1, min(steps, 64))
+    if batches is None:
+        batches = [synth.make_candidates(batch, seed=synth.BASE_SEED + rank + 1000 * b, device=dev) for b in range(nbuf)]
+    nbuf = len(batches)
+    out = torch.empty((batch, 16), dtype=torch.float32, device=dev)
     use_dist = dist.is_initialized()
 
     def barrier():
         if use_dist:
             dist.barrier()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         m.predict_device(batches[i % nbuf], out)
     torch.cuda.synchronize()
     m.setOption("profile", 1)
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         m.predict_device(batches[i % nbuf], out)
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
@@ -329,68 +382,153 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    if rank == 0:
-        total = args.steps * args.batch * ws
-        value = total / dt
-        chunk = ctypes.c_int64(); _lib.check(m._lib.cv_get_option(m._h, b"chunk", ctypes.byref(chunk)))
-        per_launch = min(args.batch, chunk.value)
-        stages = []
-        for s in range(6):
-            if cnt[s] == 0:
-                continue
-            avg_ms = ms[s] / cnt[s]
-            flop = STAGE_FLOP[args.arch][s] + (STAGE_FLOP[args.arch][0] if (s == 1 and cnt[0] == 0) else 0)
-            if s == 2 and cnt[3] == 0:          # conv3 and fc4 as one kernel (slim, variant bit 8)
-                flop += STAGE_FLOP[args.arch][3]
-            if s == 4 and cnt[5] == 0:          # the heads ride on the fc5 kernel (variant bit 9)
-                flop += STAGE_FLOP[args.arch][5]
-            tf = flop * per_launch / (avg_ms * 1e-3) / 1e12
-            kn = ctypes.c_char_p()
-            _lib.check(m._lib.cv_kernel_name(m._h, s, ctypes.byref(kn)))
-            label = STAGE_NAMES[s] + (" + fc4 (fused)" if (s == 2 and cnt[3] == 0) else "") + \
-                (" + heads (fused)" if (s == 4 and cnt[5] == 0) else "")
-            stages.append({"kernel": label, "kernel_name": kn.value.decode() if kn.value else None,
-                           "avg_ms": avg_ms, "launches": int(cnt[s]), "tflops": tf,
-                           "share": ms[s] / max(sum(ms), 1e-12)})
-        dom = max(stages, key=lambda r: r["avg_ms"]) if stages else None
-        # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_traffic.py -> profiles/): a counter
-        # run cannot share a process with the timed run, so the file is matched against the kernels THIS binary ran --
-        # an entry counts only if its template instance is the one the stage launched and the launch size is the same
-        traffic, traffic_path, traffic_note = None, None, "profiles/pmc_traffic.json has no entry for the kernels of this run"
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.arch, {})
+    value = steps * batch * ws / dt
+    chunk = ctypes.c_int64(); _lib.check(m._lib.cv_get_option(m._h, b"chunk", ctypes.byref(chunk)))
+    per_launch = min(batch, chunk.value)
+    stages = []
+    for s in range(6):
+        if cnt[s] == 0:
+            continue
+        avg_ms = ms[s] / cnt[s]
+        flop = STAGE_FLOP[arch][s] + (STAGE_FLOP[arch][0] if (s == 1 and cnt[0] == 0) else 0)
+        if s == 2 and cnt[3] == 0:          # conv3 and fc4 as one kernel (slim, variant bit 8)
+            flop += STAGE_FLOP[arch][3]
+        if s == 4 and cnt[5] == 0:          # the heads ride on the fc5 kernel (variant bit 9)
+            flop += STAGE_FLOP[arch][5]
+        tf = flop * per_launch / (avg_ms * 1e-3) / 1e12
+        kn = ctypes.c_char_p()
+        _lib.check(m._lib.cv_kernel_name(m._h, s, ctypes.byref(kn)))
+        label = STAGE_NAMES[s] + (" + fc4 (fused)" if (s == 2 and cnt[3] == 0) else "") + \
+            (" + heads (fused)" if (s == 4 and cnt[5] == 0) else "")
+        stages.append({"kernel": label, "kernel_name": kn.value.decode() if kn.value else None,
+                       "avg_ms": avg_ms, "launches": int(cnt[s]), "tflops": tf,
+                       "share": ms[s] / max(sum(ms), 1e-12)})
+    dom = max(stages, key=lambda r: r["avg_ms"]) if stages else None
+    # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_traffic.py -> profiles/): a counter
+    # run cannot share a process with the timed run, so the file is matched against the kernels THIS binary ran --
+    # an entry counts only if its template instance is the one the stage launched and the launch size is the same
+    traffic, traffic_path, traffic_note = None, None, "profiles/pmc_traffic.json has no entry for the kernels of this run"
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(arch, {})
 
-            def entry(st):
-                ent = tj.get(st["kernel"])
-                ok = ent and ent.get("kernel_name") == st["kernel_name"] and ent.get("candidates_per_launch") == per_launch
-                return ent if ok else None
-            if dom and entry(dom):
-                traffic = entry(dom)["hbm_bytes_per_launch"]
-                traffic_note = "rocprofv3 --pmc passes at git %s, kernel %s" % (tj.get("_git_head"), dom["kernel_name"])
-            if stages and all(entry(st) for st in stages):
-                tot = sum(entry(st)["hbm_bytes_per_launch"] for st in stages)
-                traffic_path = {"hbm_bytes_per_launch": tot, "compulsory_bytes_per_launch": 2176 * per_launch,
-                                "ratio_to_compulsory": tot / (2176.0 * per_launch),
-                                "per_kernel": {st["kernel"]: entry(st)["hbm_bytes_per_launch"] for st in stages}}
-        except Exception as e:
-            traffic_note = "profiles/pmc_traffic.json unreadable: %s" % e
-        roof = None
-        if dom:
-            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                    "traffic_source": traffic_note, "traffic_whole_path": traffic_path,
-                    "avg_launch_ms": dom["avg_ms"], "candidates_per_launch": per_launch,
-                    "whole_path_tflops": value / ws * FLOP_EXACT[args.arch] / 1e12,
-                    "whole_path_frac": value / ws * FLOP_EXACT[args.arch] / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                    "hbm_frac_compulsory": value / ws * 2176 / 1e9 / PEAK_HBM_GBS}
-        line = {"metric": "candidate tensors/sec", "value": value, "unit": "candidates/s", "n_gpus": ws,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-                "data": "synthetic",
-                "config": {"workload": "v3 %s inference, synthetic [33,4,4] pileup tensors resident in HBM, "
-                                       "batch %d x %d steps per GPU" % (args.arch, args.batch, args.steps),
-                           "arch": args.arch, "batch": args.batch, "parallelism": "shard%d" % ws},
-                "roofline": roof, "kernels": stages}
+        def entry(st):
+            ent = tj.get(st["kernel"])
+            ok = ent and ent.get("kernel_name") == st["kernel_name"] and ent.get("candidates_per_launch") == per_launch
+            return ent if ok else None
+        if dom and entry(dom):
+            traffic = entry(dom)["hbm_bytes_per_launch"]
+            traffic_note = "rocprofv3 --pmc passes at git %s, kernel %s" % (tj.get("_git_head"), dom["kernel_name"])
+        if stages and all(entry(st) for st in stages):
+            tot = sum(entry(st)["hbm_bytes_per_launch"] for st in stages)
+            traffic_path = {"hbm_bytes_per_launch": tot, "compulsory_bytes_per_launch": 2176 * per_launch,
+                            "ratio_to_compulsory": tot / (2176.0 * per_launch),
+                            "per_kernel": {st["kernel"]: entry(st)["hbm_bytes_per_launch"] for st in stages}}
+    except Exception as e:
+        traffic_note = "profiles/pmc_traffic.json unreadable: %s" % e
+    roof = None
+    if dom:
+        roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                "traffic_source": traffic_note, "traffic_whole_path": traffic_path,
+                "avg_launch_ms": dom["avg_ms"], "candidates_per_launch": per_launch,
+                "whole_path_tflops": value / ws * FLOP_EXACT[arch] / 1e12,
+                "whole_path_frac": value / ws * FLOP_EXACT[arch] / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                "hbm_frac_compulsory": value / ws * 2176 / 1e9 / PEAK_HBM_GBS}
+    res = {"value": value, "unit": "candidates/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "roofline": roof, "kernels": stages}
+    return res, m, P, batches
+
+
+def float64_leg(arch, P, xs, got):
+    """The GPU output against the independent float64 torch formulation (tests/torch_ref.py; no oracle/ in the loop):
+    max |dp| over the 16 outputs and per-head argmax agreement where the float64 margin between the two best classes
+    exceeds 1e-5 (closer than that, fp32 and float64 may legitimately order them differently)."""
+    import numpy as np
+    import torch
+    import torch_ref
+    import common
+    with torch.no_grad():
+        want = torch_ref.forward(arch, P, xs, dtype=torch.float64)["out"].numpy()
+    agree = []
+    for lo, hi in common.HEADS:
+        w = want[:, lo:hi]
+        srt = np.sort(w, axis=1)
+        clear = (srt[:, -1] - srt[:, -2]) > 1e-5
+        agree.append(float(np.mean(np.argmax(got[:, lo:hi], 1)[clear] == np.argmax(w, 1)[clear])) if clear.any() else 1.0)
+    return float(np.abs(got.astype(np.float64) - want).max()), agree
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--arch", default="full", choices=["full", "slim"])
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="infer mode: skip the slim / training legs (configs 4, 5)")
+    ap.add_argument("--dry", action="store_true", help="start the ranks, count them, print the skeleton; no GPU work")
+    ap.add_argument("--sync-loss", action="store_true", help="train mode: read the losses back after every step (m.train)")
+    ap.add_argument("--variant", type=int, default=None, help="infer mode: option variant (kernel selection, A/B)")
+    ap.add_argument("--overlap", type=int, default=None, help="train mode: option train_overlap (A/B)")
+    ap.add_argument("--tiny", type=int, default=None, help="train mode: option train_tiny_groups (A/B)")
+    ap.add_argument("--ksplit", type=int, default=None, help="train mode: option train_ksplit (A/B)")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "pileup"],
+                    help="infer (default, the headline metric) or train: Adam steps on the reference's global "
+                         "batch of 10 000 split over the ranks, one RCCL gradient all-reduce per step "
+                         "(BASELINE.json configs[3]); pileup: candidate extraction + tensor generation over "
+                         "alignments resident in HBM (SURVEY.md 8f N4)")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args, sys.argv[1:])          # does not return
+    if args.dry:
+        return dry_main(args)
+    if args.mode == "train":
+        return train_main(args)
+    if args.mode == "pileup":
+        return pileup_main(args)
+
+    import numpy as np
+    import torch
+    import common
+    from clairvoyante_amd import param
+
+    rank, ws, local = init_ranks(args)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    res, m, P, batches = run_infer(args.arch, args.batch, args.steps, args.warmup, rank, ws, dev, variant=args.variant)
+    line = {"metric": "candidate tensors/sec", "value": res["value"], "unit": "candidates/s", "n_gpus": ws,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "v3 %s inference, synthetic [33,4,4] pileup tensors resident in HBM, "
+                                   "batch %d x %d steps per GPU" % (args.arch, args.batch, args.steps),
+                       "arch": args.arch, "batch": args.batch, "parallelism": "shard%d" % ws},
+            "roofline": res["roofline"], "kernels": res["kernels"]}
+    line.update(rank_info(ws))
+
+    # Configs 5 and 4 under the same clock, OUTSIDE the headline's timed region: slim inference at the same batch, and
+    # optimizer steps on train.py's global batch of 10 000 split over the ranks (one gradient all-reduce per step) --
+    # at N = 1 also at 1 250, one rank's share of that batch on 8 GPUs; at N > 1 also at 10 000 PER rank.
+    if not args.no_extras and args.arch == "full" and args.variant is None:
+        t_extra = time.perf_counter()
+        sres, sm, _sp, _sb = run_infer("slim", args.batch, 16, 2, rank, ws, dev, batches=batches[:16])
+        sm.close()
+        line["slim"] = {"value": sres["value"], "unit": "candidates/s", "ms_per_step": sres["ms_per_step"], "steps": 16,
+                        "workload": "v3 slim inference, batch %d per GPU (BASELINE.json configs[4])" % args.batch,
+                        "roofline": {k: sres["roofline"][k] for k in ("kernel", "frac", "achieved", "peak", "unit",
+                                                                      "whole_path_frac", "traffic")}}
+        gb = param.trainBatchSize
+        tr = {}
+        sizes = [(str(gb), gb)] + ([("1250", gb // 8)] if ws == 1 else [("%d_per_rank" % gb, gb * ws)])
+        for key, g in sizes:
+            tr[key] = run_train("full", g, 20, 3, rank, ws, dev)
+        tr["slim_%d" % gb] = run_train("slim", gb, 20, 3, rank, ws, dev)
+        line["train"] = tr
+        line["extras_seconds"] = time.perf_counter() - t_extra
+
+    if rank == 0:
         if not args.no_cpu and ws == 1:          # the CPU leg (and the parity block it feeds) runs at N = 1 only
             xs = torch.cat([b_ for b_ in batches[:4]])[:262144].cpu().numpy()
             cb, ref, n = cpu_baseline(args.arch, P, xs)
@@ -403,11 +541,17 @@ def main():
             line["parity"] = {"n": n, "argmax_match_per_head": common.argmax_match(got, ref),
                               "max_abs_dprob": float(np.abs(got - ref).max()),
                               "bitwise_equal_frac": common.bitwise_frac(got, ref)}
+            try:
+                d64, am64 = float64_leg(args.arch, P, xs[:4096], got[:4096])
+                line["parity"]["max_abs_dprob_vs_float64"] = d64
+                line["parity"]["argmax_match_vs_float64_where_margin_gt_1e-5"] = am64
+                line["parity"]["float64_n"] = 4096
+            except Exception as e:
+                line["parity"]["max_abs_dprob_vs_float64"] = None
+                line["parity"]["float64_error"] = str(e)
         print(json.dumps(line), flush=True)
     m.close()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish_ranks()
 
 
 if __name__ == "__main__":

@@ -157,3 +157,36 @@ def test_device_selu_sweep_equals_the_oracle_sweep_and_is_monotone(oracle):
     # a small window too (different split of the range into runs)
     _lib.check(lib.cv_selu_sweep(0, 0xbe000000, 0xbe100000, ctypes.byref(viol), ctypes.byref(chk)))
     assert (viol.value, chk.value) == oracle.selu_sweep(0xbe000000, 0xbe100000)
+
+
+@pytest.mark.parametrize("arch", ["full", "slim"])
+def test_hip_path_matches_committed_float64_fixture_directly(oracle, arch):
+    """The independent check without the C oracle in the loop: the HIP path on tests/golden/forward_*.npz (inputs x,
+    seeded weights) against the committed float64 outputs of the torch formulation (tests/golden/make_golden_forward.py;
+    clairvoyante_v3.py:54-138): 16 outputs <= 1e-5 (north_star bar 1e-4), argmax-exact wherever the float64 margin
+    exceeds 1e-5, pool3 and fc5 intermediates <= 2e-5 relative.  `oracle` only supplies the weight initialiser."""
+    import os
+    import torch
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "forward_%s.npz" % arch))
+    P = common.bench_params(oracle, arch, seed=int(d["seed"]))
+    m = _model(arch)
+    try:
+        m.setParameters(P)
+        x = d["x"].astype(np.float32)
+        n = x.shape[0]
+        for variant in (common.DEFAULT_VARIANT, 0):       # pass-size default kernels, and the unfused set that keeps pool3
+            m.setOption("variant", variant)
+            got = m.predict_device(torch.from_numpy(x).cuda()).cpu().numpy()
+            out64 = d["out64"]
+            assert np.abs(got.astype(np.float64) - out64).max() <= 1e-5
+            for lo, hi in common.HEADS:
+                srt = np.sort(out64[:, lo:hi], 1)
+                clear = (srt[:, -1] - srt[:, -2]) > 1e-5
+                assert np.array_equal(np.argmax(got[clear, lo:hi], 1), np.argmax(out64[clear, lo:hi], 1))
+            fc5 = m.getActivation(5, n).cpu().numpy()
+            assert np.abs(fc5 - d["fc5_64"]).max() <= 2e-5 * max(1.0, np.abs(d["fc5_64"]).max())
+        k = d["pool3_64"].shape[0]
+        pool3 = m.getActivation(3, n).cpu().numpy()[:k]          # variant 0: conv3's map is in HBM for both topologies
+        assert np.abs(pool3 - d["pool3_64"]).max() <= 2e-5 * np.abs(d["pool3_64"]).max()
+    finally:
+        m.close()
