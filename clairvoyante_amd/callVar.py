@@ -177,20 +177,71 @@ def PrintVCFHeader(args, call_fh):
     call_fh.write("\n".join(hdr) + "\n")
 
 
-def OutputFromDevice(args, call_fh, num, XBatch, posBatch, call, qual):
-    """Formatter of the GPU path: `call` [n,8] int32 and `qual` [n,4] fp32 come from
-    cv_call_postproc (arg-maxes, two best bases, the fp32 top-2 products, dp)."""
+_tls = __import__("threading").local()
+
+
+def _out_buffer(cap):
+    """a grow-only output buffer per calling thread (a fresh ctypes buffer is zero-filled on every call)"""
+    buf = getattr(_tls, "buf", None)
+    if buf is None or len(buf) < cap:
+        buf = _tls.buf = (ctypes.c_char * max(cap, 1 << 20))()
+    return buf
+
+
+def format_records(args, num, X, pos, call, qual, xrow=None):
+    """The VCF text (bytes) of one batch through the native formatter (cv_format_vcf, csrc/cv_hostio.cpp):
+    `call` [num,8] int32 / `qual` [num,4] fp32 host arrays from cv_call_postproc, X the tensors ([rows,33,4,4]
+    fp32, C-contiguous; candidate i = row xrow[i], or row i), pos a utils_v2.PosBatch or a sequence of
+    "chrom:coord:seq" strings.  Same records as `_format_record` line for line (tests/test_host_golden.py)."""
+    from . import _lib
+    from .utils_v2 import PosBatch
     if num == 0:
-        return
-    keep = np.arange(num) if args.showRef else np.nonzero(call[:, 0] != 0)[0]
-    lines = []
-    for j in keep:
-        rec = _format_record(args, XBatch[j], posBatch[j], int(call[j, 0]), int(call[j, 1]), int(call[j, 2]),
-                             int(call[j, 3]), int(call[j, 4]), _qual(qual[j, 0], qual[j, 1]), qual[j, 2])
-        if rec is not None:
-            lines.append(rec)
-    if lines:
-        call_fh.write("\n".join(lines) + "\n")
+        return b""
+    lib = _lib.load()
+    if not isinstance(pos, PosBatch):
+        pos = PosBatch.from_strings([pos[i] for i in range(num)])
+    call = np.ascontiguousarray(call, dtype=np.int32); qual = np.ascontiguousarray(qual, dtype=np.float32)
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    if xrow is not None:
+        xrow = np.ascontiguousarray(xrow, dtype=np.int64)
+    out = []
+    nlen = ctypes.c_int64(); nrec = ctypes.c_int64()
+    row_bytes = X.strides[0] if X.ndim > 1 else 0
+    for start, rows, buf, meta in pos.pieces():
+        if rows == 0:
+            continue
+        stop = min(start + rows, num)
+        if stop <= start:
+            break
+        n = stop - start
+        kept = n if args.showRef else int(np.count_nonzero(call[start:stop, 0]))
+        if kept == 0:
+            continue
+        meta = np.ascontiguousarray(meta, dtype=np.int64)
+        cap = kept * (int(meta[:n, 1].max()) + 160)
+        cbuf = buf if isinstance(buf, bytes) else bytes(buf)
+        xptr = X.ctypes.data + (0 if xrow is not None else start * row_bytes)
+        xr = ctypes.c_void_p(xrow.ctypes.data + start * 8) if xrow is not None else None
+        for _try in range(2):
+            dst = _out_buffer(cap)
+            rc = lib.cv_format_vcf(ctypes.c_void_p(call.ctypes.data + start * 32), ctypes.c_void_p(qual.ctypes.data + start * 16),
+                                   n, ctypes.c_void_p(xptr), xr, cbuf, ctypes.c_void_p(meta.ctypes.data), None,
+                                   1 if args.showRef else 0, 0 if args.qual is None else 1,
+                                   0 if args.qual is None else int(args.qual), dst, cap, ctypes.byref(nlen), ctypes.byref(nrec))
+            if rc != 2:
+                break
+            cap = nlen.value
+        _lib.check(rc)
+        out.append(ctypes.string_at(dst, nlen.value))
+    return b"".join(out)
+
+
+def OutputFromDevice(args, call_fh, num, XBatch, posBatch, call, qual, xrow=None):
+    """Formatter of the GPU path: `call` [n,8] int32 and `qual` [n,4] fp32 come from cv_call_postproc (arg-maxes,
+    two best bases, the fp32 top-2 products, dp); the records are written by the native formatter."""
+    text = format_records(args, num, XBatch, posBatch, call, qual, xrow)
+    if text:
+        call_fh.write(text.decode("ascii"))
 
 
 def predict_and_reduce(m, xd):
@@ -206,25 +257,83 @@ def predict_and_reduce(m, xd):
     return call, qual
 
 
-def CallFromDevice(args, m, call_fh, X_dev, pos_of, batch=65536):
-    """VCF records for tensors that are already in HBM (callVarBam's fused path): X_dev [n,33,4,4] with
-    matrices 1..3 minus matrix 0; pos_of(i) -> "chrom:coord:seq33" of row i.  Only the rows that produce a
-    record (non-REF calls, or all with --showRef) are copied to the host."""
+class ResultFetcher(object):
+    """Brings the per-candidate decisions of a batch to the host WITHOUT queueing behind the next batch's kernels:
+    the copies run on a side stream that waits for the event recorded after the batch's own kernels, into page-locked
+    buffers, so the host formats batch k while the GPU computes batch k+1 (callVar.py:197-204 overlaps Output(k) with
+    predict(k+1) the same way)."""
+
+    def __init__(self, m):
+        import torch
+        self.m = m
+        self.side = torch.cuda.Stream(device=m.device)
+
+    def mark(self):
+        """call right after enqueueing a batch's kernels on the current stream"""
+        import torch
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.m.device))
+        return ev
+
+    def fetch(self, ev, call_d, qual_d, x_dev=None, show_ref=False):
+        """-> (call, qual) host arrays; with x_dev also (rows [k,33,4,4] of the candidates that give a record, xrow [n]
+        = row of candidate i in `rows`) -- only those rows cross PCIe"""
+        import torch
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            call_h = torch.empty(call_d.shape, dtype=call_d.dtype, pin_memory=True)
+            qual_h = torch.empty(qual_d.shape, dtype=qual_d.dtype, pin_memory=True)
+            call_h.copy_(call_d, non_blocking=True); qual_h.copy_(qual_d, non_blocking=True)
+            self.side.synchronize()
+            call = call_h.numpy(); qual = qual_h.numpy()
+            if x_dev is None:
+                return call, qual
+            n = call.shape[0]
+            keep = np.arange(n) if show_ref else np.flatnonzero(call[:, 0] != 0)
+            xrow = np.zeros(n, dtype=np.int64)
+            xrow[keep] = np.arange(len(keep))
+            if len(keep) == 0:
+                return call, qual, np.zeros((0, 33, 4, 4), np.float32), xrow
+            idx = torch.from_numpy(keep).to(self.m.device, non_blocking=True)
+            rows_h = torch.empty((len(keep),) + tuple(x_dev.shape[1:]), dtype=torch.float32, pin_memory=True)
+            rows_h.copy_(x_dev.index_select(0, idx), non_blocking=True)
+            self.side.synchronize()
+            return call, qual, rows_h.numpy(), xrow
+
+
+def CallFromDevice(args, m, call_fh, X_dev, pos, batch=65536):
+    """VCF records for tensors that are already in HBM (callVarBam's fused path): X_dev [n,33,4,4] with matrices 1..3
+    minus matrix 0; pos: utils_v2.PosBatch (or a function i -> "chrom:coord:seq") for the n rows.  Batch k's decisions
+    and the rows that produce a record (non-REF calls, or all with --showRef) come to the host on a side stream and
+    are formatted by the host threads while the GPU runs batch k+1."""
     import torch
+    from .utils_v2 import PosBatch
     n = X_dev.shape[0]
+    if callable(pos):
+        pos = PosBatch.from_strings([pos(i) for i in range(n)])
+    pieces = pos.pieces()
+    if len(pieces) != 1:
+        pos = PosBatch.from_strings(list(pos))
+        pieces = pos.pieces()
+    _start, _rows, buf, meta = pieces[0]
     with torch.cuda.device(m.device):
+        fetcher = ResultFetcher(m)
+        pending = None
+
+        def finish(p):
+            s, xd, call_d, qual_d, ev = p
+            call, qual, rows, xrow = fetcher.fetch(ev, call_d, qual_d, xd, bool(args.showRef))
+            OutputFromDevice(args, call_fh, call.shape[0], rows, PosBatch(buf, meta[s:s + call.shape[0]]), call, qual, xrow)
+
         for s in range(0, n, batch):
             xd = X_dev[s:s + batch].contiguous()
             call_d, qual_d = predict_and_reduce(m, xd)
-            call = call_d.cpu().numpy()
-            qual = qual_d.cpu().numpy()
-            keep = np.arange(len(call)) if args.showRef else np.nonzero(call[:, 0] != 0)[0]
-            if len(keep) == 0:
-                continue
-            xs = xd.index_select(0, torch.from_numpy(keep).to(m.device)).cpu().numpy()
-            X = {int(j): xs[k] for k, j in enumerate(keep)}
-            P = {int(j): pos_of(s + int(j)) for j in keep}
-            OutputFromDevice(args, call_fh, len(call), X, P, call, qual)
+            nxt = (s, xd, call_d, qual_d, fetcher.mark())
+            if pending is not None:
+                finish(pending)
+            pending = nxt
+        if pending is not None:
+            finish(pending)
 
 
 def Run(args):
@@ -298,8 +407,9 @@ def TestSharded(args, m, utils, rank, ws):
     logging.info("Calling variants (rank %d of %d) ..." % (rank, ws))
     predictStart = time.time()
     frag_fn = "%s.rank%d" % (args.call_fn, rank)
-    frag = open(frag_fn, "w")
+    frag = open(frag_fn, "wb")
     index = []
+    fetcher = ResultFetcher(m)
     q_in = Queue(maxsize=4)
 
     def reader():
@@ -324,18 +434,20 @@ def TestSharded(args, m, utils, rank, ws):
                 if item is not None:
                     block, num, X, pos = item
                     call = qual = None
+                    ev = None
                     if num > 0:
                         xd = torch.from_numpy(X).to(m.device, non_blocking=True)
                         call, qual = predict_and_reduce(m, xd)
-                    nxt = (block, num, X, pos, call, qual)
+                        ev = fetcher.mark()
+                    nxt = (block, num, X, pos, call, qual, ev)
                 if pending is not None:
-                    pblock, pnum, pX, ppos, pcall, pqual = pending
-                    buf = io.StringIO()
+                    pblock, pnum, pX, ppos, pcall, pqual, pev = pending
+                    text = b""
                     if pnum > 0:
-                        OutputFromDevice(args, buf, pnum, pX, ppos, pcall.cpu().numpy(), pqual.cpu().numpy())
-                    text = buf.getvalue()
+                        hcall, hqual = fetcher.fetch(pev, pcall, pqual)
+                        text = format_records(args, pnum, pX, ppos, hcall, hqual)
                     frag.write(text)
-                    index.append((pblock, len(text.encode("ascii"))))
+                    index.append((pblock, len(text)))
                 pending = nxt
                 if item is None:
                     break
@@ -388,9 +500,9 @@ def Test(args, m, utils):
 
     rt = Thread(target=reader, daemon=True)
     rt.start()
-    lib = m._lib
     pending = None                   # (num, X, pos, call_dev, qual_dev, event)
     with torch.cuda.device(m.device):
+        fetcher = ResultFetcher(m)
         while True:
             item = q_in.get()
             if isinstance(item, BaseException):
@@ -401,10 +513,11 @@ def Test(args, m, utils):
                 if num > 0:
                     xd = torch.from_numpy(X).to(m.device, non_blocking=True)
                     call, qual = predict_and_reduce(m, xd)
-                    nxt = (num, X, pos, call, qual)
+                    nxt = (num, X, pos, call, qual, fetcher.mark())
             if pending is not None:      # format batch k while the GPU works on batch k+1
-                pnum, pX, ppos, pcall, pqual = pending
-                OutputFromDevice(args, call_fh, pnum, pX, ppos, pcall.cpu().numpy(), pqual.cpu().numpy())
+                pnum, pX, ppos, pcall, pqual, pev = pending
+                hcall, hqual = fetcher.fetch(pev, pcall, pqual)
+                OutputFromDevice(args, call_fh, pnum, pX, ppos, hcall, hqual)
             pending = nxt
             if item is None:
                 break

@@ -138,8 +138,8 @@ def Run(args, model=None, source=None):
     centers, seqs = res["centers"], res["seqs"]
     with open(args.call_fn, "w") as call_fh:
         callVar.PrintVCFHeader(cargs, call_fh)
-        callVar.CallFromDevice(cargs, m, call_fh, res["tensors"],
-                               lambda i: "%s:%d:%s" % (ctg, centers[i], seqs[i].decode()))
+        from .utils_v2 import PosBatch
+        callVar.CallFromDevice(cargs, m, call_fh, res["tensors"], PosBatch.from_columns(ctg, centers, seqs))
     st = res["stats"]
     logging.info("reads %d, candidates %d, tensors %d; pileup %.2f s (GPU: candidates %.1f ms, scatter %.1f ms, "
                  "finalize %.1f ms), calling %.2f s" % (res["reads"], res["candidates"], len(centers), t1 - t0,

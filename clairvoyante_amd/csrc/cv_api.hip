@@ -238,6 +238,7 @@ extern "C" int cv_set_option(cv_model *m, const char *key, int64_t value)
     if (!strcmp(key, "train_ksplit")) { m->train_ksplit = value ? 1 : 0; return 0; }
     if (!strcmp(key, "train_tiny_groups")) { m->tiny_g = value < 0 ? 0 : (value > 160 ? 160 : (int)value); return 0; }
     if (!strcmp(key, "variant")) { m->variant = (int)value; return 0; }
+    if (!strncmp(key, "dbg", 3) && key[3] >= '0' && key[3] <= '7' && !key[4]) { m->dbg[key[3] - '0'] = (int)value; return 0; }
     if (!strcmp(key, "chunk")) {
         if (value < 16 || value > (1 << 22)) { cv_set_error("chunk must be in [16, 4194304]"); return 1; }
         m->chunk = (value + 15) / 16 * 16;
@@ -257,6 +258,7 @@ extern "C" int cv_get_option(const cv_model *m, const char *key, int64_t *value)
     if (!strcmp(key, "train_ksplit")) { *value = m->train_ksplit; return 0; }
     if (!strcmp(key, "train_tiny_groups")) { *value = m->tiny_g; return 0; }
     if (!strcmp(key, "variant")) { *value = m->variant; return 0; }
+    if (!strncmp(key, "dbg", 3) && key[3] >= '0' && key[3] <= '7' && !key[4]) { *value = m->dbg[key[3] - '0']; return 0; }
     cv_set_error("unknown option '%s'", key);
     return 1;
 }

@@ -22,6 +22,9 @@
 #include <thread>
 #include <vector>
 #include <unistd.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <string>
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
@@ -132,14 +135,16 @@ namespace {
 struct HostPool {
     std::mutex job_mu;                          // owner of the pool for the duration of a job
     std::mutex mu;
-    std::condition_variable cv_start, cv_done;
+    std::condition_variable cv_done;
+    // one condition variable per worker: a job wakes only the `want` workers that take part in it (waking all 63
+    // for a 4-task job made every small call pay for 63 wake-ups and check-ins)
+    struct Slot { std::condition_variable cv; uint64_t go = 0; };
+    Slot slot[63];
     int nworkers = 0;
-    pid_t pid = 0;                              // workers do not survive a fork
     const std::function<void(int64_t)> *fn = nullptr;
     std::atomic<int64_t> next{0};
     int64_t ntasks = 0;
-    int active = 0, want = 0;
-    uint64_t gen = 0;
+    int active = 0;
 
     void drain()
     {
@@ -149,15 +154,15 @@ struct HostPool {
             (*fn)(i);
         }
     }
-    void worker(int id, uint64_t seen)
+    void worker(int id)
     {
+        uint64_t seen = 0;
         for (;;) {
             std::unique_lock<std::mutex> lk(mu);
-            cv_start.wait(lk, [&] { return gen != seen; });
-            seen = gen;
-            const bool part = id < want;
+            slot[id].cv.wait(lk, [&] { return slot[id].go != seen; });
+            seen = slot[id].go;
             lk.unlock();
-            if (part) drain();
+            drain();
             lk.lock();
             if (--active == 0) cv_done.notify_one();
         }
@@ -176,23 +181,38 @@ struct HostPool {
             for (auto &x : th) x.join();
             return;
         }
-        if (pid != getpid()) { pid = getpid(); nworkers = 0; gen = 0; }
+        int part = T - 1 < 63 ? T - 1 : 63;
         {
             std::lock_guard<std::mutex> lk(mu);
-            while (nworkers < T - 1 && nworkers < 63) {
-                std::thread(&HostPool::worker, this, nworkers, gen).detach();
+            while (nworkers < part) {
+                std::thread(&HostPool::worker, this, nworkers).detach();
                 nworkers++;
             }
-            fn = &f; ntasks = n; next.store(0); want = T - 1; active = nworkers; gen++;
+            fn = &f; ntasks = n; next.store(0); active = part;
+            for (int w = 0; w < part; w++) slot[w].go++;
         }
-        cv_start.notify_all();
+        for (int w = 0; w < part; w++) slot[w].cv.notify_one();
         drain();
         std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [&] { return active == 0; });
         fn = nullptr;
     }
 };
-HostPool &host_pool() { static HostPool *p = new HostPool(); return *p; }   // never destroyed: workers are detached
+// The pool object is never destroyed (its workers are detached).  A forked child inherits the memory but none of the
+// threads, and possibly a mutex locked by a thread that does not exist there: the child gets a fresh pool
+// (pthread_atfork), the inherited one is abandoned.
+std::atomic<HostPool *> g_pool{nullptr};
+void pool_after_fork_child() { g_pool.store(new HostPool()); }
+HostPool &host_pool()
+{
+    HostPool *p = g_pool.load();
+    if (!p) {
+        static std::once_flag once;
+        std::call_once(once, [] { g_pool.store(new HostPool()); pthread_atfork(nullptr, nullptr, pool_after_fork_child); });
+        p = g_pool.load();
+    }
+    return *p;
+}
 }  // namespace
 
 extern "C" int cv_set_host_threads(int n)
@@ -585,4 +605,214 @@ extern "C" uint32_t cv_crc32c(uint32_t crc, const void *data, int64_t n)
     uint32_t c = ~crc;
     c = __builtin_cpu_supports("sse4.2") ? crc_hw(c, p, n) : crc_sw(c, p, n);
     return ~c;
+}
+
+// ---- VCF records (host half of callVar.Output) -------------------------------------------------------------------
+// One record per candidate from the decisions the device made (cv_call_postproc): allele / indel-length inference
+// and the text of /root/reference/clairvoyante/callVar.py:72-153, reproduced field for field:
+//   qual  = int(-4.343 * log((p2 + 1e-300) / (p1 + 1e-300)))   -- fp32 products widened to double, truncation (:72)
+//   SNP / REF allele (:91-95), insertion bases = arg-max of matrix 1 per position, first maximum (:101,:107),
+//   length guess while sum(matrix) >= 0.125 * sum(matrix 0) (:104-110, :122-127), <INS> / <DEL> + SVTYPE at >= 16
+//   inferred bases (:111-113, :129-131), LENGUESS (:139-140), GT / FILTER / "%.4f" allele fraction (:143-153).
+// Records are independent: the host threads format contiguous ranges into private buffers that are joined in order.
+namespace {
+
+struct vcf_job {
+    const int32_t *call; const float *qual; const float *x; const int64_t *xrow;
+    const char *pos_buf; const int64_t *pos_meta; const int64_t *pos_row;
+    int show_ref, has_qual, qual_min;
+};
+
+inline float sum4(const float *p, int stride) { return ((p[0] + p[stride]) + p[2 * stride]) + p[3 * stride]; }
+inline int argmax4(const float *p, int stride)
+{
+    int b = 0; float m = p[0];
+    for (int k = 1; k < 4; k++) if (p[k * stride] > m) { m = p[k * stride]; b = k; }      // first maximum (np.argmax)
+    return b;
+}
+
+inline char *put_str(char *p, const char *s) { while (*s) *p++ = *s++; return p; }
+inline char *put_int(char *p, long long v)
+{
+    unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+    if (v < 0) *p++ = '-';
+    char tmp[24]; int n = 0;
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+// "%.4f" of a float: the value times 10^4 is exact in double (24 + 14 bits), so nearbyint() -- round to nearest,
+// ties to even, the default mode -- gives the correctly rounded digits printf derives from the exact expansion
+inline char *put_f4(char *p, float v)
+{
+    const double a = fabs((double)v);
+    if (!(a < 1e9)) return p + snprintf(p, 48, "%.4f", (double)v);        // inf, nan, absurd magnitudes: the library's way
+    const unsigned long long r = (unsigned long long)nearbyint(a * 10000.0);
+    if (signbit(v)) *p++ = '-';
+    p = put_int(p, (long long)(r / 10000));
+    unsigned f = (unsigned)(r % 10000);
+    *p++ = '.';
+    p[3] = (char)('0' + f % 10); f /= 10; p[2] = (char)('0' + f % 10); f /= 10; p[1] = (char)('0' + f % 10); f /= 10; p[0] = (char)('0' + f);
+    return p + 4;
+}
+
+// appends one record; returns 0 ok / skipped, 1 error (message set)
+int vcf_record(const vcf_job &J, int64_t i, std::string &out, int64_t *nrec)
+{
+    const int F = CV_INPUT_H / 2;                      // flankingBaseNum = 16
+    const int32_t *c = J.call + i * 8;
+    int varType = c[0];
+    if (varType == 0 && !J.show_ref) return 0;
+    const float *q = J.qual + i * 4;
+    const float dp = q[2];
+    if (dp == 0.0f) return 0;
+    const int64_t *pm = J.pos_meta + (J.pos_row ? J.pos_row[i] : i) * 6;
+    const char *chrom = J.pos_buf + pm[0]; const int64_t chrom_len = pm[1];
+    const char *cs = J.pos_buf + pm[2]; int64_t cl = pm[3];
+    const char *seq = J.pos_buf + pm[4]; const int64_t seq_len = pm[5];
+    // int(coordination): optional surrounding blanks and sign, decimal digits
+    while (cl > 0 && (*cs == ' ' || *cs == '\t')) { cs++; cl--; }
+    while (cl > 0 && (cs[cl - 1] == ' ' || cs[cl - 1] == '\t' || cs[cl - 1] == '\r')) cl--;
+    bool neg = false;
+    if (cl > 0 && (*cs == '+' || *cs == '-')) { neg = *cs == '-'; cs++; cl--; }
+    if (cl <= 0 || cl > 18) { cv_set_error("cv_format_vcf: record %lld: position is not an integer", (long long)i); return 1; }
+    long long coord = 0;
+    for (int64_t k = 0; k < cl; k++) {
+        if (cs[k] < '0' || cs[k] > '9') { cv_set_error("cv_format_vcf: record %lld: position is not an integer", (long long)i); return 1; }
+        coord = coord * 10 + (cs[k] - '0');
+    }
+    if (neg) coord = -coord;
+    if (seq_len <= F) { cv_set_error("cv_format_vcf: record %lld: reference sequence shorter than %d", (long long)i, F + 1); return 1; }
+    char sq[CV_INPUT_H + 1];
+    const int sl = seq_len < CV_INPUT_H ? (int)seq_len : CV_INPUT_H;
+    for (int k = 0; k < sl; k++) { char ch = seq[k]; sq[k] = (ch >= 'a' && ch <= 'z') ? (char)(ch - 32) : ch; }
+    const float *x = J.x + (size_t)(J.xrow ? J.xrow[i] : i) * (CV_INPUT_H * 16);       // [33][4 bases][4 matrices]
+    static const char N2B[4] = {'A', 'C', 'G', 'T'};
+    char ref[CV_INPUT_H + 1]; int ref_len = 1; ref[0] = sq[F];
+    char alt[CV_INPUT_H + 8]; int alt_len = 0;
+    const char *svtype = nullptr;
+    int inferred = 0;
+    int varLength = c[2];
+    float af;
+    if (varType == 0 || varType == 1) {
+        char ab;
+        if (varType == 0) ab = sq[F];
+        else { const char b1 = N2B[c[3] & 3], b2 = N2B[c[4] & 3]; ab = b1 != sq[F] ? b1 : b2; }
+        int bi = ab == 'A' ? 0 : ab == 'C' ? 1 : ab == 'G' ? 2 : ab == 'T' ? 3 : -1;
+        if (bi < 0) { cv_set_error("cv_format_vcf: record %lld: centre base '%c' is not one of ACGT", (long long)i, ab); return 1; }
+        af = x[(F * 4 + bi) * 4 + 3] / dp;
+        alt[0] = ab; alt_len = 1;
+    } else if (varType == 2) {
+        if (varLength == 0) varLength = 1;
+        af = sum4(x + (F + 1) * 16 + 1, 4) / dp;
+        char ins[CV_INPUT_H]; int nins = 0;
+        if (varLength != 5) {
+            for (int k = F + 1; k < F + varLength + 1; k++) ins[nins++] = N2B[argmax4(x + k * 16 + 1, 4)];
+        } else {
+            for (int k = F + 1; k < 2 * F + 1; k++) {
+                if (k < F + 5 || sum4(x + k * 16 + 1, 4) >= 0.125f * sum4(x + k * 16 + 0, 4)) {
+                    inferred++;
+                    ins[nins++] = N2B[argmax4(x + k * 16 + 1, 4)];
+                } else break;
+            }
+        }
+        if (inferred >= F) { memcpy(alt, "<INS>", 5); alt_len = 5; svtype = "SVTYPE=INS"; }
+        else { alt[0] = sq[F]; memcpy(alt + 1, ins, (size_t)nins); alt_len = 1 + nins; }
+    } else {
+        if (varLength == 0) varLength = 1;
+        af = sum4(x + (F + 1) * 16 + 2, 4) / dp;
+        if (varLength == 5) {
+            for (int k = F + 1; k < 2 * F + 1; k++) {
+                if (k < F + 5 || sum4(x + k * 16 + 2, 4) >= 0.125f * sum4(x + k * 16 + 0, 4)) inferred++;
+                else break;
+            }
+        }
+        if (inferred >= F) { memcpy(alt, "<DEL>", 5); alt_len = 5; svtype = "SVTYPE=DEL"; }
+        else {
+            const int want = (varLength != 5 ? varLength : inferred) + 1;          // refSeq[F : F + want], clipped like a slice
+            ref_len = F + want <= sl ? want : sl - F;
+            memcpy(ref, sq + F, (size_t)ref_len);
+            alt[0] = sq[F]; alt_len = 1;
+        }
+    }
+    const double ratio = ((double)q[1] + 1e-300) / ((double)q[0] + 1e-300);
+    const int qv = (int)(-4.343 * log(ratio));                                      // int(): truncation toward zero
+    const char *gt = varType == 0 ? "0/0" : (c[1] == 0 ? "0/1" : "1/1");
+    const char *filt = !J.has_qual ? "." : (qv >= J.qual_min ? "PASS" : "LowQual");
+    // the line, assembled by hand (snprintf costs more than everything above): "%s\t%d\t.\t%s\t%s\t%d\t%s\t%s\tGT:GQ:DP:AF\t%s:%d:%d:%.4f"
+    char line[256]; char *p = line;
+    p = put_int(p, coord); *p++ = '\t'; *p++ = '.'; *p++ = '\t';
+    memcpy(p, ref, (size_t)ref_len); p += ref_len; *p++ = '\t';
+    memcpy(p, alt, (size_t)alt_len); p += alt_len; *p++ = '\t';
+    p = put_int(p, qv); *p++ = '\t';
+    p = put_str(p, filt); *p++ = '\t';
+    if (svtype) p = put_str(p, svtype);
+    if (inferred > 0 && inferred < F) { if (svtype) *p++ = ';'; p = put_str(p, "LENGUESS="); p = put_int(p, inferred); }
+    else if (!svtype) *p++ = '.';
+    p = put_str(p, "\tGT:GQ:DP:AF\t");
+    p = put_str(p, gt); *p++ = ':';
+    p = put_int(p, qv); *p++ = ':';
+    p = put_int(p, (long long)(int)dp); *p++ = ':';
+    p = put_f4(p, af);
+    *p++ = '\n';
+    out.append(chrom, (size_t)chrom_len);
+    out.push_back('\t');
+    out.append(line, (size_t)(p - line));
+    (*nrec)++;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int cv_format_vcf(const int32_t *call, const float *qual, int64_t n, const float *x, const int64_t *xrow,
+                             const char *pos_buf, const int64_t *pos_meta, const int64_t *pos_row, int show_ref,
+                             int has_qual, int qual_min, char *out, int64_t out_cap, int64_t *out_len, int64_t *nrecords)
+{
+    if (n < 0 || !out_len) { cv_set_error("cv_format_vcf: bad argument"); return 1; }
+    *out_len = 0;
+    if (nrecords) *nrecords = 0;
+    if (n == 0) return 0;
+    if (!call || !qual || !x || !pos_buf || !pos_meta) { cv_set_error("cv_format_vcf: null argument"); return 1; }
+    vcf_job J{call, qual, x, xrow, pos_buf, pos_meta, pos_row, show_ref, has_qual, qual_min};
+    int T = g_host_threads;
+    if (n < 2048) T = 1;
+    if (T > 64) T = 64;
+    // the scratch strings are kept between calls (a free list): after the first batches no call allocates or
+    // page-faults
+    static std::mutex scratch_mu;
+    static std::vector<std::string *> scratch_free;
+    std::vector<std::string *> part((size_t)T, nullptr);
+    {
+        std::lock_guard<std::mutex> lk(scratch_mu);
+        for (int t = 0; t < T; t++) {
+            if (!scratch_free.empty()) { part[(size_t)t] = scratch_free.back(); scratch_free.pop_back(); }
+            else part[(size_t)t] = new std::string();
+            part[(size_t)t]->clear();
+        }
+    }
+    struct give_back {
+        std::vector<std::string *> &v; std::mutex &m; std::vector<std::string *> &f;
+        ~give_back() { std::lock_guard<std::mutex> lk(m); for (auto *x : v) f.push_back(x); }
+    } gb{part, scratch_mu, scratch_free};
+    std::vector<int64_t> cnt((size_t)T, 0);
+    std::vector<int> bad((size_t)T, 0);
+    std::vector<std::string> msg((size_t)T);
+    auto body = [&](int64_t t) {
+        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+        std::string &o = *part[(size_t)t];
+        for (int64_t i = lo; i < hi; i++)
+            if (vcf_record(J, i, o, &cnt[(size_t)t])) { bad[(size_t)t] = 1; msg[(size_t)t] = cv_last_error(); return; }
+    };
+    if (T == 1) body(0); else host_pool().run(T, T, body);
+    int64_t total = 0, recs = 0;
+    for (int t = 0; t < T; t++) {
+        if (bad[(size_t)t]) { cv_set_error("%s", msg[(size_t)t].c_str()); return 1; }     // the error of a worker thread is thread-local there
+        total += (int64_t)part[(size_t)t]->size(); recs += cnt[(size_t)t];
+    }
+    *out_len = total;
+    if (nrecords) *nrecords = recs;
+    if (total > out_cap || !out) return total > 0 ? 2 : 0;        // 2: the caller's buffer is too small, *out_len = needed
+    char *p = out;
+    for (int t = 0; t < T; t++) { memcpy(p, part[(size_t)t]->data(), part[(size_t)t]->size()); p += part[(size_t)t]->size(); }
+    return 0;
 }

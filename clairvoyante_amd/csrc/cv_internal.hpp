@@ -94,7 +94,7 @@ struct cv_model {
     hipEvent_t tr_ev[16];
     hipEvent_t tr_dense_ready;
     int train_overlap;   // option: weight gradients on the side stream (default 1)
-    int train_ksplit;    // option: k-split fc4 forward at tiny batches (default 1)
+    int train_ksplit;    // option: k-split fc4 forward at tiny batches (default 0)
     int tiny_g;          // option "train_tiny_groups": batches of up to this many groups take the latency-oriented
                          // kernel variants of the training step (default 160; 0 = never)
     // fc4 dropout output / keep mask (a*keep) of the LAST training slice, for cv_get_activation 6 / 7
@@ -102,6 +102,7 @@ struct cv_model {
     int64_t last_tr_n;
     int last_tr_tile;    // 1: tile-major buffers, 0: natural [n, fc4]
     // optional per-kernel timing (option "profile")
+    int dbg[8];          // options "dbg0".."dbg7": development switches of the training step (A/B runs; 0 = default)
     int profile;
     void *prof;          // cv_prof*, owned
     const char *stage_kernel[CV_NUM_STAGES];   // kernel (template instance) each stage of the last cv_forward chunk ran

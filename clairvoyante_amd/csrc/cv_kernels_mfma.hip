@@ -2420,6 +2420,13 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
     // (pick_hsplit; config 4's per-rank batch of 1 250 is 79 groups -> 4 parts, train.py's 625 groups -> conv2 in 3);
     // same values row for row.  Option train_tiny_groups = 0 keeps one wave per (group, tile).
     const bool split = m->tiny_g > 0;
+    if (is_full(a) && m->dbg[1] > 0) {          // development: forced number of position parts
+        conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (f4 *)a1);
+        rc |= launch_conv_parts<2, 1, 2, 4, 29, 1>(m->dbg[1], p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
+        rc |= launch_conv_parts<3, 2, 3, 3, 26, 1>(m->dbg[1], p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
+        CV_HIP(hipGetLastError());
+        return rc;
+    }
     if (is_full(a)) {
         conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (f4 *)a1);
         rc |= launch_conv_parts<2, 1, 2, 4, 29, 1>(split ? pick_hsplit(G, 2, 26, 3, 4) : 1, p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
@@ -2486,6 +2493,10 @@ int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm,
     const int G = (int)((n + 15) / 16);
     const float *W = m->wpd_conv[layer];
     const bool split = m->tiny_g > 0;      // see cv_tile_train_convs
+    if (is_full(a) && m->dbg[0] > 0) {          // development: forced number of position parts
+        if (layer == 2) return launch_conv_parts<3, 3, 2, 1, 26, 2>(m->dbg[0], g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
+        return launch_conv_parts<2, 2, 1, 1, 29, 2>(m->dbg[0], g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
+    }
     if (is_full(a)) {
         if (layer == 2)
             return launch_conv_parts<3, 3, 2, 1, 26, 2>(split ? pick_hsplit(G, 2, 26, 0, 8) : 1, g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);

@@ -178,7 +178,7 @@ extern "C" int cv_flat_copy(cv_model *m, int which, float *caller_dev, int to_mo
     size_t bytes = sizeof(float) * m->poff[CV_NUM_PARAMS];
     if (to_model) {
         CV_HIP(hipMemcpyAsync(bufs[which], caller_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-        if (which == 0) m->packed_dirty = true; m->packed_train_dirty = true;
+        if (which == 0) { m->packed_dirty = true; m->packed_train_dirty = true; }
     } else {
         CV_HIP(hipMemcpyAsync(caller_dev, bufs[which], bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }

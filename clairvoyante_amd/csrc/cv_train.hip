@@ -813,7 +813,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     // conv stack
     for (int l = 2; l >= 0; l--) {
         const int H = s.hc[l], NT = s.ntile[l];
-        if (launch_pool_selu(tgin[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st, m->tiny_g)) return 1;
+        if (launch_pool_selu(tgin[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st, m->dbg[2] == 1 ? (1 << 30) : (m->dbg[2] == 2 ? 0 : m->tiny_g))) return 1;
         if (f.to_side()) return 1;
         if (l == 0) {        // first layer: X viewed as [33][16] fragments, read in place
             if (cv_tile_conv1_wgrad(m, x, tgpre[0], n, sw)) return 1;
@@ -901,7 +901,10 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
     int64_t slice = 16;
     if (train_workspace(m, n, &slice)) return 1;
     if (backward && cv_wgrad_scratch_reserve(m)) return 1;
-    hipStream_t sw = (backward && m->train_overlap) ? m->tr_side : st;
+    // the side stream exists for the tile path only (its slices join it back into st before they return); the
+    // all-plain path runs everything, the L2 term included, in stream order
+    const bool tile_path = m->impl == 1 && cv_tile_supported(m);
+    hipStream_t sw = (backward && m->train_overlap && tile_path) ? m->tr_side : st;
     CV_HIP(hipMemsetAsync(m->loss_dev, 0, sizeof(double) * 8, st));
     if (backward) CV_HIP(hipMemsetAsync(m->grads, 0, sizeof(float) * m->poff[CV_NUM_PARAMS], st));
     // lambda * sum(w^2)/2 depends on the weights alone: with a side stream it runs there, next to the forward pass

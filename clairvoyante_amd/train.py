@@ -179,7 +179,12 @@ class _BatchStream(object):
             ev.synchronize()                       # producer thread: the host arrays may go once the copy is done
 
             def ready():
-                torch.cuda.current_stream(device).wait_event(ev)
+                # consumer side: its stream waits for the copy, and the blocks -- allocated on the staging stream --
+                # are marked as in use by the consumer stream, so that the caching allocator does not hand them to a
+                # later stage() while a queued (trainDeferred: never host-synchronised) step still reads them
+                cs = torch.cuda.current_stream(device)
+                cs.wait_event(ev)
+                xd.record_stream(cs); yd.record_stream(cs)
             return xd, yd, ready
 
         def put(queue, item):

@@ -30,26 +30,68 @@ def SetupEnv():
 
 
 class PosBatch(object):
-    """The `pos` list of a GetTensor batch ("chrom:coord:seq", utils_v2.py:41), built lazily:
-    at GPU rates only the few candidates that become VCF records ever need their string."""
+    """The `pos` list of a GetTensor batch ("chrom:coord:seq", utils_v2.py:41), built lazily: at GPU rates only the
+    few candidates that become VCF records ever need their string, and the native VCF formatter (cv_format_vcf)
+    reads the fields where the parser found them.  A batch is one or more pieces (bytes, meta [rows,6] int64 =
+    offset / length of contig, position, sequence inside those bytes), in row order."""
 
-    def __init__(self, buf, meta):
-        self._buf = buf
-        self._meta = meta
+    def __init__(self, buf=None, meta=None, pieces=None):
+        self._pieces = list(pieces) if pieces is not None else [(buf, meta)]
+        self._starts = np.cumsum([0] + [m.shape[0] for _b, m in self._pieces])
 
     def __len__(self):
-        return self._meta.shape[0]
+        return int(self._starts[-1])
+
+    def pieces(self):
+        """-> [(first row, rows, bytes, meta)]"""
+        return [(int(self._starts[k]), m.shape[0], b, m) for k, (b, m) in enumerate(self._pieces)]
 
     def __getitem__(self, j):
         if isinstance(j, slice):
             return [self[i] for i in range(*j.indices(len(self)))]
-        m = self._meta[j]
-        b = self._buf
-        return (b[m[0]:m[0] + m[1]] + b":" + b[m[2]:m[2] + m[3]] + b":" + b[m[4]:m[4] + m[5]].upper()).decode("ascii")
+        if j < 0:
+            j += len(self)
+        k = int(np.searchsorted(self._starts, j, side="right")) - 1
+        b, meta = self._pieces[k]
+        m = meta[j - int(self._starts[k])]
+        return (bytes(b[m[0]:m[0] + m[1]]) + b":" + bytes(b[m[2]:m[2] + m[3]]) + b":" + bytes(b[m[4]:m[4] + m[5]]).upper()).decode("ascii")
 
     def __iter__(self):
         for j in range(len(self)):
             yield self[j]
+
+    @staticmethod
+    def from_columns(chrom, coords, seqs):
+        """one contig name, integer coordinates and the reference sequences (bytes) of n candidates"""
+        chrom = chrom if isinstance(chrom, bytes) else str(chrom).encode("ascii")
+        n = len(coords)
+        cs = [b"%d" % int(c) for c in coords]
+        clen = np.fromiter((len(c) for c in cs), dtype=np.int64, count=n)
+        slen = np.fromiter((len(q) for q in seqs), dtype=np.int64, count=n)
+        meta = np.empty((n, 6), dtype=np.int64)
+        meta[:, 0] = 0; meta[:, 1] = len(chrom)
+        c0 = len(chrom)
+        meta[:, 2] = c0 + np.concatenate(([0], np.cumsum(clen)[:-1])) if n else 0
+        meta[:, 3] = clen
+        s0 = c0 + int(clen.sum())
+        meta[:, 4] = s0 + np.concatenate(([0], np.cumsum(slen)[:-1])) if n else 0
+        meta[:, 5] = slen
+        return PosBatch(chrom + b"".join(cs) + b"".join(seqs), meta)
+
+    @staticmethod
+    def from_strings(pos):
+        """the same container from "chrom:coord:seq" strings (callers that hold Python strings)"""
+        n = len(pos)
+        meta = np.empty((n, 6), dtype=np.int64)
+        parts, off = [], 0
+        for i, p in enumerate(pos):
+            f = (p if isinstance(p, bytes) else str(p).encode("ascii")).split(b":")
+            if len(f) != 3:
+                raise ValueError("position %r is not chrom:coord:seq" % (p,))
+            for k in range(3):
+                meta[i, 2 * k] = off; meta[i, 2 * k + 1] = len(f[k])
+                parts.append(f[k]); off += len(f[k])
+        return PosBatch(b"".join(parts), meta)
 
 
 def _open_tensor_stream(tensor_fn):
@@ -118,7 +160,7 @@ def GetTensorBlocks(tensor_fn, block_lines, rank, ws):
             off += consumed.value
             if consumed.value == 0:
                 break
-        yield block, c, rows[:c].reshape((c, 2 * param.flankingBaseNum + 1, 4, param.matrixNum)), _join_pos(bufs) if bufs else []
+        yield block, c, rows[:c].reshape((c, 2 * param.flankingBaseNum + 1, 4, param.matrixNum)), _join_pos(bufs)
     fo.close()
     proc.wait()
 
@@ -181,12 +223,7 @@ def GetTensor(tensor_fn, num, log=True):
 
 
 def _join_pos(bufs):
-    if len(bufs) == 1:
-        return PosBatch(bufs[0][0], bufs[0][1])
-    out = []
-    for b, m in bufs:
-        out += list(PosBatch(b, m))
-    return out
+    return PosBatch(pieces=bufs)
 
 
 # ---- blosc container (python-blosc pack_array / unpack_array equivalents) ---------------

@@ -91,6 +91,21 @@ int cv_forward(cv_model *m, const float *x_dev, int64_t n, float *out16_dev, voi
 int cv_call_postproc(cv_model *m, const float *x_dev, const float *out16_dev, int64_t n,
                      int32_t *call_dev, float *qual_dev, void *stream);
 
+/* Host half of callVar.Output (callVar.py:72-153): the VCF records of n candidates from the decisions of
+ * cv_call_postproc -- quality int(-4.343*log((p2+1e-300)/(p1+1e-300))), SNP / REF allele, inserted bases and
+ * indel-length guess from the tensor, <INS>/<DEL> + SVTYPE, LENGUESS, GT, FILTER, "%.4f" allele fraction -- as text,
+ * one '\n'-terminated line per record, in candidate order.  All pointers are HOST pointers.
+ *   call [n,8] int32, qual [n,4] fp32: as cv_call_postproc wrote them;
+ *   x: tensors [rows,33,4,4] fp32 (matrices 1..3 minus matrix 0); candidate i uses row xrow[i] (xrow NULL: row i);
+ *   pos_buf / pos_meta [rows,6] int64: byte offset and length of contig, position and 33-base reference sequence of
+ *   a candidate inside pos_buf (what cv_parse_tensor_text emits); candidate i uses row pos_row[i] (NULL: row i);
+ *   show_ref: also candidates called REF (--showRef); has_qual / qual_min: --qual (FILTER PASS / LowQual, else ".").
+ * Candidates with depth 0 give no record.  Runs on the cv_set_host_threads() threads.
+ * Returns 0, or 2 when out_cap is too small (*out_len = bytes needed, nothing written), or 1 (cv_last_error).      */
+int cv_format_vcf(const int32_t *call, const float *qual, int64_t n, const float *x, const int64_t *xrow,
+                  const char *pos_buf, const int64_t *pos_meta, const int64_t *pos_row, int show_ref,
+                  int has_qual, int qual_min, char *out, int64_t out_cap, int64_t *out_len, int64_t *nrecords);
+
 /* debug / parity: copy one intermediate of the LAST cv_forward chunk to
  * dst_dev in the reference's natural layout ([n,h,4,c] NHWC or [n,units]).
  * layer: 1..3 = pool1..pool3 outputs (for slim: conv outputs), 4 = fc4, 5 = fc5.

@@ -244,3 +244,94 @@ def test_string_blocks_of_varying_width_take_the_generic_path():
     out, num, end = utils_v2.DecompressArray(blocks, 0, total, total)
     assert num == total and end == 1
     assert list(out) == list(wide) + list(narrow)
+
+
+def _decisions(callVar, X, base, z, t, l):
+    """what cv_call_postproc computes on the device, restated with callVar's own NumPy helpers (the checker path)"""
+    n = X.shape[0]
+    call = np.zeros((n, 8), np.int32); qual = np.zeros((n, 4), np.float32)
+    call[:, 0] = np.argmax(t, 1); call[:, 1] = np.argmax(z, 1); call[:, 2] = np.argmax(l, 1)
+    order = np.argsort(base, axis=1, kind="stable")[:, ::-1]
+    call[:, 3] = order[:, 0]; call[:, 4] = order[:, 1]
+    qual[:, 0], qual[:, 1] = callVar._top2_products(t, z, l)
+    qual[:, 2] = callVar._depth(X)
+    return call, qual
+
+
+@pytest.mark.parametrize("tag,showRef,qual,ref,sample", [
+    ("a", False, None, None, "SAMPLE"), ("b", True, 20, os.path.join(G, "mini.fa"), "HG001"),
+    ("c", False, 150, None, "SAMPLE")])
+@pytest.mark.parametrize("threads", [1, 5])
+def test_native_formatter_matches_reference_vcf(tag, showRef, qual, ref, sample, threads):
+    """cv_format_vcf (the product's formatter) against the VCF text the reference's own Output() wrote"""
+    from clairvoyante_amd import callVar, _lib
+    from clairvoyante_amd.utils_v2 import PosBatch
+    d = np.load(os.path.join(G, "output_cases.npz"))
+    X = d["X"].astype(np.float32); pos = [str(s) for s in d["pos"]]
+    args = _args(showRef, qual, ref, sample)
+    call, q = _decisions(callVar, X, d["base"], d["z"], d["t"], d["l"])
+    want = [ln for ln in open(os.path.join(G, "output_%s.vcf" % tag)).read().splitlines() if not ln.startswith("#")]
+    lib = _lib.load()
+    lib.cv_set_host_threads(threads)
+    try:
+        n = X.shape[0]
+        got = callVar.format_records(args, n, X, pos, call, q).decode().splitlines()
+        assert got == want
+        # positions as the parser delivers them (pieces of a byte buffer), tensors through a row map
+        half = n // 2
+        pb = PosBatch(pieces=[PosBatch.from_strings(pos[:half]).pieces()[0][2:], PosBatch.from_strings(pos[half:]).pieces()[0][2:]])
+        perm = np.random.RandomState(3).permutation(n)
+        inv = np.empty(n, np.int64); inv[perm] = np.arange(n)
+        got2 = callVar.format_records(args, n, X[perm], pb, call, q, xrow=inv).decode().splitlines()
+        assert got2 == want
+    finally:
+        lib.cv_set_host_threads(min(_lib.usable_cores(), 16))
+
+
+def test_native_formatter_equals_python_formatter_on_random_decisions():
+    """every branch of callVar.py:88-153 (types, lengths, length guesses up to <INS>/<DEL>, depth 0, quality filter,
+    lower-case reference) on 20 000 random candidates: cv_format_vcf == _format_record, line for line"""
+    from clairvoyante_amd import callVar, _lib
+    rng = np.random.RandomState(11)
+    n = 20000
+    X = rng.randint(-3, 40, size=(n, 33, 4, 4)).astype(np.float32)
+    long_ins = rng.rand(n) < 0.15          # long runs that pass the 0.125 rule position after position
+    X[long_ins, 17:, :, 1] += 60; X[long_ins, 17:, :, 2] += 60
+    short = rng.rand(n) < 0.3
+    cut = rng.randint(21, 33, size=n)
+    for i in np.flatnonzero(short):
+        X[i, cut[i]:, :, 1] = 0; X[i, cut[i]:, :, 2] = 0; X[i, cut[i]:, :, 0] = 50
+    zero = rng.rand(n) < 0.02
+    X[zero] = 0
+    call = np.zeros((n, 8), np.int32)
+    call[:, 0] = rng.randint(0, 4, n); call[:, 1] = rng.randint(0, 2, n); call[:, 2] = rng.randint(0, 6, n)
+    call[:, 3] = rng.randint(0, 4, n); call[:, 4] = (call[:, 3] + rng.randint(1, 4, n)) % 4
+    q = np.zeros((n, 4), np.float32)
+    q[:, 0] = rng.rand(n).astype(np.float32); q[:, 1] = (q[:, 0] * rng.rand(n)).astype(np.float32)
+    q[rng.rand(n) < 0.01, 1] = 0
+    q[:, 2] = callVar._depth(X)
+    seqs = ["".join(rng.choice(list("ACGTacgt"), 33)) for _ in range(n)]
+    pos = ["chr%d:%d:%s" % (rng.randint(1, 23), rng.randint(1, 250000000), s) for s in seqs]
+    for showRef, qual in ((False, None), (True, 30)):
+        args = _args(showRef, qual, None, "S")
+        want = []
+        for i in range(n):
+            if call[i, 0] == 0 and not showRef:
+                continue
+            p = pos[i].split(":")
+            rec = callVar._format_record(args, X[i], "%s:%s:%s" % (p[0], p[1], p[2].upper()), int(call[i, 0]), int(call[i, 1]),
+                                         int(call[i, 2]), int(call[i, 3]), int(call[i, 4]), callVar._qual(q[i, 0], q[i, 1]), q[i, 2])
+            if rec is not None:
+                want.append(rec)
+        got = callVar.format_records(args, n, X, pos, call, q).decode().splitlines()
+        assert len(got) == len(want) and got == want
+
+
+def test_native_formatter_rejects_malformed_positions():
+    from clairvoyante_amd import callVar, _lib
+    X = np.ones((1, 33, 4, 4), np.float32)
+    call = np.array([[1, 0, 0, 1, 2, 0, 0, 0]], np.int32); q = np.array([[0.9, 0.1, 8, 0]], np.float32)
+    with pytest.raises(_lib.CvError):
+        callVar.format_records(_args(False, None, None, "S"), 1, X, ["chr1:12x:" + "A" * 33], call, q)
+    with pytest.raises(_lib.CvError):
+        callVar.format_records(_args(False, None, None, "S"), 1, X, ["chr1:12:ACGT"], call, q)
