@@ -124,6 +124,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     for (int l = 1; l < 3; l++) alloc(&m->wpd_conv[l], (size_t)s.cinb[l] * arch->kh[l] * 4 * s.ntile[l] * 256);
     alloc(&m->wpd_fc4, (size_t)((s.kb4 + 23) / 24) * s.nb4 * 24 * 256);
     alloc(&m->wpd_fc5, (size_t)s.nb5 * 24 * 256);
+    if (s.nb4 == 21 && s.ntile[2] == 3 && arch->pool[2] == 3) alloc(&m->wpr_fc4, (size_t)4 * s.ntile[2] * s.hp[2] * 24 * 256);
     if (s.nb4 == 21) alloc(&m->wps_fc4, (size_t)3 * s.kb4 * 8 * 256);
     if (s.nb4 == 21) alloc(&m->wps7_fc4, (size_t)7 * s.kb4 * 3 * 256);
     if (s.nb4 == 21 && s.nb5 == 11) alloc(&m->wps3_fc5, (size_t)3 * s.nb4 * 4 * 256);
@@ -148,7 +149,7 @@ extern "C" int cv_destroy(cv_model *m)
     if (!m) return 0;
     hipSetDevice(m->device);
     float *bufs[] = {m->params, m->grads_own, m->adam_m, m->adam_v, m->wp_conv1, m->wp_conv[1], m->wp_conv[2],
-                     m->wp_fc4, m->wp_fc5, m->wp_heads0, m->wp_heads1, m->wpd_conv[1], m->wpd_conv[2], m->wpd_fc4, m->wpd_fc5, m->wps_fc4, m->wps7_fc4, m->wps3_fc5, m->wg_part, m->tm_p1, m->tm_p2, m->tm_p3, m->tm_h4, m->tm_h5, m->r_a[0],
+                     m->wp_fc4, m->wp_fc5, m->wp_heads0, m->wp_heads1, m->wpd_conv[1], m->wpd_conv[2], m->wpd_fc4, m->wpr_fc4, m->wpd_fc5, m->wps_fc4, m->wps7_fc4, m->wps3_fc5, m->wg_part, m->tm_p1, m->tm_p2, m->tm_p3, m->tm_h4, m->tm_h5, m->r_a[0],
                      m->r_a[1], m->r_a[2], m->r_p[0], m->r_p[1], m->r_p[2], m->r_h4, m->r_h5, m->t_buf};
     for (float *b : bufs)
         if (b) hipFree(b);
@@ -238,7 +239,7 @@ extern "C" int cv_set_option(cv_model *m, const char *key, int64_t value)
     if (!strcmp(key, "train_ksplit")) { m->train_ksplit = value ? 1 : 0; return 0; }
     if (!strcmp(key, "train_tiny_groups")) { m->tiny_g = value < 0 ? 0 : (value > 160 ? 160 : (int)value); return 0; }
     if (!strcmp(key, "variant")) { m->variant = (int)value; return 0; }
-    if (!strncmp(key, "dbg", 3) && key[3] >= '0' && key[3] <= '7' && !key[4]) { m->dbg[key[3] - '0'] = (int)value; return 0; }
+    if (!strncmp(key, "dbg", 3) && key[3] >= '0' && key[3] <= '7' && !key[4]) { m->dbg[key[3] - '0'] = (int)value; m->packed_train_dirty = true; return 0; }
     if (!strcmp(key, "chunk")) {
         if (value < 16 || value > (1 << 22)) { cv_set_error("chunk must be in [16, 4194304]"); return 1; }
         m->chunk = (value + 15) / 16 * 16;

@@ -62,6 +62,7 @@ struct cv_model {
     float *wp_fc5;       // [nb4][nb5][64][4]
     float *wpd_conv[3];  // data-gradient weights of conv2 / conv3 (pack_conv_dgrad)
     float *wpd_fc4;      // data-gradient weights of fc4 [slab][jb][24][64][4]
+    float *wpr_fc4;      // data-gradient weights of fc4 by column and pooled row [col][row][24][64][4] (full topology)
     float *wg_part;      // per-split tiles of the dense weight gradients (two-pass combine), owned
     size_t wg_part_bytes;
     float *wps_fc4;      // forward weights of fc4 in 3 slabs [slab][kb][8][64][4] (full topology, small batches)
@@ -144,6 +145,8 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
                       float *part = nullptr);
 int cv_tile_fc5_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
 int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
+int cv_tile_fc4_dgrad_unpool(cv_model *m, const float *g_tm, const float *pooled, const float *codes, float *gpre, int64_t n,
+                             hipStream_t st);
 int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
 int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_tm, const float *g_tm, int64_t n, hipStream_t st);
 int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_tm, const float *g_tm, int64_t n, hipStream_t st);

@@ -19,6 +19,7 @@
 // kh -> (kh-1)/2 on top; taps on padding are skipped (they add an exact zero).
 #include "cv_internal.hpp"
 #include "cv_math.hpp"
+#include "cv_unpool.hpp"
 #include <type_traits>
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -173,6 +174,25 @@ __device__ __forceinline__ void pack_dense_dgrad(int64_t t, const float *__restr
     wp[t] = (j < N && k < K) ? w[(size_t)k * N + j] : 0.0f;
 }
 
+// data-gradient weights of fc4 for dense_dgrad_unpool: one column of the pooled conv3 map per workgroup, rows in
+// sequence.  Result fragment f = r * NCOL + col (r = pooled row, col = base * tiles + tile) holds input units
+// 16 f + sigma(i); fragments [col][r][jb (padded to JBP)][lane][s], contraction index j = 16 jb + 4 s + kq.
+__device__ __forceinline__ void pack_dense_dgrad_rows(int64_t t, const float *__restrict__ w, float *__restrict__ wp, int K, int N,
+                                                      int JB, int JBP, int NCOL, int HO)
+{
+    int64_t total = (int64_t)NCOL * HO * JBP * 256;
+    if (t >= total) return;
+    int s = (int)(t & 3), lane = (int)((t >> 2) & 63);
+    int64_t frag = t >> 8;
+    int jb = (int)(frag % JBP); frag /= JBP;
+    int r = (int)(frag % HO);
+    int col = (int)(frag / HO);
+    int i = lane & 15, kq = lane >> 4;
+    int j = 16 * jb + 4 * s + kq;
+    int k = 16 * (r * NCOL + col) + cv_sigma(i);
+    wp[t] = (jb < JB && j < N && k < K) ? w[(size_t)k * N + j] : 0.0f;
+}
+
 // data-gradient weights of a conv layer (see conv_tm MODE 2): flipped taps, channels swapped
 //   Wd[nt'][kh'][kw'][cb'][lane][s] = W[KH-1-kh'][3-kw'][ci = 16 nt' + sigma(i)][co = 16 cb' + 4 s + kq]
 __device__ __forceinline__ void pack_conv_dgrad(int64_t t, const float *__restrict__ w, float *__restrict__ wp, int KH, int cin, int cout,
@@ -225,6 +245,33 @@ __global__ void dropout_tm(const float *__restrict__ h4, float *__restrict__ d4,
     amask[t] = mk;
 }
 
+
+// ---------------------------------------------------------------------------
+// Training forward: which row of its window a pooled value came from.
+// The backward pass routes the gradient of a pooled value to the FIRST maximum of its window (oracle/cv_oracle.c pool
+// backward; the reference's tf.layers.max_pooling2d gradient).  Instead of keeping the pre-pool activations for that
+// (0.68 MB per group of 16 candidates), the forward kernels record the window offset d of the first maximum: 4 bits per
+// value, the 16 values a lane holds of a pooled row (4 bases x 4 registers) in one 64-bit word -- value (w, r) at bits
+// 4 (4 w + r) .. +3 -- stored as [group][pooled row][tile][lane] (512 B per row and tile instead of 4 KiB).
+// ---------------------------------------------------------------------------
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// rows[0..P-2] = the P-1 older activated rows of the window (oldest first), v = the newest, o = their maximum
+template <int P>
+__device__ __forceinline__ unsigned pool_code4(const f4 (&older)[P > 1 ? P - 1 : 1], f4 v, f4 o)
+{
+    unsigned c = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int idx = P - 1;
+#pragma unroll
+        for (int d = P - 2; d >= 0; d--) idx = older[d][r] == o[r] ? d : idx;      // the lowest offset that holds the maximum
+        (void)v;
+        c |= (unsigned)idx << (4 * r);
+    }
+    return c;
+}
+
 // ---------------------------------------------------------------------------
 // conv1 (k(1,4), cin 4) + SELU + max-pool(POOL,1): raw X [n,33,4,4] -> TM
 // One wave per group of 16 candidates; per position 12 MFMA steps (K = 4 each).
@@ -233,8 +280,9 @@ template <int POOL, bool SAVE = false>
 __global__ __launch_bounds__(256) void conv1_tm(const float *__restrict__ x, int64_t n,
                                                  const float *__restrict__ wp1,
                                                  const float *__restrict__ bias, int cout,
-                                                 f4 *__restrict__ out_tm, int G, f4 *__restrict__ act_tm = nullptr)
+                                                 f4 *__restrict__ out_tm, int G, u32x2 *__restrict__ code_tm = nullptr)
 {
+    // SAVE (training forward): the window offset of every pooled value's first maximum goes to code_tm (pool_code4).
     // The layer has almost no arithmetic (12 MFMA steps per position) and a long dependent
     // chain per position (load -> MFMA -> SELU -> pool -> store), so it is latency-bound:
     // SPLIT waves share a group, each producing a contiguous range of pooled rows (and
@@ -301,11 +349,6 @@ __global__ __launch_bounds__(256) void conv1_tm(const float *__restrict__ x, int
         f4 v[4];
 #pragma unroll
         for (int w = 0; w < 4; w++) v[w] = selu4(acc[w] + b4);
-        if constexpr (SAVE) {     // rows shared by two parts are written twice with identical values
-            f4 *ap = act_tm + (size_t)g * HIN * 4 * 64 + lane;
-#pragma unroll
-            for (int w = 0; w < 4; w++) ap[(size_t)(h * 4 + w) * 64] = v[w];
-        }
         if constexpr (POOL > 1) {
             f4 o[4];
 #pragma unroll
@@ -313,6 +356,19 @@ __global__ __launch_bounds__(256) void conv1_tm(const float *__restrict__ x, int
                 o[w] = v[w];
 #pragma unroll
                 for (int j = 0; j < POOL - 1; j++) o[w] = max4(o[w], pw[j][w]);
+            }
+            if constexpr (SAVE) {
+                if (h - r0 >= POOL - 1) {
+                    unsigned cw[4];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        f4 older[POOL - 1];
+#pragma unroll
+                        for (int j = 0; j < POOL - 1; j++) older[j] = pw[j][w];
+                        cw[w] = pool_code4<POOL>(older, v[w], o[w]);
+                    }
+                    code_tm[((size_t)g * HOUT + (h - (POOL - 1))) * 64 + lane] = (u32x2){cw[0] | (cw[1] << 16), cw[2] | (cw[3] << 16)};
+                }
             }
 #pragma unroll
             for (int j = 0; j + 1 < POOL - 1; j++)
@@ -438,9 +494,9 @@ struct front_source {
     }
 };
 
-// MODE 0: inference forward.  MODE 1: training forward -- additionally stores the SELU
-// outputs BEFORE pooling (act_tm, [g][HIN*4*NT] fragments) that the backward pass routes the
-// pooling gradient with.  MODE 2: data-gradient pass -- the same kernel run as the transposed
+// MODE 0: inference forward.  MODE 1: training forward -- additionally records, per pooled value, the window
+// offset of its first maximum (act_tm viewed as [g][HOUT][NT][64] 64-bit code words, pool_code4) that the backward
+// pass routes the pooling gradient with; nothing extra without pooling.  MODE 2: data-gradient pass -- the same kernel run as the transposed
 // convolution  gIn[h][w][ci] = sum g[h-kh+pt][w-kw+1][co] W[kh][kw][ci][co]  on flipped,
 // in/out-swapped packed weights (pack_conv_dgrad): padding 2 left / 1 right and
 // KH-1-(KH-1)/2 on top, no bias, no activation, no pooling.
@@ -605,11 +661,6 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
             for (int w = 0; w < 4; w++) v[w] = selu4(acc[w] + b4);
 #endif
         }
-        if constexpr (MODE == 1) {
-            f4 *ap = act_tm + (size_t)g * (HIN * 4 * NT * 64) + (size_t)nt * 64 + lane;
-#pragma unroll
-            for (int w = 0; w < 4; w++) ap[(size_t)(h * 4 + w) * (NT * 64)] = v[w];
-        }
         if constexpr (POOL > 1) {
             f4 o[4];
 #pragma unroll
@@ -617,6 +668,20 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
                 o[w] = v[w];
 #pragma unroll
                 for (int j = 0; j < POOL - 1; j++) o[w] = max4(o[w], pw[j][w]);
+            }
+            if constexpr (MODE == 1) {
+                if (h - hbeg >= POOL - 1) {
+                    unsigned cw[4];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        f4 older[POOL - 1];
+#pragma unroll
+                        for (int j = 0; j < POOL - 1; j++) older[j] = pw[j][w];
+                        cw[w] = pool_code4<POOL>(older, v[w], o[w]);
+                    }
+                    u32x2 *cp = reinterpret_cast<u32x2 *>(act_tm);
+                    cp[(((size_t)g * HOUT + (h - (POOL - 1))) * NT + nt) * 64 + lane] = (u32x2){cw[0] | (cw[1] << 16), cw[2] | (cw[3] << 16)};
+                }
             }
 #pragma unroll
             for (int j = 0; j + 1 < POOL - 1; j++)
@@ -1347,6 +1412,150 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// fc4 data gradient FUSED with the max-pool backward + SELU' of conv3 (training step, full topology).
+//   gF[k] = sum_j g4pre[j] W4[k][j]      (the gradient of the pooled conv3 map, k = flatten index (h, w, c))
+//   gpre3 = unpool(gF) * selu'           (cv_unpool.hpp)
+// As separate kernels (dense_tm EPI 1 + the element-wise pass) the 18.4 KB-per-candidate gradient map is written,
+// read back together with the pre-pool activations, and written again: 0.9 MB of HBM traffic per group for zero
+// FLOPs.  Pooling runs along positions only, so the work is cut by COLUMN (base w, tile nt) of the map instead of by
+// slabs of output features: a workgroup owns WAVES * GR groups and one column; each wave keeps the NB fragments of
+// its groups' g4pre in registers for the whole kernel (they are the B operands of every row) and walks the HO pooled
+// rows in order -- per row NB x 4 MFMA steps per group on the row's weight fragments, streamed through the same 3-slot
+// LDS-DMA ring as dense_tm (one barrier per row), then the row's gradient enters the P-row unpool window and one
+// finished pre-activation gradient row leaves.  Per output value the contraction is the single ascending-j chain of
+// dense_tm EPI 1.  Loads and DMA from inline asm; per iteration: GR stores (row r-1), 2 GR loads (pooled output and codes
+// of row r), PER DMA pieces (weights of row r+2), one counted wait that leaves only the DMA pieces in flight.
+// ---------------------------------------------------------------------------
+template <int NB, int P, int WAVES, int GR>
+__global__ __launch_bounds__(WAVES * 64, 2) void dense_dgrad_unpool(const f4 *__restrict__ g_tm, const f4 *__restrict__ wpr,
+                                                                  const f4 *__restrict__ pooled, const u32x2 *__restrict__ codes,
+                                                                  f4 *__restrict__ gpre, int G, int HO, int NT)
+{
+    extern __shared__ __attribute__((aligned(16))) f4 ring[];
+    constexpr int NBP = (NB + WAVES - 1) / WAVES * WAVES;
+    constexpr int STAGE = NBP * 64;
+    constexpr int PER = NBP / WAVES;
+    const int NCOL = 4 * NT;
+    const int col = blockIdx.y, w = col / NT, nt = col % NT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g0 = (blockIdx.x * WAVES + wid) * GR;
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) f4 *)ring;
+    const f4 *wcol = wpr + (size_t)col * HO * STAGE;
+    auto stage_async = [&](int r, int slot) {
+#pragma unroll
+        for (int p = 0; p < PER; p++) {
+            const f4 *gp = wcol + ((size_t)r * NBP + wid * PER + p) * 64 + lane;
+            const unsigned ldst = ring_base + (unsigned)((slot * NBP + wid * PER + p) * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gp), "s"(ldst) : "memory");
+        }
+    };
+    auto load_f4 = [&](const f4 *ptr) {
+        f4 v;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+        return v;
+    };
+    auto load_u2 = [&](const u32x2 *ptr) {
+        u32x2 v;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+        return v;
+    };
+    int gl[GR]; bool live[GR];
+#pragma unroll
+    for (int r = 0; r < GR; r++) { live[r] = g0 + r < G; gl[r] = live[r] ? g0 + r : G - 1; }
+    stage_async(0, 0);
+    stage_async(HO > 1 ? 1 : 0, 1);
+    f4 B[GR][NB];
+#pragma unroll
+    for (int r = 0; r < GR; r++)
+#pragma unroll
+        for (int kb = 0; kb < NB; kb++) B[r][kb] = load_f4(g_tm + ((size_t)gl[r] * NB + kb) * 64 + lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < GR; r++)
+#pragma unroll
+        for (int kb = 0; kb < NB; kb++) asm volatile("" : "+v"(B[r][kb]));
+    __syncthreads();
+    unpool_col<P> U[GR];
+    const f4 *pp[GR]; const u32x2 *cp[GR]; f4 *op[GR];
+#pragma unroll
+    for (int r = 0; r < GR; r++) {
+        U[r].init();
+        pp[r] = pooled + ((size_t)gl[r] * HO * NCOL + col) * 64 + lane;
+        cp[r] = codes + ((size_t)gl[r] * HO * NT + nt) * 64 + lane;
+        op[r] = gpre + ((size_t)gl[r] * (HO + P - 1) * NCOL + col) * 64 + lane;
+    }
+    f4 acc[GR], yv[GR]; u32x2 cv[GR];
+#pragma unroll
+    for (int r = 0; r < GR; r++) { acc[r] = zero; yv[r] = zero; cv[r] = (u32x2){0u, 0u}; }
+    // row `row` leaves the accumulators: into the unpool window, one finished row out
+    auto finish_row = [&](int row) {
+#pragma unroll
+        for (int r = 0; r < GR; r++) {
+            U[r].push(acc[r], yv[r], cv_code16(cv[r][0], cv[r][1], w));
+            const f4 o = U[r].emit();
+            if (live[r]) op[r][(size_t)row * NCOL * 64] = o;      // (a plain store: older than the DMA pieces the counted wait leaves in flight)
+        }
+    };
+    int slot = 0;
+#pragma unroll 1
+    for (int row = 0; row < HO; row++) {
+        if (row > 0) finish_row(row - 1);
+#pragma unroll
+        for (int r = 0; r < GR; r++) {
+            yv[r] = load_f4(pp[r] + (size_t)row * NCOL * 64);
+            cv[r] = load_u2(cp[r] + (size_t)row * NT * 64);
+            acc[r] = zero;
+        }
+        const int rs = row + 2 < HO ? row + 2 : HO - 1;
+        int wslot = slot + 2; if (wslot >= 3) wslot -= 3;
+        stage_async(rs, wslot);
+        const f4 *wl = ring + slot * STAGE + lane;
+#pragma unroll
+        for (int kb = 0; kb < NB; kb += 3) {
+            f4 A[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                if (kb + j < NB) A[j] = wl[(kb + j) * 64];
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+                    for (int r = 0; r < GR; r++)
+                        if (kb + j < NB) acc[r] = mfma4(A[j][s4], B[r][kb + j][s4], acc[r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // counted wait: only this iteration's PER DMA pieces (weights of row + 2) stay in flight -- VMEM operations
+        // complete in order, and the pieces are the newest ones; the loads of this row and the store of the previous
+        // one are done.  The barrier then publishes the weights of row + 1.
+        if constexpr (PER == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if constexpr (PER == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < GR; r++) { asm volatile("" : "+v"(yv[r])); asm volatile("" : "+v"(cv[r])); }
+        __syncthreads();
+        slot = slot + 1 == 3 ? 0 : slot + 1;
+    }
+    finish_row(HO - 1);
+#pragma unroll
+    for (int d = 0; d + 1 < P; d++) {
+#pragma unroll
+        for (int r = 0; r < GR; r++) {
+            U[r].push_none();
+            const f4 o = U[r].emit();
+            if (live[r]) op[r][(size_t)(HO + d) * NCOL * 64] = o;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // surplus DMA pieces of the last rows
+}
+
 // ---------------------------------------------------------------------------
 // dense layer for FEW groups (a predict() call of the reference's batch of 1 000 is 63 groups): dense_tm streams the
 // weight matrix through an LDS ring with one workgroup barrier per k fragment -- ~0.9 us per step whatever the
@@ -1605,7 +1814,7 @@ bool arch_is(const cv_arch &a, int k0, int k1, int k2, int c0, int c1, int c2, i
 static bool is_full(const cv_arch &a);
 
 struct pack_job {
-    int kind;                      // 0 conv1, 1 conv, 2 dense, 3 dense slabs, 4 dense dgrad, 5 conv dgrad, 6 heads
+    int kind;                      // 0 conv1, 1 conv, 2 dense, 3 dense slabs, 4 dense dgrad, 5 conv dgrad, 6 heads, 7 dense dgrad by rows
     const float *src[4];
     float *dst[2];
     int i[8];
@@ -1627,6 +1836,7 @@ __global__ __launch_bounds__(256) void pack_all(pack_tab tab)
     case 3: pack_dense_slabs(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4], J.i[5]); break;
     case 4: pack_dense_dgrad(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4]); break;
     case 5: pack_conv_dgrad(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4]); break;
+    case 7: pack_dense_dgrad_rows(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4], J.i[5]); break;
     default: pack_heads(t, J.src[0], J.src[1], J.src[2], J.src[3], J.i[0], J.i[1], J.i[2], J.i[3], J.dst[0], J.dst[1]); break;
     }
 }
@@ -1687,8 +1897,14 @@ static int pack_launch(cv_model *m, hipStream_t st, bool fwd, bool with_train)
             J.src[0] = P + o[2 * l]; J.dst[0] = m->wpd_conv[l];
             J.i[0] = a.kh[l]; J.i[1] = s.cin[l]; J.i[2] = a.cout[l]; J.i[3] = s.ntile[l]; J.i[4] = s.cinb[l];
         }
-        { pack_job &J = pb.add(4, (int64_t)(s.kb4 / 24) * s.nb4 * 24 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wpd_fc4;
-          J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.nb4; J.i[3] = 24; J.i[4] = s.kb4 / 24; }
+        if (m->wpr_fc4 && m->dbg[3] != 1) {     // full: by column and pooled row, for dense_dgrad_unpool
+            const int ncol = 4 * s.ntile[2];
+            pack_job &J = pb.add(7, (int64_t)ncol * s.hp[2] * 24 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wpr_fc4;
+            J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.nb4; J.i[3] = 24; J.i[4] = ncol; J.i[5] = s.hp[2];
+        } else {
+            pack_job &J = pb.add(4, (int64_t)(s.kb4 / 24) * s.nb4 * 24 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wpd_fc4;
+            J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.nb4; J.i[3] = 24; J.i[4] = s.kb4 / 24;
+        }
         {   // fc5: one slab; fragment stride = dense_tm's padded count (full: 21 -> 24 with 8 waves, slim: 3 -> 4)
             const int nbp = is_full(a) ? 24 : 4;
             pack_job &J = pb.add(4, (int64_t)s.nb5 * nbp * 256); J.src[0] = P + o[8]; J.dst[0] = m->wpd_fc5;
@@ -2421,18 +2637,18 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
     // same values row for row.  Option train_tiny_groups = 0 keeps one wave per (group, tile).
     const bool split = m->tiny_g > 0;
     if (is_full(a) && m->dbg[1] > 0) {          // development: forced number of position parts
-        conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (f4 *)a1);
+        conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (u32x2 *)a1);
         rc |= launch_conv_parts<2, 1, 2, 4, 29, 1>(m->dbg[1], p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
         rc |= launch_conv_parts<3, 2, 3, 3, 26, 1>(m->dbg[1], p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
         CV_HIP(hipGetLastError());
         return rc;
     }
     if (is_full(a)) {
-        conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (f4 *)a1);
+        conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (u32x2 *)a1);
         rc |= launch_conv_parts<2, 1, 2, 4, 29, 1>(split ? pick_hsplit(G, 2, 26, 3, 4) : 1, p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
         rc |= launch_conv_parts<3, 2, 3, 3, 26, 1>(split ? pick_hsplit(G, 3, 24, 2, 4) : 1, p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
     } else {
-        conv1_tm<1, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (f4 *)a1);
+        conv1_tm<1, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (u32x2 *)a1);
         rc |= launch_conv_parts<3, 1, 1, 1, 33, 1, 2>(split ? pick_hsplit(G, 1, 33, 0, 4) : 1, p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
         rc |= launch_conv_parts<5, 1, 2, 1, 33, 1>(split ? pick_hsplit(G, 2, 33, 0, 4) : 1, p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
     }
@@ -2467,6 +2683,32 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
     }
     if (layer == 4) return launch_dense<3, 4>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);
     return launch_dense<2, 4>(in_tm, s.nb4, m->wp_fc5, P + o[9], a.fc5, out_tm, G, st);
+}
+
+// full topology: fc4 data gradient + max-pool backward + SELU' of conv3 in one kernel (dense_dgrad_unpool):
+// g_tm = fc4 pre-activation gradient, pooled / codes = conv3's pooled output and window-offset codes, gpre = conv3's
+// pre-activation gradient (hc[2] rows).  Few groups: one group per wave, more workgroups.
+int cv_tile_fc4_dgrad_unpool(cv_model *m, const float *g_tm, const float *pooled, const float *codes, float *gpre, int64_t n,
+                             hipStream_t st)
+{
+    const cv_shapes &s = m->sh;
+    const int G = (int)((n + 15) / 16);
+    if (!is_full(m->arch) || !m->wpr_fc4) { cv_set_error("cv_tile_fc4_dgrad_unpool: full topology only"); return 1; }
+    const size_t lds = (size_t)3 * 24 * 1024;
+    const int HO = s.hp[2], NT = s.ntile[2];
+    if (G > 512) {
+        auto k = dense_dgrad_unpool<21, 3, 8, 2>;
+        if (set_lds(k, lds)) return 1;
+        k<<<dim3(nblk(G, 16), 4 * NT), 512, lds, st>>>((const f4 *)g_tm, (const f4 *)m->wpr_fc4, (const f4 *)pooled,
+                                                       (const u32x2 *)codes, (f4 *)gpre, G, HO, NT);
+    } else {
+        auto k = dense_dgrad_unpool<21, 3, 8, 1>;
+        if (set_lds(k, lds)) return 1;
+        k<<<dim3(nblk(G, 8), 4 * NT), 512, lds, st>>>((const f4 *)g_tm, (const f4 *)m->wpr_fc4, (const f4 *)pooled,
+                                                      (const u32x2 *)codes, (f4 *)gpre, G, HO, NT);
+    }
+    CV_HIP(hipGetLastError());
+    return 0;
 }
 
 // gF[k] = sum_j g4pre[j] W4[k][j]  (input TM with nb4 fragments, output TM with kb4 fragments)

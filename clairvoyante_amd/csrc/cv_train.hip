@@ -17,6 +17,7 @@
 // tile kernels do not cover fall back to the all-plain path (train_slice_plain, atomics).
 #include "cv_internal.hpp"
 #include "cv_math.hpp"
+#include "cv_unpool.hpp"
 
 namespace {
 
@@ -238,12 +239,7 @@ __global__ void b_dense_dgrad(const float *__restrict__ g, int ldg, const float 
     gx[t] = accumulate ? gx[t] + acc : acc;
 }
 
-// d selu / d pre-activation expressed through the layer OUTPUT y = selu(pre):
-//   pre >= 0  <=>  y >= 0 : SCALE ;   pre < 0 : SCALE*ALPHA*exp(pre) = y + SCALE*ALPHA
-__device__ __forceinline__ float selu_grad_from_out(float y)
-{
-    return y >= 0.0f ? cvm::SELU_SCALE : y + cvm::SELU_SCALE * cvm::SELU_ALPHA;
-}
+__device__ __forceinline__ float selu_grad_from_out(float y) { return cv_selu_grad_from_out(y); }
 
 // g_pre = g_act * selu'(.) from the activation (optionally * amask for the dropout layer)
 __global__ void b_selu_act(const float *__restrict__ gact, const float *__restrict__ act,
@@ -421,129 +417,114 @@ __global__ void b_selu_tm(const tf4 *__restrict__ gact, const tf4 *__restrict__ 
     gpre[t] = r;
 }
 
-// max-pool backward + selu' on TM maps: one thread per (group, base*tile, lane) streams over the positions
-// with the P rows of the current pooling window and their gradient accumulators in registers: per pooled
-// row one activation row and one gradient row are read and one finished row is written.  The gradient of a
-// pooled value goes to the FIRST maximum of its window; contributions are added in ascending window order.
-// act: H rows, gpool: H-P+1 rows, gpre: H rows; row stride = 4*NT fragments.
+// max-pool backward + SELU' on TM maps from the forward pass's window-offset codes (cv_unpool.hpp): one thread per
+// (group, base, tile, lane) streams over the pooled rows -- per row one gradient fragment, one pooled-output fragment
+// and 8 code bytes are read, one finished row is written; the pre-pool activations are never needed.
+// gpool / pooled: HO rows of 4*NT fragments; codes: [g][HO][NT][64] 64-bit words; gpre: HO + P - 1 rows.
 template <int P>
-__global__ void b_pool_selu_tm(const tf4 *__restrict__ gpool, const tf4 *__restrict__ act, tf4 *__restrict__ gpre,
-                               int64_t G, int H, int NT)
+__global__ void b_unpool_tm(const tf4 *__restrict__ gpool, const tf4 *__restrict__ pooled, const uint2 *__restrict__ codes,
+                            tf4 *__restrict__ gpre, int64_t G, int HO, int NT)
 {
     const int cols = 4 * NT * 64;                     // f4 columns per group row
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= G * cols) return;
     const int col = (int)(t % cols);
     const int64_t g = t / cols;
-    const int Ho = H - P + 1;
-    const tf4 *a = act + (size_t)g * H * cols + col;
-    const tf4 *gp = gpool + (size_t)g * Ho * cols + col;
+    const int lane = col & 63, nt = (col >> 6) % NT, w = (col >> 6) / NT;
+    const int H = HO + P - 1;
+    const tf4 *gp = gpool + (size_t)g * HO * cols + col;
+    const tf4 *pp = pooled + (size_t)g * HO * cols + col;
+    const uint2 *cp = codes + ((size_t)g * HO * NT + nt) * 64 + lane;
     tf4 *o = gpre + (size_t)g * H * cols + col;
-    const tf4 zero = (tf4){0.f, 0.f, 0.f, 0.f};
-    tf4 w[P], ac[P];
-#pragma unroll
-    for (int d = 0; d + 1 < P; d++) { w[d] = a[(size_t)d * cols]; ac[d] = zero; }
-    for (int ho = 0; ho < Ho; ho++) {
-        w[P - 1] = a[(size_t)(ho + P - 1) * cols];
-        ac[P - 1] = zero;
-        const tf4 gv = gp[(size_t)ho * cols];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            float mx = w[0][k];
-            int idx = 0;
-#pragma unroll
-            for (int d = 1; d < P; d++) {
-                const bool gt = w[d][k] > mx;
-                mx = gt ? w[d][k] : mx;
-                idx = gt ? d : idx;
-            }
-#pragma unroll
-            for (int d = 0; d < P; d++) ac[d][k] += idx == d ? gv[k] : 0.0f;
-        }
-        tf4 r;
-#pragma unroll
-        for (int k = 0; k < 4; k++) r[k] = ac[0][k] * selu_grad_from_out(w[0][k]);
-        o[(size_t)ho * cols] = r;                     // row ho belongs to no later window
-#pragma unroll
-        for (int d = 0; d + 1 < P; d++) { w[d] = w[d + 1]; ac[d] = ac[d + 1]; }
+    unpool_col<P> U;
+    U.init();
+    for (int ho = 0; ho < HO; ho++) {
+        const uint2 c = cp[(size_t)ho * NT * 64];
+        U.push(gp[(size_t)ho * cols], pp[(size_t)ho * cols], cv_code16(c.x, c.y, w));
+        o[(size_t)ho * cols] = U.emit();
     }
 #pragma unroll
     for (int d = 0; d + 1 < P; d++) {                 // the last P-1 rows
-        tf4 r;
-#pragma unroll
-        for (int k = 0; k < 4; k++) r[k] = ac[d][k] * selu_grad_from_out(w[d][k]);
-        o[(size_t)(Ho + d) * cols] = r;
+        U.push_none();
+        o[(size_t)(HO + d) * cols] = U.emit();
     }
 }
 
-// The same result with one thread per (group, column, ROW): row h collects the gradients of the <= P windows that
-// hold it (ascending window order, first maximum wins: the order and the rule of the streaming kernel, so the bits
-// are the same) -- P*P cached reads per thread instead of a serial walk over the H rows.  For batches of few
-// groups, where the streaming kernel is a handful of waves each waiting on H dependent steps.
+// The same with one thread per (group, column, ROW): row h collects the <= P windows that hold it -- P small reads per
+// thread instead of a serial walk over the rows, for batches of few groups.  Same terms in the same order: same bits.
 template <int P>
-__global__ void b_pool_selu_rows(const tf4 *__restrict__ gpool, const tf4 *__restrict__ act, tf4 *__restrict__ gpre,
-                                 int64_t G, int H, int NT)
+__global__ void b_unpool_rows(const tf4 *__restrict__ gpool, const tf4 *__restrict__ pooled, const uint2 *__restrict__ codes,
+                              tf4 *__restrict__ gpre, int64_t G, int HO, int NT)
 {
     const int cols = 4 * NT * 64;
+    const int H = HO + P - 1;
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= G * H * cols) return;
     const int col = (int)(t % cols);
     const int h = (int)((t / cols) % H);
     const int64_t g = t / ((int64_t)cols * H);
-    const int Ho = H - P + 1;
-    const tf4 *a = act + (size_t)g * H * cols + col;
-    const tf4 *gp = gpool + (size_t)g * Ho * cols + col;
+    const int lane = col & 63, nt = (col >> 6) % NT, w = (col >> 6) / NT;
+    const tf4 *gp = gpool + (size_t)g * HO * cols + col;
+    const tf4 *pp = pooled + (size_t)g * HO * cols + col;
+    const uint2 *cp = codes + ((size_t)g * HO * NT + nt) * 64 + lane;
     tf4 acc = (tf4){0.f, 0.f, 0.f, 0.f};
-    const int lo = h - (P - 1) > 0 ? h - (P - 1) : 0, hi = h < Ho - 1 ? h : Ho - 1;
-    for (int ho = lo; ho <= hi; ho++) {
-        tf4 w[P];
 #pragma unroll
-        for (int d = 0; d < P; d++) w[d] = a[(size_t)(ho + d) * cols];
-        const tf4 gv = gp[(size_t)ho * cols];
+    for (int d = P - 1; d >= 0; d--) {                // windows ho = h - d in ascending order
+        const int ho = h - d;
+        if (ho < 0 || ho >= HO) continue;
+        const uint2 c = cp[(size_t)ho * NT * 64];
+        const unsigned c16 = cv_code16(c.x, c.y, w);
+        const tf4 gv = gp[(size_t)ho * cols], y = pp[(size_t)ho * cols];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            float mx = w[0][k];
-            int idx = 0;
-#pragma unroll
-            for (int d = 1; d < P; d++) {
-                const bool gt = w[d][k] > mx;
-                mx = gt ? w[d][k] : mx;
-                idx = gt ? d : idx;
-            }
-            acc[k] += ho + idx == h ? gv[k] : 0.0f;
+            const float gs = gv[k] * cv_selu_grad_from_out(y[k]);
+            acc[k] += ((c16 >> (4 * k)) & 15u) == (unsigned)d ? gs : 0.0f;
         }
     }
-    const tf4 me = a[(size_t)h * cols];
-    tf4 r;
-#pragma unroll
-    for (int k = 0; k < 4; k++) r[k] = acc[k] * selu_grad_from_out(me[k]);
-    gpre[(size_t)(g * H + h) * cols + col] = r;
+    gpre[(size_t)(g * H + h) * cols + col] = acc;
 }
 
-static int launch_pool_selu(const float *gpool, const float *act, float *gpre, int64_t G, int H, int NT, int p,
-                            hipStream_t st, int tiny_g)
+// gpre = gact * selu'(act) for a layer without pooling (slim): act is the layer output
+__global__ void b_selu_out_tm(const tf4 *__restrict__ gact, const tf4 *__restrict__ act, tf4 *__restrict__ gpre, int64_t nf4)
 {
-    if (G <= tiny_g && p > 1) {       // tiny batches (cv_model::tiny_g)
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nf4) return;
+    const tf4 g = gact[t], a = act[t];
+    tf4 r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k] = g[k] * cv_selu_grad_from_out(a[k]);
+    gpre[t] = r;
+}
+
+// gpool / pooled: HO = H - p + 1 rows; gpre: H rows
+static int launch_unpool(const float *gpool, const float *pooled, const float *codes, float *gpre, int64_t G, int H, int NT,
+                         int p, hipStream_t st, int tiny_g)
+{
+    const tf4 *gi = (const tf4 *)gpool, *pi = (const tf4 *)pooled;
+    const uint2 *ci = (const uint2 *)codes;
+    tf4 *go = (tf4 *)gpre;
+    if (p == 1) {
+        const int64_t nf4 = G * H * 4 * NT * 64;
+        b_selu_out_tm<<<nblk(nf4, 256), 256, 0, st>>>(gi, pi, go, nf4);
+        return 0;
+    }
+    const int HO = H - p + 1;
+    if (G <= tiny_g) {       // tiny batches (cv_model::tiny_g)
         const unsigned grid = (unsigned)((G * H * 4 * NT * 64 + 255) / 256);
-        const tf4 *gi = (const tf4 *)gpool, *ai = (const tf4 *)act;
-        tf4 *go = (tf4 *)gpre;
         switch (p) {
-        case 2: b_pool_selu_rows<2><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); return 0;
-        case 3: b_pool_selu_rows<3><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); return 0;
-        case 4: b_pool_selu_rows<4><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); return 0;
-        case 5: b_pool_selu_rows<5><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); return 0;
+        case 2: b_unpool_rows<2><<<grid, 256, 0, st>>>(gi, pi, ci, go, G, HO, NT); return 0;
+        case 3: b_unpool_rows<3><<<grid, 256, 0, st>>>(gi, pi, ci, go, G, HO, NT); return 0;
+        case 4: b_unpool_rows<4><<<grid, 256, 0, st>>>(gi, pi, ci, go, G, HO, NT); return 0;
+        case 5: b_unpool_rows<5><<<grid, 256, 0, st>>>(gi, pi, ci, go, G, HO, NT); return 0;
         default: break;
         }
     }
     const unsigned grid = (unsigned)((G * 4 * NT * 64 + 255) / 256);
-    const tf4 *gi = (const tf4 *)gpool, *ai = (const tf4 *)act;
-    tf4 *go = (tf4 *)gpre;
     switch (p) {
-    case 1: b_pool_selu_tm<1><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); break;
-    case 2: b_pool_selu_tm<2><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); break;
-    case 3: b_pool_selu_tm<3><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); break;
-    case 4: b_pool_selu_tm<4><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); break;
-    case 5: b_pool_selu_tm<5><<<grid, 256, 0, st>>>(gi, ai, go, G, H, NT); break;
+    case 2: b_unpool_tm<2><<<grid, 256, 0, st>>>(gi, pi, ci, go, G, HO, NT); break;
+    case 3: b_unpool_tm<3><<<grid, 256, 0, st>>>(gi, pi, ci, go, G, HO, NT); break;
+    case 4: b_unpool_tm<4><<<grid, 256, 0, st>>>(gi, pi, ci, go, G, HO, NT); break;
+    case 5: b_unpool_tm<5><<<grid, 256, 0, st>>>(gi, pi, ci, go, G, HO, NT); break;
     default: cv_set_error("pooling window %d is not supported by the tile backward pass", p); return 1;
     }
     return 0;
@@ -767,8 +748,11 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     size_t fp[3], fa[3];                               // floats per candidate: pooled / pre-pool maps
     for (int l = 0; l < 3; l++) { fp[l] = (size_t)s.hp[l] * 4 * s.ntile[l] * 16; fa[l] = (size_t)s.hc[l] * 4 * s.ntile[l] * 16; }
     const size_t f4u = (size_t)s.nb4 * 16, f5u = (size_t)s.nb5 * 16;
-    float *tp[3], *ta[3];
-    for (int l = 0; l < 3; l++) { tp[l] = sb.take(np * fp[l]); ta[l] = sb.take(np * fa[l]); }
+    float *tp[3], *ta[3];          // pooled maps; window-offset codes of the pooled values (pooled layers only)
+    for (int l = 0; l < 3; l++) {
+        tp[l] = sb.take(np * fp[l]);
+        ta[l] = a.pool[l] > 1 ? sb.take((size_t)Gn * s.hp[l] * s.ntile[l] * 128) : nullptr;
+    }
     float *th4 = sb.take(np * f4u), *td4 = sb.take(np * f4u), *tmask = sb.take(np * f4u), *th5 = sb.take(np * f5u);
     float *ghpre = sb.take((size_t)n * 16);
     float *kpart = sb.take((size_t)CV_DENSE_KSPLIT * np * f4u);      // partial sums of the k-split fc4 forward
@@ -809,11 +793,15 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     if (f.to_side()) return 1;
     if (cv_tile_dense_wgrad(m, 4, tp[2], tg4pre, n, sw)) return 1;
     if (dense_ready) CV_HIP(hipEventRecord(dense_ready, sw));
-    if (cv_tile_fc4_dgrad(m, tg4pre, tgin[2], n, st)) return 1;
+    // fc4's data gradient; full topology: fused with conv3's max-pool backward + SELU' (dbg3 = 1: as two kernels)
+    const bool fused3 = m->wpr_fc4 != nullptr && m->dbg[3] != 1;
+    if (fused3) { if (cv_tile_fc4_dgrad_unpool(m, tg4pre, tp[2], ta[2], tgpre[2], n, st)) return 1; }
+    else if (cv_tile_fc4_dgrad(m, tg4pre, tgin[2], n, st)) return 1;
     // conv stack
     for (int l = 2; l >= 0; l--) {
         const int H = s.hc[l], NT = s.ntile[l];
-        if (launch_pool_selu(tgin[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st, m->dbg[2] == 1 ? (1 << 30) : (m->dbg[2] == 2 ? 0 : m->tiny_g))) return 1;
+        if (l == 2 && fused3) {}
+        else if (launch_unpool(tgin[l], tp[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st, m->dbg[2] == 1 ? (1 << 30) : (m->dbg[2] == 2 ? 0 : m->tiny_g))) return 1;
         if (f.to_side()) return 1;
         if (l == 0) {        // first layer: X viewed as [33][16] fragments, read in place
             if (cv_tile_conv1_wgrad(m, x, tgpre[0], n, sw)) return 1;
