@@ -148,6 +148,8 @@ int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, 
 int cv_tile_fc4_dgrad_unpool(cv_model *m, const float *g_tm, const float *pooled, const float *codes, float *gpre, int64_t n,
                              hipStream_t st);
 int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
+int cv_tile_conv_dgrad_unpool(cv_model *m, int layer, const float *g_tm, const float *pooled, const float *codes, float *gpre,
+                              int64_t n, hipStream_t st);
 int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_tm, const float *g_tm, int64_t n, hipStream_t st);
 int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_tm, const float *g_tm, int64_t n, hipStream_t st);
 int cv_tile_conv1_wgrad(cv_model *m, const float *x, const float *g_tm, int64_t n, hipStream_t st);

@@ -1413,6 +1413,122 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
 }
 
 
+
+// ---------------------------------------------------------------------------
+// conv data gradient FUSED with the max-pool backward + SELU' of the layer below (training step, pooled layers).
+//   gIn[h][w][ci] = sum_{kh',kw',co} g[h + kh' - PT][w + kw' - 2][co] Wd[kh'][kw'][ci][co]     (conv_tm MODE 2, PT = KH-1-(KH-1)/2)
+//   gpre_below   = unpool(gIn) * selu'                                                          (cv_unpool.hpp)
+// conv_tm MODE 2 keeps a KH-row window of INPUT rows in registers (144 VGPRs for conv3's 48 gradient channels), which
+// leaves no room for the unpool window.  Here the convolution runs in SCATTER form: an input row is loaded once, used
+// by all KH taps and dropped; the KH output rows it contributes to live in KH rotating accumulator sets (the loop is
+// unrolled by KH, so set indices are constants).  For one output row the taps still arrive in ascending kh' with
+// (kw', cb, s) inside: the same chain as conv_tm MODE 2, bit for bit.  A finished row goes straight into the P-row
+// unpool window of its four bases and one pre-activation gradient row of the layer below leaves -- the pooled-map
+// gradient never exists in memory.  One wave per (group, output tile, part); a part owns a range of OUTPUT (pre-pool)
+// rows and recomputes the P-1 windows in front of it (same values).
+// ---------------------------------------------------------------------------
+template <int KH, int CINB, int NT, int HIN, int P, int HSPLIT>
+__global__ __launch_bounds__(256, 2) void conv_dgrad_unpool(const f4 *__restrict__ g_tm, const f4 *__restrict__ wp,
+                                                             const f4 *__restrict__ pooled, const u32x2 *__restrict__ codes,
+                                                             f4 *__restrict__ gpre, int G)
+{
+    extern __shared__ __attribute__((aligned(16))) f4 ldsw[];
+    constexpr int PADT = KH - 1 - (KH - 1) / 2, PADL = 2, HP = HIN + P - 1;
+    constexpr int NFRAG = NT * KH * 4 * CINB;
+    for (int i = threadIdx.x; i < NFRAG * 64; i += 256) ldsw[i] = wp[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int hs = wv % HSPLIT, gt = wv / HSPLIT;
+    const int g = gt / NT, nt = gt % NT;
+    if (g >= G) return;
+    const int pa = HP * hs / HSPLIT, pb = HP * (hs + 1) / HSPLIT;          // output rows [pa, pb)
+    const int lo = pa - (P - 1) > 0 ? pa - (P - 1) : 0;                    // windows (rows of gIn) [lo, hi]
+    const int hi = pb - 1 < HIN - 1 ? pb - 1 : HIN - 1;
+    const int hr0 = lo - PADT > 0 ? lo - PADT : 0;                         // input rows [hr0, hr1]
+    const int hr1 = hi - PADT + KH - 1 < HIN - 1 ? hi - PADT + KH - 1 : HIN - 1;
+    const f4 *inp = g_tm + (size_t)g * (HIN * 4 * CINB * 64) + lane;
+    const f4 *wl = ldsw + (size_t)nt * (KH * 4 * CINB * 64) + lane;
+    const f4 *pp = pooled + (size_t)g * (HIN * 4 * NT * 64) + (size_t)nt * 64 + lane;
+    const u32x2 *cp = codes + ((size_t)g * HIN * NT + nt) * 64 + lane;
+    f4 *op = gpre + (size_t)g * (HP * 4 * NT * 64) + (size_t)nt * 64 + lane;
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 acc[KH][4];
+#pragma unroll
+    for (int j = 0; j < KH; j++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) acc[j][w] = zero;
+    unpool_col<P> U[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) U[w].init();
+    // window h is complete in accumulator set S: into the unpool windows, output row h out
+    auto finish = [&](auto Sc, int h) __attribute__((always_inline)) {
+        constexpr int S = decltype(Sc)::value;
+        const u32x2 c = cp[(size_t)h * (NT * 64)];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const f4 y = pp[(size_t)(h * 4 + w) * (NT * 64)];
+            U[w].push(acc[S][w], y, cv_code16(c[0], c[1], w));
+            acc[S][w] = zero;
+            if (h >= pa) op[(size_t)(h * 4 + w) * (NT * 64)] = U[w].emit();
+        }
+    };
+    // input rows hr0 .. hr_end; rows past the map (SAME padding below it) contribute nothing but still retire a window
+    const int hr_end = hi - PADT + KH - 1;
+    auto step = [&](auto Uc, int hr) __attribute__((always_inline)) {
+        constexpr int UU = decltype(Uc)::value;          // hr % KH: accumulator set indices are constants
+        if (hr < hr0 || hr > hr_end) return;             // wave-uniform
+        if (hr < HIN) {
+            f4 in[4][CINB];
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+#pragma unroll
+                for (int cb = 0; cb < CINB; cb++) in[w][cb] = inp[(size_t)((hr * 4 + w) * CINB + cb) * 64];
+#pragma unroll
+            for (int kh = 0; kh < KH; kh++) {
+                const int h = hr + PADT - kh;            // the output row tap kh of this input row feeds
+                if (h >= lo && h <= hi) {                // wave-uniform
+                    const int S = (UU + PADT - kh + KH) % KH;       // a constant once the kh loop is unrolled
+#pragma unroll
+                    for (int kw = 0; kw < 4; kw++)
+#pragma unroll
+                        for (int cb = 0; cb < CINB; cb++) {
+                            const f4 A = wl[(size_t)((kh * 4 + kw) * CINB + cb) * 64];
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+                                for (int wo = 0; wo < 4; wo++) {
+                                    const int wi = wo + kw - PADL;
+                                    if (wi < 0 || wi > 3) continue;
+                                    acc[S][wo] = mfma4(A[s4], in[wi][cb][s4], acc[S][wo]);
+                                }
+                        }
+                }
+            }
+        }
+        const int hf = hr + PADT - (KH - 1);             // received its last tap
+        if (hf >= lo && hf <= hi) finish(std::integral_constant<int, (UU + PADT - (KH - 1) + KH) % KH>{}, hf);
+    };
+#pragma unroll 1
+    for (int hb = hr0 / KH * KH; hb <= hr_end; hb += KH) {
+        step(std::integral_constant<int, 0>{}, hb);
+        if constexpr (KH >= 2) { __builtin_amdgcn_sched_barrier(0); step(std::integral_constant<int, 1>{}, hb + 1); }
+        if constexpr (KH >= 3) { __builtin_amdgcn_sched_barrier(0); step(std::integral_constant<int, 2>{}, hb + 2); }
+        if constexpr (KH >= 4) { __builtin_amdgcn_sched_barrier(0); step(std::integral_constant<int, 3>{}, hb + 3); }
+        if constexpr (KH >= 5) { __builtin_amdgcn_sched_barrier(0); step(std::integral_constant<int, 4>{}, hb + 4); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (hi == HIN - 1) {                                 // the last P-1 output rows hold no window start
+        for (int h = HIN; h < pb; h++) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                U[w].push_none();
+                if (h >= pa) op[(size_t)(h * 4 + w) * (NT * 64)] = U[w].emit();
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // fc4 data gradient FUSED with the max-pool backward + SELU' of conv3 (training step, full topology).
 //   gF[k] = sum_j g4pre[j] W4[k][j]      (the gradient of the pooled conv3 map, k = flatten index (h, w, c))
@@ -2747,6 +2863,44 @@ int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm,
     if (layer == 2)
         return launch_conv_parts<5, 2, 1, 1, 33, 2>(split ? pick_hsplit(G, 1, 33, 0, 8) : 1, g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
     return launch_conv_parts<3, 1, 1, 1, 33, 2>(split ? pick_hsplit(G, 1, 33, 0, 8) : 1, g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
+}
+
+// layer 1 = conv2, 2 = conv3 (full topology): data gradient fused with the max-pool backward + SELU' of the layer below
+// (conv_dgrad_unpool): g_tm = this layer's pre-activation gradient, pooled / codes = the pooled output and window-offset
+// codes of layer - 1, gpre = pre-activation gradient of layer - 1 (hc[layer - 1] rows)
+template <int KH, int CINB, int NT, int HIN, int P>
+static int launch_dgrad_unpool(int hs, const float *g_tm, const float *wp, const float *pooled, const float *codes, float *gpre,
+                               int G, hipStream_t st)
+{
+    const size_t lds = (size_t)NT * KH * 4 * CINB * 1024;
+#define CV_DU(H) { auto k = conv_dgrad_unpool<KH, CINB, NT, HIN, P, H>; if (set_lds(k, lds)) return 1; \
+        k<<<nblk((int64_t)G * NT * H, 4), 256, lds, st>>>((const f4 *)g_tm, (const f4 *)wp, (const f4 *)pooled, (const u32x2 *)codes, (f4 *)gpre, G); }
+    switch (hs) {
+    case 2: CV_DU(2); break;
+    case 3: CV_DU(3); break;
+    case 4: CV_DU(4); break;
+    case 6: CV_DU(6); break;
+    case 8: CV_DU(8); break;
+    default: CV_DU(1); break;
+    }
+#undef CV_DU
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
+int cv_tile_conv_dgrad_unpool(cv_model *m, int layer, const float *g_tm, const float *pooled, const float *codes, float *gpre,
+                              int64_t n, hipStream_t st)
+{
+    const int G = (int)((n + 15) / 16);
+    if (!is_full(m->arch) || layer < 1 || layer > 2) { cv_set_error("cv_tile_conv_dgrad_unpool: full topology, conv2 / conv3"); return 1; }
+    const float *W = m->wpd_conv[layer];
+    const bool split = m->tiny_g > 0;
+    if (layer == 2) {
+        const int hs = m->dbg[0] > 0 ? m->dbg[0] : (split ? pick_hsplit(G, 2, 29, 3 + 2, 8) : 1);
+        return launch_dgrad_unpool<3, 3, 2, 26, 4>(hs, g_tm, W, pooled, codes, gpre, G, st);
+    }
+    const int hs = m->dbg[0] > 0 ? m->dbg[0] : (split ? pick_hsplit(G, 1, 33, 4 + 1, 8) : 1);
+    return launch_dgrad_unpool<2, 2, 1, 29, 5>(hs, g_tm, W, pooled, codes, gpre, G, st);
 }
 
 // heads of the training pass: pre-activations of the 16 outputs from the dropped-out fc4 output and fc5 (tile-major)

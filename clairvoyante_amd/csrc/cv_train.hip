@@ -797,17 +797,24 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     const bool fused3 = m->wpr_fc4 != nullptr && m->dbg[3] != 1;
     if (fused3) { if (cv_tile_fc4_dgrad_unpool(m, tg4pre, tp[2], ta[2], tgpre[2], n, st)) return 1; }
     else if (cv_tile_fc4_dgrad(m, tg4pre, tgin[2], n, st)) return 1;
-    // conv stack
+    // conv stack.  Pooled layers of the full topology: the data gradient of layer l writes the pre-activation gradient of
+    // layer l - 1 directly (conv_dgrad_unpool; dbg4 = 1: data gradient and unpool as two kernels)
+    // Measured (profiles/r03): at train.py's batch (625 groups) the fused kernel loses -- one wave per (group, tile)
+    // is 1 250 waves for 1 024 SIMDs, and position parts recompute P - 1 windows each (385 us against 254 + 79 for
+    // conv3) -- so it serves the tiny batches (a rank's share under data parallelism: 0.793 -> 0.768 ms at 1 250),
+    // where the step is a chain of latency-bound kernels and one launch less per layer counts.  dbg4 = 2: always.
+    const bool fusedc = m->wpr_fc4 != nullptr && m->dbg[4] != 1 && (Gn <= m->tiny_g || m->dbg[4] == 2);
     for (int l = 2; l >= 0; l--) {
         const int H = s.hc[l], NT = s.ntile[l];
-        if (l == 2 && fused3) {}
-        else if (launch_unpool(tgin[l], tp[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st, m->dbg[2] == 1 ? (1 << 30) : (m->dbg[2] == 2 ? 0 : m->tiny_g))) return 1;
+        const bool have_gpre = (l == 2 && fused3) || (l < 2 && fusedc);
+        if (!have_gpre && launch_unpool(tgin[l], tp[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st, m->dbg[2] == 1 ? (1 << 30) : (m->dbg[2] == 2 ? 0 : m->tiny_g))) return 1;
         if (f.to_side()) return 1;
         if (l == 0) {        // first layer: X viewed as [33][16] fragments, read in place
             if (cv_tile_conv1_wgrad(m, x, tgpre[0], n, sw)) return 1;
         } else {
             if (cv_tile_conv_wgrad(m, l, tp[l - 1], tgpre[l], n, sw)) return 1;
-            if (cv_tile_conv_dgrad(m, l, tgpre[l], tgin[l - 1], n, st)) return 1;
+            if (fusedc) { if (cv_tile_conv_dgrad_unpool(m, l, tgpre[l], tp[l - 1], ta[l - 1], tgpre[l - 1], n, st)) return 1; }
+            else if (cv_tile_conv_dgrad(m, l, tgpre[l], tgin[l - 1], n, st)) return 1;
         }
     }
     if (f.join()) return 1;
