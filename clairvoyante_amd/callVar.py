@@ -412,9 +412,16 @@ def TestSharded(args, m, utils, rank, ws):
     fetcher = ResultFetcher(m)
     q_in = Queue(maxsize=4)
 
+    # "--tensor_fn a.gz,b.gz,...": one file per chunk, file k -> rank k % ws (each rank inflates only its own files);
+    # a single file: its LINES are split block-cyclically (every rank inflates the whole stream -- the job is then
+    # capped by one core's gzip rate whatever the number of GPUs)
+    files = [f for f in args.tensor_fn.split(",") if f]
+
     def reader():
         try:
-            for item in utils.GetTensorBlocks(args.tensor_fn, SHARD_BLOCK_LINES, rank, ws):
+            src = utils.GetTensorFiles(files, max(param.predictBatchSize, 16384), rank, ws) if len(files) > 1 else \
+                utils.GetTensorBlocks(args.tensor_fn, SHARD_BLOCK_LINES, rank, ws)
+            for item in src:
                 q_in.put(item)
         except BaseException as e:
             q_in.put(e)
@@ -447,7 +454,10 @@ def TestSharded(args, m, utils, rank, ws):
                         hcall, hqual = fetcher.fetch(pev, pcall, pqual)
                         text = format_records(args, pnum, pX, ppos, hcall, hqual)
                     frag.write(text)
-                    index.append((pblock, len(text)))
+                    if index and index[-1][0] == pblock:          # further batches of the same block (a whole file)
+                        index[-1] = (pblock, index[-1][1] + len(text))
+                    else:
+                        index.append((pblock, len(text)))
                 pending = nxt
                 if item is None:
                     break

@@ -58,18 +58,6 @@ def shard_range(total, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allreduce_sum_(flat, losses=None):
-    """In-place SUM all-reduce of a flat tensor (+ optional list of python floats)."""
-    if not _active():
-        return losses
-    _all_reduce(flat)
-    if losses is not None:
-        t = torch.tensor(losses, dtype=torch.float64, device=flat.device)
-        _all_reduce(t)
-        losses = t.tolist()
-    return losses
-
-
 _host_staged = [None]      # gloo without device support: collectives of device tensors go through the host
 
 

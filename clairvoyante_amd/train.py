@@ -272,7 +272,12 @@ class _Job(Thread):
 def load_dataset(args, utils):
     """(total, XC, YC, posC) from --bin_fn or from --tensor_fn/--var_fn/--bed_fn (train.py:39-49)"""
     if args.bin_fn is not None:
-        return utils.LoadBin(args.bin_fn) if hasattr(utils, "LoadBin") else _load_bin(args.bin_fn)
+        if hasattr(utils, "LoadBin"):
+            try:
+                return utils.LoadBin(args.bin_fn, lazy=True)     # memory-mapped: one page-cache copy for all ranks
+            except TypeError:                                    # a foreign utils module with the plain signature
+                return utils.LoadBin(args.bin_fn)
+        return _load_bin(args.bin_fn)
     return utils.GetTrainingArray(args.tensor_fn, args.var_fn, args.bed_fn)
 
 

@@ -165,6 +165,18 @@ def GetTensorBlocks(tensor_fn, block_lines, rank, ws):
     proc.wait()
 
 
+def GetTensorFiles(files, num, rank, ws):
+    """Sharding of callVar under torchrun that SCALES: one tensor file per chunk of the genome (the reference's own
+    recipe is one callVarBam / callVar job per chunk, README.md:184-202), file k belongs to rank k % ws -- a rank only
+    ever opens (and inflates) its own files.  Yields (file index, c, X, pos) batches of <= num rows, at least one
+    per owned file."""
+    for k, fn in enumerate(files):
+        if k % ws != rank:
+            continue
+        for _end, c, X, pos in GetTensor(fn, num, log=False):
+            yield k, c, X, pos
+
+
 def GetTensor(tensor_fn, num, log=True):
     """Generator over batches of `num` candidates: yields (endFlag, c, X, pos) exactly like
     utils_v2.py:23-59 -- X [c,33,4,4] fp32 with matrices 1..3 minus matrix 0, rows whose
@@ -289,8 +301,83 @@ def unpack_arrays(chunks):
     return arrays
 
 
-def LoadBin(bin_fn):
-    """The four back-to-back pickles of tensor2Bin.py:24-28 (also files written by Python 2)."""
+class LazyBlocks(object):
+    """The compressed-block list of a .bin file WITHOUT loading it: (offset, length) of every block inside the
+    memory-mapped file.  Items are zero-copy memoryviews of the page cache, so the N ranks of a node share ONE copy
+    of the data set in RAM (un-pickling gives every rank its own heap copy of all blocks) and a rank only ever
+    touches the pages of the blocks its slices of the batches live in."""
+
+    def __init__(self, mm, index):
+        self._mm, self._index = mm, index
+        self._view = memoryview(mm)
+
+    def __len__(self):
+        return len(self._index)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        off, n = self._index[i]
+        return self._view[off:off + n]
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+
+def _scan_block_list(mm, pos):
+    """Walks ONE pickle that holds a list of byte strings (what tensor2Bin.py:24-28 dumps, protocols 2..5) starting at
+    byte `pos` of the mapped file, reading the opcode headers only -> ([(offset, length)], position after STOP),
+    or None when the stream holds anything else (the caller then un-pickles)."""
+    import struct
+    n = len(mm)
+    index = []
+    while pos < n:
+        op = mm[pos]
+        if op == 0x80: pos += 2                                    # PROTO
+        elif op == 0x95: pos += 9                                  # FRAME
+        elif op in (0x5d, 0x28, 0x94, 0x65, 0x61): pos += 1        # EMPTY_LIST, MARK, MEMOIZE, APPENDS, APPEND
+        elif op == 0x71: pos += 2                                  # BINPUT
+        elif op == 0x72: pos += 5                                  # LONG_BINPUT
+        elif op in (0x43, 0x55):                                   # SHORT_BINBYTES, SHORT_BINSTRING
+            ln = mm[pos + 1]; index.append((pos + 2, ln)); pos += 2 + ln
+        elif op in (0x42, 0x54):                                   # BINBYTES, BINSTRING
+            ln = struct.unpack_from("<I", mm, pos + 1)[0]; index.append((pos + 5, ln)); pos += 5 + ln
+        elif op == 0x8e:                                           # BINBYTES8
+            ln = struct.unpack_from("<Q", mm, pos + 1)[0]; index.append((pos + 9, ln)); pos += 9 + ln
+        elif op == 0x2e:                                           # STOP
+            return index, pos + 1
+        else:
+            return None
+    return None
+
+
+def LoadBin(bin_fn, lazy=False):
+    """The four back-to-back pickles of tensor2Bin.py:24-28 (also files written by Python 2) -> (total, XC, YC, posC).
+    lazy: the three block lists as LazyBlocks over the memory-mapped file (the training loop under data parallelism:
+    no rank holds a private copy of the data set); falls back to un-pickling when the file is not the plain
+    list-of-byte-strings layout."""
+    if lazy:
+        import mmap
+        fh = open(bin_fn, "rb")
+        try:
+            try:
+                total = pickle.load(fh)
+            except (UnicodeDecodeError, ValueError):
+                fh.seek(0); total = pickle.load(fh, encoding="bytes")
+            mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+            pos = fh.tell()
+            lists = []
+            for _ in range(3):
+                got = _scan_block_list(mm, pos)
+                if got is None:
+                    lists = None
+                    break
+                lists.append(LazyBlocks(mm, got[0])); pos = got[1]
+            if lists is not None and all(len(l) == len(lists[0]) for l in lists):
+                return total, lists[0], lists[1], lists[2]
+        finally:
+            fh.close()
     with open(bin_fn, "rb") as fh:
         try:
             objs = [pickle.load(fh) for _ in range(4)]
@@ -485,9 +572,12 @@ def _unpack_into_one(blocks, key):
     bs = param.bloscBlockSize
     item = int(np.prod(ishape, dtype=np.int64)) * dtype.itemsize
     n = len(blocks)
-    raw = [c.encode("latin1") if isinstance(c, str) else bytes(c) for c in blocks]
+    # addresses of the compressed blocks where they lie (bytes objects, or views of the mapped file: no copies)
+    raw = [c.encode("latin1") if isinstance(c, str) else c for c in blocks]
+    hold = [r if isinstance(r, bytes) else np.frombuffer(r, dtype=np.uint8) for r in raw]
     out = _pinned.empty((n * bs,) + tuple(ishape), dtype)
-    src = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(r), ctypes.c_void_p).value for r in raw])
+    src = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(h), ctypes.c_void_p).value if isinstance(h, bytes)
+                                  else h.ctypes.data for h in hold])
     clen = (ctypes.c_int64 * n)(*[len(r) for r in raw])
     lens = (ctypes.c_int64 * n)()
     status = (ctypes.c_int32 * n)()

@@ -443,6 +443,40 @@ def test_callvar_command_line_under_two_ranks_writes_the_single_rank_vcf(oracle,
     assert not [f for f in os.listdir(str(tmp_path)) if ".rank" in f]
 
 
+def test_callvar_command_line_under_two_ranks_over_a_list_of_files(oracle, tmp_path):
+    """--tensor_fn a.gz,b.gz,c.gz under two ranks: file k belongs to rank k % 2 -- the form that scales (no rank inflates
+    input it does not call); the VCF equals the concatenation of the three single-process runs (bodies in list order)"""
+    import subprocess
+    import test_gpu_pipeline as tp
+    P = common.bench_params(oracle, "full")
+    m = _model("full"); m.setParameters(P)
+    prefix = str(tmp_path / "model")
+    m.saveParameters(prefix); m.close()
+    files = []
+    for k, n in enumerate((1500, 20000, 700)):           # the second file spans two reader batches of 16 384 rows
+        fn = str(tmp_path / ("t%d.gz" % k))
+        tp._write_text_tensors(fn, common.inputs(n, seed=50 + k))
+        files.append(fn)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    base = [sys.executable, "-m", "clairvoyante_amd.callVar", "--chkpnt_fn", prefix, "--sampleName", "NA12878"]
+    bodies, header = [], None
+    for k, fn in enumerate(files):
+        out = str(tmp_path / ("one%d.vcf" % k))
+        subprocess.check_call(base + ["--tensor_fn", fn, "--call_fn", out], env=env, cwd=ROOT)
+        lines = open(out).read().splitlines(True)
+        header = [l for l in lines if l.startswith("#")]
+        bodies += [l for l in lines if not l.startswith("#")]
+    two = str(tmp_path / "two.vcf")
+    port = 29300 + os.getpid() % 500
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                 CV_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen(base + ["--tensor_fn", ",".join(files), "--call_fn", two], env=e, cwd=ROOT))
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    assert open(two).read() == "".join(header + bodies) and len(bodies) > 500
+
+
 _RCCL_ONE_RANK = r"""
 import os, sys, ctypes
 import numpy as np, torch, torch.distributed as dist

@@ -86,13 +86,22 @@ def test_training_array_matches_reference():
     assert [str(s) for s in P] == [str(s) for s in d["pos"]]
 
 
+@pytest.mark.parametrize("lazy", [False, True])
 @pytest.mark.parametrize("fn", ["mini.bin", "mini_py2proto.bin"])
-def test_bin_file_blocks_written_by_c_blosc(fn):
-    """`.bin` = 4 pickles (tensor2Bin.py:24-28); blocks here were packed by the real c-blosc"""
+def test_bin_file_blocks_written_by_c_blosc(fn, lazy):
+    """`.bin` = 4 pickles (tensor2Bin.py:24-28); blocks here were packed by the real c-blosc.  lazy: the block lists
+    as offsets into the memory-mapped file (what train.py loads: no private copy per rank) -- same blocks"""
     from clairvoyante_amd import utils_v2
     d = np.load(os.path.join(G, "trainarray.npz"))
-    total, XC, YC, PC = utils_v2.LoadBin(os.path.join(G, fn))
+    total, XC, YC, PC = utils_v2.LoadBin(os.path.join(G, fn), lazy=lazy)
     assert total == int(d["total"])
+    if lazy and fn == "mini_py2proto.bin":
+        assert isinstance(XC, list)          # a protocol-0 text pickle: not the plain layout, un-pickled as before
+    elif lazy:
+        assert isinstance(XC, utils_v2.LazyBlocks) and isinstance(YC, utils_v2.LazyBlocks)
+        _t, XE, YE, PE = utils_v2.LoadBin(os.path.join(G, fn))
+        enc = lambda b: b.encode("latin1") if isinstance(b, str) else bytes(b)
+        assert [bytes(b) for b in XC] == [enc(b) for b in XE] and [bytes(b) for b in PC] == [enc(b) for b in PE]
     X, _, _ = utils_v2.DecompressArray(XC, 0, total, total)
     Y, _, _ = utils_v2.DecompressArray(YC, 0, total, total)
     assert np.array_equal(X, d["X"]) and np.array_equal(Y, d["Y"])
