@@ -248,7 +248,7 @@ __global__ void dropout_tm(const float *__restrict__ h4, float *__restrict__ d4,
 
 // ---------------------------------------------------------------------------
 // Training forward: which row of its window a pooled value came from.
-// The backward pass routes the gradient of a pooled value to the FIRST maximum of its window (oracle/cv_oracle.c pool
+// The backward pass routes the gradient of a pooled value to the FIRST maximum of its window (the canonical rule of this build, pool
 // backward; the reference's tf.layers.max_pooling2d gradient).  Instead of keeping the pre-pool activations for that
 // (0.68 MB per group of 16 candidates), the forward kernels record the window offset d of the first maximum: 4 bits per
 // value, the 16 values a lane holds of a pooled row (4 bases x 4 registers) in one 64-bit word -- value (w, r) at bits
