@@ -37,6 +37,16 @@ __device__ __forceinline__ f4 selu4(f4 v)
     f4 r;
     r[0] = cvm::selu(v[0]); r[1] = cvm::selu(v[1]); r[2] = cvm::selu(v[2]); r[3] = cvm::selu(v[3]);
     return r;
+#elif defined(CV_SELU_UNIFORM)             /* development: skip the negative branch when no lane of the wave needs it */
+    // Measured on the bench's synthetic set (profiles/r03/selu_wave_uniform.txt): 12 % of the first layer's pooled
+    // registers and 1.6 % of conv2's hold no negative value in any of the 64 lanes -- too few for the two extra
+    // instructions per pair (v_cmp + s_cbranch) to pay; kept as an A/B switch, off by default.
+    cvm::f2v a, b;
+    if (__builtin_amdgcn_ballot_w64(fminf(v[0], v[1]) < 0.0f) == 0) { a[0] = cvm::SELU_SCALE * v[0]; a[1] = cvm::SELU_SCALE * v[1]; }
+    else a = cvm::selu2((cvm::f2v){v[0], v[1]});
+    if (__builtin_amdgcn_ballot_w64(fminf(v[2], v[3]) < 0.0f) == 0) { b[0] = cvm::SELU_SCALE * v[2]; b[1] = cvm::SELU_SCALE * v[3]; }
+    else b = cvm::selu2((cvm::f2v){v[2], v[3]});
+    return (f4){a[0], a[1], b[0], b[1]};
 #else
     const cvm::f2v a = cvm::selu2((cvm::f2v){v[0], v[1]}), b = cvm::selu2((cvm::f2v){v[2], v[3]});
     return (f4){a[0], a[1], b[0], b[1]};
