@@ -160,6 +160,7 @@ extern "C" int cv_destroy(cv_model *m)
         (void)hipStreamDestroy(m->tr_side);
         for (int i = 0; i < CV_TR_EVENTS; i++) (void)hipEventDestroy(m->tr_ev[i]);
         (void)hipEventDestroy(m->tr_dense_ready);
+        (void)hipEventDestroy(m->tr_pack_fork); (void)hipEventDestroy(m->tr_pack_done);
     }
     cv_prof_free(m);
     delete m;

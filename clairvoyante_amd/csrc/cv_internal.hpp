@@ -94,6 +94,7 @@ struct cv_model {
     hipStream_t tr_side;
     hipEvent_t tr_ev[16];
     hipEvent_t tr_dense_ready;
+    hipEvent_t tr_pack_fork, tr_pack_done;   // weight packing on the side stream (cv_pack_for_training)
     int train_overlap;   // option: weight gradients on the side stream (default 1)
     int train_ksplit;    // option: k-split fc4 forward at tiny batches (default 0)
     int tiny_g;          // option "train_tiny_groups": batches of up to this many groups take the latency-oriented
@@ -136,7 +137,8 @@ int cv_launch_heads(cv_model *m, const float *h4, const float *h5, int tm, int64
                     hipStream_t st);
 bool cv_tile_supported(const cv_model *m);
 int cv_pack_train_weights(cv_model *m, hipStream_t st);
-int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward);   // whatever is stale, in one launch
+int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward, hipStream_t sw = nullptr, hipEvent_t fork = nullptr,
+                         hipEvent_t done = nullptr, bool *wait_before_dense = nullptr);   // whatever is stale
 int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float *a1, float *p2, float *a2,
                         float *p3, float *a3, hipStream_t st);
 #define CV_DENSE_KSPLIT 8      // k ranges of the fc4 training forward at tiny batches (cv_tile_dense_fwd)

@@ -1982,20 +1982,24 @@ struct pack_builder {
 
 // forward fragments (inference and training); with_train: also the transposed / flipped fragments of the
 // data-gradient kernels
-static int pack_launch(cv_model *m, hipStream_t st, bool fwd, bool with_train)
+// part 0: all jobs; 1: only the convolution forward fragments (a few KB: what the first kernels of a pass need);
+// 2: everything else (the dense layers in all their slab forms, the heads, the data-gradient fragments: ~30 MB)
+static int pack_launch(cv_model *m, hipStream_t st, bool fwd, bool with_train, int part = 0)
 {
     const float *P = m->params;
     const int64_t *o = m->poff;
     const cv_shapes &s = m->sh;
     const cv_arch &a = m->arch;
     pack_builder pb;
-    if (fwd) {
+    if (fwd && part != 2) {
         { pack_job &J = pb.add(0, 256); J.src[0] = P + o[0]; J.dst[0] = m->wp_conv1; J.i[0] = a.cout[0]; }
         for (int l = 1; l < 3; l++) {
             pack_job &J = pb.add(1, (int64_t)s.ntile[l] * a.kh[l] * 4 * s.cinb[l] * 256);
             J.src[0] = P + o[2 * l]; J.dst[0] = m->wp_conv[l];
             J.i[0] = a.kh[l]; J.i[1] = s.cin[l]; J.i[2] = a.cout[l]; J.i[3] = s.cinb[l]; J.i[4] = s.ntile[l];
         }
+    }
+    if (fwd && part != 1) {
         const int nbp4 = (s.nb4 + 3) / 4 * 4, nbp5 = (s.nb5 + 3) / 4 * 4;   // launch_dense: WAVES = 4
         { pack_job &J = pb.add(2, (int64_t)s.kb4 * nbp4 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wp_fc4;
           J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = nbp4; }
@@ -2017,7 +2021,7 @@ static int pack_launch(cv_model *m, hipStream_t st, bool fwd, bool with_train)
           J.src[0] = P + o[10]; J.src[1] = P + o[12]; J.src[2] = P + o[14]; J.src[3] = P + o[16];
           J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb4; J.i[3] = s.nb5; J.dst[0] = m->wp_heads0; J.dst[1] = m->wp_heads1; }
     }
-    if (with_train) {
+    if (with_train && part != 1) {
         for (int l = 1; l < 3; l++) {
             pack_job &J = pb.add(5, (int64_t)s.cinb[l] * a.kh[l] * 4 * s.ntile[l] * 256);
             J.src[0] = P + o[2 * l]; J.dst[0] = m->wpd_conv[l];
@@ -2050,12 +2054,25 @@ int cv_pack_weights(cv_model *m, hipStream_t st)
     return 0;
 }
 
-// training step: whatever is stale in one launch
-int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward)
+// training step: whatever is stale.  One launch on `st`; or, with a side stream, the convolution fragments on `st`
+// (the first kernels need them) and the 30 MB of dense / data-gradient fragments on `sw` next to the convolution
+// forward pass -- *wait_before_dense is then the event `st` has to wait for before the first dense layer.
+int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward, hipStream_t sw, hipEvent_t fork, hipEvent_t done,
+                         bool *wait_before_dense)
 {
+    if (wait_before_dense) *wait_before_dense = false;
     const bool fwd = m->packed_dirty, tr = backward && m->packed_train_dirty;
     if (!fwd && !tr) return 0;
-    if (pack_launch(m, st, fwd, tr)) return 1;
+    if (sw == st || !sw || !wait_before_dense) {
+        if (pack_launch(m, st, fwd, tr)) return 1;
+    } else {
+        CV_HIP(hipEventRecord(fork, st));              // behind the optimizer update of the previous step
+        CV_HIP(hipStreamWaitEvent(sw, fork, 0));
+        if (pack_launch(m, st, fwd, tr, 1)) return 1;
+        if (pack_launch(m, sw, fwd, tr, 2)) return 1;
+        CV_HIP(hipEventRecord(done, sw));
+        *wait_before_dense = true;
+    }
     if (fwd) m->packed_dirty = false;
     if (tr) m->packed_train_dirty = false;
     return 0;

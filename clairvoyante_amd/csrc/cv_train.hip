@@ -404,19 +404,6 @@ __global__ void b_bias_grad(const float *__restrict__ g, int64_t rows, int C, fl
 // ---- element-wise backward steps directly on tile-major buffers ----------------------------
 typedef float tf4 __attribute__((ext_vector_type(4)));
 
-// g_pre = g_act * (mask) * selu'(act) over a whole TM buffer (padding entries carry zeros)
-__global__ void b_selu_tm(const tf4 *__restrict__ gact, const tf4 *__restrict__ act, const tf4 *__restrict__ mask,
-                          tf4 *__restrict__ gpre, int64_t nf4)
-{
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nf4) return;
-    tf4 g = gact[t], a = act[t], r;
-    if (mask) g *= mask[t];
-#pragma unroll
-    for (int k = 0; k < 4; k++) r[k] = g[k] * selu_grad_from_out(a[k]);
-    gpre[t] = r;
-}
-
 // max-pool backward + SELU' on TM maps from the forward pass's window-offset codes (cv_unpool.hpp): one thread per
 // (group, base, tile, lane) streams over the pooled rows -- per row one gradient fragment, one pooled-output fragment
 // and 8 code bytes are read, one finished row is written; the pre-pool activations are never needed.
@@ -573,12 +560,15 @@ __global__ __launch_bounds__(256) void t_heads_loss(float *__restrict__ pre, con
     if (threadIdx.x < 4) atomicAdd(&loss[threadIdx.x], part[threadIdx.x]);
 }
 
-// heads: data gradients written into TM buffers.  mode 0: gh5_tm = sum over the three fc5-side
-// heads (all entries written, padding = 0); mode 1: gd4_tm += base-head contribution.
+// heads: data gradients in TM layout, fused with the SELU' (and dropout) factor of the layer they flow into.
+//   mode 0: g5pre = (sum over the three fc5-side heads) * selu'(h5)                      -- all entries written, padding = 0
+//   mode 1: g4pre = (gd4 + base-head contribution) * amask * selu'(h4)                   -- gd4 = fc5's data gradient
+// (one pass instead of a head-gradient pass plus an element-wise pass per layer)
 __global__ void b_head_dgrad_tm(const float *__restrict__ ghpre, const float *__restrict__ wb,
                                 const float *__restrict__ wz, const float *__restrict__ wt,
                                 const float *__restrict__ wl, int K, int KB, int64_t n, int64_t G, int mode,
-                                float *__restrict__ out_tm)
+                                const float *__restrict__ gin_tm, const float *__restrict__ act_tm,
+                                const float *__restrict__ mask_tm, float *__restrict__ out_tm)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= G * KB * 256) return;
@@ -600,8 +590,9 @@ __global__ void b_head_dgrad_tm(const float *__restrict__ ghpre, const float *__
             for (int j = 0; j < 4; j++) acc = __builtin_fmaf(gi[j], wb[(size_t)k * 4 + j], acc);
         }
     }
-    if (mode == 0) out_tm[t] = acc;
-    else out_tm[t] += acc;
+    float gact = mode == 0 ? acc : gin_tm[t] + acc;
+    if (mask_tm) gact *= mask_tm[t];
+    out_tm[t] = gact * selu_grad_from_out(act_tm[t]);
 }
 
 struct slab {
@@ -758,8 +749,10 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     float *kpart = sb.take((size_t)CV_DENSE_KSPLIT * np * f4u);      // partial sums of the k-split fc4 forward
     if (!ghpre || !kpart) { cv_set_error("training workspace too small"); return 1; }
     // ---- forward
-    if (cv_pack_for_training(m, st, backward)) return 1;
+    bool pack_wait = false;       // dbg5 = 1: all packing in one launch on st, as before
+    if (cv_pack_for_training(m, st, backward, m->dbg[5] == 1 ? st : sw, m->tr_pack_fork, m->tr_pack_done, &pack_wait)) return 1;
     if (cv_tile_train_convs(m, x, n, tp[0], ta[0], tp[1], ta[1], tp[2], ta[2], st)) return 1;
+    if (pack_wait) CV_HIP(hipStreamWaitEvent(st, m->tr_pack_done, 0));
     if (cv_tile_dense_fwd(m, 4, tp[2], th4, n, st, m->train_ksplit ? kpart : nullptr)) return 1;
     if (cv_dropout_tm(m, th4, td4, tmask, n, backward ? drop4 : 0.0f, seed, step, cand0, st)) return 1;
     m->last_tr_d4 = td4; m->last_tr_mask = tmask; m->last_tr_n = n; m->last_tr_tile = 1;
@@ -769,7 +762,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     CV_HIP(hipGetLastError());
     if (!backward) return 0;
     // ---- backward buffers (TM gradients; the weight-gradient kernels transpose their operands on the way in)
-    float *tg5 = sb.take(np * f5u), *tg5pre = sb.take(np * f5u), *tgd4 = sb.take(np * f4u), *tg4pre = sb.take(np * f4u);
+    float *tg5pre = sb.take(np * f5u), *tgd4 = sb.take(np * f4u), *tg4pre = sb.take(np * f4u);
     float *tgpre[3], *tgin[3];
     for (int l = 0; l < 3; l++) { tgpre[l] = sb.take(np * fa[l]); tgin[l] = sb.take(np * fp[l]); }
     if (!tgin[2]) { cv_set_error("training workspace too small"); return 1; }
@@ -779,16 +772,14 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     if (f.to_side()) return 1;
     if (cv_tile_heads_wgrad(m, td4, th5, ghpre, n, sw)) return 1;
     b_head_dgrad_tm<<<nblk(Gn * s.nb5 * 256, 256), 256, 0, st>>>(ghpre, P + o[10], P + o[12], P + o[14], P + o[16], a.fc5,
-                                                               s.nb5, n, Gn, 0, tg5);
+                                                               s.nb5, n, Gn, 0, nullptr, th5, nullptr, tg5pre);
     // fc5
-    b_selu_tm<<<nblk(np * f5u / 4, 256), 256, 0, st>>>((const tf4 *)tg5, (const tf4 *)th5, nullptr, (tf4 *)tg5pre, np * f5u / 4);
     if (f.to_side()) return 1;
     if (cv_tile_dense_wgrad(m, 5, td4, tg5pre, n, sw)) return 1;
     if (cv_tile_fc5_dgrad(m, tg5pre, tgd4, n, st)) return 1;
+    // + the base head's contribution, then dropout4 + selu' (h4 is the SELU output before dropout)
     b_head_dgrad_tm<<<nblk(Gn * s.nb4 * 256, 256), 256, 0, st>>>(ghpre, P + o[10], P + o[12], P + o[14], P + o[16], a.fc4,
-                                                               s.nb4, n, Gn, 1, tgd4);
-    // dropout4 + selu' (h4 is the SELU output before dropout)
-    b_selu_tm<<<nblk(np * f4u / 4, 256), 256, 0, st>>>((const tf4 *)tgd4, (const tf4 *)th4, (const tf4 *)tmask, (tf4 *)tg4pre, np * f4u / 4);
+                                                               s.nb4, n, Gn, 1, tgd4, th4, tmask, tg4pre);
     // fc4
     if (f.to_side()) return 1;
     if (cv_tile_dense_wgrad(m, 4, tp[2], tg4pre, n, sw)) return 1;
@@ -879,6 +870,8 @@ static int train_workspace(cv_model *m, int64_t n, int64_t *slice_out)
         CV_HIP(hipStreamCreateWithFlags(&m->tr_side, hipStreamNonBlocking));
         for (int i = 0; i < CV_TR_EVENTS; i++) CV_HIP(hipEventCreateWithFlags(&m->tr_ev[i], hipEventDisableTiming));
         CV_HIP(hipEventCreateWithFlags(&m->tr_dense_ready, hipEventDisableTiming));
+        CV_HIP(hipEventCreateWithFlags(&m->tr_pack_fork, hipEventDisableTiming));
+        CV_HIP(hipEventCreateWithFlags(&m->tr_pack_done, hipEventDisableTiming));
     }
     *slice_out = slice;
     return 0;
