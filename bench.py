@@ -322,7 +322,8 @@ def train_main(args):
     gb = param.trainBatchSize if args.batch == BATCH else args.batch      # --batch: another global batch (default: the reference's)
     steps = args.steps if args.steps != 64 else 20
     r = run_train(args.arch, gb, steps, args.warmup, rank, ws, dev, sync_loss=args.sync_loss,
-                  options=dict({"train_overlap": args.overlap, "train_tiny_groups": args.tiny, "train_ksplit": args.ksplit},
+                  options=dict({"train_overlap": args.overlap, "train_tiny_groups": args.tiny, "train_ksplit": args.ksplit,
+                                "train_side_streams": args.sides},
                                **{"dbg" + kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.dbg.split(",") if kv}))
     if rank == 0:
         line = {"metric": "training candidate tensors/sec", "value": r["value"], "unit": "candidates/s",
@@ -334,7 +335,8 @@ def train_main(args):
                            "arch": args.arch, "global_batch": gb, "parallelism": "dp%d" % ws,
                            "losses": "read every step" if args.sync_loss else "accumulated on the device, read once",
                            "weight_gradients": "side stream" if (args.overlap is None or args.overlap) else "stream order",
-                           "dbg": args.dbg},
+                           "dbg": args.dbg + (" sides=%d" % args.sides if args.sides is not None else "") +
+                                  (" ksplit=%d" % args.ksplit if args.ksplit is not None else "")},
                 "roofline": r["roofline"], "final_loss": r["final_loss"]}
         line.update(rank_info(ws))
         print(json.dumps(line), flush=True)
@@ -475,6 +477,7 @@ def main():
     ap.add_argument("--overlap", type=int, default=None, help="train mode: option train_overlap (A/B)")
     ap.add_argument("--tiny", type=int, default=None, help="train mode: option train_tiny_groups (A/B)")
     ap.add_argument("--ksplit", type=int, default=None, help="train mode: option train_ksplit (A/B)")
+    ap.add_argument("--sides", type=int, default=None, help="train mode: option train_side_streams (A/B)")
     ap.add_argument("--dbg", default="", help="train mode: development switches, e.g. 0=3,2=1 sets options dbg0=3, dbg2=1")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "pileup"],
                     help="infer (default, the headline metric) or train: Adam steps on the reference's global "

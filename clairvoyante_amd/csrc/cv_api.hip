@@ -115,7 +115,8 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     alloc(&m->params, np); alloc(&m->grads_own, np + CV_GRAD_HEADER); alloc(&m->adam_m, np); alloc(&m->adam_v, np);
     if (m->grads_own) m->grads = m->grads_own + CV_GRAD_HEADER;
     m->train_overlap = 1;
-    m->train_ksplit = 0;
+    m->train_sides = 3;
+    m->train_ksplit = 1;
     m->tiny_g = 160;
     alloc(&m->wp_conv1, 4 * 64);
     for (int l = 1; l < 3; l++) alloc(&m->wp_conv[l], (size_t)s.ntile[l] * arch->kh[l] * 4 * s.cinb[l] * 256);
@@ -158,6 +159,7 @@ extern "C" int cv_destroy(cv_model *m)
     if (m->tr_side) {
         (void)hipStreamSynchronize(m->tr_side);
         (void)hipStreamDestroy(m->tr_side);
+        for (int i = 0; i < 2; i++) if (m->tr_side_more[i]) { (void)hipStreamSynchronize(m->tr_side_more[i]); (void)hipStreamDestroy(m->tr_side_more[i]); }
         for (int i = 0; i < CV_TR_EVENTS; i++) (void)hipEventDestroy(m->tr_ev[i]);
         (void)hipEventDestroy(m->tr_dense_ready);
         (void)hipEventDestroy(m->tr_pack_fork); (void)hipEventDestroy(m->tr_pack_done);
@@ -238,6 +240,7 @@ extern "C" int cv_set_option(cv_model *m, const char *key, int64_t value)
     if (!strcmp(key, "profile")) { m->profile = value ? 1 : 0; return 0; }
     if (!strcmp(key, "train_overlap")) { m->train_overlap = value ? 1 : 0; return 0; }
     if (!strcmp(key, "train_ksplit")) { m->train_ksplit = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "train_side_streams")) { m->train_sides = value < 1 ? 1 : (value > 3 ? 3 : (int)value); return 0; }
     if (!strcmp(key, "train_tiny_groups")) { m->tiny_g = value < 0 ? 0 : (value > 160 ? 160 : (int)value); return 0; }
     if (!strcmp(key, "variant")) { m->variant = (int)value; return 0; }
     if (!strncmp(key, "dbg", 3) && key[3] >= '0' && key[3] <= '7' && !key[4]) { m->dbg[key[3] - '0'] = (int)value; m->packed_train_dirty = true; return 0; }
@@ -258,6 +261,7 @@ extern "C" int cv_get_option(const cv_model *m, const char *key, int64_t *value)
     if (!strcmp(key, "profile")) { *value = m->profile; return 0; }
     if (!strcmp(key, "train_overlap")) { *value = m->train_overlap; return 0; }
     if (!strcmp(key, "train_ksplit")) { *value = m->train_ksplit; return 0; }
+    if (!strcmp(key, "train_side_streams")) { *value = m->train_sides; return 0; }
     if (!strcmp(key, "train_tiny_groups")) { *value = m->tiny_g; return 0; }
     if (!strcmp(key, "variant")) { *value = m->variant; return 0; }
     if (!strncmp(key, "dbg", 3) && key[3] >= '0' && key[3] <= '7' && !key[4]) { *value = m->dbg[key[3] - '0']; return 0; }

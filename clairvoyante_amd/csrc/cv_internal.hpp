@@ -65,6 +65,7 @@ struct cv_model {
     float *wpr_fc4;      // data-gradient weights of fc4 by column and pooled row [col][row][24][64][4] (full topology)
     float *wg_part;      // per-split tiles of the dense weight gradients (two-pass combine), owned
     size_t wg_part_bytes;
+    size_t wg_off[6], wg_size[6];   // regions of wg_part in floats (CV_WG_REGIONS), one per weight-gradient launch site
     float *wps_fc4;      // forward weights of fc4 in 3 slabs [slab][kb][8][64][4] (full topology, small batches)
     float *wps7_fc4;     // ... and in 7 slabs [slab][kb][3][64][4] (dense_small: one wave per group and slab)
     float *wps3_fc5;     // fc5 in 3 slabs [slab][kb][4][64][4] (dense_small)
@@ -92,11 +93,13 @@ struct cv_model {
                          // CV_GRAD_HEADER floats into it, or into the caller's bucket (cv_bind_grad_bucket)
     // training step: side stream of the weight-gradient kernels, fork / join events, "dense gradients final"
     hipStream_t tr_side;
+    hipStream_t tr_side_more[2];   // further side streams: weight gradients of different layers are independent
+    int train_sides;     // option "train_side_streams": side streams of the weight gradients at tiny batches, 1..3 (default 3)
     hipEvent_t tr_ev[16];
     hipEvent_t tr_dense_ready;
     hipEvent_t tr_pack_fork, tr_pack_done;   // weight packing on the side stream (cv_pack_for_training)
     int train_overlap;   // option: weight gradients on the side stream (default 1)
-    int train_ksplit;    // option: k-split fc4 forward at tiny batches (default 0)
+    int train_ksplit;    // option: k-split fc4 forward at tiny batches (default 1)
     int tiny_g;          // option "train_tiny_groups": batches of up to this many groups take the latency-oriented
                          // kernel variants of the training step (default 160; 0 = never)
     // fc4 dropout output / keep mask (a*keep) of the LAST training slice, for cv_get_activation 6 / 7
@@ -118,6 +121,8 @@ void cv_prof_free(cv_model *m);
 void cv_set_error(const char *fmt, ...);
 
 #define CV_TR_EVENTS 16
+#define CV_WG_REGIONS 6
+#define CV_TR_SIDES 3          // side streams of the weight-gradient kernels (tr_side + tr_side_more)
 #define CV_GRAD_HEADER 16     // floats in front of the flat gradient: the loss header (cv_train.hip)
 
 #define CV_HIP(expr)                                                                     \

@@ -1855,7 +1855,7 @@ static int pick_hsplit(int G, int NT, int rows, int overlap, int max_parts)
     return best;
 }
 
-// launch_conv with the number of position parts chosen at run time (MODE 1: 1-4, MODE 2: 1-8)
+// launch_conv with the number of position parts chosen at run time (1, 2, 3, 4, 6 or 8)
 template <int KH, int CINB, int NT, int POOL, int HIN, int MODE, int KS4 = 4>
 int launch_conv_parts(int hs, const float *in, const float *x, int64_t n, const float *wp, const float *bias, int cout,
                       float *out, int G, hipStream_t st, float *act = nullptr)
@@ -1865,8 +1865,8 @@ int launch_conv_parts(int hs, const float *in, const float *x, int64_t n, const 
     case 2: CV_PARTS(2);
     case 3: CV_PARTS(3);
     case 4: CV_PARTS(4);
-    case 6: if constexpr (MODE == 2) { CV_PARTS(6); } else { CV_PARTS(4); }
-    case 8: if constexpr (MODE == 2) { CV_PARTS(8); } else { CV_PARTS(4); }
+    case 6: CV_PARTS(6);
+    case 8: CV_PARTS(8);
     default: CV_PARTS(1);
     }
 #undef CV_PARTS
@@ -2788,8 +2788,8 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
     }
     if (is_full(a)) {
         conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (u32x2 *)a1);
-        rc |= launch_conv_parts<2, 1, 2, 4, 29, 1>(split ? pick_hsplit(G, 2, 26, 3, 4) : 1, p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
-        rc |= launch_conv_parts<3, 2, 3, 3, 26, 1>(split ? pick_hsplit(G, 3, 24, 2, 4) : 1, p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
+        rc |= launch_conv_parts<2, 1, 2, 4, 29, 1>(split ? pick_hsplit(G, 2, 26, 3, m->dbg[6] > 0 ? m->dbg[6] : 4) : 1, p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
+        rc |= launch_conv_parts<3, 2, 3, 3, 26, 1>(split ? pick_hsplit(G, 3, 24, 2, m->dbg[6] > 0 ? m->dbg[6] : 4) : 1, p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
     } else {
         conv1_tm<1, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (u32x2 *)a1);
         rc |= launch_conv_parts<3, 1, 1, 1, 33, 1, 2>(split ? pick_hsplit(G, 1, 33, 0, 4) : 1, p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
@@ -2957,59 +2957,62 @@ int cv_dropout_tm(cv_model *m, const float *h4, float *d4, float *amask, int64_t
 // enough workgroups to cover the chip once (one 8-wave workgroup per CU); the per-split tiles go to a scratch
 // buffer and are summed in a fixed order by wgrad_dense_reduce (no float atomics on the weights).
 // scratch for the per-split tiles of a weight gradient (one kernel pair at a time uses it, in stream order)
-static int wg_part_reserve(cv_model *m, size_t need, hipStream_t st)
+// Scratch of the per-split tiles: one REGION per weight-gradient launch site (0 heads, 1 fc5, 2 fc4, 3 conv3, 4 conv2,
+// 5 conv1), so that the sites may run on different streams at the same time.  The regions are sized at their upper
+// bounds (the split counts are capped, so they do not depend on the batch) and reserved before a step is enqueued
+// (cv_wgrad_scratch_reserve): nothing inside the step synchronises or reallocates.
+static int wg_region(cv_model *m, int region, size_t need_bytes, float **out)
 {
-    if (m->wg_part_bytes >= need) return 0;
-    CV_HIP(hipStreamSynchronize(st));
-    if (m->wg_part) CV_HIP(hipFree(m->wg_part));
-    m->wg_part = nullptr; m->wg_part_bytes = 0;
-    CV_HIP(hipMalloc(&m->wg_part, need));
-    m->wg_part_bytes = need;
+    if (!m->wg_part || region < 0 || region >= CV_WG_REGIONS || need_bytes > m->wg_size[region] * sizeof(float)) {
+        cv_set_error("weight-gradient scratch region %d not reserved (%zu bytes needed)", region, need_bytes);
+        return 1;
+    }
+    *out = m->wg_part + m->wg_off[region];
     return 0;
 }
 
-// Upper bound of the scratch over the weight-gradient launches of one step (their split counts are capped, so it
-// does not depend on the batch): reserved before a step is enqueued, so that nothing inside the step
-// synchronises or reallocates -- the kernels of the step run on two streams.
 int cv_wgrad_scratch_reserve(cv_model *m)
 {
     const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
-    size_t need = 0;
-    auto upd = [&](size_t b) { if (b > need) need = b; };
+    size_t sz[CV_WG_REGIONS];
     const int njb4 = s.nb4, njb5 = s.nb5;
-    upd((size_t)(256 / ((s.kb4 + 15) / 16) + 1) * ((size_t)s.kb4 * njb4 * 256 + njb4 * 16));
-    upd((size_t)(256 / ((s.nb4 + 15) / 16) + 1) * ((size_t)s.nb4 * njb5 * 256 + njb5 * 16));
-    upd((size_t)65 * ((size_t)s.nb4 * 256 + 16));
-    for (int l = 1; l < 3; l++) {
+    sz[0] = (size_t)65 * ((size_t)s.nb4 * 256 + 16);
+    sz[1] = (size_t)(256 / ((s.nb4 + 15) / 16) + 1) * ((size_t)s.nb4 * njb5 * 256 + njb5 * 16);
+    sz[2] = (size_t)(256 / ((s.kb4 + 15) / 16) + 1) * ((size_t)s.kb4 * njb4 * 256 + njb4 * 16);
+    for (int l = 2; l >= 1; l--) {
         const size_t NT = s.ntile[l], TILES = (size_t)a.kh[l] * 4 * s.cinb[l];
-        upd(((2048 + NT - 1) / NT) * NT * (TILES + 1) * 256);
+        sz[5 - l] = ((2048 + NT - 1) / NT) * NT * (TILES + 1) * 256;
     }
-    upd((size_t)1024 * 5 * 256);
-    need *= sizeof(float);
-    if (m->wg_part_bytes >= need) return 0;
+    sz[5] = (size_t)1024 * 5 * 256;
+    size_t total = 0;
+    for (int r = 0; r < CV_WG_REGIONS; r++) { sz[r] = (sz[r] + 63) / 64 * 64; total += sz[r]; }
+    if (m->wg_part && m->wg_part_bytes >= total * sizeof(float)) return 0;
     CV_HIP(hipDeviceSynchronize());
     if (m->wg_part) CV_HIP(hipFree(m->wg_part));
     m->wg_part = nullptr; m->wg_part_bytes = 0;
-    CV_HIP(hipMalloc(&m->wg_part, need));
-    m->wg_part_bytes = need;
+    CV_HIP(hipMalloc(&m->wg_part, total * sizeof(float)));
+    m->wg_part_bytes = total * sizeof(float);
+    size_t off = 0;
+    for (int r = 0; r < CV_WG_REGIONS; r++) { m->wg_off[r] = off; m->wg_size[r] = sz[r]; off += sz[r]; }
     return 0;
 }
 
 template <int NJB>
-static int dense_wgrad_launch(cv_model *m, const float *x_tm, int KB, const float *g_tm, int G, int K, int N, float *dw,
+static int dense_wgrad_launch(cv_model *m, int region, const float *x_tm, int KB, const float *g_tm, int G, int K, int N, float *dw,
                               float *db, hipStream_t st)
 {
+    float *scratch = nullptr;
     const int kblocks = (KB + 15) / 16;
     int splits = 256 / kblocks;
     if (splits > G) splits = G;
     if (splits < 1) splits = 1;
-    if (wg_part_reserve(m, (size_t)splits * (KB * NJB * 256 + NJB * 16) * sizeof(float), st)) return 1;
+    if (wg_region(m, region, (size_t)splits * (KB * NJB * 256 + NJB * 16) * sizeof(float), &scratch)) return 1;
     const size_t lds = (size_t)2 * (NJB + 16) * 1024;
     if (set_lds(wgrad_dense_cm<NJB>, lds)) return 1;
     wgrad_dense_cm<NJB><<<dim3(kblocks, splits), 512, lds, st>>>((const f4 *)x_tm, KB, (const f4 *)g_tm, G, 0,
-                                                                 (f4 *)m->wg_part);
+                                                                 (f4 *)scratch);
     const int64_t per = (int64_t)KB * NJB * 64;
-    wgrad_dense_reduce<<<nblk(per + NJB * 16, 256), 256, 0, st>>>((const f4 *)m->wg_part, splits, KB, NJB, K, N, dw, db);
+    wgrad_dense_reduce<<<nblk(per + NJB * 16, 256), 256, 0, st>>>((const f4 *)scratch, splits, KB, NJB, K, N, dw, db);
     CV_HIP(hipGetLastError());
     return 0;
 }
@@ -3020,11 +3023,11 @@ int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_tm, const float *
     const int G = (int)((n + 15) / 16);
     float *Gd = m->grads; const int64_t *o = m->poff;
     if (layer == 4) {
-        if (is_full(a)) return dense_wgrad_launch<21>(m, x_tm, s.kb4, g_tm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7], st);
-        return dense_wgrad_launch<3>(m, x_tm, s.kb4, g_tm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7], st);
+        if (is_full(a)) return dense_wgrad_launch<21>(m, 2, x_tm, s.kb4, g_tm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7], st);
+        return dense_wgrad_launch<3>(m, 2, x_tm, s.kb4, g_tm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7], st);
     }
-    if (is_full(a)) return dense_wgrad_launch<11>(m, x_tm, s.nb4, g_tm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9], st);
-    return dense_wgrad_launch<2>(m, x_tm, s.nb4, g_tm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9], st);
+    if (is_full(a)) return dense_wgrad_launch<11>(m, 1, x_tm, s.nb4, g_tm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9], st);
+    return dense_wgrad_launch<2>(m, 1, x_tm, s.nb4, g_tm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9], st);
 }
 
 // heads: dW16[k][j] = sum_c X[c][k] g[c][j] for the 16 head outputs j at once (wgrad_dense_cm with the natural
@@ -3095,10 +3098,11 @@ int cv_tile_heads_wgrad(cv_model *m, const float *d4_tm, const float *h5_tm, con
         const int kblocks = (KB + 15) / 16;
         int splits = 64 / kblocks;               // little work per group: few, longer ranges keep the second pass short
         if (splits > G) splits = G;
-        if (wg_part_reserve(m, (size_t)splits * (KB * 256 + 16) * sizeof(float), st)) return 1;
+        float *scratch = nullptr;
+        if (wg_region(m, 0, (size_t)splits * (KB * 256 + 16) * sizeof(float), &scratch)) return 1;
         wgrad_dense_cm<1, true><<<dim3(kblocks, splits), 512, lds, st>>>((const f4 *)x_tm, KB, (const f4 *)g16, G, n,
-                                                                          (f4 *)m->wg_part);
-        wgrad_heads_reduce<<<nblk((int64_t)KB * 64 + 16, 256), 256, 0, st>>>((const f4 *)m->wg_part, splits, KB, K,
+                                                                          (f4 *)scratch);
+        wgrad_heads_reduce<<<nblk((int64_t)KB * 64 + 16, 256), 256, 0, st>>>((const f4 *)scratch, splits, KB, K,
                                                                              pass == 0 ? 0 : 4, pass == 0 ? 4 : 16, hc);
     }
     CV_HIP(hipGetLastError());
@@ -3109,19 +3113,20 @@ int cv_tile_heads_wgrad(cv_model *m, const float *d4_tm, const float *h5_tm, con
 // One wave per (output fragment, split): enough splits for ~2 waves per SIMD (1024 SIMDs); the per-split tiles go
 // to the scratch buffer and are summed in a fixed order by wgrad_conv_reduce (no float atomics).
 template <int KH, int CINB, int NT, int HIN>
-static int conv_wgrad_launch(cv_model *m, const float *in_tm, const float *g_tm, int G, int cin, int cout, float *dw,
+static int conv_wgrad_launch(cv_model *m, int region, const float *in_tm, const float *g_tm, int G, int cin, int cout, float *dw,
                              float *db, hipStream_t st)
 {
+    float *scratch = nullptr;
     constexpr int TILES = KH * 4 * CINB;
     const int want = (2048 + NT - 1) / NT;
     const int splits = G < want ? (G > 0 ? G : 1) : want;
     const int per = (G + splits - 1) / splits;
     const int used = per > 0 ? (G + per - 1) / per : 0;          // splits that own at least one group
     if (used == 0) return 0;
-    if (wg_part_reserve(m, (size_t)splits * NT * (TILES + 1) * 256 * sizeof(float), st)) return 1;
+    if (wg_region(m, region, (size_t)splits * NT * (TILES + 1) * 256 * sizeof(float), &scratch)) return 1;
     wgrad_conv_cm<KH, CINB, NT, HIN><<<8 * NT * ((splits + 7) / 8), 64, (4 * CINB + 4) * 1024, st>>>(
-        (const f4 *)in_tm, (const f4 *)g_tm, G, splits, (f4 *)m->wg_part);
-    wgrad_conv_reduce<<<NT * (TILES + 1), 1024, 0, st>>>((const f4 *)m->wg_part, used, NT, TILES, CINB, cin, cout, dw, db);
+        (const f4 *)in_tm, (const f4 *)g_tm, G, splits, (f4 *)scratch);
+    wgrad_conv_reduce<<<NT * (TILES + 1), 1024, 0, st>>>((const f4 *)scratch, used, NT, TILES, CINB, cin, cout, dw, db);
     CV_HIP(hipGetLastError());
     return 0;
 }
@@ -3134,11 +3139,11 @@ int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_tm, const float *
     float *db = m->grads + m->poff[2 * layer + 1];
     const int cin = s.cin[layer], cout = a.cout[layer];
     if (is_full(a)) {
-        if (layer == 2) return conv_wgrad_launch<3, 2, 3, 26>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
-        return conv_wgrad_launch<2, 1, 2, 29>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
+        if (layer == 2) return conv_wgrad_launch<3, 2, 3, 26>(m, 5 - layer, in_tm, g_tm, G, cin, cout, dw, db, st);
+        return conv_wgrad_launch<2, 1, 2, 29>(m, 5 - layer, in_tm, g_tm, G, cin, cout, dw, db, st);
     }
-    if (layer == 2) return conv_wgrad_launch<5, 1, 2, 33>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
-    return conv_wgrad_launch<3, 1, 1, 33>(m, in_tm, g_tm, G, cin, cout, dw, db, st);
+    if (layer == 2) return conv_wgrad_launch<5, 1, 2, 33>(m, 5 - layer, in_tm, g_tm, G, cin, cout, dw, db, st);
+    return conv_wgrad_launch<3, 1, 1, 33>(m, 5 - layer, in_tm, g_tm, G, cin, cout, dw, db, st);
 }
 
 // first layer: X as the caller holds it ([n][33 positions][16 = base*4 + matrix] floats, transposed by the
@@ -3150,9 +3155,10 @@ int cv_tile_conv1_wgrad(cv_model *m, const float *x, const float *g_tm, int64_t 
     const int splits = G < 1024 ? G : 1024;
     const int per = (G + splits - 1) / splits;
     const int used = (G + per - 1) / per;
-    if (wg_part_reserve(m, (size_t)splits * 5 * 256 * sizeof(float), st)) return 1;
-    wgrad_conv1_cm<<<splits, 64, CV_WG1_RING * 5 * 1024, st>>>(x, n, (const f4 *)g_tm, G, (f4 *)m->wg_part);
-    wgrad_conv1_reduce<<<5, 1024, 0, st>>>((const f4 *)m->wg_part, used, m->arch.cout[0], m->grads + m->poff[0],
+    float *scratch = nullptr;
+    if (wg_region(m, 5, (size_t)splits * 5 * 256 * sizeof(float), &scratch)) return 1;
+    wgrad_conv1_cm<<<splits, 64, CV_WG1_RING * 5 * 1024, st>>>(x, n, (const f4 *)g_tm, G, (f4 *)scratch);
+    wgrad_conv1_reduce<<<5, 1024, 0, st>>>((const f4 *)scratch, used, m->arch.cout[0], m->grads + m->poff[0],
                                           m->grads + m->poff[1]);
     CV_HIP(hipGetLastError());
     return 0;

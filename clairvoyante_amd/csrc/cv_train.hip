@@ -701,24 +701,37 @@ static int train_slice_plain(cv_model *m, const float *x, const float *y, int64_
 // the kernel that produces its gradient operand.  All weight gradients share one scratch buffer and one stream, so
 // they stay in a fixed order (bit-reproducible); at train.py's batch and below the grids do not fill the chip and
 // the two chains overlap.  sw == st: everything in stream order (option "train_overlap" = 0).
+// Up to CV_TR_SIDES side streams: the weight gradients of different layers touch different gradient tensors and
+// different scratch regions, so they are independent of each other as well; at small batches (a kernel covers a
+// fraction of the chip) one side stream made them a second critical path as long as the data-gradient chain.
 struct tr_fork {
-    cv_model *m; hipStream_t st, sw; int k;
-    int to_side()                 // sw continues behind everything enqueued on st so far
+    cv_model *m; hipStream_t st; hipStream_t side[CV_TR_SIDES]; int nside; int k; bool used[CV_TR_SIDES];
+    hipEvent_t next_event() { return m->tr_ev[k++ % (CV_TR_EVENTS - 1)]; }
+    // side stream of launch site `site` (0 heads, 1 fc5, 2 fc4, 3 conv3, 4 conv2, 5 conv1), made to wait for
+    // everything enqueued on st so far; st itself when the step runs in stream order
+    int to_side(int site, hipStream_t *out)
     {
-        if (sw == st) return 0;
-        hipEvent_t e = m->tr_ev[k++ % (CV_TR_EVENTS - 1)];
+        if (nside == 0) { *out = st; return 0; }
+        const int i = site % nside;
+        hipEvent_t e = next_event();
         CV_HIP(hipEventRecord(e, st));
-        CV_HIP(hipStreamWaitEvent(sw, e, 0));
+        CV_HIP(hipStreamWaitEvent(side[i], e, 0));
+        used[i] = true;
+        *out = side[i];
         return 0;
     }
-    int join()                    // st continues behind everything enqueued on sw so far
+    // stream `to` continues behind everything enqueued so far on the side streams other than `to`
+    int gather(hipStream_t to)
     {
-        if (sw == st) return 0;
-        hipEvent_t e = m->tr_ev[k++ % (CV_TR_EVENTS - 1)];
-        CV_HIP(hipEventRecord(e, sw));
-        CV_HIP(hipStreamWaitEvent(st, e, 0));
+        for (int i = 0; i < nside; i++) {
+            if (!used[i] || side[i] == to) continue;
+            hipEvent_t e = next_event();
+            CV_HIP(hipEventRecord(e, side[i]));
+            CV_HIP(hipStreamWaitEvent(to, e, 0));
+        }
         return 0;
     }
+    int join() { return nside == 0 ? 0 : gather(st); }      // st continues behind all side streams
 };
 
 // forward (+ optional backward) of one slice of the batch on the tile kernels; every
@@ -766,44 +779,57 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     float *tgpre[3], *tgin[3];
     for (int l = 0; l < 3; l++) { tgpre[l] = sb.take(np * fa[l]); tgin[l] = sb.take(np * fp[l]); }
     if (!tgin[2]) { cv_set_error("training workspace too small"); return 1; }
-    tr_fork f{m, st, sw, 0};
+    tr_fork f;
+    f.m = m; f.st = st; f.k = 0; f.nside = 0;
+    for (int i = 0; i < CV_TR_SIDES; i++) { f.side[i] = nullptr; f.used[i] = false; }
+    if (sw != st) {
+        f.side[f.nside++] = sw;
+        // more than one side stream only for tiny batches: at train.py's 625 groups every kernel fills the chip and three
+        // concurrent weight-gradient kernels just take CUs from the data-gradient chain (2.25 -> 2.34 ms, profiles/r03)
+        for (int i = 0; i < 2 && f.nside < m->train_sides && Gn <= m->tiny_g; i++) f.side[f.nside++] = m->tr_side_more[i];
+        f.used[0] = true;                    // sw already carries the L2 term / the weight packing of this step
+    }
+    hipStream_t sx = st;
     // heads: weight gradients on the matrix cores (inputs tile-major, the 16 gradients as they lie), data
-    // gradients written to TM
-    if (f.to_side()) return 1;
-    if (cv_tile_heads_wgrad(m, td4, th5, ghpre, n, sw)) return 1;
+    // gradients written to TM, times selu'(h5)
+    if (f.to_side(0, &sx)) return 1;
+    if (cv_tile_heads_wgrad(m, td4, th5, ghpre, n, sx)) return 1;
     b_head_dgrad_tm<<<nblk(Gn * s.nb5 * 256, 256), 256, 0, st>>>(ghpre, P + o[10], P + o[12], P + o[14], P + o[16], a.fc5,
                                                                s.nb5, n, Gn, 0, nullptr, th5, nullptr, tg5pre);
     // fc5
-    if (f.to_side()) return 1;
-    if (cv_tile_dense_wgrad(m, 5, td4, tg5pre, n, sw)) return 1;
+    if (f.to_side(1, &sx)) return 1;
+    if (cv_tile_dense_wgrad(m, 5, td4, tg5pre, n, sx)) return 1;
     if (cv_tile_fc5_dgrad(m, tg5pre, tgd4, n, st)) return 1;
     // + the base head's contribution, then dropout4 + selu' (h4 is the SELU output before dropout)
     b_head_dgrad_tm<<<nblk(Gn * s.nb4 * 256, 256), 256, 0, st>>>(ghpre, P + o[10], P + o[12], P + o[14], P + o[16], a.fc4,
                                                                s.nb4, n, Gn, 1, tgd4, th4, tmask, tg4pre);
     // fc4
-    if (f.to_side()) return 1;
-    if (cv_tile_dense_wgrad(m, 4, tp[2], tg4pre, n, sw)) return 1;
-    if (dense_ready) CV_HIP(hipEventRecord(dense_ready, sw));
+    if (f.to_side(2, &sx)) return 1;
+    if (cv_tile_dense_wgrad(m, 4, tp[2], tg4pre, n, sx)) return 1;
+    if (dense_ready) {                       // heads, fc5 and fc4 gradients final: behind all three launch sites
+        if (f.nside > 0 && f.gather(sx)) return 1;
+        CV_HIP(hipEventRecord(dense_ready, sx));
+    }
     // fc4's data gradient; full topology: fused with conv3's max-pool backward + SELU' (dbg3 = 1: as two kernels)
     const bool fused3 = m->wpr_fc4 != nullptr && m->dbg[3] != 1;
     if (fused3) { if (cv_tile_fc4_dgrad_unpool(m, tg4pre, tp[2], ta[2], tgpre[2], n, st)) return 1; }
     else if (cv_tile_fc4_dgrad(m, tg4pre, tgin[2], n, st)) return 1;
     // conv stack.  Pooled layers of the full topology: the data gradient of layer l writes the pre-activation gradient of
     // layer l - 1 directly (conv_dgrad_unpool; dbg4 = 1: data gradient and unpool as two kernels)
-    // Measured (profiles/r03): at train.py's batch (625 groups) the fused kernel loses -- one wave per (group, tile)
-    // is 1 250 waves for 1 024 SIMDs, and position parts recompute P - 1 windows each (385 us against 254 + 79 for
-    // conv3) -- so it serves the tiny batches (a rank's share under data parallelism: 0.793 -> 0.768 ms at 1 250),
-    // where the step is a chain of latency-bound kernels and one launch less per layer counts.  dbg4 = 2: always.
-    const bool fusedc = m->wpr_fc4 != nullptr && m->dbg[4] != 1 && (Gn <= m->tiny_g || m->dbg[4] == 2);
+    // Measured (profiles/r03): the fused kernel loses at every batch -- at train.py's 625 groups one wave per (group,
+    // tile) is 1 250 waves for 1 024 SIMDs and position parts recompute P - 1 windows each (385 us against 254 + 79
+    // for conv3); at 79 groups (a rank's share under data parallelism) 114 + 78 us against 60 + 25 + 17 + 24 once the
+    // weight gradients run on their own streams (0.698 against 0.672 ms per step).  Kept as a tested variant: dbg4 = 2.
+    const bool fusedc = m->wpr_fc4 != nullptr && m->dbg[4] == 2;
     for (int l = 2; l >= 0; l--) {
         const int H = s.hc[l], NT = s.ntile[l];
         const bool have_gpre = (l == 2 && fused3) || (l < 2 && fusedc);
         if (!have_gpre && launch_unpool(tgin[l], tp[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st, m->dbg[2] == 1 ? (1 << 30) : (m->dbg[2] == 2 ? 0 : m->tiny_g))) return 1;
-        if (f.to_side()) return 1;
+        if (f.to_side(5 - l, &sx)) return 1;
         if (l == 0) {        // first layer: X viewed as [33][16] fragments, read in place
-            if (cv_tile_conv1_wgrad(m, x, tgpre[0], n, sw)) return 1;
+            if (cv_tile_conv1_wgrad(m, x, tgpre[0], n, sx)) return 1;
         } else {
-            if (cv_tile_conv_wgrad(m, l, tp[l - 1], tgpre[l], n, sw)) return 1;
+            if (cv_tile_conv_wgrad(m, l, tp[l - 1], tgpre[l], n, sx)) return 1;
             if (fusedc) { if (cv_tile_conv_dgrad_unpool(m, l, tgpre[l], tp[l - 1], ta[l - 1], tgpre[l - 1], n, st)) return 1; }
             else if (cv_tile_conv_dgrad(m, l, tgpre[l], tgin[l - 1], n, st)) return 1;
         }
@@ -868,6 +894,7 @@ static int train_workspace(cv_model *m, int64_t n, int64_t *slice_out)
     }
     if (!m->tr_side) {
         CV_HIP(hipStreamCreateWithFlags(&m->tr_side, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) CV_HIP(hipStreamCreateWithFlags(&m->tr_side_more[i], hipStreamNonBlocking));
         for (int i = 0; i < CV_TR_EVENTS; i++) CV_HIP(hipEventCreateWithFlags(&m->tr_ev[i], hipEventDisableTiming));
         CV_HIP(hipEventCreateWithFlags(&m->tr_dense_ready, hipEventDisableTiming));
         CV_HIP(hipEventCreateWithFlags(&m->tr_pack_fork, hipEventDisableTiming));

@@ -128,9 +128,12 @@ int cv_selu_sweep(int device, uint32_t lo_bits, uint32_t hi_bits, uint64_t *viol
  * "chunk" (candidates per internal pass), "profile" (0/1, see cv_kernel_times), "train_overlap" (0/1: weight
  * gradients of the training step on a side stream next to the data-gradient chain; default 1, same bits),
  * "train_tiny_groups" (0..160, default 160: training batches of up to that many groups of 16 candidates split the
- * serial loops of their layers over more waves -- same bits) and "train_ksplit" (0/1, default 0; 1: at such batches
+ * serial loops of their layers over more waves -- same bits), "train_ksplit" (0/1, default 1: at such batches
  * the fc4 forward of the TRAINING pass adds eight partial sums over k ranges instead of one ascending-k chain; fixed
- * order, within the gradient tolerance, 4 % faster at 1 250 candidates, never used by cv_forward),
+ * order, reproducible run to run, within the gradient tolerance of the single chain, 4 % faster at 1 250 candidates;
+ * never used by cv_forward) and "train_side_streams" (1..3, default 3: at such batches the weight gradients of
+ * different layers -- independent of each other -- run on up to that many side streams; same bits),
+ * "dbg0".."dbg7" (development A/B switches of the training step, 0 = shipped path; see cv_train.hip),
  * "variant" (bit 0: first layer fused into the conv2 kernel, bit 1: MFMA heads kernel,
  * bit 2: 8-wave fc4 workgroups, bit 3: rotating-window conv3 kernel, bit 5: fc4 with two groups of
  * 16 candidates per wave, bit 6: fused conv1+conv2 kernel whose two waves per group share the first layer through
