@@ -881,10 +881,13 @@ __global__ __launch_bounds__(256, 2) void front2_tm(const float *__restrict__ x,
 // 17 dwords per lane into the loop and the kernel is 27 % slower, so it runs at two (measured
 // -2.4 % on conv3 against conv_tm).  Same arithmetic in the same order: bit-identical results.
 // ---------------------------------------------------------------------------
-template <int CINB, int NT, int HIN, int WAVES, int MINW>
+// SAVE (training forward): every row is activated as it is produced (the backward pass routes the pooling gradient
+// by the ACTIVATED values), the window's maximum is taken over the three activated rows in the rotating slots and
+// the window offset of its first occurrence goes to code_tm (pool_code4) -- conv_tm MODE 1 with the rotating window.
+template <int CINB, int NT, int HIN, int WAVES, int MINW, bool SAVE = false>
 __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restrict__ in_tm, const f4 *__restrict__ wp,
                                                             const float *__restrict__ bias, int cout,
-                                                            f4 *__restrict__ out_tm, int G)
+                                                            f4 *__restrict__ out_tm, int G, u32x2 *__restrict__ code_tm = nullptr)
 {
     constexpr int KH = 3, PADT = 1, POOL = 3, HOUT = HIN - POOL + 1;
     extern __shared__ __attribute__((aligned(16))) f4 ldsw[];
@@ -949,9 +952,23 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
         // the three pre-activation rows of the window sit in rotating slots (like the input window): one v_max3 per
         // value and row
         for (int w = 0; w < 4; w++) {
-            tp[R][w] = acc[w] + b4;                  // (a sum needs no canonicalising v_max x, x, x; a raw MFMA result would)
-            if (h >= POOL - 1)
-                op[(size_t)((h - (POOL - 1)) * 4 + w) * (NT * 64)] = selu4(max3_4(tp[0][w], tp[1][w], tp[2][w]));
+            if constexpr (SAVE) tp[R][w] = selu4(acc[w] + b4);
+            else tp[R][w] = acc[w] + b4;             // (a sum needs no canonicalising v_max x, x, x; a raw MFMA result would)
+            if (h >= POOL - 1) {
+                if constexpr (SAVE) op[(size_t)((h - (POOL - 1)) * 4 + w) * (NT * 64)] = max3_4(tp[0][w], tp[1][w], tp[2][w]);
+                else op[(size_t)((h - (POOL - 1)) * 4 + w) * (NT * 64)] = selu4(max3_4(tp[0][w], tp[1][w], tp[2][w]));
+            }
+        }
+        if constexpr (SAVE) {
+            if (h >= POOL - 1) {                     // rows h-2, h-1, h sit in slots (R+1)%3, (R+2)%3, R
+                unsigned cw[4];
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const f4 older[2] = {tp[(R + 1) % 3][w], tp[(R + 2) % 3][w]};
+                    cw[w] = pool_code4<3>(older, tp[R][w], max3_4(tp[0][w], tp[1][w], tp[2][w]));
+                }
+                code_tm[(((size_t)g * HOUT + (h - (POOL - 1))) * NT + nt) * 64 + lane] = (u32x2){cw[0] | (cw[1] << 16), cw[2] | (cw[3] << 16)};
+            }
         }
     };
 #pragma unroll 1
@@ -1872,13 +1889,15 @@ int launch_conv_parts(int hs, const float *in, const float *x, int64_t n, const 
 #undef CV_PARTS
 }
 
-template <int CINB, int NT, int HIN, int WAVES, int MINW>
-int launch_conv3_rot(const float *in, const float *wp, const float *bias, int cout, float *out, int G, hipStream_t st)
+template <int CINB, int NT, int HIN, int WAVES, int MINW, bool SAVE = false>
+int launch_conv3_rot(const float *in, const float *wp, const float *bias, int cout, float *out, int G, hipStream_t st,
+                     float *codes = nullptr)
 {
-    auto k = conv3_rot<CINB, NT, HIN, WAVES, MINW>;
+    auto k = conv3_rot<CINB, NT, HIN, WAVES, MINW, SAVE>;
     size_t lds = (size_t)NT * 3 * 4 * CINB * 1024;
     if (set_lds(k, lds)) return 1;
-    k<<<nblk((int64_t)G * NT, WAVES), WAVES * 64, lds, st>>>((const f4 *)in, (const f4 *)wp, bias, cout, (f4 *)out, G);
+    k<<<nblk((int64_t)G * NT, WAVES), WAVES * 64, lds, st>>>((const f4 *)in, (const f4 *)wp, bias, cout, (f4 *)out, G,
+                                                            (u32x2 *)codes);
     CV_HIP(hipGetLastError());
     return 0;
 }
@@ -2789,7 +2808,11 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
     if (is_full(a)) {
         conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (u32x2 *)a1);
         rc |= launch_conv_parts<2, 1, 2, 4, 29, 1>(split ? pick_hsplit(G, 2, 26, 3, m->dbg[6] > 0 ? m->dbg[6] : 4) : 1, p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
-        rc |= launch_conv_parts<3, 2, 3, 3, 26, 1>(split ? pick_hsplit(G, 3, 24, 2, m->dbg[6] > 0 ? m->dbg[6] : 4) : 1, p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
+        const int hs3 = split ? pick_hsplit(G, 3, 24, 2, m->dbg[6] > 0 ? m->dbg[6] : 4) : 1;
+        if (hs3 == 1 && m->dbg[7] != 1)          // one wave per (group, tile): the rotating-window kernel (dbg7 = 1: conv_tm)
+            rc |= launch_conv3_rot<2, 3, 26, 4, 2, true>(p2, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
+        else
+            rc |= launch_conv_parts<3, 2, 3, 3, 26, 1>(hs3, p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
     } else {
         conv1_tm<1, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (u32x2 *)a1);
         rc |= launch_conv_parts<3, 1, 1, 1, 33, 1, 2>(split ? pick_hsplit(G, 1, 33, 0, 4) : 1, p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
