@@ -151,10 +151,12 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
 int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm, int64_t n, hipStream_t st,
                       float *part = nullptr);
 int cv_tile_fc5_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
-int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
+// act_below (layers without pooling, slim): the layer-below output; the result is then times selu' = its pre-activation gradient
+int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st, const float *act_below = nullptr);
 int cv_tile_fc4_dgrad_unpool(cv_model *m, const float *g_tm, const float *pooled, const float *codes, float *gpre, int64_t n,
                              hipStream_t st);
-int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
+int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st,
+                       const float *act_below = nullptr);
 int cv_tile_conv_dgrad_unpool(cv_model *m, int layer, const float *g_tm, const float *pooled, const float *codes, float *gpre,
                               int64_t n, hipStream_t st);
 int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_tm, const float *g_tm, int64_t n, hipStream_t st);

@@ -662,6 +662,15 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
         if constexpr (MODE == 2) {
 #pragma unroll
             for (int w = 0; w < 4; w++) v[w] = acc[w];
+            if (act_tm) {                    // the layer below has no pooling: its pre-activation gradient = this times selu'
+                const f4 *yp = act_tm + (size_t)g * (HOUT * 4 * NT * 64) + (size_t)nt * 64 + lane;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const f4 y = yp[(size_t)(h * 4 + w) * (NT * 64)];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[w][k] *= cv_selu_grad_from_out(y[k]);
+                }
+            }
         } else {
 #if defined(CV_ABL) && (CV_ABL & 1)
 #pragma unroll
@@ -1257,6 +1266,7 @@ struct heads_args {
     const float *bb, *bz, *bt, *bl;      // biases
     int64_t n;
     float *out16;
+    const f4 *dact = nullptr;            // EPI 1 only: the output is multiplied by selu'-from-output of this map (same layout)
 };
 
 // ---------------------------------------------------------------------------
@@ -1433,7 +1443,13 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
                 const f4 b4 = load_bias4(bias, (int)blockIdx.y * NB + ob, q, nout);
                 op[ob * 64] = selu4(acc[r][ob] + b4);
             } else {
-                op[ob * 64] = acc[r][ob];
+                f4 v = acc[r][ob];
+                if (hd.dact) {               // data gradient times selu' of the layer below (a layer without pooling)
+                    const f4 y = hd.dact[(op - out_tm) + ob * 64];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[k] *= cv_selu_grad_from_out(y[k]);
+                }
+                op[ob * 64] = v;
             }
         }
     }
@@ -2878,11 +2894,13 @@ int cv_tile_fc4_dgrad_unpool(cv_model *m, const float *g_tm, const float *pooled
 }
 
 // gF[k] = sum_j g4pre[j] W4[k][j]  (input TM with nb4 fragments, output TM with kb4 fragments)
-int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st)
+int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st, const float *act_below)
 {
     const cv_shapes &s = m->sh;
     const int G = (int)((n + 15) / 16);
-    return launch_dense<24, 8, 1>(g_tm, s.nb4, m->wpd_fc4, nullptr, 0, gin_tm, G, st, s.kb4 / 24);
+    heads_args hd;
+    hd.dact = (const f4 *)act_below;        // not null: the result is already the pre-activation gradient of conv3 (no pooling)
+    return launch_dense<24, 8, 1>(g_tm, s.nb4, m->wpd_fc4, nullptr, 0, gin_tm, G, st, s.kb4 / 24, 1, nullptr, hd);
 }
 
 // g(d4)[k] = sum_j g5pre[j] W5[k][j]  (input TM with nb5 fragments, output TM with nb4 fragments)
@@ -2895,8 +2913,9 @@ int cv_tile_fc5_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, 
 }
 
 // layer 1 = conv2, 2 = conv3: gradient w.r.t. the layer input from the pre-activation gradient
-int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st)
+int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st, const float *act_below)
 {
+    float *act = const_cast<float *>(act_below);      // conv_tm MODE 2 reads it (selu' factor of a layer without pooling)
     const cv_arch &a = m->arch;
     const int G = (int)((n + 15) / 16);
     const float *W = m->wpd_conv[layer];
@@ -2911,8 +2930,8 @@ int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm,
         return launch_conv_parts<2, 2, 1, 1, 29, 2>(split ? pick_hsplit(G, 1, 29, 0, 8) : 1, g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
     }
     if (layer == 2)
-        return launch_conv_parts<5, 2, 1, 1, 33, 2>(split ? pick_hsplit(G, 1, 33, 0, 8) : 1, g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
-    return launch_conv_parts<3, 1, 1, 1, 33, 2>(split ? pick_hsplit(G, 1, 33, 0, 8) : 1, g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
+        return launch_conv_parts<5, 2, 1, 1, 33, 2>(split ? pick_hsplit(G, 1, 33, 0, 8) : 1, g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st, act);
+    return launch_conv_parts<3, 1, 1, 1, 33, 2>(split ? pick_hsplit(G, 1, 33, 0, 8) : 1, g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st, act);
 }
 
 // layer 1 = conv2, 2 = conv3 (full topology): data gradient fused with the max-pool backward + SELU' of the layer below

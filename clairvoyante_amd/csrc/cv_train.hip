@@ -812,7 +812,11 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     }
     // fc4's data gradient; full topology: fused with conv3's max-pool backward + SELU' (dbg3 = 1: as two kernels)
     const bool fused3 = m->wpr_fc4 != nullptr && m->dbg[3] != 1;
+    // layers without pooling (slim): the selu' factor of the layer below rides on the data-gradient kernel's store
+    // (dbg4 = 3: as a separate element-wise pass)
+    const bool nopool_fused = a.pool[0] == 1 && a.pool[1] == 1 && a.pool[2] == 1 && m->dbg[4] != 3;
     if (fused3) { if (cv_tile_fc4_dgrad_unpool(m, tg4pre, tp[2], ta[2], tgpre[2], n, st)) return 1; }
+    else if (nopool_fused) { if (cv_tile_fc4_dgrad(m, tg4pre, tgpre[2], n, st, tp[2])) return 1; }
     else if (cv_tile_fc4_dgrad(m, tg4pre, tgin[2], n, st)) return 1;
     // conv stack.  Pooled layers of the full topology: the data gradient of layer l writes the pre-activation gradient of
     // layer l - 1 directly (conv_dgrad_unpool; dbg4 = 1: data gradient and unpool as two kernels)
@@ -823,7 +827,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     const bool fusedc = m->wpr_fc4 != nullptr && m->dbg[4] == 2;
     for (int l = 2; l >= 0; l--) {
         const int H = s.hc[l], NT = s.ntile[l];
-        const bool have_gpre = (l == 2 && fused3) || (l < 2 && fusedc);
+        const bool have_gpre = (l == 2 && fused3) || (l < 2 && fusedc) || nopool_fused;
         if (!have_gpre && launch_unpool(tgin[l], tp[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st, m->dbg[2] == 1 ? (1 << 30) : (m->dbg[2] == 2 ? 0 : m->tiny_g))) return 1;
         if (f.to_side(5 - l, &sx)) return 1;
         if (l == 0) {        // first layer: X viewed as [33][16] fragments, read in place
@@ -831,6 +835,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
         } else {
             if (cv_tile_conv_wgrad(m, l, tp[l - 1], tgpre[l], n, sx)) return 1;
             if (fusedc) { if (cv_tile_conv_dgrad_unpool(m, l, tgpre[l], tp[l - 1], ta[l - 1], tgpre[l - 1], n, st)) return 1; }
+            else if (nopool_fused) { if (cv_tile_conv_dgrad(m, l, tgpre[l], tgpre[l - 1], n, st, tp[l - 1])) return 1; }
             else if (cv_tile_conv_dgrad(m, l, tgpre[l], tgin[l - 1], n, st)) return 1;
         }
     }

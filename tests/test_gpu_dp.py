@@ -196,20 +196,21 @@ def test_tiny_batch_kernel_variants_give_the_same_bits(oracle, arch, n):
     assert np.isfinite(ks[1]).all()
 
 
-@pytest.mark.parametrize("n", [1250, 83, 10000])
-def test_backward_kernel_variants_give_the_same_bits(oracle, n):
+@pytest.mark.parametrize("arch,n", [("full", 1250), ("full", 83), ("full", 10000), ("slim", 1250), ("slim", 10000)])
+def test_backward_kernel_variants_give_the_same_bits(oracle, arch, n):
     """development switches of the backward pass (full topology): fc4's data gradient fused with conv3's unpool or as
     two kernels (dbg3), the convolution data gradients fused with the unpool of the layer below (dbg4 = 2: scatter-form
     kernel, kept as a variant) or as two kernels, one or three side streams for the weight gradients, weight packing on
-    the side stream or in stream order (dbg5): the same arithmetic in the same order -- same losses, weights, gradients"""
+    the side stream or in stream order (dbg5); slim: the selu' factor of a layer without pooling on the data-gradient
+    kernel's store or as its own pass (dbg4 = 3): the same arithmetic in the same order -- same losses, weights, gradients"""
     import torch
     from clairvoyante_amd import synth
     xt, cls, rf, alt, il = synth.make_candidates(n, seed=47, device="cuda", return_class=True)
     y = synth.make_labels(cls, rf, alt, il)
-    P = common.bench_params(oracle, "full")
+    P = common.bench_params(oracle, arch)
 
     def run(opts):
-        m = _model("full"); m.setParameters(P)
+        m = _model(arch); m.setParameters(P)
         for k, v in opts.items():
             m.setOption(k, v)
         m._dropout_seed = 99; m.setLearningRate(1e-3); m.setL2RegularizationLambda(1e-3)
@@ -218,8 +219,10 @@ def test_backward_kernel_variants_give_the_same_bits(oracle, n):
         m.close()
         return out
     ref = run({})
-    for opts in ({"dbg3": 1}, {"dbg4": 2}, {"dbg4": 2, "dbg0": 3}, {"train_side_streams": 1}, {"dbg5": 1},
-                 {"dbg3": 1, "dbg4": 2, "train_overlap": 0}):
+    variants = ({"dbg3": 1}, {"dbg4": 2}, {"dbg4": 2, "dbg0": 3}, {"train_side_streams": 1}, {"dbg5": 1},
+                {"dbg3": 1, "dbg4": 2, "train_overlap": 0}) if arch == "full" else \
+               ({"dbg4": 3}, {"train_side_streams": 1}, {"dbg5": 1, "dbg4": 3, "train_overlap": 0})
+    for opts in variants:
         got = run(opts)
         assert np.allclose(ref[0], got[0], rtol=1e-12, atol=0), opts
         assert np.array_equal(ref[1].view(np.uint32), got[1].view(np.uint32)), opts

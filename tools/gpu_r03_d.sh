@@ -13,6 +13,7 @@ for fl in "${SETS[@]}"; do
   for b in 10000 1250; do
     python bench.py --mode train --batch $b --steps 40 --warmup 4 $fl >> $OUT/train_ab.jsonl 2>> $OUT/bench.err
   done
+  python bench.py --mode train --arch slim --batch 10000 --steps 40 --warmup 4 $fl >> $OUT/train_ab.jsonl 2>> $OUT/bench.err
 done
 python - $OUT/train_ab.jsonl <<'PY'
 import json, sys
