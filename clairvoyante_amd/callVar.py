@@ -401,9 +401,11 @@ def TestSharded(args, m, utils, rank, ws):
     every rank calls its blocks with its own replica of the weights -- no collective on the data path -- and
     rank 0 joins the per-rank record fragments in input order: the VCF is byte-identical to the single-process
     one."""
-    import io
     import torch
     import torch.distributed as dist
+    # the fragments are files next to --call_fn that rank 0 reads back: one node, or a file system all ranks share
+    if int(os.environ.get("LOCAL_WORLD_SIZE", str(ws))) != ws and rank == 0:
+        logging.warning("callVar under %d ranks on several nodes: --call_fn must lie on a file system every rank shares" % ws)
     logging.info("Calling variants (rank %d of %d) ..." % (rank, ws))
     predictStart = time.time()
     frag_fn = "%s.rank%d" % (args.call_fn, rank)
@@ -480,9 +482,17 @@ def TestSharded(args, m, utils, rank, ws):
             raise failure
         sys.exit("callVar: another rank failed; no VCF written")
     if rank == 0:
-        with open(args.call_fn, "w") as call_fh:
-            PrintVCFHeader(args, call_fh)
-            merge_fragments(args.call_fn, ws, call_fh)
+        try:
+            with open(args.call_fn, "w") as call_fh:
+                PrintVCFHeader(args, call_fh)
+                merge_fragments(args.call_fn, ws, call_fh)
+        finally:                                    # also when the merge fails: no fragment is left behind
+            for r in range(ws):
+                for fn in ("%s.rank%d" % (args.call_fn, r), "%s.rank%d.idx" % (args.call_fn, r)):
+                    try:
+                        os.remove(fn)
+                    except OSError:
+                        pass
         logging.info("Total time elapsed: %.2f s" % (time.time() - predictStart))
     dist.barrier()
 

@@ -2823,8 +2823,8 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
     }
     if (is_full(a)) {
         conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (u32x2 *)a1);
-        rc |= launch_conv_parts<2, 1, 2, 4, 29, 1>(split ? pick_hsplit(G, 2, 26, 3, m->dbg[6] > 0 ? m->dbg[6] : 4) : 1, p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
-        const int hs3 = split ? pick_hsplit(G, 3, 24, 2, m->dbg[6] > 0 ? m->dbg[6] : 4) : 1;
+        rc |= launch_conv_parts<2, 1, 2, 4, 29, 1>(split ? pick_hsplit(G, 2, 26, 3, 4) : 1, p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
+        const int hs3 = split ? pick_hsplit(G, 3, 24, 2, 4) : 1;
         if (hs3 == 1 && m->dbg[7] != 1)          // one wave per (group, tile): the rotating-window kernel (dbg7 = 1: conv_tm)
             rc |= launch_conv3_rot<2, 3, 26, 4, 2, true>(p2, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
         else
@@ -2855,7 +2855,8 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
             // 7 x 625 times -- 2.63 against 2.41 ms per step)
             if (G <= m->tiny_g && (m->variant & 128))
                 return launch_dense_small<3, 8>(in_tm, s.kb4, m->wps7_fc4, P + o[7], a.fc4, out_tm, G, 7, st);
-            // (two k ranges at train.py's batch of 10 000 -- 237 workgroups otherwise -- measured: no gain)
+            // (measured at train.py's batch of 10 000, no gain: two k ranges of the 3-slab form; 3 / 4 / 6 / 8 k ranges of the
+            // two-groups-per-wave, all-21-tiles form -- 2.47 / 2.36 / 2.25 / 2.39 ms per step against 2.25)
             if (G <= CV_FC4_SLAB_MAX_G) return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3);
             return launch_dense<21, 8>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);
         }
