@@ -1,7 +1,8 @@
 #!/bin/bash
-# Full validation on the GPU box (what profiles/r02/ was made with): every GPU test, smoke(), the PMC passes of the
-# shipped kernels (tools/gpu_pmc.sh), bench full + slim, rocprofv3 kernel stats of the bench.
-#   gpurun --timeout 1500 -- 'bash tools/gpu_validate.sh TAG GITHEAD'
+# Full validation on the GPU box (what profiles/rNN/ is made with): every GPU test, smoke(), the PMC passes of the
+# shipped kernels (inference: tools/gpu_pmc.sh; training step: tools/gpu_pmc_train.sh), the bench line, slim / training
+# lines, rocprofv3 kernel stats of the bench and of the training step, the host-side probes.
+#   gpurun --timeout 2400 -- 'bash tools/gpu_validate.sh TAG GITHEAD'
 set -u
 OUT=gpurun_out/${1:-validate}
 HEAD=${2:-unknown}
@@ -12,10 +13,38 @@ echo "pytest rc=$?" >> $OUT/status.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
 echo "smoke rc=$?" >> $OUT/status.txt
 bash tools/gpu_pmc.sh $(basename $OUT) $HEAD > $OUT/pmc.log 2>&1
+cp $OUT/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null     # the bench below reads it (this copy stays on the box)
+bash tools/gpu_pmc_train.sh $(basename $OUT)_t $HEAD > $OUT/pmc_train.log 2>&1
+cp gpurun_out/$(basename $OUT)_t/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null
+cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 python bench.py --arch slim --no-cpu > $OUT/bench_slim.json 2>> $OUT/bench.err
 for b in 1250 10000; do python bench.py --mode train --batch $b --steps 50 --warmup 5 >> $OUT/bench_train.jsonl 2>> $OUT/bench.err; done
 python bench.py --mode train --batch 10000 --steps 50 --warmup 5 --arch slim >> $OUT/bench_train.jsonl 2>> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o b -- python bench.py --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/prof_bench.err
+python bench.py --mode train --batch 1250 --steps 50 --warmup 5 --arch slim >> $OUT/bench_train.jsonl 2>> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o b -- python bench.py --no-cpu --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/prof_bench.err
 f=$(find $OUT/prof_bench -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/bench_kernel_stats.csv; rm -rf $OUT/prof_bench
-tail -3 $OUT/pytest_gpu.log; tail -3 $OUT/smoke.log; grep -v "^at::\|rocprim\|rocclr\|elementwise" $OUT/pmc.log | tail -16
+for b in 10000 1250; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_t$b -o t -- python bench.py --mode train --batch $b --steps 20 --warmup 3 --overlap 0 > $OUT/train_serial_$b.json 2> $OUT/prof_t$b.err
+  f=$(find $OUT/prof_t$b -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/train_serial_${b}_kernel_stats.csv; rm -rf $OUT/prof_t$b
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/tl_$b -o t -- python bench.py --mode train --batch $b --steps 12 --warmup 3 > /dev/null 2> $OUT/tl_$b.err
+  f=$(find $OUT/tl_$b -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_timeline.py "$f" > $OUT/train_${b}_timeline.txt; rm -rf $OUT/tl_$b
+done
+python tools/vcf_format_probe.py 2000000 16 > $OUT/vcf_format_probe.txt 2>&1
+python tools/vcf_format_probe.py 2000000 1 >> $OUT/vcf_format_probe.txt 2>&1
+timeout 600 python tools/gpu_callvar_text_probe.py 200000 > $OUT/callvar_text_probe.txt 2>&1
+timeout 600 python tools/gpu_e2e_bam.py > $OUT/e2e_bam.txt 2>&1
+timeout 300 python tools/gpu_small_batch_probe.py > $OUT/small_batch.txt 2>&1
+tail -3 $OUT/pytest_gpu.log; tail -3 $OUT/smoke.log; cat $OUT/status.txt
+python - $OUT <<'PY'
+import json, sys, os
+o = sys.argv[1]
+b = json.load(open(os.path.join(o, "bench.json")))
+print("bench: %.2f M cand/s, dominant %.3f, whole path %.3f; slim %.2f M/s; train %s" % (
+    b["value"] / 1e6, b["roofline"]["frac"], b["roofline"]["whole_path_frac"], b["slim"]["value"] / 1e6,
+    {k: "%.3f ms (%.3f)" % (v["ms_per_step"], v["roofline"]["frac"]) for k, v in b["train"].items()}))
+print("parity:", b.get("parity"))
+for l in open(os.path.join(o, "bench_train.jsonl")):
+    r = json.loads(l)
+    print("train %-4s %6d: %.3f ms, frac %.3f, traffic %s" % (r["config"]["arch"], r["config"]["global_batch"], r["ms_per_step"], r["roofline"]["frac"], r["roofline"]["traffic"]))
+PY
