@@ -2196,7 +2196,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         }
         cv_prof_begin(m, 2, st);
         if (small_pass) { m->stage_kernel[2] = "conv_tm<3, 2, 3, 3, 26, 0, 0, 4>"; rc |= launch_conv<3, 2, 3, 3, 26, 0, 0, 4>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st); }
-        else if (m->variant & 8) { m->stage_kernel[2] = "conv3_rot<2, 3, 26, 4, 2>"; rc |= launch_conv3_rot<2, 3, 26, 4, 2>(m->tm_p2, m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st); }
+        else if (m->variant & 8) { m->stage_kernel[2] = "conv3_rot<2, 3, 26, 4, 2, false>"; rc |= launch_conv3_rot<2, 3, 26, 4, 2>(m->tm_p2, m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st); }
         else { m->stage_kernel[2] = "conv_tm<3, 2, 3, 3, 26, 0, 0, 1>"; rc |= launch_conv<3, 2, 3, 3, 26, 0>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st); }
         cv_prof_end(m, 2, st);
         cv_prof_begin(m, 3, st);

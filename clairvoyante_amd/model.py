@@ -108,42 +108,13 @@ class Clairvoyante(object):
 
     accepts_device_batches = True      # train/getLoss/predict take torch tensors that already live on self.device
 
-    STAGE_ROWS = 8192          # candidates per piece of a staged host -> device copy
-    STAGE_MIN = 4096           # smaller host batches go through torch's own (pageable) copy
-
-    def _stage_host(self, arr):
-        """numpy [n, k] fp32 -> device tensor through two page-locked pieces: the host copy of piece i+1 (torch's
-        threaded CPU copy) runs under the DMA of piece i, instead of one blocking copy out of pageable memory that the
-        driver bounces through its own small staging buffers.  The consumer kernel follows in stream order."""
-        n, k = arr.shape
-        src = torch.from_numpy(arr)
-        dst = torch.empty((n, k), dtype=torch.float32, device=self.device)
-        st = getattr(self, "_stage", None)
-        if st is None or st[0].shape[1] != k:
-            st = self._stage = (torch.empty((self.STAGE_ROWS, k), dtype=torch.float32, pin_memory=True),
-                                torch.empty((self.STAGE_ROWS, k), dtype=torch.float32, pin_memory=True),
-                                [torch.cuda.Event(), torch.cuda.Event()], [False, False])
-        stream = torch.cuda.current_stream(self.device)
-        for i, s in enumerate(range(0, n, self.STAGE_ROWS)):
-            b = i & 1
-            c = min(self.STAGE_ROWS, n - s)
-            if st[3][b]:
-                st[2][b].synchronize()                 # the DMA that last read this piece is done
-            st[b][:c].copy_(src[s:s + c])
-            dst[s:s + c].copy_(st[b][:c], non_blocking=True)
-            st[2][b].record(stream); st[3][b] = True
-        return dst
-
     def _to_dev(self, a, last):
         if torch.is_tensor(a):
             t = a.to(device=self.device, dtype=torch.float32).contiguous()
         else:
-            h = np.ascontiguousarray(a, dtype=np.float32)
-            k = int(np.prod(last))
-            if h.size >= self.STAGE_MIN * k and h.size % k == 0:
-                t = self._stage_host(h.reshape(-1, k))
-            else:
-                t = torch.from_numpy(h).to(self.device)
+            # (a pageable source: the runtime's own staged copy moves 138 MB in ~4 ms, ~34 GB/s, on this platform; copying
+            # through page-locked pieces of our own was measured 7x slower -- profiles/r03/small_batch_staged.txt)
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
         return t.reshape((-1,) + last)
 
     def setOption(self, key, value):

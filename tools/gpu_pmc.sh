@@ -5,12 +5,13 @@ set -u
 TAG=${1:-pmc}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
+[ -f $OUT/pmc_traffic.json ] || cp profiles/pmc_traffic.json $OUT/pmc_traffic.json    # keep the other sections (pileup, train)
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 HEAD=${2:-unknown}
 for arch in full slim; do
-  python bench.py --steps 8 --warmup 2 --no-cpu --arch $arch > $OUT/bench_$arch.json 2> $OUT/bench_$arch.err
+  python bench.py --steps 8 --warmup 2 --no-cpu --no-extras --arch $arch > $OUT/bench_$arch.json 2> $OUT/bench_$arch.err
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/p_${arch}_$c -o p -- python bench.py --steps 8 --warmup 2 --no-cpu --arch $arch > /dev/null 2> $OUT/p_${arch}_$c.err
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/p_${arch}_$c -o p -- python bench.py --steps 8 --warmup 2 --no-cpu --no-extras --arch $arch > /dev/null 2> $OUT/p_${arch}_$c.err
     f=$(find $OUT/p_${arch}_$c -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && cp "$f" $OUT/${arch}_${c}_counter_collection.csv
     rm -rf $OUT/p_${arch}_$c
@@ -19,7 +20,7 @@ for arch in full slim; do
       --bench-json $OUT/bench_$arch.json --head $HEAD --out $OUT/pmc_traffic.json
 done
 # MFMA-busy and VALU instruction counters (own pass)
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/p_sq -o p -- python bench.py --steps 8 --warmup 2 --no-cpu > /dev/null 2> $OUT/p_sq.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/p_sq -o p -- python bench.py --steps 8 --warmup 2 --no-cpu --no-extras > /dev/null 2> $OUT/p_sq.err
 f=$(find $OUT/p_sq -name "*counter_collection.csv" | head -1)
 [ -n "$f" ] && python - "$f" > $OUT/sq_summary.txt <<'PY'
 import csv, sys, collections
