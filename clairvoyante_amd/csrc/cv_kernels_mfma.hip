@@ -1628,8 +1628,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void dense_dgrad_unpool(const f4 *__
     int gl[GR]; bool live[GR];
 #pragma unroll
     for (int r = 0; r < GR; r++) { live[r] = g0 + r < G; gl[r] = live[r] ? g0 + r : G - 1; }
-    stage_async(0, 0);
-    stage_async(HO > 1 ? 1 : 0, 1);
+    // gridDim.z row parts (tiny batches: a shorter chain per workgroup): part z owns the OUTPUT rows [pa, pb) of the
+    // HO + P - 1 and walks the windows [lo, hi] -- the P - 1 windows in front of its rows are recomputed (same values)
+    const int HP = HO + P - 1;
+    const int pa = HP * (int)blockIdx.z / (int)gridDim.z, pb = HP * ((int)blockIdx.z + 1) / (int)gridDim.z;
+    const int lo = pa - (P - 1) > 0 ? pa - (P - 1) : 0;
+    const int hi = pb - 1 < HO - 1 ? pb - 1 : HO - 1;
+    stage_async(lo, 0);
+    stage_async(lo + 1 <= hi ? lo + 1 : hi, 1);
     f4 B[GR][NB];
 #pragma unroll
     for (int r = 0; r < GR; r++)
@@ -1659,20 +1665,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void dense_dgrad_unpool(const f4 *__
         for (int r = 0; r < GR; r++) {
             U[r].push(acc[r], yv[r], cv_code16(cv[r][0], cv[r][1], w));
             const f4 o = U[r].emit();
-            if (live[r]) op[r][(size_t)row * NCOL * 64] = o;      // (a plain store: older than the DMA pieces the counted wait leaves in flight)
+            if (live[r] && row >= pa) op[r][(size_t)row * NCOL * 64] = o;      // (a plain store: older than the DMA pieces the counted wait leaves in flight)
         }
     };
     int slot = 0;
 #pragma unroll 1
-    for (int row = 0; row < HO; row++) {
-        if (row > 0) finish_row(row - 1);
+    for (int row = lo; row <= hi; row++) {
+        if (row > lo) finish_row(row - 1);
 #pragma unroll
         for (int r = 0; r < GR; r++) {
             yv[r] = load_f4(pp[r] + (size_t)row * NCOL * 64);
             cv[r] = load_u2(cp[r] + (size_t)row * NT * 64);
             acc[r] = zero;
         }
-        const int rs = row + 2 < HO ? row + 2 : HO - 1;
+        const int rs = row + 2 <= hi ? row + 2 : hi;
         int wslot = slot + 2; if (wslot >= 3) wslot -= 3;
         stage_async(rs, wslot);
         const f4 *wl = ring + slot * STAGE + lane;
@@ -1702,14 +1708,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void dense_dgrad_unpool(const f4 *__
         __syncthreads();
         slot = slot + 1 == 3 ? 0 : slot + 1;
     }
-    finish_row(HO - 1);
+    finish_row(hi);
+    if (hi == HO - 1) {                                    // the last P - 1 output rows start no window
+        for (int row = HO; row < pb; row++) {
 #pragma unroll
-    for (int d = 0; d + 1 < P; d++) {
-#pragma unroll
-        for (int r = 0; r < GR; r++) {
-            U[r].push_none();
-            const f4 o = U[r].emit();
-            if (live[r]) op[r][(size_t)(HO + d) * NCOL * 64] = o;
+            for (int r = 0; r < GR; r++) {
+                U[r].push_none();
+                const f4 o = U[r].emit();
+                if (live[r] && row >= pa) op[r][(size_t)row * NCOL * 64] = o;
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // surplus DMA pieces of the last rows
@@ -2886,10 +2893,15 @@ int cv_tile_fc4_dgrad_unpool(cv_model *m, const float *g_tm, const float *pooled
         k<<<dim3(nblk(G, 16), 4 * NT), 512, lds, st>>>((const f4 *)g_tm, (const f4 *)m->wpr_fc4, (const f4 *)pooled,
                                                        (const u32x2 *)codes, (f4 *)gpre, G, HO, NT);
     } else {
+        // few groups: row parts (gridDim.z; each recomputes the two windows in front of its rows) would shorten the
+        // 24-row walk of a workgroup -- measured at 79 groups: 0.672 / 0.690 / 0.688 / 0.719 ms per step with 1 / 2 / 3 / 4
+        // parts, so one; dbg6 = parts for A/B
+        int parts = m->dbg[6] > 0 ? m->dbg[6] : 1;
+        if (parts > 6) parts = 6;
         auto k = dense_dgrad_unpool<21, 3, 8, 1>;
         if (set_lds(k, lds)) return 1;
-        k<<<dim3(nblk(G, 8), 4 * NT), 512, lds, st>>>((const f4 *)g_tm, (const f4 *)m->wpr_fc4, (const f4 *)pooled,
-                                                      (const u32x2 *)codes, (f4 *)gpre, G, HO, NT);
+        k<<<dim3(nblk(G, 8), 4 * NT, parts), 512, lds, st>>>((const f4 *)g_tm, (const f4 *)m->wpr_fc4, (const f4 *)pooled,
+                                                             (const u32x2 *)codes, (f4 *)gpre, G, HO, NT);
     }
     CV_HIP(hipGetLastError());
     return 0;
