@@ -107,7 +107,13 @@ struct cv_model {
     int64_t last_tr_n;
     int last_tr_tile;    // 1: tile-major buffers, 0: natural [n, fc4]
     // optional per-kernel timing (option "profile")
-    int dbg[8];          // options "dbg0".."dbg7": development switches of the training step (A/B runs; 0 = default)
+    // options "dbg0".."dbg7": development switches of the training step (A/B runs and variant tests; 0 = shipped path).
+    //   dbg0 = n: position parts of the convolution data gradients      dbg1 = n: ... of the training-forward convolutions
+    //   dbg2 = 1 / 2: unpool always thread-per-row / always streaming   dbg3 = 1: fc4 data gradient and conv3 unpool as two kernels
+    //   dbg4 = 2: conv data gradients fused with the unpool below (conv_dgrad_unpool), 3: slim selu' as its own pass
+    //   dbg5 = 1: all weight packing in one launch in stream order      dbg6 = n: row parts of dense_dgrad_unpool (few groups)
+    //   dbg7 = 1: training-forward conv3 on conv_tm instead of conv3_rot
+    int dbg[8];
     int profile;
     void *prof;          // cv_prof*, owned
     const char *stage_kernel[CV_NUM_STAGES];   // kernel (template instance) each stage of the last cv_forward chunk ran

@@ -219,7 +219,7 @@ def test_backward_kernel_variants_give_the_same_bits(oracle, arch, n):
         m.close()
         return out
     ref = run({})
-    variants = ({"dbg3": 1}, {"dbg4": 2}, {"dbg4": 2, "dbg0": 3}, {"train_side_streams": 1}, {"dbg5": 1},
+    variants = ({"dbg3": 1}, {"dbg4": 2}, {"dbg4": 2, "dbg0": 3}, {"train_side_streams": 1}, {"dbg5": 1}, {"dbg6": 3}, {"dbg7": 1},
                 {"dbg3": 1, "dbg4": 2, "train_overlap": 0}) if arch == "full" else \
                ({"dbg4": 3}, {"train_side_streams": 1}, {"dbg5": 1, "dbg4": 3, "train_overlap": 0})
     for opts in variants:
