@@ -129,9 +129,10 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     if (s.nb4 == 21) alloc(&m->wps_fc4, (size_t)3 * s.kb4 * 8 * 256);
     if (s.nb4 == 21) alloc(&m->wps7_fc4, (size_t)7 * s.kb4 * 3 * 256);
     if (s.nb4 == 21 && s.nb5 == 11) alloc(&m->wps3_fc5, (size_t)3 * s.nb4 * 4 * 256);
+    if (s.nb4 == 21 && s.nb5 == 11) alloc(&m->wp5p_fc5, (size_t)((s.nb4 + 3) / 4) * 48 * 256);
     alloc(&m->wp_heads0, (size_t)s.nb4 * 256);
     alloc(&m->wp_heads1, (size_t)s.nb5 * 256);
-    m->variant = 495;
+    m->variant = 1519;
     if (e == hipSuccess) e = hipMalloc(&m->loss_dev, sizeof(double) * 8);
     if (e == hipSuccess) e = hipMalloc(&m->loss_acc, sizeof(double) * 8);
     if (e == hipSuccess) e = hipMemset(m->loss_acc, 0, sizeof(double) * 8);
@@ -150,10 +151,11 @@ extern "C" int cv_destroy(cv_model *m)
     if (!m) return 0;
     hipSetDevice(m->device);
     float *bufs[] = {m->params, m->grads_own, m->adam_m, m->adam_v, m->wp_conv1, m->wp_conv[1], m->wp_conv[2],
-                     m->wp_fc4, m->wp_fc5, m->wp_heads0, m->wp_heads1, m->wpd_conv[1], m->wpd_conv[2], m->wpd_fc4, m->wpr_fc4, m->wpd_fc5, m->wps_fc4, m->wps7_fc4, m->wps3_fc5, m->wg_part, m->tm_p1, m->tm_p2, m->tm_p3, m->tm_h4, m->tm_h5, m->r_a[0],
+                     m->wp_fc4, m->wp_fc5, m->wp_heads0, m->wp_heads1, m->wpd_conv[1], m->wpd_conv[2], m->wpd_fc4, m->wpr_fc4, m->wpd_fc5, m->wps_fc4, m->wps7_fc4, m->wps3_fc5, m->wp5p_fc5, m->wg_part, m->tm_p1, m->tm_p2, m->tm_p3, m->tm_h4, m->tm_h5, m->r_a[0],
                      m->r_a[1], m->r_a[2], m->r_p[0], m->r_p[1], m->r_p[2], m->r_h4, m->r_h5, m->t_buf};
     for (float *b : bufs)
         if (b) hipFree(b);
+    if (m->tail_dev) hipFree(m->tail_dev);
     if (m->loss_dev) hipFree(m->loss_dev);
     if (m->loss_acc) hipFree(m->loss_acc);
     if (m->tr_side) {

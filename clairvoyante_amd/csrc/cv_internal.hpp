@@ -69,10 +69,13 @@ struct cv_model {
     float *wps_fc4;      // forward weights of fc4 in 3 slabs [slab][kb][8][64][4] (full topology, small batches)
     float *wps7_fc4;     // ... and in 7 slabs [slab][kb][3][64][4] (dense_small: one wave per group and slab)
     float *wps3_fc5;     // fc5 in 3 slabs [slab][kb][4][64][4] (dense_small)
+    void *tail_dev;      // device copy of the tail arguments of the fused fc4 + fc5 + heads kernel (dense_tm EPI 3)
+    unsigned char tail_host[160];   // what tail_dev holds
+    float *wp5p_fc5;     // fc5 in k pairs [kp][24][64][4] (tail of the large-pass fc4 kernel, dense_tm EPI 3; full topology)
     float *wpd_fc5;      // data-gradient weights of fc5 [jb][24 | 4][64][4]
     float *wp_heads0;    // [nb4][64][4]  base head (rows 0..3)
     float *wp_heads1;    // [nb5][64][4]  zygosity / type / length heads
-    int variant;         // bit 0: first layer fused into conv2; bit 1: MFMA heads kernel; bit 2: 8-wave fc4 workgroups; bit 3: rotating-window conv3
+    int variant;         // kernel selection bits, see include/clairvoyante_amd.h (cv_set_option "variant")
     bool packed_dirty;         // forward fragments are stale
     bool packed_train_dirty;   // data-gradient fragments are stale
     // workspaces (allocated lazily for `ws_cap` candidates)

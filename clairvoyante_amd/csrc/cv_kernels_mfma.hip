@@ -21,6 +21,7 @@
 #include "cv_math.hpp"
 #include "cv_unpool.hpp"
 #include <type_traits>
+#include <string.h>
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -146,6 +147,24 @@ __device__ __forceinline__ void pack_dense(int64_t t, const float *__restrict__ 
     int i = lane & 15, kq = lane >> 4;
     int k = 16 * kb + 4 * s + kq, o = 16 * ob + cv_sigma(i);
     wp[t] = (k < K && o < N) ? w[(size_t)k * N + o] : 0.0f;
+}
+
+// forward weights of a small dense layer in PAIRS of k fragments: [kp][2 x NBH][lane][s] -- one 2*NBH-fragment stage of
+// the LDS ring carries two k steps (dense_tm EPI 3 streams fc5 that way on fc4's ring: half the barriers)
+__device__ __forceinline__ void pack_dense_kpairs(int64_t t, const float *__restrict__ w, float *__restrict__ wp, int K, int N, int KB, int NBH,
+                                                  int KS)
+{
+    const int KP = (KB + KS - 1) / KS;             // stages of KS k fragments x NBH output fragments
+    int64_t total = (int64_t)KP * KS * NBH * 256;
+    if (t >= total) return;
+    int s = (int)(t & 3), lane = (int)((t >> 2) & 63);
+    int64_t frag = t >> 8;
+    int f = (int)(frag % (KS * NBH));
+    int kp = (int)(frag / (KS * NBH));
+    int kb = KS * kp + f / NBH, ob = f % NBH;
+    int i = lane & 15, kq = lane >> 4;
+    int k = 16 * kb + 4 * s + kq, o = 16 * ob + cv_sigma(i);
+    wp[t] = (kb < KB && k < K && o < N) ? w[(size_t)k * N + o] : 0.0f;
 }
 
 // forward weights of a dense layer in NSLAB slabs of NBS output fragments (padded to NBSP per k step):
@@ -1267,6 +1286,12 @@ struct heads_args {
     int64_t n;
     float *out16;
     const f4 *dact = nullptr;            // EPI 1 only: the output is multiplied by selu'-from-output of this map (same layout)
+    // EPI 3 only (fc4 with fc5 and the heads on its tail): fc5's weights in k PAIRS [kp][24][64] (pack_dense_kpairs),
+    // its bias / width, and where its output goes (kept for cv_get_activation and the parity tests)
+    const f4 *wp5p = nullptr; const float *bias5 = nullptr; int nout5 = 0; f4 *h5_out = nullptr;
+    // EPI 3: the kernel reads all of the above from this DEVICE copy on its tail, so that the two dozen scalars stay out
+    // of the main loop's register budget (by value they are loaded at kernel entry and live across the whole kernel)
+    const heads_args *tail = nullptr;
 };
 
 // ---------------------------------------------------------------------------
@@ -1292,6 +1317,7 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
                                                         heads_args hd = heads_args())
 {
     static_assert(EPI != 2 || GR == 1, "the fused heads keep one group per wave");
+    static_assert(EPI != 3 || (GR == 2 && NB == 21 && WAVES == 8), "the fc5 + heads tail is written for the full topology's fc4");
     // The packed weight matrix holds NBP = roundup(NB, WAVES) fragments per k step (the pad
     // fragments are zero and never multiplied), so every thread stages exactly PER 16-byte
     // pieces per step: no conditional loads in the loop, which lets the waits sit at the
@@ -1312,11 +1338,14 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = (blockIdx.x * WAVES + wid) * GR;
-    const f4 *bp[GR];
+    // this wave's activation fragments: byte offsets from in_tm (a scalar base + a 32-bit vector offset per group
+    // instead of a 64-bit pointer: 2 VGPRs less per group, which the fc5 + heads tail of EPI 3 needs; a pass is at most
+    // 4 096 groups x 288 fragments = 1.2 GB)
+    unsigned bo[GR];
 #pragma unroll
     for (int r = 0; r < GR; r++) {
         const int gl = g + r < G ? g + r : G - 1;
-        bp[r] = in_tm + ((size_t)gl * KBA + kb0) * 64 + lane;
+        bo[r] = (unsigned)((((size_t)gl * KBA + kb0) * 64 + lane) * sizeof(f4));
     }
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
     f4 acc[GR][NB];
@@ -1349,13 +1378,18 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
         return v;
     };
+    auto load_frag_off = [&](unsigned byte_off) {
+        f4 v;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(in_tm) : "memory");
+        return v;
+    };
     stage_async(0, 0);
     stage_async(KB > 1 ? 1 : 0, 1);
     f4 hacc0 = zero, hA = zero;                 // EPI 2: base-head tile and its weight fragment of the current k step
     if constexpr (EPI == 2) hA = load_frag(hd.wp0 + lane);
     f4 B[GR];
 #pragma unroll
-    for (int r = 0; r < GR; r++) B[r] = load_frag(bp[r]);
+    for (int r = 0; r < GR; r++) B[r] = load_frag_off(bo[r]);
 #pragma unroll
     for (int r = 0; r < GR; r++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(B[r]) : : "memory");
     if constexpr (EPI == 2) asm volatile("" : "+v"(hA) : : "memory");
@@ -1370,21 +1404,22 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
         int wslot = slot + 2; if (wslot >= 3) wslot -= 3;
         f4 Bn[GR];
 #pragma unroll
-        for (int r = 0; r < GR; r++) Bn[r] = load_frag(bp[r] + (size_t)kn * 64);
+        for (int r = 0; r < GR; r++) Bn[r] = load_frag_off(bo[r] + (unsigned)kn * 1024u);
         f4 hAn = zero;
         if constexpr (EPI == 2) hAn = load_frag(hd.wp0 + (size_t)kn * 64 + lane);      // issued before this step's DMA pieces
         stage_async(ks, wslot);          // slot (kb+2)%3 was last read in step kb-1 (barrier passed)
         const f4 *wl = ring + slot * STAGE + lane;
+        constexpr int AB = EPI == 3 ? 2 : 3;      // weight fragments read ahead of their MFMAs (EPI 3 is short of 4 VGPRs)
 #pragma unroll
-        for (int ob = 0; ob < NB; ob += 3) {
-            f4 A[3];
+        for (int ob = 0; ob < NB; ob += AB) {
+            f4 A[AB];
 #pragma unroll
-            for (int j = 0; j < 3; j++)
+            for (int j = 0; j < AB; j++)
                 if (ob + j < NB) A[j] = wl[(ob + j) * 64];
 #pragma unroll
             for (int s = 0; s < 4; s++)
 #pragma unroll
-                for (int j = 0; j < 3; j++)
+                for (int j = 0; j < AB; j++)
 #pragma unroll
                     for (int r = 0; r < GR; r++)
                         if (ob + j < NB) acc[r][ob + j] = mfma4(A[j][s], B[r][s], acc[r][ob + j]);
@@ -1409,6 +1444,113 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
         slot = slot + 1 == 3 ? 0 : slot + 1;
     }
     const int q = lane >> 4;
+    if constexpr (EPI == 3) {
+        // ---- fc5 and the four heads on the tail of fc4 (inference, variant bit 10).  After bias + SELU the wave's
+        // accumulators ARE fc5's k fragments (and the base head's): they never leave the registers.  fc5's weights come
+        // through the same ring, two k fragments per stage (24 fragments, the same three DMA pieces per wave and the same
+        // counted wait as the main loop), one group of the wave at a time (11 accumulator tiles next to the 42 fragments
+        // of fc4 output that stay live).  Per output value the chain is dense_tm<11,..>'s and heads_tm's: same bits.
+        constexpr int NB5 = 11, NBH = 12, KS5 = 4, KP = (NB + KS5 - 1) / KS5, ST5 = KS5 * NBH * 64, PER5 = KS5 * NBH / WAVES;
+        const heads_args *tp = hd.tail;
+        asm volatile("" : "+s"(tp));                 // the loads below stay below
+        const heads_args hd = *tp;                   // (shadows the by-value argument from here on)
+        // lane id recomputed here (v_mbcnt) instead of carried through the main loop in a register: the loop is at its
+        // register limit, and a value that is live across it would be spilled and reloaded on every one of its 288 steps
+        int lane_t;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
+        const int q_t = lane_t >> 4;
+#pragma unroll
+        for (int r = 0; r < GR; r++)
+#pragma unroll
+            for (int ob = 0; ob < NB; ob++) {
+                // (nout == 16 NB here -- checked by the launcher --, so no bounds test per lane: 168 predicates less)
+                const float *bq = bias + 16 * ob + q_t;
+                acc[r][ob] = selu4(acc[r][ob] + (f4){bq[0], bq[4], bq[8], bq[12]});
+                if (g + r < G) out_tm[((size_t)(g + r) * NBT + ob) * 64 + lane_t] = acc[r][ob];
+            }
+        f4 hacc0[GR], hacc1[GR];
+#pragma unroll
+        for (int r = 0; r < GR; r++) { hacc0[r] = zero; hacc1[r] = zero; }
+#pragma unroll
+        for (int kb = 0; kb < NB; kb++) {                    // base head over the fc4 output (v3.py:124-126)
+            const f4 A = hd.wp0[(size_t)kb * 64 + lane_t];
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int r = 0; r < GR; r++) hacc0[r] = mfma4(A[s], acc[r][kb][s], hacc0[r]);
+        }
+        auto stage5 = [&](int kp, int sl) {
+#pragma unroll
+            for (int p = 0; p < PER5; p++) {
+                const f4 *gp = hd.wp5p + ((size_t)kp * (KS5 * NBH) + wid * PER5 + p) * 64 + lane_t;
+                const unsigned ldst = ring_base + (unsigned)((sl * (KS5 * NBH) + wid * PER5 + p) * 1024);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(gp), "s"(ldst) : "memory");
+            }
+        };
+#pragma unroll
+        for (int r = 0; r < GR; r++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // nothing of the previous pipeline is in flight,
+            __syncthreads();                                       // nobody still reads the ring
+            stage5(0, 0);
+            stage5(1, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            f4 acc5[NB5];
+#pragma unroll
+            for (int ob = 0; ob < NB5; ob++) acc5[ob] = zero;
+            // The stage loop stays ROLLED (unrolled, the compiler hoists the weight reads of all stages and spills 165
+            // registers): the four k fragments of a step are always acc[r][0..3]; the fragments are rotated down by four
+            // at the end of a step.
+            int sl = 0;
+#pragma unroll 1
+            for (int kp = 0; kp < KP; kp++) {
+                int wsl = sl + 2; if (wsl >= 3) wsl -= 3;
+                stage5(kp + 2 < KP ? kp + 2 : KP - 1, wsl);
+                const f4 *wl5 = ring + sl * ST5 + lane_t;
+#pragma unroll
+                for (int half = 0; half < KS5; half++) {
+                    if (KS5 * kp + half < NB) {                    // wave-uniform: the last stage holds one k fragment
+#pragma unroll
+                        for (int ob = 0; ob < NB5; ob += 3) {
+                            f4 A[3];
+#pragma unroll
+                            for (int j = 0; j < 3; j++)
+                                if (ob + j < NB5) A[j] = wl5[(half * NBH + ob + j) * 64];
+#pragma unroll
+                            for (int s = 0; s < 4; s++)
+#pragma unroll
+                                for (int j = 0; j < 3; j++)
+                                    if (ob + j < NB5) acc5[ob + j] = mfma4(A[j][s], acc[r][half][s], acc5[ob + j]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i + KS5 < NB; i++) acc[r][i] = acc[r][i + KS5];
+                __builtin_amdgcn_sched_barrier(0);
+                static_assert(PER5 == 6, "counted wait below");
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // stage kp + 2 (6 pieces per wave) stays in flight, kp + 1 has landed
+                __syncthreads();
+                sl = sl + 1 == 3 ? 0 : sl + 1;
+            }
+            // fc5 output of this group: bias + SELU, kept for cv_get_activation, and straight into the three fc5-side heads
+#pragma unroll
+            for (int ob = 0; ob < NB5; ob++) {
+                const f4 h = selu4(acc5[ob] + load_bias4(hd.bias5, ob, q_t, hd.nout5));
+                if (g + r < G) hd.h5_out[((size_t)(g + r) * NB5 + ob) * 64 + lane_t] = h;
+                const f4 W = hd.wp1[(size_t)ob * 64 + lane_t];
+#pragma unroll
+                for (int s = 0; s < 4; s++) hacc1[r] = mfma4(W[s], h[s], hacc1[r]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // surplus DMA pieces of the last stages
+#pragma unroll
+        for (int r = 0; r < GR; r++)
+            if (g + r < G) heads_finish(hacc0[r], hacc1[r], hd.bb, hd.bz, hd.bt, hd.bl, hd.n, hd.out16, g + r, lane_t);
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < GR; r++) {
         if (g + r >= G) break;
@@ -1931,6 +2073,7 @@ int launch_dense(const float *in, int KB, const float *wp, const float *bias, in
 {
     auto k = dense_tm<NB, WAVES, EPI, GR>;
     size_t lds = (size_t)3 * ((NB + WAVES - 1) / WAVES * WAVES) * 1024;
+    if (EPI == 3) lds = (size_t)3 * 48 * 1024;          // the tail streams fc5 in stages of 4 k fragments x 12 output fragments
     if (set_lds(k, lds)) return 1;
     if (ksplit > 1) {       // partial sums per k range, then dense_ksum (EPI 0 layers only)
         static_assert(EPI == 0 || true, "");
@@ -2005,6 +2148,7 @@ __global__ __launch_bounds__(256) void pack_all(pack_tab tab)
     case 4: pack_dense_dgrad(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4]); break;
     case 5: pack_conv_dgrad(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4]); break;
     case 7: pack_dense_dgrad_rows(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4], J.i[5]); break;
+    case 8: pack_dense_kpairs(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4]); break;
     default: pack_heads(t, J.src[0], J.src[1], J.src[2], J.src[3], J.i[0], J.i[1], J.i[2], J.i[3], J.dst[0], J.dst[1]); break;
     }
 }
@@ -2047,6 +2191,10 @@ static int pack_launch(cv_model *m, hipStream_t st, bool fwd, bool with_train, i
           J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = nbp4; }
         { pack_job &J = pb.add(2, (int64_t)s.nb4 * nbp5 * 256); J.src[0] = P + o[8]; J.dst[0] = m->wp_fc5;
           J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb4; J.i[3] = nbp5; }
+        if (m->wp5p_fc5) {      // full topology: fc5 in k pairs for the tail of the large-pass fc4 kernel (dense_tm EPI 3)
+            pack_job &J = pb.add(8, (int64_t)((s.nb4 + 3) / 4) * 48 * 256); J.src[0] = P + o[8]; J.dst[0] = m->wp5p_fc5;
+            J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb4; J.i[3] = 12; J.i[4] = 4;
+        }
         if (m->wps_fc4) {       // full topology: fc4 in 3 slabs of 7 fragments for small batches
             pack_job &J = pb.add(3, (int64_t)3 * s.kb4 * 8 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wps_fc4;
             J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = 7; J.i[4] = 8; J.i[5] = 3;
@@ -2157,6 +2305,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
     const bool fuse_front = (m->variant & 1) != 0;
     const float *W1 = m->wp_conv1, *B1 = P + o[1];
     bool heads_done = false;             // the heads rode on the fc5 kernel (variant bit 9)
+    bool tail_done = false;              // fc5 and the heads rode on the fc4 kernel (variant bit 10)
     heads_args hd;
     hd.wp0 = (const f4 *)m->wp_heads0; hd.wp1 = (const f4 *)m->wp_heads1;
     hd.bb = P + o[11]; hd.bz = P + o[13]; hd.bt = P + o[15]; hd.bl = P + o[17];
@@ -2209,10 +2358,32 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         cv_prof_begin(m, 3, st);
         if (G <= CV_FC4_SMALL_MAX_G && (m->variant & 128)) { m->stage_kernel[3] = "dense_small<3, 8, 0>"; rc |= launch_dense_small<3, 8>(m->tm_p3, s.kb4, m->wps7_fc4, P + o[7], a.fc4, m->tm_h4, G, 7, st); }
         else if (G <= CV_FC4_SLAB_MAX_G) { m->stage_kernel[3] = "dense_tm<7, 8, 0, 1>"; rc |= launch_dense<7, 8>(m->tm_p3, s.kb4, m->wps_fc4, P + o[7], a.fc4, m->tm_h4, G, st, 3); }
+        else if ((m->variant & 1024) && (m->variant & 32) && m->wp5p_fc5) {      // fc4 + fc5 + heads as one kernel
+            m->stage_kernel[3] = "dense_tm<21, 8, 3, 2>";
+            heads_args h3 = hd;
+            h3.wp5p = (const f4 *)m->wp5p_fc5; h3.bias5 = P + o[9]; h3.nout5 = a.fc5; h3.h5_out = (f4 *)m->tm_h5;
+            static_assert(sizeof(heads_args) <= sizeof(m->tail_host), "cv_model::tail_host holds a heads_args");
+            if (a.fc4 != 16 * s.nb4) { cv_set_error("fused fc4 tail: fc4 width must be a whole number of tiles"); return 1; }
+            if (!m->tail_dev) CV_HIP(hipMalloc(&m->tail_dev, sizeof(heads_args)));
+            if (memcmp(m->tail_host, &h3, sizeof(heads_args)) != 0) {       // pointers / sizes of this pass differ from the device copy
+                memcpy(m->tail_host, &h3, sizeof(heads_args));
+                CV_HIP(hipMemcpyAsync(m->tail_dev, m->tail_host, sizeof(heads_args), hipMemcpyHostToDevice, st));
+            }
+            heads_args hk;                           // by value: only the pointer to the device copy
+            hk.tail = (const heads_args *)m->tail_dev;
+            rc |= launch_dense<21, 8, 3, 2>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st, 1, 1, nullptr, hk);
+            tail_done = true;
+        }
         else if (m->variant & 32) { m->stage_kernel[3] = "dense_tm<21, 8, 0, 2>"; rc |= launch_dense<21, 8, 0, 2>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st); }
         else if (m->variant & 4) { m->stage_kernel[3] = "dense_tm<21, 8, 0, 1>"; rc |= launch_dense<21, 8>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st); }
         else { m->stage_kernel[3] = "dense_tm<21, 4, 0, 1>"; rc |= launch_dense<21, 4>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st); }
         cv_prof_end(m, 3, st);
+        if (tail_done) {
+            if (rc) return 1;
+            CV_HIP(hipGetLastError());
+            m->last_n = n; m->last_impl = 1; m->last_variant = m->variant;
+            return 0;
+        }
         cv_prof_begin(m, 4, st);
         if (G <= CV_FC4_SMALL_MAX_G && (m->variant & 128)) {
             m->stage_kernel[4] = "dense_small<4, 7, 0>";

@@ -92,7 +92,7 @@ def test_plain_and_tile_kernels_agree_bitwise(setup):
     m.setOption("impl", 0)
     a = np.concatenate(m.predict(x), axis=1)
     m.setOption("impl", 1)
-    for variant in (0, 1, 2, 4, 7, 8, 15, 47, 111, 65, 239, 128, 495, 256, 1007, 512, 879):       # every kernel variant computes the same bits
+    for variant in (0, 1, 2, 4, 7, 8, 15, 47, 111, 65, 239, 128, 495, 256, 1007, 512, 879, 1519):       # every kernel variant computes the same bits
         m.setOption("variant", variant)
         b = np.concatenate(m.predict(x), axis=1)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), variant
@@ -111,11 +111,17 @@ def test_large_pass_kernels_equal_small_pass_kernels(setup):
     m.setOption("impl", 1)
     m.setOption("chunk", 8192)
     small = m.predict_device(xd).cpu().numpy()
-    for variant in (1007, 495, 239, 111, 47, 15, 11):        # two groups per wave / one group per wave with 8 or 4 waves per workgroup
+    for variant in (1519, 2031, 1007, 495, 239, 111, 47, 15, 11):        # fc5 + heads on fc4's tail / two groups per wave / one group per wave with 8 or 4 waves per workgroup
         m.setOption("variant", variant)
         m.setOption("chunk", 65536)
         big = m.predict_device(xd).cpu().numpy()
         assert np.array_equal(small.view(np.uint32), big.view(np.uint32)), variant
+        if arch == "full" and variant in (1519, 495):      # fc4 / fc5 maps of the whole pass: written by the fused tail or by their own kernels
+            acts = [m.getActivation(layer, n).cpu().numpy() for layer in (4, 5)]
+            if variant == 1519:
+                tail_acts = acts
+            else:
+                assert all(np.array_equal(u.view(np.uint32), v.view(np.uint32)) for u, v in zip(tail_acts, acts))
     m.setOption("variant", common.DEFAULT_VARIANT)
     m.setOption("chunk", 65536)
     head = m.predict(xd[:256].cpu().numpy())
