@@ -397,6 +397,8 @@ def run_infer(arch, batch, steps, warmup, rank, ws, dev, variant=None, batches=N
         flop = STAGE_FLOP[arch][s] + (STAGE_FLOP[arch][0] if (s == 1 and cnt[0] == 0) else 0)
         if s == 2 and cnt[3] == 0:          # conv3 and fc4 as one kernel (slim, variant bit 8)
             flop += STAGE_FLOP[arch][3]
+            if cnt[4] == 0 and cnt[5] == 0:             # ... with fc5 and the heads on its tail (variant bit 10)
+                flop += STAGE_FLOP[arch][4] + STAGE_FLOP[arch][5]
         if s == 4 and cnt[5] == 0:          # the heads ride on the fc5 kernel (variant bit 9)
             flop += STAGE_FLOP[arch][5]
         if s == 3 and cnt[4] == 0 and cnt[5] == 0:      # fc5 and the heads ride on the fc4 kernel (variant bit 10)
@@ -405,6 +407,7 @@ def run_infer(arch, batch, steps, warmup, rank, ws, dev, variant=None, batches=N
         kn = ctypes.c_char_p()
         _lib.check(m._lib.cv_kernel_name(m._h, s, ctypes.byref(kn)))
         label = STAGE_NAMES[s] + (" + fc4 (fused)" if (s == 2 and cnt[3] == 0) else "") + \
+            (" + fc5 + heads" if (s == 2 and cnt[3] == 0 and cnt[4] == 0 and cnt[5] == 0) else "") + \
             (" + heads (fused)" if (s == 4 and cnt[5] == 0) else "") + \
             (" + fc5 + heads (fused)" if (s == 3 and cnt[4] == 0 and cnt[5] == 0 and arch == "full") else "")
         stages.append({"kernel": label, "kernel_name": kn.value.decode() if kn.value else None,

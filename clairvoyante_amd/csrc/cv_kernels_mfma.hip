@@ -1011,155 +1011,6 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
 }
 
 // ---------------------------------------------------------------------------
-// Slim topology: conv3 k(5,4) 16 -> 32 (no pooling) FUSED with fc4 (4 224 -> 36), variant bit 8.
-// Separate kernels write the 16.9 KB conv3 map of every candidate to HBM and read it back for a 36-wide
-// contraction: slim fc4 sits on the HBM roof (1.1 GB in 0.26 ms), not on the matrix cores.  Here ONE wave owns a
-// group and computes BOTH output tiles of conv3, so after bias + SELU its registers hold, position by position,
-// exactly the fragments fc4 contracts over, in fc4's own order: kb = (h*4 + w)*2 + nt ascending = flatten order
-// (v3_slim.py:84-87).  They feed the three fc4 accumulator tiles straight from registers -- the conv3 map never
-// exists in memory.  fc4's weights (24 KB per position) are DMA'd global -> LDS two positions ahead into a 3-slot
-// ring shared by the 8 waves of the workgroup (each wave moves the 3 fragments of one kb), one barrier per
-// position (~600 MFMAs apart).  Same ascending-k chain per output value as conv_tm + dense_tm: bit-identical.
-// LDS: 40 KB conv3 weights + 3 x 24 KB.  All VMEM from inline asm with one counted wait per position (dense_tm).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void conv3fc4_slim(const f4 *__restrict__ in_tm, const f4 *__restrict__ wp3,
-                                                        const float *__restrict__ bias3, int cout3,
-                                                        const f4 *__restrict__ wp4, const float *__restrict__ bias4,
-                                                        int nout4, f4 *__restrict__ out_h4, int G)
-{
-    constexpr int KH = 5, PADT = 2, HIN = CV_INPUT_H, NT = 2, NB4 = 3, NBP4 = 4, WAVES = 8;
-    constexpr int NW3 = NT * KH * 4 * 64;                 // f4 of packed conv3 weights [nt][kh][kw][64]
-    constexpr int SLOT = 8 * NB4 * 64;                    // f4 per ring slot: 8 k fragments x 3 output fragments
-    extern __shared__ __attribute__((aligned(16))) f4 lds[];
-    f4 *ring = lds + NW3;
-    for (int i = threadIdx.x; i < NW3; i += WAVES * 64) lds[i] = wp3[i];
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gq = blockIdx.x * WAVES + wid;
-    const bool live = gq < G;
-    const int g = live ? gq : G - 1;
-    const int q = lane >> 4;
-    const f4 b3[NT] = {load_bias4(bias3, 0, q, cout3), load_bias4(bias3, 1, q, cout3)};
-    const f4 *inp = in_tm + (size_t)g * (HIN * 4 * 64) + lane;
-    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
-    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) f4 *)ring;
-    // this wave's share of the fc4 slab of position h: k fragment (h*8 + wid), its 3 real output fragments
-    auto stage_async = [&](int h, int slot) {
-        const int hc = h < HIN ? h : HIN - 1;              // surplus stages of the last positions re-read valid data
-#pragma unroll
-        for (int ob = 0; ob < NB4; ob++) {
-            const f4 *gp = wp4 + ((size_t)(hc * 8 + wid) * NBP4 + ob) * 64 + lane;
-            const unsigned ldst = ring_base + (unsigned)(((slot * 8 + wid) * NB4 + ob) * 1024);
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                         "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(gp), "s"(ldst) : "memory");
-        }
-    };
-    auto load_frag = [&](const f4 *ptr) {
-        f4 v;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
-        return v;
-    };
-    f4 win[KH][4];            // win[kh] = input row h + kh - PADT
-    f4 nxt[4];
-    f4 acc4[NB4];
-#pragma unroll
-    for (int ob = 0; ob < NB4; ob++) acc4[ob] = zero;
-    stage_async(0, 0);
-    stage_async(1, 1);
-    // prologue: rows -2..1 -> win[0..3], row 2 -> nxt
-#pragma unroll
-    for (int j = 0; j < KH; j++) {
-        const int hr = j - PADT;
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const f4 v = hr >= 0 ? load_frag(inp + (size_t)(hr * 4 + w) * 64) : zero;
-            if (j < KH - 1) win[j][w] = v; else nxt[w] = v;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < KH - 1; j++)
-#pragma unroll
-        for (int w = 0; w < 4; w++) asm volatile("" : "+v"(win[j][w]));
-#pragma unroll
-    for (int w = 0; w < 4; w++) asm volatile("" : "+v"(nxt[w]));
-    __syncthreads();          // conv3 weights and ring slots 0, 1 are in LDS
-    int slot = 0;
-#pragma unroll 1
-    for (int h = 0; h < HIN; h++) {
-#pragma unroll
-        for (int w = 0; w < 4; w++) win[KH - 1][w] = nxt[w];
-        {   // row h + 3 for the next position, fc4 slab of position h + 2
-            const int hr = h + 1 + (KH - 1) - PADT;
-            const int hc = hr < HIN ? hr : HIN - 1;
-#pragma unroll
-            for (int w = 0; w < 4; w++) nxt[w] = load_frag(inp + (size_t)(hc * 4 + w) * 64);
-            int wslot = slot + 2; if (wslot >= 3) wslot -= 3;
-            stage_async(h + 2, wslot);
-        }
-        f4 v[NT][4];
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-            f4 acc[4];
-#pragma unroll
-            for (int w = 0; w < 4; w++) acc[w] = zero;
-            const f4 *wl = lds + (size_t)nt * (KH * 4 * 64) + lane;
-#pragma unroll
-            for (int kh = 0; kh < KH; kh++) {
-                const int hr = h + kh - PADT;
-                if (hr >= 0 && hr < HIN) {             // wave-uniform; SAME padding rows are skipped
-#pragma unroll
-                    for (int kw = 0; kw < 4; kw++) {
-                        const f4 A = wl[(size_t)(kh * 4 + kw) * 64];
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; s4++)
-#pragma unroll
-                            for (int wo = 0; wo < 4; wo++) {
-                                const int wi = wo + kw - 1;
-                                if (wi < 0 || wi > 3) continue;
-                                acc[wo] = mfma4(A[s4], win[kh][wi][s4], acc[wo]);
-                            }
-                    }
-                }
-            }
-#pragma unroll
-            for (int w = 0; w < 4; w++) v[nt][w] = selu4(acc[w] + b3[nt]);
-        }
-        // fc4: k fragments of this position in flatten order (w, nt), weights from the ring slot
-        const f4 *rl = ring + (size_t)slot * SLOT + lane;
-#pragma unroll
-        for (int w = 0; w < 4; w++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
-                f4 A[NB4];
-#pragma unroll
-                for (int ob = 0; ob < NB4; ob++) A[ob] = rl[(size_t)((w * NT + nt) * NB4 + ob) * 64];
-#pragma unroll
-                for (int s4 = 0; s4 < 4; s4++)
-#pragma unroll
-                    for (int ob = 0; ob < NB4; ob++) acc4[ob] = mfma4(A[ob][s4], v[nt][w][s4], acc4[ob]);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-        // counted wait: this position's 3 DMA pieces (slab h + 2) stay in flight; the row loads issued before them
-        // and the pieces of slab h + 1 (issued one position ago) have landed; the barrier publishes slab h + 1
-        asm volatile("s_waitcnt vmcnt(3)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j + 1 < KH; j++)
-#pragma unroll
-            for (int w = 0; w < 4; w++) win[j][w] = win[j + 1][w];
-        slot = slot + 1 == 3 ? 0 : slot + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the surplus stages before the wave retires
-    if (!live) return;
-    f4 *op = out_h4 + (size_t)g * NB4 * 64 + lane;
-#pragma unroll
-    for (int ob = 0; ob < NB4; ob++) op[ob * 64] = selu4(acc4[ob] + load_bias4(bias4, ob, q, nout4));
-}
-
-// ---------------------------------------------------------------------------
 // heads (v3.py:124-138): one wave per group of 16 candidates.
 //   tile 0 (input fc4 side, K = NB4*16): rows 0..3  = base logits -> sigmoid
 //   tile 1 (input fc5,      K = NB5*16): rows 0..1  = zygosity, rows 4..7 = variant type,
@@ -1293,6 +1144,190 @@ struct heads_args {
     // of the main loop's register budget (by value they are loaded at kernel entry and live across the whole kernel)
     const heads_args *tail = nullptr;
 };
+
+// ---------------------------------------------------------------------------
+// Slim topology: conv3 k(5,4) 16 -> 32 (no pooling) FUSED with fc4 (4 224 -> 36), variant bit 8.
+// Separate kernels write the 16.9 KB conv3 map of every candidate to HBM and read it back for a 36-wide
+// contraction: slim fc4 sits on the HBM roof (1.1 GB in 0.26 ms), not on the matrix cores.  Here ONE wave owns a
+// group and computes BOTH output tiles of conv3, so after bias + SELU its registers hold, position by position,
+// exactly the fragments fc4 contracts over, in fc4's own order: kb = (h*4 + w)*2 + nt ascending = flatten order
+// (v3_slim.py:84-87).  They feed the three fc4 accumulator tiles straight from registers -- the conv3 map never
+// exists in memory.  fc4's weights (24 KB per position) are DMA'd global -> LDS two positions ahead into a 3-slot
+// ring shared by the 8 waves of the workgroup (each wave moves the 3 fragments of one kb), one barrier per
+// position (~600 MFMAs apart).  Same ascending-k chain per output value as conv_tm + dense_tm: bit-identical.
+// LDS: 40 KB conv3 weights + 3 x 24 KB.  All VMEM from inline asm with one counted wait per position (dense_tm).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void conv3fc4_slim(const f4 *__restrict__ in_tm, const f4 *__restrict__ wp3,
+                                                        const float *__restrict__ bias3, int cout3,
+                                                        const f4 *__restrict__ wp4, const float *__restrict__ bias4,
+                                                        int nout4, f4 *__restrict__ out_h4, int G,
+                                                        const heads_args *__restrict__ tail = nullptr)
+{
+    // tail != nullptr (variant bit 10): fc5 (36 -> 18: 3 k fragments x 2 tiles) and the four heads follow on the same
+    // wave from the fc4 fragments in its registers -- 44 MFMAs instead of two more launches; weights straight from L2
+    constexpr int KH = 5, PADT = 2, HIN = CV_INPUT_H, NT = 2, NB4 = 3, NBP4 = 4, WAVES = 8;
+    constexpr int NW3 = NT * KH * 4 * 64;                 // f4 of packed conv3 weights [nt][kh][kw][64]
+    constexpr int SLOT = 8 * NB4 * 64;                    // f4 per ring slot: 8 k fragments x 3 output fragments
+    extern __shared__ __attribute__((aligned(16))) f4 lds[];
+    f4 *ring = lds + NW3;
+    for (int i = threadIdx.x; i < NW3; i += WAVES * 64) lds[i] = wp3[i];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gq = blockIdx.x * WAVES + wid;
+    const bool live = gq < G;
+    const int g = live ? gq : G - 1;
+    const int q = lane >> 4;
+    const f4 b3[NT] = {load_bias4(bias3, 0, q, cout3), load_bias4(bias3, 1, q, cout3)};
+    const f4 *inp = in_tm + (size_t)g * (HIN * 4 * 64) + lane;
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) f4 *)ring;
+    // this wave's share of the fc4 slab of position h: k fragment (h*8 + wid), its 3 real output fragments
+    auto stage_async = [&](int h, int slot) {
+        const int hc = h < HIN ? h : HIN - 1;              // surplus stages of the last positions re-read valid data
+#pragma unroll
+        for (int ob = 0; ob < NB4; ob++) {
+            const f4 *gp = wp4 + ((size_t)(hc * 8 + wid) * NBP4 + ob) * 64 + lane;
+            const unsigned ldst = ring_base + (unsigned)(((slot * 8 + wid) * NB4 + ob) * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gp), "s"(ldst) : "memory");
+        }
+    };
+    auto load_frag = [&](const f4 *ptr) {
+        f4 v;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+        return v;
+    };
+    f4 win[KH][4];            // win[kh] = input row h + kh - PADT
+    f4 nxt[4];
+    f4 acc4[NB4];
+#pragma unroll
+    for (int ob = 0; ob < NB4; ob++) acc4[ob] = zero;
+    stage_async(0, 0);
+    stage_async(1, 1);
+    // prologue: rows -2..1 -> win[0..3], row 2 -> nxt
+#pragma unroll
+    for (int j = 0; j < KH; j++) {
+        const int hr = j - PADT;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const f4 v = hr >= 0 ? load_frag(inp + (size_t)(hr * 4 + w) * 64) : zero;
+            if (j < KH - 1) win[j][w] = v; else nxt[w] = v;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < KH - 1; j++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) asm volatile("" : "+v"(win[j][w]));
+#pragma unroll
+    for (int w = 0; w < 4; w++) asm volatile("" : "+v"(nxt[w]));
+    __syncthreads();          // conv3 weights and ring slots 0, 1 are in LDS
+    int slot = 0;
+#pragma unroll 1
+    for (int h = 0; h < HIN; h++) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) win[KH - 1][w] = nxt[w];
+        {   // row h + 3 for the next position, fc4 slab of position h + 2
+            const int hr = h + 1 + (KH - 1) - PADT;
+            const int hc = hr < HIN ? hr : HIN - 1;
+#pragma unroll
+            for (int w = 0; w < 4; w++) nxt[w] = load_frag(inp + (size_t)(hc * 4 + w) * 64);
+            int wslot = slot + 2; if (wslot >= 3) wslot -= 3;
+            stage_async(h + 2, wslot);
+        }
+        f4 v[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            f4 acc[4];
+#pragma unroll
+            for (int w = 0; w < 4; w++) acc[w] = zero;
+            const f4 *wl = lds + (size_t)nt * (KH * 4 * 64) + lane;
+#pragma unroll
+            for (int kh = 0; kh < KH; kh++) {
+                const int hr = h + kh - PADT;
+                if (hr >= 0 && hr < HIN) {             // wave-uniform; SAME padding rows are skipped
+#pragma unroll
+                    for (int kw = 0; kw < 4; kw++) {
+                        const f4 A = wl[(size_t)(kh * 4 + kw) * 64];
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+                            for (int wo = 0; wo < 4; wo++) {
+                                const int wi = wo + kw - 1;
+                                if (wi < 0 || wi > 3) continue;
+                                acc[wo] = mfma4(A[s4], win[kh][wi][s4], acc[wo]);
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < 4; w++) v[nt][w] = selu4(acc[w] + b3[nt]);
+        }
+        // fc4: k fragments of this position in flatten order (w, nt), weights from the ring slot
+        const f4 *rl = ring + (size_t)slot * SLOT + lane;
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                f4 A[NB4];
+#pragma unroll
+                for (int ob = 0; ob < NB4; ob++) A[ob] = rl[(size_t)((w * NT + nt) * NB4 + ob) * 64];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+                    for (int ob = 0; ob < NB4; ob++) acc4[ob] = mfma4(A[ob][s4], v[nt][w][s4], acc4[ob]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        // counted wait: this position's 3 DMA pieces (slab h + 2) stay in flight; the row loads issued before them
+        // and the pieces of slab h + 1 (issued one position ago) have landed; the barrier publishes slab h + 1
+        asm volatile("s_waitcnt vmcnt(3)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j + 1 < KH; j++)
+#pragma unroll
+            for (int w = 0; w < 4; w++) win[j][w] = win[j + 1][w];
+        slot = slot + 1 == 3 ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the surplus stages before the wave retires
+    if (!live) return;
+    f4 *op = out_h4 + (size_t)g * NB4 * 64 + lane;
+    f4 h4[NB4];
+#pragma unroll
+    for (int ob = 0; ob < NB4; ob++) { h4[ob] = selu4(acc4[ob] + load_bias4(bias4, ob, q, nout4)); op[ob * 64] = h4[ob]; }
+    if (!tail) return;
+    const heads_args hd = *tail;
+    constexpr int NB5 = 2, NBP5 = 4;                       // fc5's packed weights: [kb][4][64] (two real tiles)
+    f4 a0 = zero, h5[NB5];
+#pragma unroll
+    for (int ob = 0; ob < NB5; ob++) {
+        f4 a = zero;
+#pragma unroll
+        for (int kb = 0; kb < NB4; kb++) {
+            const f4 A = hd.wp5p[((size_t)kb * NBP5 + ob) * 64 + lane];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) a = mfma4(A[s4], h4[kb][s4], a);
+        }
+        h5[ob] = selu4(a + load_bias4(hd.bias5, ob, q, hd.nout5));
+        hd.h5_out[((size_t)g * NB5 + ob) * 64 + lane] = h5[ob];
+    }
+#pragma unroll
+    for (int kb = 0; kb < NB4; kb++) {                     // base head over the fc4 output
+        const f4 A = hd.wp0[(size_t)kb * 64 + lane];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) a0 = mfma4(A[s4], h4[kb][s4], a0);
+    }
+    f4 a1 = zero;
+#pragma unroll
+    for (int ob = 0; ob < NB5; ob++) {
+        const f4 A = hd.wp1[(size_t)ob * 64 + lane];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) a1 = mfma4(A[s4], h5[ob][s4], a1);
+    }
+    heads_finish(a0, a1, hd.bb, hd.bz, hd.bt, hd.bl, hd.n, hd.out16, g, lane);
+}
+
 
 // ---------------------------------------------------------------------------
 // dense (KB*16 -> NB*16) + bias + SELU, TM -> TM.  One wave per group of 16
@@ -2419,10 +2454,29 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             {
                 const size_t lds = (size_t)(40 + 3 * 24) * 1024;
                 if (set_lds(conv3fc4_slim, lds)) return 1;
+                const heads_args *tail = nullptr;
+                if (m->variant & 1024) {            // fc5 + heads on the kernel's tail: arguments through a device copy
+                    heads_args h3 = hd;
+                    h3.wp5p = (const f4 *)m->wp_fc5; h3.bias5 = P + o[9]; h3.nout5 = a.fc5; h3.h5_out = (f4 *)m->tm_h5;
+                    static_assert(sizeof(heads_args) <= sizeof(m->tail_host), "cv_model::tail_host holds a heads_args");
+                    if (!m->tail_dev) CV_HIP(hipMalloc(&m->tail_dev, sizeof(heads_args)));
+                    if (memcmp(m->tail_host, &h3, sizeof(heads_args)) != 0) {
+                        memcpy(m->tail_host, &h3, sizeof(heads_args));
+                        CV_HIP(hipMemcpyAsync(m->tail_dev, m->tail_host, sizeof(heads_args), hipMemcpyHostToDevice, st));
+                    }
+                    tail = (const heads_args *)m->tail_dev;
+                    tail_done = true;
+                }
                 conv3fc4_slim<<<nblk(G, 8), 512, lds, st>>>((const f4 *)m->tm_p2, (const f4 *)m->wp_conv[2], P + o[5], a.cout[2],
-                                                          (const f4 *)m->wp_fc4, P + o[7], a.fc4, (f4 *)m->tm_h4, G);
+                                                          (const f4 *)m->wp_fc4, P + o[7], a.fc4, (f4 *)m->tm_h4, G, tail);
             }
             cv_prof_end(m, 2, st);
+            if (tail_done) {
+                if (rc) return 1;
+                CV_HIP(hipGetLastError());
+                m->last_n = n; m->last_impl = 1; m->last_variant = m->variant;
+                return 0;
+            }
         } else {
         cv_prof_begin(m, 2, st);
         m->stage_kernel[2] = "conv_tm<5, 1, 2, 1, 33, 0, 0, 1>";
