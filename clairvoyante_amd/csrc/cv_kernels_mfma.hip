@@ -3090,7 +3090,7 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
             // (measured at train.py's batch of 10 000, no gain: two k ranges of the 3-slab form; 3 / 4 / 6 / 8 k ranges of the
             // two-groups-per-wave, all-21-tiles form -- 2.47 / 2.36 / 2.25 / 2.39 ms per step against 2.25)
             if (G <= CV_FC4_SLAB_MAX_G) return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3);
-            return launch_dense<21, 8>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);
+            return launch_dense<21, 8, 0, 2>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);      // slices of more than 2 048 groups: the inference kernel
         }
         if (G <= m->tiny_g && (m->variant & 128))
             return launch_dense_small<4, 7>(in_tm, s.nb4, m->wps3_fc5, P + o[9], a.fc5, out_tm, G, 3, st, s.nb5);
