@@ -1161,7 +1161,8 @@ __global__ __launch_bounds__(512, 2) void conv3fc4_slim(const f4 *__restrict__ i
                                                         const float *__restrict__ bias3, int cout3,
                                                         const f4 *__restrict__ wp4, const float *__restrict__ bias4,
                                                         int nout4, f4 *__restrict__ out_h4, int G,
-                                                        const heads_args *__restrict__ tail = nullptr)
+                                                        const heads_args *__restrict__ tail = nullptr, int64_t n_cand = 0,
+                                                        float *__restrict__ out16 = nullptr)
 {
     // tail != nullptr (variant bit 10): fc5 (36 -> 18: 3 k fragments x 2 tiles) and the four heads follow on the same
     // wave from the fc4 fragments in its registers -- 44 MFMAs instead of two more launches; weights straight from L2
@@ -1325,7 +1326,7 @@ __global__ __launch_bounds__(512, 2) void conv3fc4_slim(const f4 *__restrict__ i
 #pragma unroll
         for (int s4 = 0; s4 < 4; s4++) a1 = mfma4(A[s4], h5[ob][s4], a1);
     }
-    heads_finish(a0, a1, hd.bb, hd.bz, hd.bt, hd.bl, hd.n, hd.out16, g, lane);
+    heads_finish(a0, a1, hd.bb, hd.bz, hd.bt, hd.bl, n_cand, out16, g, lane);
 }
 
 
@@ -1487,6 +1488,8 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
         // of fc4 output that stay live).  Per output value the chain is dense_tm<11,..>'s and heads_tm's: same bits.
         constexpr int NB5 = 11, NBH = 12, KS5 = 4, KP = (NB + KS5 - 1) / KS5, ST5 = KS5 * NBH * 64, PER5 = KS5 * NBH / WAVES;
         const heads_args *tp = hd.tail;
+        const int64_t n_cand = hd.n;                 // by value: they change from call to call
+        float *const out16 = hd.out16;
         asm volatile("" : "+s"(tp));                 // the loads below stay below
         const heads_args hd = *tp;                   // (shadows the by-value argument from here on)
         // lane id recomputed here (v_mbcnt) instead of carried through the main loop in a register: the loop is at its
@@ -1583,7 +1586,7 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // surplus DMA pieces of the last stages
 #pragma unroll
         for (int r = 0; r < GR; r++)
-            if (g + r < G) heads_finish(hacc0[r], hacc1[r], hd.bb, hd.bz, hd.bt, hd.bl, hd.n, hd.out16, g + r, lane_t);
+            if (g + r < G) heads_finish(hacc0[r], hacc1[r], hd.bb, hd.bz, hd.bt, hd.bl, n_cand, out16, g + r, lane_t);
         return;
     }
 #pragma unroll
@@ -2318,6 +2321,28 @@ static int mfma_alloc(cv_model *m, int64_t cap)
     return 0;
 }
 
+
+// Device copy of the per-model (stable) tail arguments of the fused kernels: refreshed synchronously, and only when a
+// pointer changed (first pass, a workspace that grew).  What changes from call to call -- the number of candidates and
+// the output pointer -- travels by value, so that no launch ever depends on host memory a later call may overwrite.
+static int tail_args_refresh(cv_model *m, heads_args h, hipStream_t st, const heads_args **dev)
+{
+    static_assert(sizeof(heads_args) <= sizeof(m->tail_host), "cv_model::tail_host holds a heads_args");
+    unsigned char clean[sizeof(heads_args)];            // field by field into zeroed bytes: padding must not make two equal sets differ
+    memset(clean, 0, sizeof(clean));
+    heads_args *c = reinterpret_cast<heads_args *>(clean);
+    c->wp0 = h.wp0; c->wp1 = h.wp1; c->bb = h.bb; c->bz = h.bz; c->bt = h.bt; c->bl = h.bl;
+    c->wp5p = h.wp5p; c->bias5 = h.bias5; c->nout5 = h.nout5; c->h5_out = h.h5_out;
+    if (!m->tail_dev) CV_HIP(hipMalloc(&m->tail_dev, sizeof(heads_args)));
+    if (memcmp(m->tail_host, clean, sizeof(heads_args)) != 0) {
+        CV_HIP(hipStreamSynchronize(st));               // no kernel in flight reads the old copy
+        memcpy(m->tail_host, clean, sizeof(heads_args));
+        CV_HIP(hipMemcpy(m->tail_dev, m->tail_host, sizeof(heads_args), hipMemcpyHostToDevice));
+    }
+    *dev = (const heads_args *)m->tail_dev;
+    return 0;
+}
+
 // one chunk (n <= chunk) through the tile kernels
 int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStream_t st)
 {
@@ -2397,15 +2422,10 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             m->stage_kernel[3] = "dense_tm<21, 8, 3, 2>";
             heads_args h3 = hd;
             h3.wp5p = (const f4 *)m->wp5p_fc5; h3.bias5 = P + o[9]; h3.nout5 = a.fc5; h3.h5_out = (f4 *)m->tm_h5;
-            static_assert(sizeof(heads_args) <= sizeof(m->tail_host), "cv_model::tail_host holds a heads_args");
             if (a.fc4 != 16 * s.nb4) { cv_set_error("fused fc4 tail: fc4 width must be a whole number of tiles"); return 1; }
-            if (!m->tail_dev) CV_HIP(hipMalloc(&m->tail_dev, sizeof(heads_args)));
-            if (memcmp(m->tail_host, &h3, sizeof(heads_args)) != 0) {       // pointers / sizes of this pass differ from the device copy
-                memcpy(m->tail_host, &h3, sizeof(heads_args));
-                CV_HIP(hipMemcpyAsync(m->tail_dev, m->tail_host, sizeof(heads_args), hipMemcpyHostToDevice, st));
-            }
-            heads_args hk;                           // by value: only the pointer to the device copy
-            hk.tail = (const heads_args *)m->tail_dev;
+            heads_args hk;                           // by value: the pointer to the device copy + what changes per call
+            if (tail_args_refresh(m, h3, st, &hk.tail)) return 1;
+            hk.n = n; hk.out16 = out16;
             rc |= launch_dense<21, 8, 3, 2>(m->tm_p3, s.kb4, m->wp_fc4, P + o[7], a.fc4, m->tm_h4, G, st, 1, 1, nullptr, hk);
             tail_done = true;
         }
@@ -2458,17 +2478,11 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
                 if (m->variant & 1024) {            // fc5 + heads on the kernel's tail: arguments through a device copy
                     heads_args h3 = hd;
                     h3.wp5p = (const f4 *)m->wp_fc5; h3.bias5 = P + o[9]; h3.nout5 = a.fc5; h3.h5_out = (f4 *)m->tm_h5;
-                    static_assert(sizeof(heads_args) <= sizeof(m->tail_host), "cv_model::tail_host holds a heads_args");
-                    if (!m->tail_dev) CV_HIP(hipMalloc(&m->tail_dev, sizeof(heads_args)));
-                    if (memcmp(m->tail_host, &h3, sizeof(heads_args)) != 0) {
-                        memcpy(m->tail_host, &h3, sizeof(heads_args));
-                        CV_HIP(hipMemcpyAsync(m->tail_dev, m->tail_host, sizeof(heads_args), hipMemcpyHostToDevice, st));
-                    }
-                    tail = (const heads_args *)m->tail_dev;
+                    if (tail_args_refresh(m, h3, st, &tail)) return 1;
                     tail_done = true;
                 }
                 conv3fc4_slim<<<nblk(G, 8), 512, lds, st>>>((const f4 *)m->tm_p2, (const f4 *)m->wp_conv[2], P + o[5], a.cout[2],
-                                                          (const f4 *)m->wp_fc4, P + o[7], a.fc4, (f4 *)m->tm_h4, G, tail);
+                                                          (const f4 *)m->wp_fc4, P + o[7], a.fc4, (f4 *)m->tm_h4, G, tail, n, out16);
             }
             cv_prof_end(m, 2, st);
             if (tail_done) {
