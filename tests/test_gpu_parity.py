@@ -128,6 +128,27 @@ def test_large_pass_kernels_equal_small_pass_kernels(setup):
     assert np.array_equal(np.concatenate(head, axis=1), small[:256])
 
 
+def test_fused_tail_back_to_back_calls_with_changing_outputs(setup):
+    """fc5 + heads ride on the tail of the large-pass fc4 kernel (variant bit 10) and take the number of candidates and the
+    output pointer per call: several large passes enqueued back to back, each with its own output tensor and size, no
+    synchronisation in between -- every one must equal the separate-kernel result"""
+    import torch
+    from clairvoyante_amd import synth
+    arch, P, m, x, ref = setup
+    m.setOption("impl", 1); m.setOption("chunk", 65536)
+    sizes = (40010, 33000, 65536, 40010)
+    xs = [synth.make_candidates(n, seed=90 + i, device="cuda") for i, n in enumerate(sizes)]
+    m.setOption("variant", 495)
+    want = [m.predict_device(xd).cpu().numpy() for xd in xs]
+    m.setOption("variant", common.DEFAULT_VARIANT)
+    outs = [torch.full((n, 16), -1.0, device="cuda") for n in sizes]
+    for xd, o in zip(xs, outs):
+        m.predict_device(xd, o)
+    torch.cuda.synchronize()
+    for o, w in zip(outs, want):
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), w.view(np.uint32))
+
+
 def test_candidates_are_independent_at_scale(setup):
     """size-independent property on 300 000 candidates: a candidate's 16 outputs do not depend on which other candidates
     share its pass, group of 16 or lane -- predicting a permuted batch gives the permuted outputs, bit for bit; and the
