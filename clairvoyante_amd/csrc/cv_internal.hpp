@@ -157,8 +157,11 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
                         float *p3, float *a3, hipStream_t st);
 #define CV_DENSE_KSPLIT 8      // k ranges of the fc4 training forward at tiny batches (cv_tile_dense_fwd)
 // part: scratch of CV_DENSE_KSPLIT * groups * nb4 fragments, or NULL = always the single ascending-k chain
+// drop / drop_done (fc4 of a training pass): where the kernel set allows it the alpha-dropout is applied by the layer's
+// last kernel (*drop_done = true); otherwise the caller runs cv_dropout_tm
+struct cv_train_dropout { float *d4, *amask; float rate; uint64_t seed, step; int64_t cand0; };
 int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm, int64_t n, hipStream_t st,
-                      float *part = nullptr);
+                      float *part = nullptr, const cv_train_dropout *drop = nullptr, bool *drop_done = nullptr);
 int cv_tile_fc5_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
 // act_below (layers without pooling, slim): the layer-below output; the result is then times selu' = its pre-activation gradient
 int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st, const float *act_below = nullptr);
@@ -174,6 +177,8 @@ int cv_tile_conv1_wgrad(cv_model *m, const float *x, const float *g_tm, int64_t 
 int cv_wgrad_scratch_reserve(cv_model *m);      // scratch of the weight-gradient kernels at its upper bound
 int cv_tile_heads_wgrad(cv_model *m, const float *d4_tm, const float *h5_tm, const float *g16, int64_t n, hipStream_t st);
 int cv_tile_heads_pre(cv_model *m, const float *d4_tm, const float *h5_tm, int64_t n, float *pre16, hipStream_t st);
+int cv_tile_heads_train(cv_model *m, const float *d4_tm, const float *h5_tm, const float *y, int64_t n, int want_grad,
+                        float *g16, float *g5pre_tm, hipStream_t st);
 int cv_dropout_tm(cv_model *m, const float *h4, float *d4, float *amask, int64_t n, float rate, uint64_t seed,
                   uint64_t step, int64_t cand0, hipStream_t st);
 int cv_tm_to_natural(const float *tm, int KB, int feat_per_pos_padded, int feat_per_pos, int npos,

@@ -240,8 +240,33 @@ __device__ __forceinline__ void pack_conv_dgrad(int64_t t, const float *__restri
     wp[t] = (ci < cin && co < cout) ? w[(((size_t)(KH - 1 - kh) * 4 + (3 - kw)) * cin + ci) * cout + co] : 0.0f;
 }
 
-// alpha-dropout on fc4 in TM layout (selu.py:34-69): d4 = a*(h4*keep + alpha'*(1-keep)) + b;
-// amask = a*keep is kept for the backward pass.  Counter-based stream of (seed, step, cand, unit).
+// alpha-dropout of one fc4 value (selu.py:34-69): d4 = a*(h4*keep + alpha'*(1-keep)) + b; mk = a*keep is kept for the
+// backward pass.  Counter-based stream of (seed, step, candidate, unit).
+struct cv_dropout_args { float *d4, *amask; int nunits; float rate; uint64_t seed, step; int64_t cand0; };
+
+__device__ __forceinline__ void dropout_value(float &v, float &mk, int unit, int nunits, int64_t cand, float rate, uint64_t seed,
+                                              uint64_t step)
+{
+    mk = 1.0f;
+    if (unit >= nunits) { v = 0.0f; mk = 0.0f; }
+    else if (rate > 0.0f) {
+        const float ap = -1.7580993408473766f;
+        float q = 1.0f - rate;
+        float a = sqrtf(1.0f / (q * ((1.0f - q) * (ap * ap) + 1.0f)));
+        float b = 0.0f - a * ((1.0f - q) * ap);
+        uint64_t ctr = (seed * 0x9E3779B97F4A7C15ull) ^ (step << 40) ^ (uint64_t)(cand * nunits + unit);
+        ctr += 0x9E3779B97F4A7C15ull;
+        ctr = (ctr ^ (ctr >> 30)) * 0xBF58476D1CE4E5B9ull;
+        ctr = (ctr ^ (ctr >> 27)) * 0x94D2049BB133111Bull;
+        ctr = ctr ^ (ctr >> 31);
+        float u = (float)((uint32_t)(ctr >> 32) >> 8) * (1.0f / 16777216.0f);
+        float keep = floorf(q + u);
+        v = a * (v * keep + ap * (1.0f - keep)) + b;
+        mk = a * keep;
+    }
+}
+
+// alpha-dropout on fc4 in TM layout
 __global__ void dropout_tm(const float *__restrict__ h4, float *__restrict__ d4, float *__restrict__ amask,
                            int NB, int nunits, int64_t G, float rate, uint64_t seed, uint64_t step, int64_t cand0)
 {
@@ -253,23 +278,8 @@ __global__ void dropout_tm(const float *__restrict__ h4, float *__restrict__ d4,
     int64_t g = frag / NB;
     int c = lane & 15, kq = lane >> 4;
     int unit = 16 * ob + 4 * s + kq;
-    float v = h4[t], mk = 1.0f;
-    if (unit >= nunits) { v = 0.0f; mk = 0.0f; }
-    else if (rate > 0.0f) {
-        const float ap = -1.7580993408473766f;
-        float q = 1.0f - rate;
-        float a = sqrtf(1.0f / (q * ((1.0f - q) * (ap * ap) + 1.0f)));
-        float b = 0.0f - a * ((1.0f - q) * ap);
-        uint64_t ctr = (seed * 0x9E3779B97F4A7C15ull) ^ (step << 40) ^ (uint64_t)((cand0 + g * 16 + c) * nunits + unit);
-        ctr += 0x9E3779B97F4A7C15ull;
-        ctr = (ctr ^ (ctr >> 30)) * 0xBF58476D1CE4E5B9ull;
-        ctr = (ctr ^ (ctr >> 27)) * 0x94D2049BB133111Bull;
-        ctr = ctr ^ (ctr >> 31);
-        float u = (float)((uint32_t)(ctr >> 32) >> 8) * (1.0f / 16777216.0f);
-        float keep = floorf(q + u);
-        v = a * (v * keep + ap * (1.0f - keep)) + b;
-        mk = a * keep;
-    }
+    float v = h4[t], mk;
+    dropout_value(v, mk, unit, nunits, cand0 + g * 16 + c, rate, seed, step);
     d4[t] = v;
     amask[t] = mk;
 }
@@ -1964,9 +1974,10 @@ __global__ __launch_bounds__(256) void dense_small(const f4 *__restrict__ in_tm,
     }
 }
 
-// second pass of a k-split dense layer: out = selu(sum_z part[z] + bias), ranges added in ascending z
+// second pass of a k-split dense layer: out = selu(sum_z part[z] + bias), ranges added in ascending z; with dr.d4 set
+// (fc4 of a training pass) the alpha-dropout of the value follows in the same thread -- dropout_tm's arithmetic, one launch less
 __global__ void dense_ksum(const f4 *__restrict__ part, int KS, int G, int NBT, const float *__restrict__ bias, int nout,
-                           f4 *__restrict__ out_tm)
+                           f4 *__restrict__ out_tm, cv_dropout_args dr)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t per = (int64_t)G * NBT * 64;
@@ -1974,7 +1985,20 @@ __global__ void dense_ksum(const f4 *__restrict__ part, int KS, int G, int NBT, 
     f4 v = part[t];
     for (int z = 1; z < KS; z++) v += part[(size_t)z * per + t];
     const int lane = (int)(t & 63), ob = (int)((t >> 6) % NBT);
-    out_tm[t] = selu4(v + load_bias4(bias, ob, lane >> 4, nout));
+    const f4 h = selu4(v + load_bias4(bias, ob, lane >> 4, nout));
+    out_tm[t] = h;
+    if (dr.d4) {
+        const int64_t g = t / ((int64_t)64 * NBT);
+        f4 d, mk;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            float x = h[s], k;
+            dropout_value(x, k, 16 * ob + 4 * s + (lane >> 4), dr.nunits, dr.cand0 + g * 16 + (lane & 15), dr.rate, dr.seed, dr.step);
+            d[s] = x; mk[s] = k;
+        }
+        reinterpret_cast<f4 *>(dr.d4)[t] = d;
+        reinterpret_cast<f4 *>(dr.amask)[t] = mk;
+    }
 }
 
 // training: the same two tile products, stored as pre-activations (+ bias) in candidate-major [n][16] order
@@ -2020,6 +2044,136 @@ __global__ __launch_bounds__(256) void heads_pre_tm(const f4 *__restrict__ h4, c
         o[10] = a1[0] + bl[0]; o[11] = a1[1] + bl[1]; o[12] = a1[2] + bl[2]; o[13] = a1[3] + bl[3];
     } else {
         o[14] = a1[0] + bl[4]; o[15] = a1[1] + bl[5];
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Heads of the TRAINING pass in one kernel (was: heads_pre_tm, then the loss kernel, then the head data-gradient pass):
+//   1. the two tile products (base head over the dropped-out fc4 output, zygosity / type / length heads over fc5) on the
+//      matrix cores, one wave per group, as heads_pre_tm;
+//   2. the 16 pre-activations of the group's 16 candidates through LDS to a (candidate, head) lane mapping: losses
+//      (v3.py:140-149: squared error of the sigmoid head, cross-entropy of softmax(selu(.) + 1e-10) for the others) and
+//      the gradients w.r.t. the pre-activations, written to g16 [n][16] (the heads' weight gradients and the base
+//      head's data gradient read them later) and kept in LDS;
+//   3. the data gradient of the three fc5-side heads, times selu'(fc5 output) -- the fc5 fragments are still in the
+//      registers they were loaded into for step 1 -- straight into the tile-major pre-activation gradient of fc5.
+// The arithmetic per value is that of the three kernels it replaces (same order): same bits.
+// ---------------------------------------------------------------------------
+template <int NB5>
+__global__ __launch_bounds__(256) void heads_train_tm(const f4 *__restrict__ d4, const f4 *__restrict__ h5, int NB4,
+                                                       const f4 *__restrict__ wp0, const f4 *__restrict__ wp1,
+                                                       const float *__restrict__ bb, const float *__restrict__ bz,
+                                                       const float *__restrict__ bt, const float *__restrict__ bl,
+                                                       const float *__restrict__ wz, const float *__restrict__ wt,
+                                                       const float *__restrict__ wl, int K5, const float *__restrict__ y,
+                                                       int64_t n, int want_grad, float *__restrict__ g16,
+                                                       f4 *__restrict__ g5pre_tm, double *__restrict__ loss, int G)
+{
+    __shared__ float sh[4][16][17];
+    __shared__ double part[4];
+    __shared__ float shw[NB5 * 16][12];            // fc5-side head weights of a unit side by side: zygosity 2 | type 4 | length 6
+    if (g5pre_tm && want_grad) {
+        for (int i = threadIdx.x; i < NB5 * 16 * 12; i += 256) {
+            const int k = i / 12, jj = i % 12;
+            float v = 0.0f;
+            if (k < K5) v = jj < 2 ? wz[(size_t)k * 2 + jj] : (jj < 6 ? wt[(size_t)k * 4 + (jj - 2)] : wl[(size_t)k * 6 + (jj - 6)]);
+            shw[k][jj] = v;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.x * 4 + wave;
+    const bool live = g < G;
+    const int gc = live ? g : G - 1;
+    const int c = lane & 15, q = lane >> 4;
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 a0 = zero, a1 = zero;
+    const f4 *p4 = d4 + (size_t)gc * NB4 * 64 + lane;
+    const f4 *p5 = h5 + (size_t)gc * NB5 * 64 + lane;
+#pragma unroll 3
+    for (int kb = 0; kb < NB4; kb++) {
+        const f4 B = p4[(size_t)kb * 64];
+        const f4 A = wp0[(size_t)kb * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 4; s++) a0 = mfma4(A[s], B[s], a0);
+    }
+    f4 H5[NB5];
+#pragma unroll
+    for (int kb = 0; kb < NB5; kb++) {
+        H5[kb] = p5[(size_t)kb * 64];
+        const f4 A = wp1[(size_t)kb * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 4; s++) a1 = mfma4(A[s], H5[kb][s], a1);
+    }
+    float (*S)[17] = sh[wave];
+    // rows of the second tile: q 0 = zygosity (2), q 1 = type (4), q 2 = length 0..3, q 3 = length 4..5
+    if (q == 0) {
+        S[c][0] = a0[0] + bb[0]; S[c][1] = a0[1] + bb[1]; S[c][2] = a0[2] + bb[2]; S[c][3] = a0[3] + bb[3];
+        S[c][4] = a1[0] + bz[0]; S[c][5] = a1[1] + bz[1];
+    } else if (q == 1) {
+        S[c][6] = a1[0] + bt[0]; S[c][7] = a1[1] + bt[1]; S[c][8] = a1[2] + bt[2]; S[c][9] = a1[3] + bt[3];
+    } else if (q == 2) {
+        S[c][10] = a1[0] + bl[0]; S[c][11] = a1[1] + bl[1]; S[c][12] = a1[2] + bl[2]; S[c][13] = a1[3] + bl[3];
+    } else {
+        S[c][14] = a1[0] + bl[4]; S[c][15] = a1[1] + bl[5];
+    }
+    if (threadIdx.x < 4) part[threadIdx.x] = 0.0;
+    __syncthreads();
+    {   // losses and gradients: lane -> (candidate lane >> 2 of the group, head lane & 3)
+        const int cc = lane >> 2, j = lane & 3;
+        const int64_t cand = (int64_t)g * 16 + cc;
+        if (live && cand < n) {
+            const float *yi = y + (size_t)cand * 16;
+            float *gl = S[cc];
+            float *go = g16 + (size_t)cand * 16;
+            double l = 0.0;
+            if (j == 0) {
+                float v[4];
+                for (int k = 0; k < 4; k++) v[k] = gl[k];
+                for (int k = 0; k < 4; k++) {
+                    float sg = cvm::sigmoid(v[k]);
+                    float d = sg - yi[k];
+                    l += (double)d * d;
+                    if (want_grad) { const float gr = 2.0f * d * sg * (1.0f - sg); gl[k] = gr; go[k] = gr; }
+                }
+            } else {
+                const int off = j == 1 ? 4 : (j == 2 ? 6 : 10);
+                const int cnt = j == 1 ? 2 : (j == 2 ? 4 : 6);
+                float v[6], lg[6], p[6];
+                float mx = -__builtin_inff();
+                for (int k = 0; k < cnt; k++) { v[k] = gl[off + k]; lg[k] = cvm::selu(v[k]) + 1e-10f; mx = fmaxf(mx, lg[k]); }
+                float se = 0.0f, ysum = 0.0f;
+                for (int k = 0; k < cnt; k++) { p[k] = cvm::expf_fixed(lg[k] - mx); se += p[k]; ysum += yi[off + k]; }
+                float lse = mx + logf(se);
+                for (int k = 0; k < cnt; k++) {
+                    l += -(double)yi[off + k] * (double)(lg[k] - lse);
+                    if (want_grad) { const float gr = (p[k] / se * ysum - yi[off + k]) * cvm::selu_grad(v[k]); gl[off + k] = gr; go[off + k] = gr; }
+                }
+            }
+            atomicAdd(&part[j], l);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(&loss[threadIdx.x], part[threadIdx.x]);
+    if (!g5pre_tm || !want_grad || !live) return;
+    // fc5-side head data gradients (zygosity, type, length; k = fc5 unit), times selu'(fc5 output)
+    const bool cand_ok = (int64_t)g * 16 + c < n;
+    const float *gi = S[c];
+#pragma unroll
+    for (int kb = 0; kb < NB5; kb++) {
+        f4 o;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int k = 16 * kb + 4 * s + q;
+            float acc = 0.0f;
+            if (cand_ok && k < K5) {                 // (weights from LDS: staged at the top, published by the barriers above)
+                const float *wk = shw[k];
+#pragma unroll
+                for (int jj = 0; jj < 12; jj++) acc = __builtin_fmaf(gi[4 + jj], wk[jj], acc);
+            }
+            o[s] = acc * cv_selu_grad_from_out(H5[kb][s]);
+        }
+        g5pre_tm[((size_t)g * NB5 + kb) * 64 + lane] = o;
     }
 }
 
@@ -2107,7 +2261,8 @@ int launch_conv3_rot(const float *in, const float *wp, const float *bias, int co
 
 template <int NB, int WAVES, int EPI = 0, int GR = 1>
 int launch_dense(const float *in, int KB, const float *wp, const float *bias, int nout, float *out, int G,
-                 hipStream_t st, int slabs = 1, int ksplit = 1, float *part = nullptr, heads_args hd = heads_args())
+                 hipStream_t st, int slabs = 1, int ksplit = 1, float *part = nullptr, heads_args hd = heads_args(),
+                 cv_dropout_args dr = cv_dropout_args())
 {
     auto k = dense_tm<NB, WAVES, EPI, GR>;
     size_t lds = (size_t)3 * ((NB + WAVES - 1) / WAVES * WAVES) * 1024;
@@ -2118,7 +2273,7 @@ int launch_dense(const float *in, int KB, const float *wp, const float *bias, in
         k<<<dim3(nblk(G, WAVES * GR), slabs, ksplit), WAVES * 64, lds, st>>>((const f4 *)in, KB, (const f4 *)wp, bias, nout,
                                                                         (f4 *)part, G, NB * slabs, heads_args());
         dense_ksum<<<nblk((int64_t)G * NB * slabs * 64, 256), 256, 0, st>>>((const f4 *)part, ksplit, G, NB * slabs, bias, nout,
-                                                                          (f4 *)out);
+                                                                          (f4 *)out, dr);
         CV_HIP(hipGetLastError());
         return 0;
     }
@@ -3084,8 +3239,10 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
     return rc;
 }
 
-int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm, int64_t n, hipStream_t st, float *part)
+int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm, int64_t n, hipStream_t st, float *part,
+                      const cv_train_dropout *drop, bool *drop_done)
 {
+    if (drop_done) *drop_done = false;
     const cv_arch &a = m->arch;
     const float *P = m->params;
     const int64_t *o = m->poff;
@@ -3095,8 +3252,16 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
         if (layer == 4) {
             // tiny batches: 288 dependent k steps at ~0.9 us each are the longest kernel of the step; eight k ranges
             // (CV_DENSE_KSPLIT) run side by side instead and a second pass adds them up in order
-            if (part && G <= m->tiny_g)
-                return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3, CV_DENSE_KSPLIT, part);
+            if (part && G <= m->tiny_g) {
+                cv_dropout_args dr = cv_dropout_args();
+                if (drop && drop_done) {            // the alpha-dropout of fc4 rides on the second pass of the k-split
+                    dr.d4 = drop->d4; dr.amask = drop->amask; dr.nunits = a.fc4; dr.rate = drop->rate; dr.seed = drop->seed;
+                    dr.step = drop->step; dr.cand0 = drop->cand0;
+                    *drop_done = true;
+                }
+                return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3, CV_DENSE_KSPLIT, part,
+                                          heads_args(), dr);
+            }
             // (dense_small beyond the tiny range loses: at 625 groups its 4 375 waves re-read the weight matrix from L2
             // 7 x 625 times -- 2.63 against 2.41 ms per step)
             if (G <= m->tiny_g && (m->variant & 128))
@@ -3223,6 +3388,26 @@ int cv_tile_conv_dgrad_unpool(cv_model *m, int layer, const float *g_tm, const f
     }
     const int hs = m->dbg[0] > 0 ? m->dbg[0] : (split ? pick_hsplit(G, 1, 33, 4 + 1, 8) : 1);
     return launch_dgrad_unpool<2, 2, 1, 29, 5>(hs, g_tm, W, pooled, codes, gpre, G, st);
+}
+
+// heads of the training pass in one launch: products, losses (added to loss[0..3]), gradients w.r.t. the 16
+// pre-activations (g16 [n][16], when want_grad) and the fc5-side data gradient times selu'(fc5) (g5pre_tm, when not null)
+int cv_tile_heads_train(cv_model *m, const float *d4_tm, const float *h5_tm, const float *y, int64_t n, int want_grad,
+                        float *g16, float *g5pre_tm, hipStream_t st)
+{
+    const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
+    const float *P = m->params; const int64_t *o = m->poff;
+    const int G = (int)((n + 15) / 16);
+    if (G <= 0) return 0;
+#define CV_HT(NB5) heads_train_tm<NB5><<<nblk(G, 4), 256, 0, st>>>((const f4 *)d4_tm, (const f4 *)h5_tm, s.nb4, (const f4 *)m->wp_heads0, \
+        (const f4 *)m->wp_heads1, P + o[11], P + o[13], P + o[15], P + o[17], P + o[12], P + o[14], P + o[16], a.fc5, y, n, want_grad, \
+        g16, (f4 *)g5pre_tm, m->loss_dev, G)
+    if (s.nb5 == 11) CV_HT(11);
+    else if (s.nb5 == 2) CV_HT(2);
+    else { cv_set_error("heads_train_tm: %d fc5 fragments not instantiated", s.nb5); return 1; }
+#undef CV_HT
+    CV_HIP(hipGetLastError());
+    return 0;
 }
 
 // heads of the training pass: pre-activations of the 16 outputs from the dropped-out fc4 output and fc5 (tile-major)

@@ -517,49 +517,6 @@ static int launch_unpool(const float *gpool, const float *pooled, const float *c
     return 0;
 }
 
-// loss and head gradients from the 16 pre-activations of every candidate (cv_tile_heads_pre); the gradients
-// wrt the pre-activations replace them in place.  Thread = (candidate, head).
-__global__ __launch_bounds__(256) void t_heads_loss(float *__restrict__ pre, const float *__restrict__ y, int64_t n,
-                                                    int want_grad, double *__restrict__ loss)
-{
-    __shared__ double part[4];
-    if (threadIdx.x < 4) part[threadIdx.x] = 0.0;
-    __syncthreads();
-    const int64_t cand = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
-    const int j = threadIdx.x & 3;
-    if (cand < n) {
-        const float *yi = y + (size_t)cand * 16;
-        float *g = pre + (size_t)cand * 16;
-        double l = 0.0;
-        if (j == 0) {
-            float v[4];
-            for (int k = 0; k < 4; k++) v[k] = g[k];
-            for (int k = 0; k < 4; k++) {
-                float s = cvm::sigmoid(v[k]);
-                float d = s - yi[k];
-                l += (double)d * d;
-                if (want_grad) g[k] = 2.0f * d * s * (1.0f - s);
-            }
-        } else {
-            const int off = j == 1 ? 4 : (j == 2 ? 6 : 10);
-            const int cnt = j == 1 ? 2 : (j == 2 ? 4 : 6);
-            float v[6], lg[6], p[6];
-            float mx = -__builtin_inff();
-            for (int k = 0; k < cnt; k++) { v[k] = g[off + k]; lg[k] = cvm::selu(v[k]) + 1e-10f; mx = fmaxf(mx, lg[k]); }
-            float se = 0.0f, ysum = 0.0f;
-            for (int k = 0; k < cnt; k++) { p[k] = cvm::expf_fixed(lg[k] - mx); se += p[k]; ysum += yi[off + k]; }
-            float lse = mx + logf(se);
-            for (int k = 0; k < cnt; k++) {
-                l += -(double)yi[off + k] * (double)(lg[k] - lse);
-                if (want_grad) g[off + k] = (p[k] / se * ysum - yi[off + k]) * cvm::selu_grad(v[k]);
-            }
-        }
-        atomicAdd(&part[j], l);
-    }
-    __syncthreads();
-    if (threadIdx.x < 4) atomicAdd(&loss[threadIdx.x], part[threadIdx.x]);
-}
-
 // heads: data gradients in TM layout, fused with the SELU' (and dropout) factor of the layer they flow into.
 //   mode 0: g5pre = (sum over the three fc5-side heads) * selu'(h5)                      -- all entries written, padding = 0
 //   mode 1: g4pre = (gd4 + base-head contribution) * amask * selu'(h4)                   -- gd4 = fc5's data gradient
@@ -766,16 +723,20 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     if (cv_pack_for_training(m, st, backward, m->dbg[5] == 1 ? st : sw, m->tr_pack_fork, m->tr_pack_done, &pack_wait)) return 1;
     if (cv_tile_train_convs(m, x, n, tp[0], ta[0], tp[1], ta[1], tp[2], ta[2], st)) return 1;
     if (pack_wait) CV_HIP(hipStreamWaitEvent(st, m->tr_pack_done, 0));
-    if (cv_tile_dense_fwd(m, 4, tp[2], th4, n, st, m->train_ksplit ? kpart : nullptr)) return 1;
-    if (cv_dropout_tm(m, th4, td4, tmask, n, backward ? drop4 : 0.0f, seed, step, cand0, st)) return 1;
+    const cv_train_dropout drop{td4, tmask, backward ? drop4 : 0.0f, seed, step, cand0};
+    bool drop_done = false;
+    if (cv_tile_dense_fwd(m, 4, tp[2], th4, n, st, m->train_ksplit ? kpart : nullptr, &drop, &drop_done)) return 1;
+    if (!drop_done && cv_dropout_tm(m, th4, td4, tmask, n, drop.rate, seed, step, cand0, st)) return 1;
     m->last_tr_d4 = td4; m->last_tr_mask = tmask; m->last_tr_n = n; m->last_tr_tile = 1;
     if (cv_tile_dense_fwd(m, 5, td4, th5, n, st)) return 1;
-    if (cv_tile_heads_pre(m, td4, th5, n, ghpre, st)) return 1;
-    t_heads_loss<<<nblk(n, 64), 256, 0, st>>>(ghpre, y, n, backward ? 1 : 0, m->loss_dev);
+    // heads: products, losses, head gradients and the fc5-side data gradient (times selu'(h5)) in one launch
+    float *tg5pre = backward ? sb.take(np * f5u) : nullptr;
+    if (backward && !tg5pre) { cv_set_error("training workspace too small"); return 1; }
+    if (cv_tile_heads_train(m, td4, th5, y, n, backward ? 1 : 0, ghpre, tg5pre, st)) return 1;
     CV_HIP(hipGetLastError());
     if (!backward) return 0;
     // ---- backward buffers (TM gradients; the weight-gradient kernels transpose their operands on the way in)
-    float *tg5pre = sb.take(np * f5u), *tgd4 = sb.take(np * f4u), *tg4pre = sb.take(np * f4u);
+    float *tgd4 = sb.take(np * f4u), *tg4pre = sb.take(np * f4u);
     float *tgpre[3], *tgin[3];
     for (int l = 0; l < 3; l++) { tgpre[l] = sb.take(np * fa[l]); tgin[l] = sb.take(np * fp[l]); }
     if (!tgin[2]) { cv_set_error("training workspace too small"); return 1; }
@@ -794,9 +755,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     // gradients written to TM, times selu'(h5)
     if (f.to_side(0, &sx)) return 1;
     if (cv_tile_heads_wgrad(m, td4, th5, ghpre, n, sx)) return 1;
-    b_head_dgrad_tm<<<nblk(Gn * s.nb5 * 256, 256), 256, 0, st>>>(ghpre, P + o[10], P + o[12], P + o[14], P + o[16], a.fc5,
-                                                               s.nb5, n, Gn, 0, nullptr, th5, nullptr, tg5pre);
-    // fc5
+    // fc5 (its pre-activation gradient came out of the heads kernel)
     if (f.to_side(1, &sx)) return 1;
     if (cv_tile_dense_wgrad(m, 5, td4, tg5pre, n, sx)) return 1;
     if (cv_tile_fc5_dgrad(m, tg5pre, tgd4, n, st)) return 1;
