@@ -95,6 +95,9 @@ def init_ranks(args):
     """-> (rank, world size, local rank).  A line whose n_gpus is not --gpus is never printed: mismatch = exit 2."""
     from clairvoyante_amd import parallel
     rank, ws, local = parallel.init_from_env()
+    if os.environ.get("CV_SHARE_DEVICES"):       # functional test on a box with fewer GPUs than ranks (backend gloo): ranks share devices
+        import torch
+        local %= max(torch.cuda.device_count(), 1)
     if ws != args.gpus:
         if rank == 0:
             print("bench.py: --gpus %d but %d rank(s) are running (WORLD_SIZE); refusing to report a line whose "

@@ -565,3 +565,24 @@ def test_rccl_code_path_with_one_rank_equals_the_plain_step(oracle, tmp_path):
     assert int(got["steps"]) == steps == 2 and np.allclose(got["acc"], acc, rtol=1e-9, atol=0)
     assert float(got["one"]) == 1.5
     m.close()
+
+
+def test_bench_line_under_two_ranks_sharing_the_gpu(tmp_path):
+    """`python bench.py --gpus 2` end to end with two real ranks (backend gloo, both on the one GPU: CV_SHARE_DEVICES): it
+    starts its own ranks, rank 0 prints one line with n_gpus = rccl_ranks = 2, the slim leg and the training legs (global
+    batch 10 000 split over the ranks, and 10 000 per rank) -- the flow the driver runs at N > 1, timings aside"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CV_SHARE_DEVICES="1", CV_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    b = lines[0]
+    assert b["n_gpus"] == 2 and b["rccl_ranks"] == 2 and b["backend"] == "gloo" and b["value"] > 1e6
+    assert b["slim"]["value"] > 1e6
+    assert set(b["train"]) == {"10000", "10000_per_rank", "slim_10000"}
+    assert b["train"]["10000"]["per_rank_batch"] == 5000 and b["train"]["10000_per_rank"]["per_rank_batch"] == 10000
+    assert all(np.isfinite(v["final_loss"]) for v in b["train"].values())
