@@ -1542,6 +1542,15 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
         for (int r = 0; r < GR; r++) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // nothing of the previous pipeline is in flight,
             __syncthreads();                                       // nobody still reads the ring
+            if (r > 0) {
+                // The fc4 fragments of this group come back from the map they were stored to above (this wave's own
+                // stores, complete after the wait): while the previous group's tail ran they did not occupy 84 registers,
+                // which lets the compiler read weight fragments ahead of their MFMAs there.  Rows of a group past the
+                // batch are read from the last real group (their results are never stored).
+                const int gr = g + r < G ? g + r : G - 1;
+#pragma unroll
+                for (int kb = 0; kb < NB; kb++) acc[r][kb] = out_tm[((size_t)gr * NBT + kb) * 64 + lane_t];
+            }
             stage5(0, 0);
             stage5(1, 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
