@@ -1,5 +1,5 @@
 #!/bin/bash
-# parity tests + inference bench A/B over kernel variants: bash tools/gpu_r03_e.sh TAG "v1 v2 ..."
+# parity tests + inference bench A/B over kernel variants: bash tools/gpu_infer_ab.sh TAG "v1 v2 ..."
 set -u
 OUT=gpurun_out/${1:-r03o}
 mkdir -p $OUT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU tests (training subset or all) + A/B over bench flags: bash tools/gpu_r03_d.sh TAG "flagset1|flagset2|..." [all]
+# GPU tests (training subset or all) + A/B over bench flags: bash tools/gpu_train_ab.sh TAG "flagset1|flagset2|..." [all]
 set -u
 OUT=gpurun_out/${1:-r03f}
 mkdir -p $OUT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# serialized per-kernel profile of the training step: bash tools/gpu_r03_prof.sh TAG BATCH "dbg settings ('-' = none)"
+# serialized per-kernel profile of the training step: bash tools/gpu_train_profile.sh TAG BATCH "dbg settings ('-' = none)"
 set -u
 OUT=gpurun_out/${1:-r03p}
 B=${2:-10000}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# timeline of one optimizer step (two streams): bash tools/gpu_r03_timeline.sh TAG BATCH "dbg" [extra bench args]
+# timeline of one optimizer step (two streams): bash tools/gpu_train_timeline.sh TAG BATCH "dbg" [extra bench args]
 set -u
 OUT=gpurun_out/${1:-r03t}
 B=${2:-1250}
