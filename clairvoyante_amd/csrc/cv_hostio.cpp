@@ -666,6 +666,7 @@ int vcf_record(const vcf_job &J, int64_t i, std::string &out, int64_t *nrec)
     const float *q = J.qual + i * 4;
     const float dp = q[2];
     if (dp == 0.0f) return 0;
+    if (!(fabsf(dp) < 2.0e9f)) { cv_set_error("cv_format_vcf: record %lld: depth is not a finite count", (long long)i); return 1; }
     const int64_t *pm = J.pos_meta + (J.pos_row ? J.pos_row[i] : i) * 6;
     const char *chrom = J.pos_buf + pm[0]; const int64_t chrom_len = pm[1];
     const char *cs = J.pos_buf + pm[2]; int64_t cl = pm[3];
