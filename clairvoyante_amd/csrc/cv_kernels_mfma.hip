@@ -2922,6 +2922,10 @@ __global__ void wgrad_dense_reduce(const f4 *__restrict__ part, int splits, int 
 //   taps kh < KA (older rows)  |  read input row s  |  taps KA..KH-2  |  DMA input row s+1, read G row s+1
 //   | tap KH-1 (the new row)   -- the DMA of G row s+1 goes out at the top of the step.
 // grid = 8 * NT * ceil(splits / 8) one-wave workgroups, dynamic LDS = (4*CINB + 4) KiB.
+// (measured, round 3: the same waves as 4-wave workgroups -- four independent waves, no barrier, own LDS each, so
+// that the dispatcher has 469 instead of 1 875 workgroups to place -- are slower inside the step, conv3 280 -> 289 us
+// and conv2 88 -> 103 us, step 2.25 -> 2.32 ms: a 4-wave workgroup needs four free slots on ONE CU while the dgrad
+// chain's kernels hold slots on every CU, one-wave workgroups fill whatever is free.)
 template <int KH, int CINB, int NT, int HIN>
 __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm, const f4 *__restrict__ g_tm,
                                                      int G, int splits, f4 *__restrict__ part)
