@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libclairvoyante_hip.so")
+# CV_HIP_LIB: another build of the SAME library (development: two builds timed on one GPU box, tools/gpu_lib_ab.sh)
+LIB_PATH = os.environ.get("CV_HIP_LIB") or os.path.join(_HERE, "csrc", "libclairvoyante_hip.so")
 
 NUM_PARAMS = 18
 NUM_OUT = 16

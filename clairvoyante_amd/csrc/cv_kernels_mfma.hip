@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
     for (int i = threadIdx.x; i < NFRAG * 64; i += 256) ldsw[i] = wp[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int hs = wv % HSPLIT, gt = wv / HSPLIT;
     const int g = gt / NT, nt = gt % NT;
     if (g >= G) return;
@@ -591,6 +591,18 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
                 for (int cb = 0; cb < CINB; cb++) row[w][cb] = inp[(size_t)((hr * 4 + w) * CINB + cb) * 64];
         }
     };
+    // Without a fused first layer the row the NEXT position needs is loaded one fragment at a time between the MFMA
+    // blocks of the first kernel row, from asm (scalar base + this lane's 16 bytes) so that the loads stay where they
+    // are put: as a burst of 4 CINB loads at the top of the position the wave sits in the CU's vector-memory queue
+    // behind the bursts of the other seven waves and multiplies nothing meanwhile (measured on wgrad_conv_cm).
+    constexpr bool SPREAD = FRONT == 0;
+    static_assert(CINB <= 3, "the counted wait below names at most 12 fragments");
+    const f4 *const inp_s = in_tm + (size_t)__builtin_amdgcn_readfirstlane(g) * (HIN * 4 * CINB * 64);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto load_piece = [&](int hr, int w, int cb, f4 &dst) {
+        const f4 *ps = inp_s + (size_t)((hr * 4 + w) * CINB + cb) * 64;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane16), "s"(ps));    // (no memory clobber: the
+    };                                                       //  weight reads from LDS may move across it)
 
     f4 win[KH][4][CINB];   // win[kh] = input row h + kh - PADT
     f4 nxt[4][CINB];
@@ -628,9 +640,11 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
 #if defined(CV_ABL) && (CV_ABL & 2)
             (void)hr;                                          // ablation: no row fetch
 #else
-            if (hr < HIN) fetch_row(hr, nxt);
+            if (!SPREAD && hr < HIN) fetch_row(hr, nxt);
 #endif
         }
+        // (past the last row the loads re-read it -- nobody uses the result: no branch around every load)
+        const int hnext = h + 1 + (KH - 1) - PADT < HIN ? h + 1 + (KH - 1) - PADT : HIN - 1;
         f4 acc[4];
 #pragma unroll
         for (int w = 0; w < 4; w++) acc[w] = zero;
@@ -640,8 +654,9 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
 #pragma unroll
         for (int kh = 0; kh < KH; kh++) {
             const int hr = h + kh - PADT;
-            if (hr >= 0 && hr < HIN) {     // wave-uniform; SAME padding rows are skipped
-#pragma unroll
+            const bool on = hr >= 0 && hr < HIN;     // wave-uniform; SAME padding rows are skipped
+            if (on) {                                // (one branch per kernel row, not per block: the weight reads
+#pragma unroll                                       //  run ahead of their MFMAs only inside a basic block)
                 for (int kw = 0; kw < 4; kw++)
 #pragma unroll
                     for (int cb = 0; cb < CINB; cb++) {
@@ -654,7 +669,28 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
                                 if (wi < 0 || wi > 3) continue;
                                 acc[wo] = mfma4(A[s], win[kh][wi][cb][s], acc[wo]);
                             }
+                        if constexpr (SPREAD) {
+                            if (kh == 0) load_piece(hnext, kw, cb, nxt[kw][cb]);
+                        }
                     }
+            } else if (SPREAD && kh == 0) {          // padding row on top: nothing to hide the loads under
+#pragma unroll
+                for (int kw = 0; kw < 4; kw++)
+#pragma unroll
+                    for (int cb = 0; cb < CINB; cb++) load_piece(hnext, kw, cb, nxt[kw][cb]);
+            }
+        }
+        if constexpr (SPREAD) {            // the row has had the other kernel rows' MFMAs to land
+            {
+                if constexpr (CINB == 1)
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt[0][0]), "+v"(nxt[1][0]), "+v"(nxt[2][0]), "+v"(nxt[3][0]) : : "memory");
+                else if constexpr (CINB == 2)
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt[0][0]), "+v"(nxt[1][0]), "+v"(nxt[2][0]), "+v"(nxt[3][0]),
+                                 "+v"(nxt[0][1]), "+v"(nxt[1][1]), "+v"(nxt[2][1]), "+v"(nxt[3][1]) : : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt[0][0]), "+v"(nxt[1][0]), "+v"(nxt[2][0]), "+v"(nxt[3][0]),
+                                 "+v"(nxt[0][1]), "+v"(nxt[1][1]), "+v"(nxt[2][1]), "+v"(nxt[3][1]),
+                                 "+v"(nxt[0][CINB - 1]), "+v"(nxt[1][CINB - 1]), "+v"(nxt[2][CINB - 1]), "+v"(nxt[3][CINB - 1]) : : "memory");
             }
         }
 #ifdef CV_SETPRIO
@@ -933,7 +969,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
     for (int i = threadIdx.x; i < NFRAG * 64; i += WAVES * 64) ldsw[i] = wp[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int wv = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
     const int g = wv / NT, nt = wv % NT;
     if (g >= G) return;
     const int q = lane >> 4;
@@ -955,19 +991,36 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
             for (int cb = 0; cb < CINB; cb++) row[w][cb] = inp[(size_t)((hr * 4 + w) * CINB + cb) * 64];
     };
     load_row(0, win[1]);         // row 0 -> slot 1 ; row -1 (slot 0) is padding and never read
+    // The row the last kernel row needs is loaded one fragment at a time between the MFMA blocks of the FIRST kernel
+    // row, from asm (scalar base + this lane's 16 bytes) so that the loads stay where they are put: as a burst of
+    // 4 CINB loads the wave queues on the CU's vector-memory port behind the other waves' bursts (see conv_tm).
+    static_assert(CINB == 2, "the counted wait below names 8 fragments");
+    const f4 *const inp_s = in_tm + (size_t)__builtin_amdgcn_readfirstlane(g) * (HIN * 4 * CINB * 64);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto load_piece = [&](int hr, int w, int cb, f4 &dst) {
+        const f4 *ps = inp_s + (size_t)((hr * 4 + w) * CINB + cb) * 64;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane16), "s"(ps));    // (no memory clobber: the
+    };                                                       //  weight reads from LDS may move across it)
     // one position; R = h % 3 is a compile-time constant so that slot indices are static
     auto step = [&](auto Rc, int h) {
         constexpr int R = decltype(Rc)::value;
-        // rows h-1, h, h+1 are in slots R, (R+1)%3, (R+2)%3; fetch row h+1 now, use it last
-        if (h + 1 < HIN) load_row(h + 1, win[(R + 2) % 3]);
+        // rows h-1, h, h+1 are in slots R, (R+1)%3, (R+2)%3; row h+1 is fetched under the first kernel row and used last
+        // (past the last row the loads re-read it -- nobody uses the result: no branch around every load)
+        const int hnext = h + 1 < HIN ? h + 1 : HIN - 1;
         f4 acc[4];
 #pragma unroll
         for (int w = 0; w < 4; w++) acc[w] = zero;
 #pragma unroll
         for (int kh = 0; kh < KH; kh++) {
             const int hr = h + kh - PADT;
-            if (hr >= 0 && hr < HIN) {
-#pragma unroll
+            const bool on = hr >= 0 && hr < HIN;
+            if (kh == KH - 1) {
+                f4 (&nw)[4][CINB] = win[(R + 2) % 3];
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(nw[0][0]), "+v"(nw[1][0]), "+v"(nw[2][0]), "+v"(nw[3][0]),
+                             "+v"(nw[0][1]), "+v"(nw[1][1]), "+v"(nw[2][1]), "+v"(nw[3][1]) : : "memory");
+            }
+            if (on) {                                // (one branch per kernel row, not per block: the weight reads
+#pragma unroll                                       //  run ahead of their MFMAs only inside a basic block)
                 for (int kw = 0; kw < 4; kw++)
 #pragma unroll
                     for (int cb = 0; cb < CINB; cb++) {
@@ -980,7 +1033,13 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
                                 if (wi < 0 || wi > 3) continue;
                                 acc[wo] = mfma4(A[s], win[(R + kh) % 3][wi][cb][s], acc[wo]);
                             }
+                        if (kh == 0) load_piece(hnext, kw, cb, win[(R + 2) % 3][kw][cb]);
                     }
+            } else if (kh == 0) {                    // padding row on top (h == 0): nothing to hide the loads under
+#pragma unroll
+                for (int kw = 0; kw < 4; kw++)
+#pragma unroll
+                    for (int cb = 0; cb < CINB; cb++) load_piece(hnext, kw, cb, win[(R + 2) % 3][kw][cb]);
             }
         }
         // max-pool on the PRE-activations, SELU once per pooled row (SELU is monotone over all of fp32 --
@@ -2734,6 +2793,17 @@ struct cm_stage {
                      "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gp), "s"(ldst) : "memory");
     }
+    // the same with the fragment address as a SCALAR base (the caller's pointer must be provably wave-uniform) + this
+    // lane's byte offset: no 64-bit vector address per piece
+    __device__ __forceinline__ void fetch_s(const f4 *frag, int slot) const
+    {
+        const unsigned off = (unsigned)src_lane * 16u;
+        const unsigned ldst = __builtin_amdgcn_readfirstlane(base + (unsigned)slot * 1024u);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(ldst), "s"(frag) : "memory");
+    }
     __device__ __forceinline__ f4 read(int slot) const
     {
         const float *q = slots + slot * 256 + ridx;
@@ -2803,26 +2873,42 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
 #pragma unroll
     for (int i = 0; i < NBS; i++) bs[i] = zero;
     const bool do_bias = blockIdx.x == 0;
-    auto stage = [&](int g, int buf) {
-        if constexpr (GNAT) {
-            if (wid == 0) S.fetch_nat((const float *)g_tm, (int64_t)g * 16, n, 16, buf * NSLOT, lane);
-        } else {
-#pragma unroll
-            for (int i = 0; i < PERG; i++) {
+    // this wave's DMA pieces of group g: i < PERG gradient fragments, then its two input fragments
+    constexpr int NP = PERG + 2;
+    auto piece = [&](int g, int buf, int i) {
+        if (i < PERG) {
+            if constexpr (GNAT) {
+                if (wid == 0) S.fetch_nat((const float *)g_tm, (int64_t)g * 16, n, 16, buf * NSLOT, lane);
+            } else {
                 const int jb = wid + 8 * i < NJB ? wid + 8 * i : NJB - 1;
-                S.fetch(g_tm + ((size_t)g * NJB + jb) * 64, buf * NSLOT + jb);
+                S.fetch_s(g_tm + ((size_t)g * NJB + jb) * 64, buf * NSLOT + jb);
             }
+        } else {
+            const int a = i - PERG;
+            S.fetch_s(x_tm + ((size_t)g * KB + (a ? kc1 : kc0)) * 64, buf * NSLOT + NJB + 2 * wid + a);
         }
-        S.fetch(x_tm + ((size_t)g * KB + kc0) * 64, buf * NSLOT + NJB + 2 * wid);
-        S.fetch(x_tm + ((size_t)g * KB + kc1) * 64, buf * NSLOT + NJB + 2 * wid + 1);
     };
-    if (g0 < g1) stage(g0, 0);
+    // In the loop the pieces of group g+1 go out one at a time between the multiplications of group g (every
+    // PSTEP-th gradient fragment): as a burst behind the barrier all 8 waves queue on the CU's vector-memory port at
+    // once and none of them multiplies meanwhile (see wgrad_conv_cm).
+    constexpr bool SPREAD = NJB >= NP;
+    constexpr int PSTEP = SPREAD ? NJB / NP : 1;
+    if (g0 < g1) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) piece(g0, 0, i);
+    }
     int buf = 0;
 #pragma unroll 1
     for (int g = g0; g < g1; g++) {
         cm_stage::landed<0>();
         __syncthreads();                     // group g is in LDS for everyone; buffer buf^1 is no longer read
-        if (g + 1 < g1) stage(g + 1, buf ^ 1);
+        // (past the last group the pieces re-fetch it into the idle buffer: no branch around every piece -- with
+        // branches the loop body falls into blocks and hipcc spills accumulators across them)
+        const int gn = g + 1 < g1 ? g + 1 : g;
+        if (!SPREAD) {
+#pragma unroll
+            for (int i = 0; i < NP; i++) piece(gn, buf ^ 1, i);
+        }
         f4 X0 = S.read(buf * NSLOT + NJB + 2 * wid), X1 = S.read(buf * NSLOT + NJB + 2 * wid + 1);
         if (!v0) X0 = zero;
         if (!v1) X1 = zero;
@@ -2848,10 +2934,12 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
                 acc[1][jb] = mfma4(X1[t], B[t], acc[1][jb]);
             }
             if (do_bias && (jb & 7) == wid) bs[jb >> 3] += B;
+            if (SPREAD && jb % PSTEP == 0 && jb / PSTEP < NP) piece(gn, buf ^ 1, jb / PSTEP);
         }
         cm_stage::reads_done();
         buf ^= 1;
     }
+    cm_stage::landed<0>();                   // the surplus pieces of the last group
     // this split's tiles as whole fragments, then its bias sums: combined by wgrad_dense_reduce
     if (do_bias) {
         // CM fragment: lane (f, rg) register t = G(feature f, candidate 4 rg + t): sum registers, then lanes rg
@@ -2913,9 +3001,19 @@ __global__ void wgrad_dense_reduce(const f4 *__restrict__ part, int splits, int 
     }
 }
 
+#ifdef CV_WG_STAMP
+// development build (tools/gpu_wgrad_stamps.sh): when and where every wave of the conv3 weight-gradient kernel ran --
+// 100 MHz wall clock at entry / exit, shader cycles in between, HW_ID, XCC_ID
+__device__ unsigned long long cv_wg_stamp[4096 * 4];
+extern "C" int cv_debug_wg_stamps(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(cv_wg_stamp), sizeof(cv_wg_stamp)) != hipSuccess;
+}
+#endif
+
 // conv layer: dW[kh][kw][ci][co] += sum_{cand,h,wo} In[cand][h+kh-PT][wo+kw-1][ci] G[cand][h][wo][co].
-// One wave per (output fragment cob, candidate-range split); it keeps all KH*4*CINB tiles of
-// that cob in registers and streams over groups and rows with a KH-row window of input CM fragments.
+// One wave per (output fragment cob, split = a range of the flat (group, row) sequence); it keeps all KH*4*CINB tiles
+// of that cob in registers and streams over groups and rows with a KH-row window of input CM fragments.
 // Step s of a group brings in input row s and gradient row s - PRE (PRE = KH-1-PADT rows of lead; rows
 // outside the map are fetched clamped and never multiplied) through two private LDS slots, one per operand,
 // software-pipelined so that neither the DMA nor the LDS reads wait in front of the matrix pipe:
@@ -2928,7 +3026,7 @@ __global__ void wgrad_dense_reduce(const f4 *__restrict__ part, int splits, int 
 // chain's kernels hold slots on every CU, one-wave workgroups fill whatever is free.)
 template <int KH, int CINB, int NT, int HIN>
 __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm, const f4 *__restrict__ g_tm,
-                                                     int G, int splits, f4 *__restrict__ part)
+                                                     int G, int splits, int rows_per, f4 *__restrict__ part)
 {
     extern __shared__ __attribute__((aligned(16))) float wg_lds[];
     constexpr int PADT = (KH - 1) / 2;
@@ -2937,13 +3035,27 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm
     constexpr int STEPS = HIN + PRE;                 // steps per group
     constexpr int KA = KH >= 3 ? KH - 2 : KH - 1;    // taps multiplied before the new input row is read
     const int lane = threadIdx.x;
+#ifdef CV_WG_STAMP
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime(), st_c0 = __builtin_amdgcn_s_memtime();
+#endif
     const cm_stage S(wg_lds, lane);
     // workgroups go round-robin over the 8 XCDs: the NT waves of one split (same input rows) take ids 8 apart, so
     // they share one XCD's L2 and start back to back
     const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
     const int cob = rest % NT, split = (rest / NT) * 8 + xcd;
-    const int per = (G + splits - 1) / splits;
-    const int g0 = split * per, g1 = split >= splits ? g0 : (g0 + per < G ? g0 + per : G);
+    // A split owns the gradient rows [r0, r1) of the flat (group, row) sequence -- rows_per of them, whatever the
+    // group boundaries: every wave of the launch has the same work (with whole groups per wave train.py's batch gave
+    // 1 875 waves for 2 048 slots: 173 SIMDs held one wave instead of two and idled for the second half), and a small
+    // batch still fills the chip.  Before its first row a wave streams the KH - 1 input rows above it (`warm` steps
+    // that fetch but do not multiply), as every group start does.
+    const int R = G * HIN;
+    const int r0 = split * rows_per, r1 = split >= splits ? r0 : (r0 + rows_per < R ? r0 + rows_per : R);
+    if (r0 >= r1) return;
+    const int gF = r0 / HIN, hF = r0 - gF * HIN, sF = hF > PADT ? hF - PADT : 0;
+    const int gL = (r1 - 1) / HIN, hL = (r1 - 1) - gL * HIN;
+    const int total = (gL * STEPS + hL + PRE + 1) - (gF * STEPS + sF);
+    const int warm = hF + PRE - sF;
+    const int g1 = gL + 1;
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
     f4 acc[KH][4][CINB];
 #pragma unroll
@@ -2953,48 +3065,53 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm
 #pragma unroll
             for (int c = 0; c < CINB; c++) acc[a][b][c] = zero;
     f4 bsum = zero;
-    const int total = (g1 > g0 ? g1 - g0 : 0) * STEPS;
-    if (total == 0) return;
     // fetch cursors (group, step) of the two operands; past the end they re-read valid data nobody uses
-    int ig = g0, is = 0, gg_ = g0, gs = 0;
-    auto fetch_in = [&]() {
+    int ig = gF, is = sF, gg_ = gF, gs = sF;
+    auto next_in = [&]() -> const f4 * {
         const int gc = ig < g1 ? ig : g1 - 1;
         const int hr = is < HIN ? is : HIN - 1;
-        const f4 *ip = in_tm + ((size_t)gc * HIN + hr) * (NI * 64);
-#pragma unroll
-        for (int f = 0; f < NI; f++) S.fetch(ip + f * 64, f);
         if (++is == STEPS) { is = 0; ig++; }
+        return in_tm + ((size_t)gc * HIN + hr) * (NI * 64);
     };
-    auto fetch_g = [&]() {
+    auto next_g = [&]() -> const f4 * {
         const int gc = gg_ < g1 ? gg_ : g1 - 1;
         const int hg = gs - PRE < 0 ? 0 : gs - PRE;
-        const f4 *gp = g_tm + (((size_t)gc * HIN + hg) * 4 * NT + cob) * 64;
-#pragma unroll
-        for (int w = 0; w < 4; w++) S.fetch(gp + (size_t)w * (NT * 64), NI + w);
         if (++gs == STEPS) { gs = 0; gg_++; }
+        return g_tm + (((size_t)gc * HIN + hg) * 4 * NT + cob) * 64;
     };
     // window of the KH newest input rows, rotating: flat step j keeps its row in win[j % KH], so tap kh of the row
     // being accumulated (input row s - (KH-1-kh)) sits in win[(j - (KH-1-kh)) % KH] -- no register moves.  Rows
     // outside the map are never multiplied (the hr test), so stale or clamped contents are harmless.
     f4 win[KH][4][CINB];
     f4 Gr[4];
-    fetch_g();
-    fetch_in();
+    {
+        const f4 *gp = next_g(), *ip = next_in();
+#pragma unroll
+        for (int w = 0; w < 4; w++) S.fetch_s(gp + (size_t)w * (NT * 64), NI + w);
+#pragma unroll
+        for (int f = 0; f < NI; f++) S.fetch_s(ip + f * 64, f);
+    }
     cm_stage::landed<NI>();                          // G row of step 0
 #pragma unroll
     for (int w = 0; w < 4; w++) Gr[w] = S.read(NI + w);
     cm_stage::reads_done();
-    int s = 0;
+    // The DMA pieces of the next rows go out ONE AT A TIME between the MFMA blocks of a tap, not as a burst: the
+    // vector-memory issue port is shared by the CU's waves, a burst of 8 pieces holds its wave for ~1 k cycles without
+    // an MFMA, and with 8 waves per CU the bursts queue behind each other (measured with per-wave time stamps: the
+    // same wave takes 108 us alone on its CU, 118 us with 3 neighbours, 156 us with 5, 178 us with 7).
+    constexpr bool SPREAD_G = KH >= 3;               // KH == 2: the G row is needed one tap later -- no room
+    int s = sF;
 #pragma unroll 1
     for (int i = 0; i < total; i += KH) {
 #pragma unroll
         for (int u = 0; u < KH; u++) {
             if (i + u >= total) break;
-            const int h = s - PRE;
-            auto taps = [&](int kh) {                 // kh is a constant after unrolling
+            const int h = i + u >= warm ? s - PRE : -1;      // -1: no gradient row is accumulated in this step
+            auto taps = [&](int kh, auto piece) {     // kh is a constant after unrolling; piece(b) after block b < 12
                 const int hr = h + kh - PADT;
                 const int ws = (u + kh + 1) % KH;     // = (u - (KH-1-kh)) mod KH
-                if (h >= 0 && hr >= 0 && hr < HIN) {
+                if (h >= 0 && hr >= 0 && hr < HIN) {  // (one branch per tap, not per block)
+                    int b = 0;
 #pragma unroll
                     for (int kw = 0; kw < 4; kw++)
 #pragma unroll
@@ -3006,13 +3123,25 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm
 #pragma unroll
                                 for (int cb = 0; cb < CINB; cb++)
                                     acc[kh][kw][cb] = mfma4(win[ws][wi][cb][t], Gr[wo][t], acc[kh][kw][cb]);
+                            piece(b++);
                         }
+                } else {                              // a row outside the map: nothing to hide the pieces under
+#pragma unroll
+                    for (int b = 0; b < 12; b++) piece(b);
                 }
             };
-            fetch_g();                                // G row of step j+1 (its slot was read one step ago)
+            auto none = [](int) {};
+            const f4 *gp = next_g();                  // G row of step j+1 (its slot was read one step ago)
+            auto g_piece = [&](int b) { if (b < 4) S.fetch_s(gp + (size_t)b * (NT * 64), NI + b); };
+            if (!SPREAD_G) {
+#pragma unroll
+                for (int w = 0; w < 4; w++) g_piece(w);
+            }
             if (h >= 0) bsum += (Gr[0] + Gr[1]) + (Gr[2] + Gr[3]);
 #pragma unroll
-            for (int kh = 0; kh < KA; kh++) taps(kh);
+            for (int kh = 0; kh < KA; kh++) {
+                if (SPREAD_G && kh == 0) taps(kh, g_piece); else taps(kh, none);
+            }
             cm_stage::landed<4>();                    // input row of this step (the G pieces above may still fly)
 #pragma unroll
             for (int w = 0; w < 4; w++)
@@ -3021,14 +3150,14 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm
             // (measured: issuing the next DMAs earlier, so that both have a whole step to land, at the price of waiting for the
             // LDS reads instead of running MFMAs under them: 281 -> 322 us for conv3 -- the reads must stay hidden)
 #pragma unroll
-            for (int kh = KA; kh < KH - 1; kh++) taps(kh);
+            for (int kh = KA; kh < KH - 1; kh++) taps(kh, none);
             cm_stage::reads_done();
-            fetch_in();                               // input row of step j+1
-            cm_stage::landed<NI>();                   // G row of step j+1
+            cm_stage::landed<0>();                    // G row of step j+1
             f4 Gn[4];
 #pragma unroll
             for (int w = 0; w < 4; w++) Gn[w] = S.read(NI + w);
-            taps(KH - 1);
+            const f4 *ip = next_in();                 // input row of step j+1, under the last tap
+            taps(KH - 1, [&](int b) { if (b < NI) S.fetch_s(ip + b * 64, b); });
             cm_stage::reads_done();
 #pragma unroll
             for (int w = 0; w < 4; w++) Gr[w] = Gn[w];
@@ -3046,6 +3175,17 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm
 #pragma unroll
             for (int cb = 0; cb < CINB; cb++) pp[((kh * 4 + kw) * CINB + cb) * 64] = acc[kh][kw][cb];
     pp[TILES * 64] = bsum;
+#ifdef CV_WG_STAMP
+    if (KH == 3 && CINB == 2 && blockIdx.x < 4096) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_amdgcn_s_memtime();
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+        if (lane == 0) {
+            unsigned long long *o = cv_wg_stamp + (size_t)blockIdx.x * 4;
+            o[0] = st_t0; o[1] = t1; o[2] = c1 - st_c0; o[3] = ((unsigned long long)xcc << 32) | hw;
+        }
+    }
+#endif
 }
 
 // second pass of the convolution weight gradients: fragment f = cob * (TILES + 1) + tile of every split, summed
@@ -3605,22 +3745,25 @@ int cv_tile_heads_wgrad(cv_model *m, const float *d4_tm, const float *h5_tm, con
 }
 
 // layer 1 = conv2 (in = pool1 TM), 2 = conv3 (in = pool2 TM); g = pre-activation gradient TM.
-// One wave per (output fragment, split): enough splits for ~2 waves per SIMD (1024 SIMDs); the per-split tiles go
-// to the scratch buffer and are summed in a fixed order by wgrad_conv_reduce (no float atomics).
+// One wave per (output fragment, split): splits for 2 waves per SIMD (1024 SIMDs) with the same number of gradient
+// rows each; the per-split tiles go to the scratch buffer and are summed in a fixed order by wgrad_conv_reduce (no
+// float atomics).  The split boundaries depend on the number of groups only: the same batch gives the same bits.
 template <int KH, int CINB, int NT, int HIN>
 static int conv_wgrad_launch(cv_model *m, int region, const float *in_tm, const float *g_tm, int G, int cin, int cout, float *dw,
                              float *db, hipStream_t st)
 {
     float *scratch = nullptr;
     constexpr int TILES = KH * 4 * CINB;
-    const int want = (2048 + NT - 1) / NT;
-    const int splits = G < want ? (G > 0 ? G : 1) : want;
-    const int per = (G + splits - 1) / splits;
-    const int used = per > 0 ? (G + per - 1) / per : 0;          // splits that own at least one group
-    if (used == 0) return 0;
-    if (wg_region(m, region, (size_t)splits * NT * (TILES + 1) * 256 * sizeof(float), &scratch)) return 1;
-    wgrad_conv_cm<KH, CINB, NT, HIN><<<8 * NT * ((splits + 7) / 8), 64, (4 * CINB + 4) * 1024, st>>>(
-        (const f4 *)in_tm, (const f4 *)g_tm, G, splits, (f4 *)scratch);
+    // rows of the flat (group, row) sequence per wave: 2 048 / NT waves per output fragment (two per SIMD), but at
+    // least 8 rows each (a wave re-streams KH - 1 rows above its range and leaves TILES + 1 fragments to the second pass)
+    if (G <= 0) return 0;
+    const int R = G * HIN, wmax = 2048 / NT;
+    int rows_per = (R + wmax - 1) / wmax;
+    if (rows_per < 8) rows_per = 8;
+    const int used = (R + rows_per - 1) / rows_per;              // = splits: every one owns at least one row
+    if (wg_region(m, region, (size_t)used * NT * (TILES + 1) * 256 * sizeof(float), &scratch)) return 1;
+    wgrad_conv_cm<KH, CINB, NT, HIN><<<8 * NT * ((used + 7) / 8), 64, (4 * CINB + 4) * 1024, st>>>(
+        (const f4 *)in_tm, (const f4 *)g_tm, G, used, rows_per, (f4 *)scratch);
     wgrad_conv_reduce<<<NT * (TILES + 1), 1024, 0, st>>>((const f4 *)scratch, used, NT, TILES, CINB, cin, cout, dw, db);
     CV_HIP(hipGetLastError());
     return 0;
