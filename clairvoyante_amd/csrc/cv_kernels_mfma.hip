@@ -25,6 +25,41 @@
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+#ifdef CV_WG_STAMP
+// Development build (tools/gpu_wave_stamps.sh): when and where the waves of the instrumented kernels ran -- 100 MHz
+// wall clock at entry / exit, shader cycles in between, HW_ID, XCC_ID; one ring of 4 096 records per kernel id (the
+// reader takes the newest launch).  ids: 0 wgrad_conv_cm (conv3), 1 conv3_rot (training), 2 conv_tm (conv3 data
+// gradient), 3 dense_tm (training fc4), 4 dense_dgrad_unpool, 5 wgrad_dense_cm (fc4), 6 conv_tm (conv2 forward)
+constexpr int CV_STAMP_KERNELS = 8;
+__device__ unsigned long long cv_wg_stamp[CV_STAMP_KERNELS * 4096 * 4];
+__device__ unsigned cv_wg_stamp_n[CV_STAMP_KERNELS];
+extern "C" int cv_debug_wg_stamps(unsigned long long *out, unsigned *counts)
+{
+    if (hipMemcpyFromSymbol(counts, HIP_SYMBOL(cv_wg_stamp_n), sizeof(cv_wg_stamp_n)) != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(cv_wg_stamp), sizeof(cv_wg_stamp)) != hipSuccess;
+}
+struct cv_stamp {
+    unsigned long long t0, c0;
+    __device__ __forceinline__ cv_stamp() : t0(__builtin_amdgcn_s_memrealtime()), c0(__builtin_amdgcn_s_memtime()) {}
+    __device__ __forceinline__ void end(int kid) const
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_amdgcn_s_memtime();
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned i = atomicAdd(&cv_wg_stamp_n[kid], 1u) & 4095u;
+            unsigned long long *o = cv_wg_stamp + ((size_t)kid * 4096 + i) * 4;
+            o[0] = t0; o[1] = t1; o[2] = c1 - c0; o[3] = ((unsigned long long)xcc << 32) | hw;
+        }
+    }
+};
+#define CV_STAMP_BEGIN const cv_stamp cv_st;
+#define CV_STAMP_END(cond, kid) do { if (cond) cv_st.end(kid); } while (0)
+#else
+#define CV_STAMP_BEGIN
+#define CV_STAMP_END(cond, kid) do { } while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c)
@@ -548,11 +583,13 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
                                                    int64_t n, const float *__restrict__ wp1,
                                                    const float *__restrict__ bias1, int cout1,
                                                    const f4 *__restrict__ wp, const float *__restrict__ bias,
-                                                   int cout, f4 *__restrict__ out_tm, f4 *__restrict__ act_tm, int G)
+                                                   int cout, f4 *__restrict__ out_tm, f4 *__restrict__ act_tm, int G,
+                                                   int rows_per = 0)
 {
     static_assert(FRONT == 0 || CINB == 1, "the fused first layer feeds one 16-channel fragment");
     static_assert(MODE != 2 || (POOL == 1 && FRONT == 0), "the data-gradient pass has no pooling / first layer");
     static_assert(HSPLIT == 1 || FRONT == 0, "position ranges read their rows from a TM buffer");
+    static_assert(HSPLIT != 0 || (FRONT == 0 && MODE != 0), "flat ranges: training kernels");
     extern __shared__ __attribute__((aligned(16))) f4 ldsw[];
     constexpr int PADT = MODE == 2 ? KH - 1 - (KH - 1) / 2 : (KH - 1) / 2;
     constexpr int PADL = MODE == 2 ? 2 : 1;
@@ -562,17 +599,41 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int hs = wv % HSPLIT, gt = wv / HSPLIT;
-    const int g = gt / NT, nt = gt % NT;
-    if (g >= G) return;
-    // positions [hbeg, hend): with pooling a part owns the pooled rows [HOUT*hs/HSPLIT, HOUT*(hs+1)/HSPLIT) and
-    // computes the POOL-1 convolution rows behind them as well (recomputed by its neighbour: same values)
-    const int hbeg = POOL > 1 ? HOUT * hs / HSPLIT : HIN * hs / HSPLIT;
-    const int hend = POOL > 1 ? HOUT * (hs + 1) / HSPLIT + POOL - 1 : HIN * (hs + 1) / HSPLIT;
+    // HSPLIT >= 1: a wave owns part hs of the positions of ONE (group, tile).
+    // HSPLIT == 0 (training, larger batches): a wave owns the output rows [r0, r1) of the flat (group, row) sequence
+    // of its tile -- rows_per of them, whatever the group boundaries -- so that a launch is ONE round of equal waves
+    // (parts of whole groups gave 3 750 waves for 2 048 slots at train.py's batch: a second round on a third of the
+    // chip).  The rows of each group in the range are one segment of the loop below; same values row for row.
+    constexpr int HSD = HSPLIT > 0 ? HSPLIT : 1;
+    int nt, gF, gL, hs = 0, r0 = 0, r1 = 0;
+    if constexpr (HSPLIT == 0) {
+        nt = wv % NT;
+        r0 = (wv / NT) * rows_per;
+        r1 = r0 + rows_per < G * HOUT ? r0 + rows_per : G * HOUT;
+        if (r0 >= r1) return;
+        gF = r0 / HOUT; gL = (r1 - 1) / HOUT;
+    } else {
+        const int gt = wv / HSD;
+        hs = wv % HSD; nt = gt % NT; gF = gL = gt / NT;
+        if (gF >= G) return;
+    }
+    CV_STAMP_BEGIN
     const int q = lane >> 4;
     const f4 b4 = MODE == 2 ? (f4){0.f, 0.f, 0.f, 0.f} : load_bias4(bias, nt, q, cout);
-    const f4 *inp = in_tm + (size_t)g * (HIN * 4 * CINB * 64) + lane;
     const f4 *wl = ldsw + (size_t)nt * (KH * 4 * CINB * 64) + lane;
+#pragma unroll 1
+    for (int g = gF; g <= gL; g++) {
+    // positions [hbeg, hend): with pooling a part owns the pooled rows [HOUT*hs/HSPLIT, HOUT*(hs+1)/HSPLIT) and
+    // computes the POOL-1 convolution rows behind them as well (recomputed by its neighbour: same values)
+    int hbeg, hend;
+    if constexpr (HSPLIT == 0) {
+        const int oa = r0 - g * HOUT > 0 ? r0 - g * HOUT : 0, ob = r1 - g * HOUT < HOUT ? r1 - g * HOUT : HOUT;
+        hbeg = oa; hend = POOL > 1 ? ob + POOL - 1 : ob;
+    } else {
+        hbeg = POOL > 1 ? HOUT * hs / HSD : HIN * hs / HSD;
+        hend = POOL > 1 ? HOUT * (hs + 1) / HSD + POOL - 1 : HIN * (hs + 1) / HSD;
+    }
+    const f4 *inp = in_tm + (size_t)g * (HIN * 4 * CINB * 64) + lane;
     f4 *op = out_tm + (size_t)g * (HOUT * 4 * NT * 64) + (size_t)nt * 64 + lane;
 
     front_source<FRONT, (KS4 <= 2)> fs;          // KS4 <= 2: the fused first layer has <= 8 output channels
@@ -788,6 +849,9 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
 #pragma unroll
                 for (int cb = 0; cb < CINB; cb++) win[j][w][cb] = win[j + 1][w][cb];
     }
+    }                                      // segments (groups) of this wave
+    CV_STAMP_END(MODE == 2 && KH == 3 && CINB == 3, 2);
+    CV_STAMP_END(MODE == 1 && KH == 2 && CINB == 1 && FRONT == 0, 6);
 }
 
 // ---------------------------------------------------------------------------
@@ -961,7 +1025,8 @@ __global__ __launch_bounds__(256, 2) void front2_tm(const float *__restrict__ x,
 template <int CINB, int NT, int HIN, int WAVES, int MINW, bool SAVE = false>
 __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restrict__ in_tm, const f4 *__restrict__ wp,
                                                             const float *__restrict__ bias, int cout,
-                                                            f4 *__restrict__ out_tm, int G, u32x2 *__restrict__ code_tm = nullptr)
+                                                            f4 *__restrict__ out_tm, int G, u32x2 *__restrict__ code_tm = nullptr,
+                                                            int rows_per = 0)
 {
     constexpr int KH = 3, PADT = 1, POOL = 3, HOUT = HIN - POOL + 1;
     extern __shared__ __attribute__((aligned(16))) f4 ldsw[];
@@ -970,16 +1035,36 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
-    const int g = wv / NT, nt = wv % NT;
-    if (g >= G) return;
+    const int nt = wv % NT;
+    // rows_per == 0: one wave per (group, tile), all HIN positions.  rows_per > 0 (training forward, larger batches):
+    // the wave owns the POOLED rows [r0, r1) of the flat (group, row) sequence of its tile, so that a launch is one round
+    // of equal waves (conv_tm HSPLIT == 0); the rows of each group in the range are one segment of the loop below --
+    // positions [hbeg, hend) = its pooled rows and the POOL - 1 behind them; same values row for row.
+    int gF = wv / NT, gL = gF, r0 = 0, r1 = 0;
+    if (SAVE && rows_per > 0) {
+        r0 = (wv / NT) * rows_per;
+        r1 = r0 + rows_per < G * HOUT ? r0 + rows_per : G * HOUT;
+        if (r0 >= r1) return;
+        gF = r0 / HOUT; gL = (r1 - 1) / HOUT;
+    } else if (gF >= G) return;
+    CV_STAMP_BEGIN
     const int q = lane >> 4;
     const f4 b4 = load_bias4(bias, nt, q, cout);
-    const f4 *inp = in_tm + (size_t)g * (HIN * 4 * CINB * 64) + lane;
     const f4 *wl = ldsw + (size_t)nt * (KH * 4 * CINB * 64) + lane;
-    f4 *op = out_tm + (size_t)g * (HOUT * 4 * NT * 64) + (size_t)nt * 64 + lane;
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
-    f4 win[3][4][CINB];          // slot (r + 1) % 3 holds input row r
-    f4 tp[3][4];                 // pre-activation rows h-2, h-1, h of the pooling window (slot h % 3)
+    const unsigned lane16 = (unsigned)lane * 16u;
+#pragma unroll 1
+    for (int g = gF; g <= gL; g++) {
+    int hbeg = 0, hend = HIN;
+    if (SAVE && rows_per > 0) {
+        hbeg = r0 - g * HOUT > 0 ? r0 - g * HOUT : 0;
+        hend = (r1 - g * HOUT < HOUT ? r1 - g * HOUT : HOUT) + POOL - 1;
+    }
+    const f4 *inp = in_tm + (size_t)g * (HIN * 4 * CINB * 64) + lane;
+    f4 *op = out_tm + (size_t)g * (HOUT * 4 * NT * 64) + (size_t)nt * 64 + lane;
+    // slots are relative to the segment: position hbeg + j runs as R = j % 3 and input row hbeg + j sits in slot (j + 1) % 3
+    f4 win[3][4][CINB];
+    f4 tp[3][4];                 // rows h-2, h-1, h of the pooling window (slot R of their position)
 #pragma unroll
     for (int j = 0; j < 3; j++)
 #pragma unroll
@@ -990,18 +1075,18 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
 #pragma unroll
             for (int cb = 0; cb < CINB; cb++) row[w][cb] = inp[(size_t)((hr * 4 + w) * CINB + cb) * 64];
     };
-    load_row(0, win[1]);         // row 0 -> slot 1 ; row -1 (slot 0) is padding and never read
+    load_row(hbeg, win[1]);      // first row -> slot 1 ; the row above it -> slot 0 (padding, never read, when hbeg == 0)
+    if (hbeg > 0) load_row(hbeg - 1, win[0]);
     // The row the last kernel row needs is loaded one fragment at a time between the MFMA blocks of the FIRST kernel
     // row, from asm (scalar base + this lane's 16 bytes) so that the loads stay where they are put: as a burst of
     // 4 CINB loads the wave queues on the CU's vector-memory port behind the other waves' bursts (see conv_tm).
     static_assert(CINB == 2, "the counted wait below names 8 fragments");
-    const f4 *const inp_s = in_tm + (size_t)__builtin_amdgcn_readfirstlane(g) * (HIN * 4 * CINB * 64);
-    const unsigned lane16 = (unsigned)lane * 16u;
+    const f4 *const inp_s = in_tm + (size_t)g * (HIN * 4 * CINB * 64);
     auto load_piece = [&](int hr, int w, int cb, f4 &dst) {
         const f4 *ps = inp_s + (size_t)((hr * 4 + w) * CINB + cb) * 64;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane16), "s"(ps));    // (no memory clobber: the
     };                                                       //  weight reads from LDS may move across it)
-    // one position; R = h % 3 is a compile-time constant so that slot indices are static
+    // one position; R = (h - hbeg) % 3 is a compile-time constant so that slot indices are static
     auto step = [&](auto Rc, int h) {
         constexpr int R = decltype(Rc)::value;
         // rows h-1, h, h+1 are in slots R, (R+1)%3, (R+2)%3; row h+1 is fetched under the first kernel row and used last
@@ -1051,13 +1136,13 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
         for (int w = 0; w < 4; w++) {
             if constexpr (SAVE) tp[R][w] = selu4(acc[w] + b4);
             else tp[R][w] = acc[w] + b4;             // (a sum needs no canonicalising v_max x, x, x; a raw MFMA result would)
-            if (h >= POOL - 1) {
+            if (h - hbeg >= POOL - 1) {
                 if constexpr (SAVE) op[(size_t)((h - (POOL - 1)) * 4 + w) * (NT * 64)] = max3_4(tp[0][w], tp[1][w], tp[2][w]);
                 else op[(size_t)((h - (POOL - 1)) * 4 + w) * (NT * 64)] = selu4(max3_4(tp[0][w], tp[1][w], tp[2][w]));
             }
         }
         if constexpr (SAVE) {
-            if (h >= POOL - 1) {                     // rows h-2, h-1, h sit in slots (R+1)%3, (R+2)%3, R
+            if (h - hbeg >= POOL - 1) {              // rows h-2, h-1, h sit in slots (R+1)%3, (R+2)%3, R
                 unsigned cw[4];
 #pragma unroll
                 for (int w = 0; w < 4; w++) {
@@ -1069,14 +1154,16 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
         }
     };
 #pragma unroll 1
-    for (int h0 = 0; h0 < HIN; h0 += 3) {
+    for (int h0 = hbeg; h0 < hend; h0 += 3) {
         step(std::integral_constant<int, 0>{}, h0);
         __builtin_amdgcn_sched_barrier(0);     // keep the three positions apart: register budget
-        if (h0 + 1 < HIN) step(std::integral_constant<int, 1>{}, h0 + 1);
+        if (h0 + 1 < hend) step(std::integral_constant<int, 1>{}, h0 + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (h0 + 2 < HIN) step(std::integral_constant<int, 2>{}, h0 + 2);
+        if (h0 + 2 < hend) step(std::integral_constant<int, 2>{}, h0 + 2);
         __builtin_amdgcn_sched_barrier(0);
     }
+    }                                          // segments (groups) of this wave
+    CV_STAMP_END(SAVE, 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -1443,6 +1530,7 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = (blockIdx.x * WAVES + wid) * GR;
+    CV_STAMP_BEGIN
     // this wave's activation fragments: byte offsets from in_tm (a scalar base + a 32-bit vector offset per group
     // instead of a 64-bit pointer: 2 VGPRs less per group, which the fc5 + heads tail of EPI 3 needs; a pass is at most
     // 4 096 groups x 288 fragments = 1.2 GB)
@@ -1548,6 +1636,7 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
         for (int r = 0; r < GR; r++) B[r] = Bn[r];
         slot = slot + 1 == 3 ? 0 : slot + 1;
     }
+    CV_STAMP_END(NB == 7 && EPI == 0, 3);
     const int q = lane >> 4;
     if constexpr (EPI == 3) {
         // ---- fc5 and the four heads on the tail of fc4 (inference, variant bit 10).  After bias + SELU the wave's
@@ -1859,6 +1948,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void dense_dgrad_unpool(const f4 *__
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g0 = (blockIdx.x * WAVES + wid) * GR;
+    CV_STAMP_BEGIN
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
     const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) f4 *)ring;
     const f4 *wcol = wpr + (size_t)col * HO * STAGE;
@@ -1978,6 +2068,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void dense_dgrad_unpool(const f4 *__
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // surplus DMA pieces of the last rows
+    CV_STAMP_END(true, 4);
 }
 
 // ---------------------------------------------------------------------------
@@ -2271,8 +2362,24 @@ int launch_conv(const float *in, const float *x, int64_t n, const float *wp1, co
     size_t lds = (size_t)NT * KH * 4 * CINB * 1024;
     if (set_lds(k, lds)) return 1;
     unsigned grid = nblk((int64_t)G * NT * HSPLIT, 4);
+    int rows_per = 0;
+    if constexpr (HSPLIT == 0) {
+        // flat ranges: one round of equal waves.  slots = resident waves of this kernel (4-wave workgroups per CU by its
+        // registers and LDS, asked once); at least 4 output rows per wave (a pooled layer recomputes POOL - 1 per segment).
+        static int slots = 0;
+        if (slots == 0) {
+            int nb = 0;
+            CV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), 256, lds));
+            slots = (nb > 0 ? nb : 2) * 4 * 256;
+        }
+        const int64_t rows = (int64_t)G * (HIN - POOL + 1);
+        const int per_tile = slots / NT;
+        rows_per = (int)((rows + per_tile - 1) / per_tile);
+        if (rows_per < 4) rows_per = 4;
+        grid = nblk((rows + rows_per - 1) / rows_per * NT, 4);
+    }
     k<<<grid, 256, lds, st>>>((const f4 *)in, x, n, wp1, bias1, cout1, (const f4 *)wp, bias, cout, (f4 *)out,
-                              (f4 *)act, G);
+                              (f4 *)act, G, rows_per);
     CV_HIP(hipGetLastError());
     return 0;
 }
@@ -2297,13 +2404,24 @@ static int pick_hsplit(int G, int NT, int rows, int overlap, int max_parts)
     return best;
 }
 
-// launch_conv with the number of position parts chosen at run time (1, 2, 3, 4, 6 or 8)
+// Training layers: position parts of whole groups for small batches (pick_hsplit), flat ranges (0) beyond
+// train_tiny_groups -- there a launch would take more than one round of waves.  dbg 9 at the call site's switch keeps
+// the parts (development A/B).
+static int conv_parts(const cv_model *m, int dbg, int G, int NT, int rows, int overlap, int max_parts)
+{
+    if (m->tiny_g <= 0) return 1;
+    if (G > m->tiny_g && dbg != 9) return 0;
+    return pick_hsplit(G, NT, rows, overlap, max_parts);
+}
+
+// launch_conv with the number of position parts chosen at run time (1, 2, 3, 4, 6 or 8; 0 = flat ranges)
 template <int KH, int CINB, int NT, int POOL, int HIN, int MODE, int KS4 = 4>
 int launch_conv_parts(int hs, const float *in, const float *x, int64_t n, const float *wp, const float *bias, int cout,
                       float *out, int G, hipStream_t st, float *act = nullptr)
 {
 #define CV_PARTS(H) return launch_conv<KH, CINB, NT, POOL, HIN, 0, MODE, H, KS4>(in, x, n, nullptr, nullptr, 0, wp, bias, cout, out, G, st, act)
     switch (hs) {
+    case 0: CV_PARTS(0);          // flat ranges of the (group, row) sequence
     case 2: CV_PARTS(2);
     case 3: CV_PARTS(3);
     case 4: CV_PARTS(4);
@@ -2316,13 +2434,21 @@ int launch_conv_parts(int hs, const float *in, const float *x, int64_t n, const 
 
 template <int CINB, int NT, int HIN, int WAVES, int MINW, bool SAVE = false>
 int launch_conv3_rot(const float *in, const float *wp, const float *bias, int cout, float *out, int G, hipStream_t st,
-                     float *codes = nullptr)
+                     float *codes = nullptr, int flat_slots = 0)
 {
     auto k = conv3_rot<CINB, NT, HIN, WAVES, MINW, SAVE>;
     size_t lds = (size_t)NT * 3 * 4 * CINB * 1024;
     if (set_lds(k, lds)) return 1;
-    k<<<nblk((int64_t)G * NT, WAVES), WAVES * 64, lds, st>>>((const f4 *)in, (const f4 *)wp, bias, cout, (f4 *)out, G,
-                                                            (u32x2 *)codes);
+    unsigned grid = nblk((int64_t)G * NT, WAVES);
+    int rows_per = 0;
+    if (SAVE && flat_slots > 0) {            // training forward: one round of equal waves (see launch_conv)
+        const int64_t rows = (int64_t)G * (HIN - 2);
+        const int per_tile = flat_slots / NT;
+        rows_per = (int)((rows + per_tile - 1) / per_tile);
+        if (rows_per < 4) rows_per = 4;
+        grid = nblk((rows + rows_per - 1) / rows_per * NT, WAVES);
+    }
+    k<<<grid, WAVES * 64, lds, st>>>((const f4 *)in, (const f4 *)wp, bias, cout, (f4 *)out, G, (u32x2 *)codes, rows_per);
     CV_HIP(hipGetLastError());
     return 0;
 }
@@ -2856,6 +2982,7 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
                                                      // of the last one land on identical bytes)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    CV_STAMP_BEGIN
     const cm_stage S(wg_lds, lane);
     const int kb0 = blockIdx.x * 16 + wid * 2;
     const int per = (G + gridDim.y - 1) / gridDim.y;
@@ -2961,6 +3088,7 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
 #pragma unroll
         for (int jb = 0; jb < NJB; jb++) pp[jb * 64] = acc[a][jb];
     }
+    CV_STAMP_END(NJB == 21, 5);
 }
 
 // second pass of the dense weight gradient: dW += sum over splits (ascending: a fixed summation order),
@@ -3001,16 +3129,6 @@ __global__ void wgrad_dense_reduce(const f4 *__restrict__ part, int splits, int 
     }
 }
 
-#ifdef CV_WG_STAMP
-// development build (tools/gpu_wgrad_stamps.sh): when and where every wave of the conv3 weight-gradient kernel ran --
-// 100 MHz wall clock at entry / exit, shader cycles in between, HW_ID, XCC_ID
-__device__ unsigned long long cv_wg_stamp[4096 * 4];
-extern "C" int cv_debug_wg_stamps(unsigned long long *out)
-{
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(cv_wg_stamp), sizeof(cv_wg_stamp)) != hipSuccess;
-}
-#endif
-
 // conv layer: dW[kh][kw][ci][co] += sum_{cand,h,wo} In[cand][h+kh-PT][wo+kw-1][ci] G[cand][h][wo][co].
 // One wave per (output fragment cob, split = a range of the flat (group, row) sequence); it keeps all KH*4*CINB tiles
 // of that cob in registers and streams over groups and rows with a KH-row window of input CM fragments.
@@ -3035,9 +3153,7 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm
     constexpr int STEPS = HIN + PRE;                 // steps per group
     constexpr int KA = KH >= 3 ? KH - 2 : KH - 1;    // taps multiplied before the new input row is read
     const int lane = threadIdx.x;
-#ifdef CV_WG_STAMP
-    const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime(), st_c0 = __builtin_amdgcn_s_memtime();
-#endif
+    CV_STAMP_BEGIN
     const cm_stage S(wg_lds, lane);
     // workgroups go round-robin over the 8 XCDs: the NT waves of one split (same input rows) take ids 8 apart, so
     // they share one XCD's L2 and start back to back
@@ -3175,17 +3291,7 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm
 #pragma unroll
             for (int cb = 0; cb < CINB; cb++) pp[((kh * 4 + kw) * CINB + cb) * 64] = acc[kh][kw][cb];
     pp[TILES * 64] = bsum;
-#ifdef CV_WG_STAMP
-    if (KH == 3 && CINB == 2 && blockIdx.x < 4096) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_amdgcn_s_memtime();
-        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11));
-        if (lane == 0) {
-            unsigned long long *o = cv_wg_stamp + (size_t)blockIdx.x * 4;
-            o[0] = st_t0; o[1] = t1; o[2] = c1 - st_c0; o[3] = ((unsigned long long)xcc << 32) | hw;
-        }
-    }
-#endif
+    CV_STAMP_END(KH == 3 && CINB == 2, 0);
 }
 
 // second pass of the convolution weight gradients: fragment f = cob * (TILES + 1) + tile of every split, summed
@@ -3370,7 +3476,7 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
     // (pick_hsplit; config 4's per-rank batch of 1 250 is 79 groups -> 4 parts, train.py's 625 groups -> conv2 in 3);
     // same values row for row.  Option train_tiny_groups = 0 keeps one wave per (group, tile).
     const bool split = m->tiny_g > 0;
-    if (is_full(a) && m->dbg[1] > 0) {          // development: forced number of position parts
+    if (is_full(a) && m->dbg[1] > 0 && m->dbg[1] < 8) {          // development: forced number of position parts
         conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (u32x2 *)a1);
         rc |= launch_conv_parts<2, 1, 2, 4, 29, 1>(m->dbg[1], p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
         rc |= launch_conv_parts<3, 2, 3, 3, 26, 1>(m->dbg[1], p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
@@ -3379,16 +3485,22 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
     }
     if (is_full(a)) {
         conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (u32x2 *)a1);
-        rc |= launch_conv_parts<2, 1, 2, 4, 29, 1>(split ? pick_hsplit(G, 2, 26, 3, 4) : 1, p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
-        const int hs3 = split ? pick_hsplit(G, 3, 24, 2, 4) : 1;
-        if (hs3 == 1 && m->dbg[7] != 1)          // one wave per (group, tile): the rotating-window kernel (dbg7 = 1: conv_tm)
-            rc |= launch_conv3_rot<2, 3, 26, 4, 2, true>(p2, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
+        // conv2 stays on position parts (measured at train.py's batch on one box: flat ranges -- dbg1 = 8 -- make the
+        // kernel 4 us shorter on its own and the step 40 us longer: its 3 waves per SIMD then hold every slot to the
+        // end and the weight packing on the side stream waits)
+        rc |= launch_conv_parts<2, 1, 2, 4, 29, 1>(conv_parts(m, m->dbg[1] == 8 ? 0 : 9, G, 2, 26, 3, 4), p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
+        const int hs3 = conv_parts(m, m->dbg[1], G, 3, 24, 2, 4);
+        // one wave per (group, tile) or flat ranges: the rotating-window kernel (dbg7 = 1: conv_tm; dbg7 = 2 / 3: flat
+        // ranges sized for 2 / 3 waves per SIMD)
+        if ((hs3 == 1 || hs3 == 0) && m->dbg[7] != 1)
+            rc |= launch_conv3_rot<2, 3, 26, 4, 2, true>(p2, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3,
+                                                         hs3 == 0 ? (m->dbg[7] == 3 ? 3072 : 2048) : 0);
         else
             rc |= launch_conv_parts<3, 2, 3, 3, 26, 1>(hs3, p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
     } else {
         conv1_tm<1, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (u32x2 *)a1);
-        rc |= launch_conv_parts<3, 1, 1, 1, 33, 1, 2>(split ? pick_hsplit(G, 1, 33, 0, 4) : 1, p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
-        rc |= launch_conv_parts<5, 1, 2, 1, 33, 1>(split ? pick_hsplit(G, 2, 33, 0, 4) : 1, p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
+        rc |= launch_conv_parts<3, 1, 1, 1, 33, 1, 2>(conv_parts(m, m->dbg[1], G, 1, 33, 0, 4), p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
+        rc |= launch_conv_parts<5, 1, 2, 1, 33, 1>(conv_parts(m, m->dbg[1], G, 2, 33, 0, 4), p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
     }
     CV_HIP(hipGetLastError());
     return rc;
@@ -3493,18 +3605,18 @@ int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm,
     const int G = (int)((n + 15) / 16);
     const float *W = m->wpd_conv[layer];
     const bool split = m->tiny_g > 0;      // see cv_tile_train_convs
-    if (is_full(a) && m->dbg[0] > 0) {          // development: forced number of position parts
+    if (is_full(a) && m->dbg[0] > 0 && m->dbg[0] != 9) {          // development: forced number of position parts
         if (layer == 2) return launch_conv_parts<3, 3, 2, 1, 26, 2>(m->dbg[0], g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
         return launch_conv_parts<2, 2, 1, 1, 29, 2>(m->dbg[0], g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
     }
     if (is_full(a)) {
         if (layer == 2)
-            return launch_conv_parts<3, 3, 2, 1, 26, 2>(split ? pick_hsplit(G, 2, 26, 0, 8) : 1, g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
-        return launch_conv_parts<2, 2, 1, 1, 29, 2>(split ? pick_hsplit(G, 1, 29, 0, 8) : 1, g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
+            return launch_conv_parts<3, 3, 2, 1, 26, 2>(conv_parts(m, m->dbg[0], G, 2, 26, 0, 8), g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
+        return launch_conv_parts<2, 2, 1, 1, 29, 2>(conv_parts(m, m->dbg[0], G, 1, 29, 0, 8), g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
     }
     if (layer == 2)
-        return launch_conv_parts<5, 2, 1, 1, 33, 2>(split ? pick_hsplit(G, 1, 33, 0, 8) : 1, g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st, act);
-    return launch_conv_parts<3, 1, 1, 1, 33, 2>(split ? pick_hsplit(G, 1, 33, 0, 8) : 1, g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st, act);
+        return launch_conv_parts<5, 2, 1, 1, 33, 2>(conv_parts(m, m->dbg[0], G, 1, 33, 0, 8), g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st, act);
+    return launch_conv_parts<3, 1, 1, 1, 33, 2>(conv_parts(m, m->dbg[0], G, 1, 33, 0, 8), g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st, act);
 }
 
 // layer 1 = conv2, 2 = conv3 (full topology): data gradient fused with the max-pool backward + SELU' of the layer below

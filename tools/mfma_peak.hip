@@ -52,8 +52,17 @@ void run(int wgs, int iters)
            RANDOM ? "random  " : "constant", NACC, wgs, iters, ms, flops / ms / 1e9, c0, c0 / (ms * 1e6), (double)c0 / (iters * 4.0 * NACC));
     hipFree(out); hipFree(cyc);
 }
-int main()
+// dependent-chain distance: NACC accumulators in rotation = NACC - 1 other MFMAs between two on the same accumulator,
+// at 1, 2 and 4 waves per SIMD (256 CUs x 4 SIMDs: 256 / 512 / 1024 workgroups of 4 waves)
+void chains()
 {
+    run<1, true>(256, 40000); run<2, true>(256, 40000); run<3, true>(256, 30000); run<4, true>(256, 20000); run<8, true>(256, 10000);
+    run<1, true>(512, 40000); run<2, true>(512, 40000); run<3, true>(512, 30000); run<4, true>(512, 20000); run<8, true>(512, 10000);
+    run<1, true>(1024, 40000); run<2, true>(1024, 40000);
+}
+int main(int argc, char **argv)
+{
+    if (argc > 1) { chains(); return 0; }
     run<8, false>(1024, 10000); run<8, true>(1024, 10000); run<8, true>(2048, 10000); run<8, true>(1024, 100000);
     run<4, true>(1024, 20000); run<8, false>(1024, 100000);
     return 0;
