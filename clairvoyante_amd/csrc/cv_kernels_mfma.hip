@@ -1601,6 +1601,9 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
         f4 hAn = zero;
         if constexpr (EPI == 2) hAn = load_frag(hd.wp0 + (size_t)kn * 64 + lane);      // issued before this step's DMA pieces
         stage_async(ks, wslot);          // slot (kb+2)%3 was last read in step kb-1 (barrier passed)
+        // (measured, round 3: these loads and pieces issued one per MFMA block instead of here -- what helped the
+        // convolution kernels -- makes this ring slower: training step 2.15 -> 2.21 ms, inference 18.41 -> 18.28 M/s on
+        // one box; a wave issues at most 5 of them per step, and the barrier needs them early)
         const f4 *wl = ring + slot * STAGE + lane;
         constexpr int AB = EPI == 3 ? 2 : 3;      // weight fragments read ahead of their MFMAs (EPI 3 is short of 4 VGPRs)
 #pragma unroll

@@ -15,5 +15,5 @@ for l in err.splitlines():
 for k, v in rows.items():
     if not pats or any(p in k for p in pats):
         name = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip().split("(")[0]
-        print("%-60s VGPR %3s AGPR %3s spillV %s spillS %s occ %s LDS %s" % (name[-60:], v.get("VGPRs"), v.get("AGPRs"), v.get("VGPRs Spill"),
+        print("%-70s VGPR %3s AGPR %3s spillV %s spillS %s occ %s LDS %s" % ((name if len(name) > 6 else k)[-70:], v.get("VGPRs"), v.get("AGPRs"), v.get("VGPRs Spill"),
               v.get("SGPRs Spill"), v.get("Occupancy [waves/SIMD]"), v.get("LDS Size [bytes/block]")))
