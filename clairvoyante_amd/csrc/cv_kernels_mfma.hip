@@ -2413,7 +2413,7 @@ static int pick_hsplit(int G, int NT, int rows, int overlap, int max_parts)
 static int conv_parts(const cv_model *m, int dbg, int G, int NT, int rows, int overlap, int max_parts)
 {
     if (m->tiny_g <= 0) return 1;
-    if (G > m->tiny_g && dbg != 9) return 0;
+    if ((G > m->tiny_g && dbg != 9) || dbg == 7) return 0;      // (dbg 7: flat ranges for a small batch too)
     return pick_hsplit(G, NT, rows, overlap, max_parts);
 }
 
@@ -3022,7 +3022,7 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
     // PSTEP-th gradient fragment): as a burst behind the barrier all 8 waves queue on the CU's vector-memory port at
     // once and none of them multiplies meanwhile (see wgrad_conv_cm).
     constexpr bool SPREAD = NJB >= NP;
-    constexpr int PSTEP = SPREAD ? NJB / NP : 1;
+    constexpr int PSTEP = SPREAD ? NJB / NP : 1;       // (every block instead, so that all pieces are out early: no difference)
     if (g0 < g1) {
 #pragma unroll
         for (int i = 0; i < NP; i++) piece(g0, 0, i);
@@ -3479,7 +3479,7 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
     // (pick_hsplit; config 4's per-rank batch of 1 250 is 79 groups -> 4 parts, train.py's 625 groups -> conv2 in 3);
     // same values row for row.  Option train_tiny_groups = 0 keeps one wave per (group, tile).
     const bool split = m->tiny_g > 0;
-    if (is_full(a) && m->dbg[1] > 0 && m->dbg[1] < 8) {          // development: forced number of position parts
+    if (is_full(a) && m->dbg[1] > 0 && m->dbg[1] < 7) {          // development: forced number of position parts
         conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (u32x2 *)a1);
         rc |= launch_conv_parts<2, 1, 2, 4, 29, 1>(m->dbg[1], p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
         rc |= launch_conv_parts<3, 2, 3, 3, 26, 1>(m->dbg[1], p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
@@ -3608,7 +3608,7 @@ int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm,
     const int G = (int)((n + 15) / 16);
     const float *W = m->wpd_conv[layer];
     const bool split = m->tiny_g > 0;      // see cv_tile_train_convs
-    if (is_full(a) && m->dbg[0] > 0 && m->dbg[0] != 9) {          // development: forced number of position parts
+    if (is_full(a) && m->dbg[0] > 0 && m->dbg[0] < 7) {          // development: forced number of position parts
         if (layer == 2) return launch_conv_parts<3, 3, 2, 1, 26, 2>(m->dbg[0], g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
         return launch_conv_parts<2, 2, 1, 1, 29, 2>(m->dbg[0], g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
     }
