@@ -221,21 +221,22 @@ __device__ __forceinline__ void pack_dense_slabs(int64_t t, const float *__restr
 }
 
 // data-gradient weights of a dense layer: out feature = original input k, in feature =
-// original output j; fragments [slab][jb][ob_in_slab][lane][s] (slabs of NBS output fragments)
+// original output j; fragments [slab][jb][ob_in_slab][lane][s] (slabs of NBS output fragments, stored with a stride
+// of NBSP >= NBS: dense_tm's count padded to its waves, the pad fragments zero)
 __device__ __forceinline__ void pack_dense_dgrad(int64_t t, const float *__restrict__ w, float *__restrict__ wp, int K, int N, int JB,
-                                 int NBS, int NSLAB)
+                                 int NBS, int NSLAB, int NBSP)
 {
-    int64_t total = (int64_t)NSLAB * JB * NBS * 256;
+    int64_t total = (int64_t)NSLAB * JB * NBSP * 256;
     if (t >= total) return;
     int s = (int)(t & 3), lane = (int)((t >> 2) & 63);
     int64_t frag = t >> 8;
-    int obs = (int)(frag % NBS); frag /= NBS;
+    int obs = (int)(frag % NBSP); frag /= NBSP;
     int jb = (int)(frag % JB);
     int slab = (int)(frag / JB);
     int i = lane & 15, kq = lane >> 4;
     int j = 16 * jb + 4 * s + kq;                       // contraction index = original output unit
     int k = 16 * (slab * NBS + obs) + cv_sigma(i);      // result feature = original input unit
-    wp[t] = (j < N && k < K) ? w[(size_t)k * N + j] : 0.0f;
+    wp[t] = (obs < NBS && j < N && k < K) ? w[(size_t)k * N + j] : 0.0f;
 }
 
 // data-gradient weights of fc4 for dense_dgrad_unpool: one column of the pooled conv3 map per workgroup, rows in
@@ -2535,7 +2536,7 @@ __global__ __launch_bounds__(256) void pack_all(pack_tab tab)
     case 1: pack_conv(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4]); break;
     case 2: pack_dense(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3]); break;
     case 3: pack_dense_slabs(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4], J.i[5]); break;
-    case 4: pack_dense_dgrad(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4]); break;
+    case 4: pack_dense_dgrad(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4], J.i[5]); break;
     case 5: pack_conv_dgrad(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4]); break;
     case 7: pack_dense_dgrad_rows(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4], J.i[5]); break;
     case 8: pack_dense_kpairs(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4]); break;
@@ -2613,12 +2614,12 @@ static int pack_launch(cv_model *m, hipStream_t st, bool fwd, bool with_train, i
             J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.nb4; J.i[3] = 24; J.i[4] = ncol; J.i[5] = s.hp[2];
         } else {
             pack_job &J = pb.add(4, (int64_t)(s.kb4 / 24) * s.nb4 * 24 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wpd_fc4;
-            J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.nb4; J.i[3] = 24; J.i[4] = s.kb4 / 24;
+            J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.nb4; J.i[3] = 24; J.i[4] = s.kb4 / 24; J.i[5] = 24;
         }
-        {   // fc5: one slab; fragment stride = dense_tm's padded count (full: 21 -> 24 with 8 waves, slim: 3 -> 4)
-            const int nbp = is_full(a) ? 24 : 4;
-            pack_job &J = pb.add(4, (int64_t)s.nb5 * nbp * 256); J.src[0] = P + o[8]; J.dst[0] = m->wpd_fc5;
-            J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb5; J.i[3] = nbp; J.i[4] = 1;
+        {   // fc5: full = 3 slabs of 7 fragments (stride 8 = dense_tm<7, 8>'s padded count), slim = one slab of 3 (stride 4)
+            const int nbs = is_full(a) ? 7 : s.nb4, nbsp = is_full(a) ? 8 : 4, nslab = is_full(a) ? 3 : 1;
+            pack_job &J = pb.add(4, (int64_t)nslab * s.nb5 * nbsp * 256); J.src[0] = P + o[8]; J.dst[0] = m->wpd_fc5;
+            J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb5; J.i[3] = nbs; J.i[4] = nslab; J.i[5] = nbsp;
         }
     }
     if (pb.blocks == 0) return 0;
@@ -3541,7 +3542,9 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
             if (G <= CV_FC4_SLAB_MAX_G) return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3);
             return launch_dense<21, 8, 0, 2>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);      // slices of more than 2 048 groups: the inference kernel
         }
-        if (G <= m->tiny_g && (m->variant & 128))
+        // fc5 (21 k fragments): one wave per (group, slab of 4 output fragments), no barriers, weights straight from L2 --
+        // up to a slice of 2 048 groups (dense_tm<11, 4> with its 4-group workgroups took 25 us at 625 groups)
+        if (G <= CV_FC4_SLAB_MAX_G && (m->variant & 128))
             return launch_dense_small<4, 7>(in_tm, s.nb4, m->wps3_fc5, P + o[9], a.fc5, out_tm, G, 3, st, s.nb5);
         return launch_dense<11, 4>(in_tm, s.nb4, m->wp_fc5, P + o[9], a.fc5, out_tm, G, st);
     }
@@ -3596,7 +3599,9 @@ int cv_tile_fc5_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, 
 {
     const cv_shapes &s = m->sh;
     const int G = (int)((n + 15) / 16);
-    if (is_full(m->arch)) return launch_dense<21, 8, 1>(g_tm, s.nb5, m->wpd_fc5, nullptr, 0, gin_tm, G, st);
+    // full: three slabs of 7 output fragments -- as one workgroup per 8 groups with all 21 the kernel took 32 us at ANY
+    // batch (2 waves x 11 k steps x 84 MFMAs per SIMD on 10 .. 79 CUs); the values do not depend on the slab width
+    if (is_full(m->arch)) return launch_dense<7, 8, 1>(g_tm, s.nb5, m->wpd_fc5, nullptr, 0, gin_tm, G, st, 3);
     return launch_dense<3, 4, 1>(g_tm, s.nb5, m->wpd_fc5, nullptr, 0, gin_tm, G, st);
 }
 
