@@ -112,8 +112,11 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
         if (e == hipSuccess) e = hipMalloc(p, sizeof(float) * nfloat);
         if (e == hipSuccess) e = hipMemset(*p, 0, sizeof(float) * nfloat);
     };
-    alloc(&m->params, np); alloc(&m->grads_own, np + CV_GRAD_HEADER); alloc(&m->adam_m, np); alloc(&m->adam_v, np);
-    if (m->grads_own) m->grads = m->grads_own + CV_GRAD_HEADER;
+    // the 8 doubles of the current pass's losses live right behind the model's own gradient array: the step zeroes both
+    // with ONE memset (a launch less at the head of every step)
+    const int64_t np4 = (np + 3) / 4 * 4;
+    alloc(&m->params, np); alloc(&m->grads_own, np4 + CV_GRAD_HEADER + 16); alloc(&m->adam_m, np); alloc(&m->adam_v, np);
+    if (m->grads_own) { m->grads = m->grads_own + CV_GRAD_HEADER; m->loss_dev = reinterpret_cast<double *>(m->grads + np4); }
     m->train_overlap = 1;
     m->train_sides = 3;
     m->train_ksplit = 1;
@@ -133,7 +136,6 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     alloc(&m->wp_heads0, (size_t)s.nb4 * 256);
     alloc(&m->wp_heads1, (size_t)s.nb5 * 256);
     m->variant = 1519;
-    if (e == hipSuccess) e = hipMalloc(&m->loss_dev, sizeof(double) * 8);
     if (e == hipSuccess) e = hipMalloc(&m->loss_acc, sizeof(double) * 8);
     if (e == hipSuccess) e = hipMemset(m->loss_acc, 0, sizeof(double) * 8);
     if (e != hipSuccess) {
@@ -156,7 +158,6 @@ extern "C" int cv_destroy(cv_model *m)
     for (float *b : bufs)
         if (b) hipFree(b);
     if (m->tail_dev) hipFree(m->tail_dev);
-    if (m->loss_dev) hipFree(m->loss_dev);
     if (m->loss_acc) hipFree(m->loss_acc);
     if (m->tr_side) {
         (void)hipStreamSynchronize(m->tr_side);

@@ -90,7 +90,7 @@ struct cv_model {
     int64_t tr_cap;
     float *t_buf;        // one slab, carved by the training code
     size_t t_bytes;
-    double *loss_dev;    // 8 doubles: losses of the current pass
+    double *loss_dev;    // 8 doubles: losses of the current pass (inside the grads_own allocation, behind the gradients)
     double *loss_acc;    // 8 doubles: losses accumulated over steps (cv_loss_accumulate / cv_loss_read)
     float *grads_own;    // the library's own gradient bucket (CV_GRAD_HEADER + count floats); `grads` points
                          // CV_GRAD_HEADER floats into it, or into the caller's bucket (cv_bind_grad_bucket)

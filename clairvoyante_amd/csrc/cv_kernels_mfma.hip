@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(256) void heads_tm(const f4 *__restrict__ h4, const
     f4 a0 = zero, a1 = zero;
     const f4 *p4 = h4 + (size_t)g * NB4 * 64 + lane;
     const f4 *p5 = h5 + (size_t)g * NB5 * 64 + lane;
-#pragma unroll 3
+#pragma unroll 7                           // (two loads per k fragment, 14 in flight: the 21-step chain is latency, not work)
     for (int kb = 0; kb < NB4; kb++) {
         const f4 B = p4[(size_t)kb * 64];
         const f4 A = wp0[(size_t)kb * 64 + lane];
@@ -2235,7 +2235,7 @@ __global__ __launch_bounds__(256) void heads_train_tm(const f4 *__restrict__ d4,
 {
     __shared__ float sh[4][16][17];
     __shared__ double part[4];
-    __shared__ float shw[NB5 * 16][12];            // fc5-side head weights of a unit side by side: zygosity 2 | type 4 | length 6
+    __shared__ __attribute__((aligned(16))) float shw[NB5 * 16][12];   // fc5-side head weights of a unit side by side: zygosity 2 | type 4 | length 6
     if (g5pre_tm && want_grad) {
         for (int i = threadIdx.x; i < NB5 * 16 * 12; i += 256) {
             const int k = i / 12, jj = i % 12;
@@ -2330,7 +2330,9 @@ __global__ __launch_bounds__(256) void heads_train_tm(const f4 *__restrict__ d4,
             const int k = 16 * kb + 4 * s + q;
             float acc = 0.0f;
             if (cand_ok && k < K5) {                 // (weights from LDS: staged at the top, published by the barriers above)
-                const float *wk = shw[k];
+                const f4 *wk4 = reinterpret_cast<const f4 *>(shw[k]);      // three 16-byte reads instead of twelve words
+                const f4 w0 = wk4[0], w1 = wk4[1], w2 = wk4[2];
+                const float wk[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
 #pragma unroll
                 for (int jj = 0; jj < 12; jj++) acc = __builtin_fmaf(gi[4 + jj], wk[jj], acc);
             }

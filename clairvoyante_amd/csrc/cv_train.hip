@@ -886,8 +886,14 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
     // all-plain path runs everything, the L2 term included, in stream order
     const bool tile_path = m->impl == 1 && cv_tile_supported(m);
     hipStream_t sw = (backward && m->train_overlap && tile_path) ? m->tr_side : st;
-    CV_HIP(hipMemsetAsync(m->loss_dev, 0, sizeof(double) * 8, st));
-    if (backward) CV_HIP(hipMemsetAsync(m->grads, 0, sizeof(float) * m->poff[CV_NUM_PARAMS], st));
+    if (backward && m->grads == m->grads_own + CV_GRAD_HEADER) {
+        // gradients and the loss sums behind them (cv_create) in one memset
+        const size_t bytes = (size_t)(reinterpret_cast<char *>(m->loss_dev + 8) - reinterpret_cast<char *>(m->grads));
+        CV_HIP(hipMemsetAsync(m->grads, 0, bytes, st));
+    } else {
+        CV_HIP(hipMemsetAsync(m->loss_dev, 0, sizeof(double) * 8, st));
+        if (backward) CV_HIP(hipMemsetAsync(m->grads, 0, sizeof(float) * m->poff[CV_NUM_PARAMS], st));      // (a caller's bucket)
+    }
     // lambda * sum(w^2)/2 depends on the weights alone: with a side stream it runs there, next to the forward pass
     // (the slices join the side stream before they return), instead of at the tail of the step
     bool l2_done = false;
