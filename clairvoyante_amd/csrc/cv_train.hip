@@ -663,13 +663,15 @@ static int train_slice_plain(cv_model *m, const float *x, const float *y, int64_
 // fraction of the chip) one side stream made them a second critical path as long as the data-gradient chain.
 struct tr_fork {
     cv_model *m; hipStream_t st; hipStream_t side[CV_TR_SIDES]; int nside; int k; bool used[CV_TR_SIDES];
+    bool tail_only;        // large batches: the second side stream takes the launch sites from tail_first on (see train_slice_tile)
+    int tail_first;
     hipEvent_t next_event() { return m->tr_ev[k++ % (CV_TR_EVENTS - 1)]; }
     // side stream of launch site `site` (0 heads, 1 fc5, 2 fc4, 3 conv3, 4 conv2, 5 conv1), made to wait for
     // everything enqueued on st so far; st itself when the step runs in stream order
     int to_side(int site, hipStream_t *out)
     {
         if (nside == 0) { *out = st; return 0; }
-        const int i = site % nside;
+        const int i = tail_only ? (site >= tail_first && nside > 1 ? 1 : 0) : site % nside;
         hipEvent_t e = next_event();
         CV_HIP(hipEventRecord(e, st));
         CV_HIP(hipStreamWaitEvent(side[i], e, 0));
@@ -741,13 +743,19 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     for (int l = 0; l < 3; l++) { tgpre[l] = sb.take(np * fa[l]); tgin[l] = sb.take(np * fp[l]); }
     if (!tgin[2]) { cv_set_error("training workspace too small"); return 1; }
     tr_fork f;
-    f.m = m; f.st = st; f.k = 0; f.nside = 0;
+    f.m = m; f.st = st; f.k = 0; f.nside = 0; f.tail_only = Gn > m->tiny_g; f.tail_first = m->wpr_fc4 ? 4 : 3;
     for (int i = 0; i < CV_TR_SIDES; i++) { f.side[i] = nullptr; f.used[i] = false; }
     if (sw != st) {
         f.side[f.nside++] = sw;
-        // more than one side stream only for tiny batches: at train.py's 625 groups every kernel fills the chip and three
-        // concurrent weight-gradient kernels just take CUs from the data-gradient chain (2.25 -> 2.34 ms, profiles/r03)
-        for (int i = 0; i < 2 && f.nside < m->train_sides && Gn <= m->tiny_g; i++) f.side[f.nside++] = m->tr_side_more[i];
+        // Three side streams, launch sites round robin, only for tiny batches: at train.py's 625 groups every kernel fills
+        // the chip and three concurrent weight-gradient kernels just take CUs from the data-gradient chain (2.25 -> 2.34 ms,
+        // profiles/r03).  A large batch gets ONE more stream for the last layers: behind conv3's weight gradient on the
+        // single side stream conv2 and conv1 started 280 us after their inputs were ready and ran on past the end of the
+        // data-gradient chain (the last 100 us of the step had two small kernels on the chip).  Full topology: conv2 and
+        // conv1 (with conv3 as well 2.13 -> 2.17 ms: its kernel fills the chip next to fc4's); slim: conv3, conv2, conv1
+        // (1.233 / 1.176 / 1.167 ms with one stream / two layers / three layers on the second; profiles/r03).
+        const int want = Gn <= m->tiny_g ? m->train_sides : (m->train_sides >= 2 ? 2 : 1);
+        for (int i = 0; i < 2 && f.nside < want; i++) f.side[f.nside++] = m->tr_side_more[i];
         f.used[0] = true;                    // sw already carries the L2 term / the weight packing of this step
     }
     hipStream_t sx = st;
