@@ -3574,7 +3574,8 @@ int cv_tile_fc4_dgrad_unpool(cv_model *m, const float *g_tm, const float *pooled
     } else {
         // few groups: row parts (gridDim.z; each recomputes the two windows in front of its rows) would shorten the
         // 24-row walk of a workgroup -- measured at 79 groups: 0.672 / 0.690 / 0.688 / 0.719 ms per step with 1 / 2 / 3 / 4
-        // parts, so one; dbg6 = parts for A/B
+        // parts, so one; dbg6 = parts for A/B.  (4-wave workgroups -- 240 instead of 120 CUs busy at 79 groups -- change
+        // nothing either, 0.620 against 0.615 ms: the weight gradients on the side streams use the other CUs meanwhile)
         int parts = m->dbg[6] > 0 ? m->dbg[6] : 1;
         if (parts > 6) parts = 6;
         auto k = dense_dgrad_unpool<21, 3, 8, 1>;
