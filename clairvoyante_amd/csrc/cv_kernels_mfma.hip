@@ -3550,7 +3550,23 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
             return launch_dense_small<4, 7>(in_tm, s.nb4, m->wps3_fc5, P + o[9], a.fc5, out_tm, G, 3, st, s.nb5);
         return launch_dense<11, 4>(in_tm, s.nb4, m->wp_fc5, P + o[9], a.fc5, out_tm, G, st);
     }
-    if (layer == 4) return launch_dense<3, 4>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);
+    if (layer == 4) {
+        // slim fc4 is 396 dependent k steps of 12 MFMAs on 4-wave workgroups, one barrier each: 133 us at 625 groups for
+        // 40 us of matrix work, the longest kernel of the slim step.  With the k-split scratch (training passes, option
+        // train_ksplit) eight k ranges run side by side at ANY batch and dense_ksum adds them in order (+ bias, SELU and the
+        // alpha-dropout): a fixed order, within the gradient tolerance of the single chain, never used by cv_forward.
+        if (part) {
+            cv_dropout_args dr = cv_dropout_args();
+            if (drop && drop_done) {
+                dr.d4 = drop->d4; dr.amask = drop->amask; dr.nunits = a.fc4; dr.rate = drop->rate; dr.seed = drop->seed;
+                dr.step = drop->step; dr.cand0 = drop->cand0;
+                *drop_done = true;
+            }
+            return launch_dense<3, 4>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st, 1, CV_DENSE_KSPLIT, part,
+                                      heads_args(), dr);
+        }
+        return launch_dense<3, 4>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);
+    }
     return launch_dense<2, 4>(in_tm, s.nb4, m->wp_fc5, P + o[9], a.fc5, out_tm, G, st);
 }
 
