@@ -68,6 +68,8 @@ _SIGS = {
                                      ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "cv_apply_adam": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_int64,
                                      ctypes.c_void_p]),
+    "cv_apply_adam_accumulate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_int64,
+                                     ctypes.c_void_p]),
     "cv_flat_copy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                     ctypes.c_void_p]),
     "cv_adam_buffers": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),

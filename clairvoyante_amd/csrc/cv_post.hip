@@ -57,10 +57,19 @@ struct offs_t { int64_t o[CV_NUM_PARAMS + 1]; };
 
 // TF1 AdamOptimizer update (/root/reference/clairvoyante/clairvoyante_v3.py:174) on
 // g + lambda*w for kernels (the l2 term of v3.py:150), g for biases.
+// acc != NULL (cv_apply_adam_accumulate): the first threads also add the loss header in front of the gradients to the
+// accumulator -- cv_loss_accumulate's arithmetic (cv_train.hip t_loss_accumulate) without its launch
 __global__ void adam_kernel(float *__restrict__ w, float *__restrict__ mm, float *__restrict__ vv,
-                            const float *__restrict__ g, offs_t offs, float lr_t, float lambda)
+                            const float *__restrict__ g, offs_t offs, float lr_t, float lambda, double *__restrict__ acc)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (acc && i < 7) {
+        const float *hdr = g - CV_GRAD_HEADER;
+        const int t = (int)i;
+        if (t < 4) acc[t] += (double)hdr[2 * t] + (double)hdr[2 * t + 1];
+        else if (t == 4) acc[4] += ((double)hdr[8] + (double)hdr[9]) / (double)(hdr[10] > 0.5f ? hdr[10] : 1.0f);
+        else if (t == 6) acc[6] += 1.0;
+    }
     if (i >= offs.o[CV_NUM_PARAMS]) return;
     int p = 0;
     while (i >= offs.o[p + 1]) p++;
@@ -185,7 +194,7 @@ extern "C" int cv_flat_copy(cv_model *m, int which, float *caller_dev, int to_mo
     return 0;
 }
 
-extern "C" int cv_apply_adam(cv_model *m, float lr, float lambda, int64_t t, void *stream)
+static int apply_adam(cv_model *m, float lr, float lambda, int64_t t, void *stream, bool accumulate)
 {
     if (!m) { cv_set_error("null model"); return 1; }
     if (t < 1) { cv_set_error("cv_apply_adam: step count t must be >= 1"); return 1; }
@@ -195,8 +204,19 @@ extern "C" int cv_apply_adam(cv_model *m, float lr, float lambda, int64_t t, voi
     double lr_t = (double)lr * sqrt(1.0 - pow(0.999, (double)t)) / (1.0 - pow(0.9, (double)t));
     int64_t n = m->poff[CV_NUM_PARAMS];
     adam_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(m->params, m->adam_m, m->adam_v,
-                                                                             m->grads, offs, (float)lr_t, lambda);
+                                                                             m->grads, offs, (float)lr_t, lambda,
+                                                                             accumulate ? m->loss_acc : nullptr);
     CV_HIP(hipGetLastError());
     m->packed_dirty = true; m->packed_train_dirty = true;
     return 0;
+}
+
+extern "C" int cv_apply_adam(cv_model *m, float lr, float lambda, int64_t t, void *stream)
+{
+    return apply_adam(m, lr, lambda, t, stream, false);
+}
+
+extern "C" int cv_apply_adam_accumulate(cv_model *m, float lr, float lambda, int64_t t, void *stream)
+{
+    return apply_adam(m, lr, lambda, t, stream, true);
 }

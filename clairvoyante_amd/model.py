@@ -277,10 +277,9 @@ class Clairvoyante(object):
                                            ctypes.c_void_p(comm.cuda_stream) if comm is not None else None))
         parallel.exchange_bucket(self, comm)
         self._adam_t += 1
-        _lib.check(self._lib.cv_apply_adam(self._h, ctypes.c_float(self.learningRateVal),
-                                           ctypes.c_float(self.l2RegularizationLambdaVal),
-                                           self._adam_t, self._stream()))
-        _lib.check(self._lib.cv_loss_accumulate(self._h, self._stream()))
+        _lib.check(self._lib.cv_apply_adam_accumulate(self._h, ctypes.c_float(self.learningRateVal),
+                                                      ctypes.c_float(self.l2RegularizationLambdaVal),
+                                                      self._adam_t, self._stream()))      # Adam + losses to the accumulator
         self._keep = (x, y)          # the step is still running: the batch stays referenced until the next one
 
     def _read_acc(self):

@@ -203,6 +203,9 @@ int cv_loss_read(cv_model *m, double losses_host[6], int64_t *steps, int reset, 
 /* TF1 Adam (beta1 .9, beta2 .999, eps 1e-8, lr_t = lr*sqrt(1-b2^t)/(1-b1^t)) on
  * grad + lambda*w for non-bias variables (l2 term of v3.py:150); t = 1,2,...     */
 int cv_apply_adam(cv_model *m, float lr, float lambda, int64_t t, void *stream);
+/* cv_apply_adam followed by cv_loss_accumulate in ONE launch (the step of train.run_epoch: a launch less at the tail
+ * of every step); same arithmetic as the two calls.                                                            */
+int cv_apply_adam_accumulate(cv_model *m, float lr, float lambda, int64_t t, void *stream);
 /* optimizer slots m / v (checkpoint variables "<name>/Adam", "<name>/Adam_1")   */
 int cv_adam_buffers(cv_model *m, float **m_dev, float **v_dev, int64_t *count);
 /* device-to-device copy between a caller buffer (e.g. a torch tensor handed to
