@@ -114,7 +114,7 @@ struct cv_model {
     //   dbg0 = n: position parts of the convolution data gradients      dbg1 = n: ... of the training-forward convolutions
     //        (n = 9: the batch-dependent number of parts instead of flat row ranges; n = 7: flat ranges for a small batch too;
     //         dbg1 = 8: conv2 forward on flat ranges too)
-    //   dbg2 = 1 / 2: unpool always thread-per-row / always streaming   dbg3 = 1: fc4 data gradient and conv3 unpool as two kernels
+    //   dbg2 = 1 / 2: unpool always thread-per-row / always streaming, 3: fc4's alpha-dropout as its own pass   dbg3 = 1: fc4 data gradient and conv3 unpool as two kernels
     //   dbg4 = 2: conv data gradients fused with the unpool below (conv_dgrad_unpool), 3: slim selu' as its own pass
     //   dbg5 = 1: all weight packing in one launch in stream order      dbg6 = n: row parts of dense_dgrad_unpool (few groups)
     //   dbg7 = 1: training-forward conv3 on conv_tm instead of conv3_rot

@@ -1300,6 +1300,10 @@ struct heads_args {
     // EPI 3: the kernel reads all of the above from this DEVICE copy on its tail, so that the two dozen scalars stay out
     // of the main loop's register budget (by value they are loaded at kernel entry and live across the whole kernel)
     const heads_args *tail = nullptr;
+    // EPI 0, three-slab form (fc4 of a training pass): the alpha-dropout of the value follows in the same thread
+    // (dropout_tm's arithmetic, one launch and one round trip of the map less -- the step time does not move, 2.107 against
+    // 2.108 ms at 10 000: the 12 us pass ran next to the weight packing on the side stream); d4 == NULL: none
+    cv_dropout_args drop = cv_dropout_args();
 };
 
 // ---------------------------------------------------------------------------
@@ -1792,7 +1796,23 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
         for (int ob = 0; ob < NB; ob++) {
             if constexpr (EPI == 0) {
                 const f4 b4 = load_bias4(bias, (int)blockIdx.y * NB + ob, q, nout);
-                op[ob * 64] = selu4(acc[r][ob] + b4);
+                const f4 h = selu4(acc[r][ob] + b4);
+                op[ob * 64] = h;
+                if constexpr (NB == 7 && GR == 1) {
+                    if (hd.drop.d4) {
+                        f4 d, mk;
+#pragma unroll
+                        for (int s = 0; s < 4; s++) {
+                            float x = h[s], k;
+                            dropout_value(x, k, 16 * ((int)blockIdx.y * NB + ob) + 4 * s + q, hd.drop.nunits,
+                                          hd.drop.cand0 + (int64_t)(g + r) * 16 + (lane & 15), hd.drop.rate, hd.drop.seed, hd.drop.step);
+                            d[s] = x; mk[s] = k;
+                        }
+                        const size_t t = (size_t)(op - out_tm) + ob * 64;
+                        reinterpret_cast<f4 *>(hd.drop.d4)[t] = d;
+                        reinterpret_cast<f4 *>(hd.drop.amask)[t] = mk;
+                    }
+                }
             } else {
                 f4 v = acc[r][ob];
                 if (hd.dact) {               // data gradient times selu' of the layer below (a layer without pooling)
@@ -3541,7 +3561,15 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
                 return launch_dense_small<3, 8>(in_tm, s.kb4, m->wps7_fc4, P + o[7], a.fc4, out_tm, G, 7, st);
             // (measured at train.py's batch of 10 000, no gain: two k ranges of the 3-slab form; 3 / 4 / 6 / 8 k ranges of the
             // two-groups-per-wave, all-21-tiles form -- 2.47 / 2.36 / 2.25 / 2.39 ms per step against 2.25)
-            if (G <= CV_FC4_SLAB_MAX_G) return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3);
+            if (G <= CV_FC4_SLAB_MAX_G) {
+                heads_args hd = heads_args();
+                if (drop && drop_done && m->dbg[2] != 3) {      // the alpha-dropout rides on the kernel's store (dbg2 = 3: dropout_tm)
+                    hd.drop.d4 = drop->d4; hd.drop.amask = drop->amask; hd.drop.nunits = a.fc4; hd.drop.rate = drop->rate;
+                    hd.drop.seed = drop->seed; hd.drop.step = drop->step; hd.drop.cand0 = drop->cand0;
+                    *drop_done = true;
+                }
+                return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3, 1, nullptr, hd);
+            }
             return launch_dense<21, 8, 0, 2>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);      // slices of more than 2 048 groups: the inference kernel
         }
         // fc5 (21 k fragments): one wave per (group, slab of 4 output fragments), no barriers, weights straight from L2 --

@@ -203,6 +203,7 @@ def test_backward_kernel_variants_give_the_same_bits(oracle, arch, n):
     kernel, kept as a variant) or as two kernels, one or three side streams for the weight gradients, weight packing on
     the side stream or in stream order (dbg5); slim: the selu' factor of a layer without pooling on the data-gradient
     kernel's store or as its own pass (dbg4 = 3); the convolution kernels over position parts of whole groups (dbg0 = dbg1 = 9)
+    fc4's alpha-dropout on the store of its forward kernel or as its own pass (dbg2 = 3);
     or over equal ranges of the flat (group, row) sequence (dbg0 = dbg1 = 7: also at small batches, where the parts are the
     default): the same arithmetic in the same order -- same losses, weights, gradients"""
     import torch
@@ -222,7 +223,7 @@ def test_backward_kernel_variants_give_the_same_bits(oracle, arch, n):
         return out
     ref = run({})
     variants = ({"dbg3": 1}, {"dbg4": 2}, {"dbg4": 2, "dbg0": 3}, {"train_side_streams": 1}, {"dbg5": 1}, {"dbg6": 3}, {"dbg7": 1},
-                {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7}, {"dbg1": 8}, {"dbg3": 1, "dbg4": 2, "train_overlap": 0}) if arch == "full" else \
+                {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7}, {"dbg1": 8}, {"dbg2": 3}, {"dbg3": 1, "dbg4": 2, "train_overlap": 0}) if arch == "full" else \
                ({"dbg4": 3}, {"train_side_streams": 1}, {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7},
                 {"dbg5": 1, "dbg4": 3, "train_overlap": 0})
     for opts in variants:
