@@ -1265,7 +1265,6 @@ __global__ __launch_bounds__(256) void heads_tm(const f4 *__restrict__ h4, const
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= G) return;
-    const int c = lane & 15, q = lane >> 4;
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
     f4 a0 = zero, a1 = zero;
     const f4 *p4 = h4 + (size_t)g * NB4 * 64 + lane;
@@ -1859,8 +1858,7 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_unpool(const f4 *__restrict
     const int pa = HP * hs / HSPLIT, pb = HP * (hs + 1) / HSPLIT;          // output rows [pa, pb)
     const int lo = pa - (P - 1) > 0 ? pa - (P - 1) : 0;                    // windows (rows of gIn) [lo, hi]
     const int hi = pb - 1 < HIN - 1 ? pb - 1 : HIN - 1;
-    const int hr0 = lo - PADT > 0 ? lo - PADT : 0;                         // input rows [hr0, hr1]
-    const int hr1 = hi - PADT + KH - 1 < HIN - 1 ? hi - PADT + KH - 1 : HIN - 1;
+    const int hr0 = lo - PADT > 0 ? lo - PADT : 0;                         // first input row
     const f4 *inp = g_tm + (size_t)g * (HIN * 4 * CINB * 64) + lane;
     const f4 *wl = ldsw + (size_t)nt * (KH * 4 * CINB * 64) + lane;
     const f4 *pp = pooled + (size_t)g * (HIN * 4 * NT * 64) + (size_t)nt * 64 + lane;
@@ -3498,10 +3496,10 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
     const int64_t *o = m->poff;
     const int G = (int)((n + 15) / 16);
     int rc = 0;
-    // the positions of a (group, tile) are split over as many waves as fills the chip best for this batch
-    // (pick_hsplit; config 4's per-rank batch of 1 250 is 79 groups -> 4 parts, train.py's 625 groups -> conv2 in 3);
-    // same values row for row.  Option train_tiny_groups = 0 keeps one wave per (group, tile).
-    const bool split = m->tiny_g > 0;
+    // small batches: the positions of a (group, tile) are split over as many waves as fills the chip best (pick_hsplit;
+    // config 4's per-rank batch of 1 250 is 79 groups -> 4 parts); beyond train_tiny_groups: equal ranges of the flat
+    // (group, row) sequence (conv_parts); same values row for row.  Option train_tiny_groups = 0 keeps one wave per
+    // (group, tile).
     if (is_full(a) && m->dbg[1] > 0 && m->dbg[1] < 7) {          // development: forced number of position parts
         conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (u32x2 *)a1);
         rc |= launch_conv_parts<2, 1, 2, 4, 29, 1>(m->dbg[1], p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
@@ -3659,7 +3657,6 @@ int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm,
     const cv_arch &a = m->arch;
     const int G = (int)((n + 15) / 16);
     const float *W = m->wpd_conv[layer];
-    const bool split = m->tiny_g > 0;      // see cv_tile_train_convs
     if (is_full(a) && m->dbg[0] > 0 && m->dbg[0] < 7) {          // development: forced number of position parts
         if (layer == 2) return launch_conv_parts<3, 3, 2, 1, 26, 2>(m->dbg[0], g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
         return launch_conv_parts<2, 2, 1, 1, 29, 2>(m->dbg[0], g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);

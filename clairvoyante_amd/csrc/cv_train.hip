@@ -241,45 +241,6 @@ __global__ void b_dense_dgrad(const float *__restrict__ g, int ldg, const float 
 
 __device__ __forceinline__ float selu_grad_from_out(float y) { return cv_selu_grad_from_out(y); }
 
-// g_pre = g_act * selu'(.) from the activation (optionally * amask for the dropout layer)
-__global__ void b_selu_act(const float *__restrict__ gact, const float *__restrict__ act,
-                           const float *__restrict__ amask, float *__restrict__ gpre, int64_t total)
-{
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    float g = gact[t];
-    if (amask) g *= amask[t];
-    gpre[t] = g * selu_grad_from_out(act[t]);
-}
-
-// max-pool backward on the saved SELU outputs (monotone in the pre-activation, so the first
-// maximum is the same element) fused with selu'
-__global__ void b_pool_selu_act(const float *__restrict__ gpool, const float *__restrict__ act,
-                                float *__restrict__ gpre, int64_t n, int H, int c, int p)
-{
-    int Ho = H - p + 1, row = 4 * c;
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * H * row) return;
-    int e = (int)(t % row);
-    int64_t r = t / row;
-    int h = (int)(r % H);
-    int64_t i = r / H;
-    const float *b = act + (size_t)i * H * row + e;
-    float me = b[(size_t)h * row];
-    float acc = 0.0f;
-    for (int ho = h - p + 1; ho <= h; ho++) {
-        if (ho < 0 || ho >= Ho) continue;
-        bool win = true;
-        for (int d = 0; d < p; d++) {
-            float v = b[(size_t)(ho + d) * row];
-            int hh = ho + d;
-            if (hh < h ? v >= me : v > me) { win = false; break; }
-        }
-        if (win) acc += gpool[((size_t)i * Ho + ho) * row + e];
-    }
-    gpre[t] = acc * selu_grad_from_out(me);
-}
-
 // g_pre = g_act * selu'(pre) (optionally * amask for the dropout layer)
 __global__ void b_selu(const float *__restrict__ gact, const float *__restrict__ pre,
                        const float *__restrict__ amask, float *__restrict__ gpre, int64_t total)
@@ -387,18 +348,6 @@ __global__ void b_conv_dgrad(const float *__restrict__ gpre, const float *__rest
         }
     }
     gin[t] = acc;
-}
-
-// db[c] += sum over rows of g[rows][C] (natural layout); blockIdx.y slices the rows
-__global__ void b_bias_grad(const float *__restrict__ g, int64_t rows, int C, float *__restrict__ db)
-{
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    int64_t per = (rows + gridDim.y - 1) / gridDim.y;
-    int64_t r0 = per * blockIdx.y, r1 = r0 + per < rows ? r0 + per : rows;
-    float acc = 0.0f;
-    for (int64_t r = r0; r < r1; r++) acc += g[(size_t)r * C + c];
-    atomicAdd(&db[c], acc);
 }
 
 // ---- element-wise backward steps directly on tile-major buffers ----------------------------
