@@ -131,9 +131,11 @@ int cv_selu_sweep(int device, uint32_t lo_bits, uint32_t hi_bits, uint64_t *viol
  * serial loops of their layers over more waves -- same bits), "train_ksplit" (0/1, default 1: at such batches
  * the fc4 forward of the TRAINING pass adds eight partial sums over k ranges instead of one ascending-k chain; fixed
  * order, reproducible run to run, within the gradient tolerance of the single chain, 4 % faster at 1 250 candidates;
- * never used by cv_forward) and "train_side_streams" (1..3, default 3: at such batches the weight gradients of
- * different layers -- independent of each other -- run on up to that many side streams; same bits),
- * "dbg0".."dbg7" (development A/B switches of the training step, 0 = shipped path; see cv_train.hip),
+ * the slim topology's fc4 -- 396 dependent k steps -- does so at every batch; never used by cv_forward) and
+ * "train_side_streams" (1..3, default 3: at such batches the weight gradients of different layers -- independent of
+ * each other -- run on up to that many side streams; larger batches use two when the value is >= 2, the second one
+ * for the last layers only; same bits),
+ * "dbg0".."dbg7" (development A/B switches of the training step, 0 = shipped path; see cv_internal.hpp),
  * "variant" (bit 0: first layer fused into the conv2 kernel, bit 1: MFMA heads kernel,
  * bit 2: 8-wave fc4 workgroups, bit 3: rotating-window conv3 kernel, bit 5: fc4 with two groups of
  * 16 candidates per wave, bit 6: fused conv1+conv2 kernel whose two waves per group share the first layer through
