@@ -91,9 +91,68 @@ def relaunch_under_torchrun(args, argv):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+_RCCL_LOG = [None]
+
+
+def rccl_logging():
+    """Before the process group exists: have RCCL write its INFO log (init, topology graph, per-collective algorithm /
+    protocol choice) to a file per process, so that rank 0 can say ONCE in the line what the exchange ran on.  Nothing is
+    touched when the user set NCCL_DEBUG, the backend is not RCCL, or there is one rank."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if (ws <= 1 and not os.environ.get("CV_FORCE_DIST")) or "NCCL_DEBUG" in os.environ:
+        return
+    if (os.environ.get("CV_DIST_BACKEND") or "nccl") != "nccl":
+        return
+    import tempfile
+    tmpl = os.path.join(tempfile.gettempdir(), "cv_rccl_%s_%%p.log" % os.environ.get("MASTER_PORT", "0"))
+    os.environ["NCCL_DEBUG"] = "INFO"
+    os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,TUNING"
+    os.environ["NCCL_DEBUG_FILE"] = tmpl
+    _RCCL_LOG[0] = tmpl.replace("%p", str(os.getpid()))
+
+
+def rccl_summary(max_lines=8):
+    """-> dict from this process's RCCL INFO log (None if there is none): library version, channel counts, transports
+    between peers, and the distinct (collective, bytes, algorithm, protocol) choices it logged."""
+    import re
+    fn = _RCCL_LOG[0]
+    if not fn or not os.path.exists(fn):
+        return None
+    try:
+        text = open(fn, errors="replace").read()
+    except OSError:
+        return None
+    out = {"log_bytes": len(text)}
+    mo = re.search(r"(RCCL|NCCL) version[ :]*([^\n]+)", text)
+    if mo:
+        out["version"] = mo.group(0).strip()[:120]
+    mo = re.search(r"(\d+) coll channels[^\n]*", text)
+    if mo:
+        out["channels"] = mo.group(0).strip()[:160]
+    tr = {}
+    for mo in re.finditer(r" via ([A-Za-z0-9_/ ]+?)(?:\n|$|\s+comm)", text):
+        k = mo.group(1).strip()
+        tr[k] = tr.get(k, 0) + 1
+    if tr:
+        out["transports"] = tr
+    seen, choices = set(), []
+    for ln in text.splitlines():
+        low = ln.lower()
+        if "algo" in low and "proto" in low:
+            body = re.sub(r"^.*?(NCCL|RCCL) INFO ", "", ln)
+            key = re.sub(r"time [-0-9.e+]+", "", body)
+            if key not in seen:
+                seen.add(key); choices.append(body.strip()[:200])
+    if choices:
+        out["algo_proto"] = choices[:max_lines]
+        out["algo_proto_distinct"] = len(choices)
+    return out
+
+
 def init_ranks(args):
     """-> (rank, world size, local rank).  A line whose n_gpus is not --gpus is never printed: mismatch = exit 2."""
     from clairvoyante_amd import parallel
+    rccl_logging()
     rank, ws, local = parallel.init_from_env()
     if os.environ.get("CV_SHARE_DEVICES"):       # functional test on a box with fewer GPUs than ranks (backend gloo): ranks share devices
         import torch
@@ -111,7 +170,10 @@ def rank_info(ws):
     """what actually ran: number of ranks of the process group and its backend ("nccl" = RCCL on ROCm)"""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        return {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
+        info = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
+        if dist.get_backend() == "nccl":
+            info["rccl_log"] = rccl_summary()
+        return info
     return {"rccl_ranks": ws, "backend": None}
 
 
@@ -288,6 +350,7 @@ def run_train(arch, gb, steps, warmup, rank, ws, dev, sync_loss=False, options=N
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    exchange = exchange_timing(m, step, x, y, steps, dt / steps * 1e3, dev) if use_dist else None
     m.close()
     # whole step against the matrix-core roof: forward + data gradients + weight gradients = 3 x the forward
     # FLOPs per candidate; the step is a chain of ~40 kernels, no single one dominates
@@ -296,8 +359,86 @@ def run_train(arch, gb, steps, warmup, rank, ws, dev, sync_loss=False, options=N
     roof = {"bound": "mfma", "kernel": "whole step (forward, data gradients, weight gradients, Adam)",
             "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
             "traffic": traffic, "traffic_source": note}
-    return {"value": steps * gb / dt, "unit": "candidates/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "global_batch": gb, "per_rank_batch": hi - lo, "roofline": roof, "final_loss": float(loss)}
+    res = {"value": steps * gb / dt, "unit": "candidates/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "global_batch": gb, "per_rank_batch": hi - lo, "roofline": roof, "final_loss": float(loss)}
+    if exchange:
+        res.update(exchange)
+    return res
+
+
+def exchange_timing(m, step, x, y, steps, step_ms, dev):
+    """What the gradient exchange costs and how much of it the backward pass hides, measured AFTER the timed region on
+    the same model (N > 1 only):
+      exchange_ms          the two in-place bucket all-reduces of one step alone (parallel.exchange_bucket: the dense
+                           95 % on the communication stream, the rest in stream order), 20 iterations, no compute;
+      compute_ms_per_step  the same optimizer steps with the exchange suspended (every rank applies its own shard's
+                           gradient -- measurement only, the replicas diverge, the model is closed afterwards);
+      exchange_hidden_frac 1 - (ms_per_step - compute_ms_per_step) / exchange_ms, clipped to [0, 1].
+    Each is barrier + synchronize bracketed and the MAX over ranks."""
+    import torch
+    import torch.distributed as dist
+    from clairvoyante_amd import parallel
+
+    def timed(fn, k):
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize(); dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / k * 1e3
+
+    comm = parallel.comm_stream(m)
+    m._bucket.zero_()                      # sums of zeros: the bucket cannot overflow over the iterations
+    timed(lambda: parallel.exchange_bucket(m, comm), 3)
+    ex_ms = timed(lambda: parallel.exchange_bucket(m, comm), 20)
+    with parallel.exchange_suspended():
+        timed(lambda: step(x, y), 2)
+        comp_ms = timed(lambda: step(x, y), steps)
+    m.readLosses()
+    hidden = 1.0 - (step_ms - comp_ms) / ex_ms if ex_ms > 0 else None
+    return {"exchange_ms": ex_ms, "compute_ms_per_step": comp_ms,
+            "exchange_hidden_frac": None if hidden is None else max(0.0, min(1.0, hidden)),
+            "exchange_bytes": int(m._bucket.numel()) * 4}
+
+
+def train_parity(arch, gb, dev):
+    """The benchmarked training batch against the CPU oracle (checker only, outside every timed region; N = 1): one
+    optimizer step of a fresh model on the batch the timed leg runs (same generator seed, same initial weights, default
+    options, dropout 0.5), the keep mask the device drew handed to oracle/cv_oracle.c -- the five loss parts and all 18
+    gradients.  The full set of sizes lives in tests/test_gpu_train_parity.py."""
+    import numpy as np
+    import torch
+    from oracle import cv_oracle as O
+    from clairvoyante_amd import clairvoyante_v3, clairvoyante_v3_slim, synth, _lib
+    t0 = time.perf_counter()
+    m = clairvoyante_v3.Clairvoyante() if arch == "full" else clairvoyante_v3_slim.Clairvoyante()
+    m._seed_rng.seed(1234)
+    m.init()
+    P = m.getParameters()
+    xt, cls, rf, alt, il = synth.make_candidates(gb, seed=synth.BASE_SEED, device=dev, return_class=True)
+    y = synth.make_labels(cls, rf, alt, il)
+    lam, rate = m.l2RegularizationLambdaVal, m.dropoutRateFC4Val
+    loss, summ = m.train(xt, y)
+    keep = (m.getActivation(6, gb) != 0).to(torch.float32).cpu().numpy()
+    g = torch.empty(m.numParameters, device=dev)
+    _lib.check(m._lib.cv_flat_copy(m._h, 1, ctypes.c_void_p(g.data_ptr()), 0, None))
+    torch.cuda.synchronize()
+    g = g.cpu().numpy()
+    m.close()
+    l_or, parts, g_or = O.loss_grad(arch, P, xt.cpu().numpy(), y.cpu().numpy(), lam=lam, mask4=keep, rate4=rate)
+    rel = [abs(summ[k] - ref) / max(1.0, abs(ref)) for k, ref in zip(("loss1", "loss2", "loss3", "loss4", "lossL2"), parts)]
+    worst, off = 0.0, 0
+    for name in O.PARAM_NAMES:
+        gref = g_or[name] - (lam * P[name] if "bias" not in name else 0)
+        sz = gref.size
+        worst = max(worst, float(np.abs(g[off:off + sz].reshape(gref.shape) - gref).max() / (np.abs(gref).max() + 1e-30)))
+        off += sz
+    return {"n": gb, "arch": arch, "dropout": rate, "lambda": lam, "loss": float(loss), "loss_oracle": l_or,
+            "loss_rel_err": abs(float(loss) - l_or) / abs(l_or), "loss_parts_max_rel_err": max(rel),
+            "grad_max_err_rel_to_max": worst, "keep_fraction": float(keep.mean()),
+            "checker": "oracle/cv_oracle.c cvo_loss_grad under the device's keep mask", "seconds": time.perf_counter() - t0}
 
 
 def train_traffic(arch, per_rank):
@@ -341,6 +482,9 @@ def train_main(args):
                            "dbg": args.dbg + (" sides=%d" % args.sides if args.sides is not None else "") +
                                   (" ksplit=%d" % args.ksplit if args.ksplit is not None else "")},
                 "roofline": r["roofline"], "final_loss": r["final_loss"]}
+        for k in ("exchange_ms", "compute_ms_per_step", "exchange_hidden_frac", "exchange_bytes"):
+            if k in r:
+                line[k] = r[k]
         line.update(rank_info(ws))
         print(json.dumps(line), flush=True)
     finish_ranks()
@@ -351,11 +495,9 @@ def run_infer(arch, batch, steps, warmup, rank, ws, dev, variant=None, batches=N
     MAX over ranks.  -> (result dict, model, parameters, batches); the caller closes the model."""
     import torch
     import torch.distributed as dist
-    import common
-    from oracle import cv_oracle as O          # seeded weights only (common.bench_params); nothing is computed with it here
     from clairvoyante_amd import clairvoyante_v3, clairvoyante_v3_slim, synth, _lib
     m = clairvoyante_v3.Clairvoyante() if arch == "full" else clairvoyante_v3_slim.Clairvoyante()
-    P = common.bench_params(O, arch)          # identical seeded weights on every rank
+    P = synth.bench_params(arch)          # identical seeded weights on every rank (nothing from oracle/ in the timed function)
     m.setParameters(P)
     if variant is not None:
         m.setOption("variant", variant)
@@ -542,6 +684,11 @@ def main():
         tr["slim_%d" % gb] = run_train("slim", gb, 20, 3, rank, ws, dev)
         line["train"] = tr
         line["extras_seconds"] = time.perf_counter() - t_extra
+        if rank == 0 and ws == 1 and not args.no_cpu:
+            try:
+                tr["parity"] = train_parity("full", gb, dev)
+            except Exception as e:      # the checker must not take the line down
+                tr["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         if not args.no_cpu and ws == 1:          # the CPU leg (and the parity block it feeds) runs at N = 1 only

@@ -7,7 +7,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CV_HIP_LIB: another build of the SAME library (development: two builds timed on one GPU box, tools/gpu_lib_ab.sh)
-LIB_PATH = os.environ.get("CV_HIP_LIB") or os.path.join(_HERE, "csrc", "libclairvoyante_hip.so")
+_DEFAULT_LIB = os.path.join(_HERE, "csrc", "libclairvoyante_hip.so")
+LIB_PATH = os.environ.get("CV_HIP_LIB") or _DEFAULT_LIB
 
 NUM_PARAMS = 18
 NUM_OUT = 16
@@ -152,6 +153,10 @@ def load():
     # and its runtime mapped -- before this library, whose libamdhip64 dependency then
     # resolves to the copy already loaded.
     import torch  # noqa: F401
+    if os.path.abspath(LIB_PATH) != os.path.abspath(_DEFAULT_LIB):
+        import logging
+        logging.warning("clairvoyante_amd: CV_HIP_LIB overrides the HIP library: loading %s instead of %s",
+                        LIB_PATH, _DEFAULT_LIB)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)      # AttributeError = a declared entry point is not exported

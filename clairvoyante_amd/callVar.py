@@ -219,7 +219,11 @@ def format_records(args, num, X, pos, call, qual, xrow=None):
             continue
         meta = np.ascontiguousarray(meta, dtype=np.int64)
         cap = kept * (int(meta[:n, 1].max()) + 160)
-        cbuf = buf if isinstance(buf, bytes) else bytes(buf)
+        if isinstance(buf, np.ndarray):              # a view of the memory-mapped input: its address, no copy
+            hold = buf if buf.flags.c_contiguous else np.ascontiguousarray(buf)
+            cbuf = ctypes.c_void_p(hold.ctypes.data)
+        else:
+            cbuf = buf if isinstance(buf, bytes) else bytes(buf)
         xptr = X.ctypes.data + (0 if xrow is not None else start * row_bytes)
         xr = ctypes.c_void_p(xrow.ctypes.data + start * 8) if xrow is not None else None
         for _try in range(2):
@@ -363,6 +367,15 @@ def Run(args):
         Test(args, m, utils)
 
 
+def tensor_files(tensor_fn):
+    """--tensor_fn as a list: "a.gz,b.gz,c.gz" names one tensor file per chunk of the genome, called in list order (one
+    process) or file k by rank k % N (torchrun).  A name that exists as given is ONE file even if it holds a comma; PIPE
+    stays PIPE.  (A list whose every item holds a comma of its own cannot be expressed: rename the files.)"""
+    if tensor_fn == "PIPE" or "," not in tensor_fn or os.path.exists(tensor_fn):
+        return [tensor_fn]
+    return [f for f in tensor_fn.split(",") if f]
+
+
 # input lines per block of the multi-rank split (block k -> rank k % N); CV_SHARD_BLOCK_LINES overrides (tests)
 SHARD_BLOCK_LINES = int(os.environ.get("CV_SHARD_BLOCK_LINES", "16384"))
 
@@ -417,12 +430,12 @@ def TestSharded(args, m, utils, rank, ws):
     # "--tensor_fn a.gz,b.gz,...": one file per chunk, file k -> rank k % ws (each rank inflates only its own files);
     # a single file: its LINES are split block-cyclically (every rank inflates the whole stream -- the job is then
     # capped by one core's gzip rate whatever the number of GPUs)
-    files = [f for f in args.tensor_fn.split(",") if f]
+    files = tensor_files(args.tensor_fn)
 
     def reader():
         try:
             src = utils.GetTensorFiles(files, max(param.predictBatchSize, 16384), rank, ws) if len(files) > 1 else \
-                utils.GetTensorBlocks(args.tensor_fn, SHARD_BLOCK_LINES, rank, ws)
+                utils.GetTensorBlocks(files[0], SHARD_BLOCK_LINES, rank, ws)
             for item in src:
                 q_in.put(item)
         except BaseException as e:
@@ -507,13 +520,18 @@ def Test(args, m, utils):
     PrintVCFHeader(args, call_fh)
     logging.info("Calling variants ...")
     predictStart = time.time()
-    batch = getattr(args, "batch_size", None) or max(param.predictBatchSize, 16384)
-    q_in = Queue(maxsize=4)
+    files = tensor_files(args.tensor_fn)
+    # plain text is parsed where the page cache holds it at millions of rows/s: batches of 65 536 (the pass size of
+    # the network); a compressed stream arrives at one core's inflate rate: smaller batches keep the stages overlapped
+    mapped = utils._map_plain_text(files[0]) is not None if hasattr(utils, "_map_plain_text") else False
+    batch = getattr(args, "batch_size", None) or (65536 if mapped else max(param.predictBatchSize, 16384))
+    q_in = Queue(maxsize=2 if mapped else 4)
 
     def reader():
         try:
-            for item in utils.GetTensor(args.tensor_fn, batch):
-                q_in.put(item)
+            for fn in files:                     # a list of files is called in list order (one VCF, like TestSharded)
+                for item in utils.GetTensor(fn, batch):
+                    q_in.put(item)
         except BaseException as e:   # surfaced on the consumer side (the reference loses it)
             q_in.put(e)
         q_in.put(None)

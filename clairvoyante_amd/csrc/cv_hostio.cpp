@@ -72,6 +72,40 @@ inline bool parse_number(const char *&p, const char *end, float &out)
     return true;
 }
 
+// The 528 numbers of a row in the producer's own format (CreateTensor.py:24,56: "%0.1f" tokens, one blank between
+// them): [-]digits[.digit] each followed by ' ' or the line's '\n' (the newline is the sentinel -- no bounds checks).
+// Returns false at the first token that is anything else (the caller then re-parses the row with parse_number, which
+// takes every format strtod does); true with q at the newline when exactly nv_want numbers fill the line.  The value
+// is formed exactly as parse_number forms it: (double)integer + digit / 10.0, rounded to float once.
+inline bool parse_row_fast(const char *q, const char *nl, float *xr, int nv_want)
+{
+    static const double tenth[10] = {0.0 / 10.0, 1.0 / 10.0, 2.0 / 10.0, 3.0 / 10.0, 4.0 / 10.0,
+                                     5.0 / 10.0, 6.0 / 10.0, 7.0 / 10.0, 8.0 / 10.0, 9.0 / 10.0};
+    for (int nv = 0; nv < nv_want; nv++) {
+        if (*q != ' ') return false;
+        q++;
+        const bool neg = *q == '-';
+        q += neg;
+        unsigned d = (unsigned)(*q - '0');
+        if (d > 9) return false;
+        uint32_t ip = d;
+        const char *s = q + 1;
+        while ((d = (unsigned)(*s - '0')) <= 9) { ip = ip * 10 + d; s++; }
+        if (s - q > 9) return false;                      // would not fit 32 bits: the general path
+        double v = (double)ip;
+        if (*s == '.') {
+            const unsigned f = (unsigned)(s[1] - '0');
+            if (f > 9) return false;
+            v += tenth[f];
+            s += 2;
+        }
+        if (*s != ' ' && *s != '\n') return false;
+        xr[nv] = (float)(neg ? -v : v);
+        q = s;
+    }
+    return q == nl;
+}
+
 }  // namespace
 
 // Parses the complete lines of [p, end): for every accepted row (centre base of the upper-cased refSeq in ACGT,
@@ -101,6 +135,7 @@ static const char *parse_lines(const char *buf, const char *p, const char *end, 
         float *xr = x_out + (size_t)rows * NV;
         bool ok = nt == 3;
         int nv = 0;
+        if (ok && parse_row_fast(q, nl, xr, NV)) { nv = NV; q = nl; }
         while (ok) {
             while (q < nl && is_space(*q)) q++;
             if (q >= nl) break;
@@ -221,11 +256,38 @@ extern "C" int cv_set_host_threads(int n)
     return 0;
 }
 
-// Parses complete lines from buf[0..len): see parse_lines.  Stops after max_rows rows or at the last complete
+namespace {
+inline int64_t count_newlines(const char *p, const char *e)
+{
+    int64_t n = 0;
+    while (p < e) {
+        const char *q = (const char *)memchr(p, '\n', (size_t)(e - p));
+        if (!q) break;
+        n++; p = q + 1;
+    }
+    return n;
+}
+// the byte after the k-th newline of [p, e) (k >= 1), or nullptr when there are fewer
+inline const char *after_kth_newline(const char *p, const char *e, int64_t k)
+{
+    while (p < e) {
+        const char *q = (const char *)memchr(p, '\n', (size_t)(e - p));
+        if (!q) return nullptr;
+        p = q + 1;
+        if (--k == 0) return p;
+    }
+    return nullptr;
+}
+}  // namespace
+
+// Parses complete lines from buf[0..len): see parse_lines.  Stops after max_rows LINES or at the last complete
 // line.  *consumed = bytes eaten (whole lines only), *nrows = accepted rows, *nbad = malformed rows.
-// With cv_set_host_threads(T > 1) the first max_rows lines are cut into T slices parsed concurrently, each into
-// the row range its line count reserves; ranges are closed up afterwards if a slice dropped rows.  The result is
-// the single-threaded one.
+// With cv_set_host_threads(T > 1) nothing walks the text serially: the threads count the newlines of equal byte
+// slices of a window sized from the first line (so a caller may hand over a whole memory-mapped file), the end of the
+// max_rows-th line follows from the counts, the lines up to it are cut into T byte slices moved to line starts, every
+// slice is parsed into the row range its line count reserves, and the ranges are closed up if a slice dropped rows.
+// When the window holds fewer than max_rows lines the call returns what it holds (the caller asks again).  The rows
+// are the single-threaded ones.
 extern "C" int cv_parse_tensor_text(const char *buf, int64_t len, int64_t max_rows, float *x_out,
                                     int64_t *meta_out, int64_t *consumed, int64_t *nrows, int64_t *nbad)
 {
@@ -234,35 +296,61 @@ extern "C" int cv_parse_tensor_text(const char *buf, int64_t len, int64_t max_ro
     const char *end = buf + len;
     int T = g_host_threads;
     if (T > 1 && (len < (1 << 20) || max_rows < 4 * T)) T = 1;
+    const char *nl0 = T > 1 ? (const char *)memchr(buf, '\n', (size_t)len) : nullptr;
+    if (T > 1 && !nl0) T = 1;
+    const char *lim = nullptr;          // end of the last line taken
+    int64_t lines = 0;
+    if (T > 1) {
+        // window: 1.25 x (first line + its newline) x max_rows, whole buffer if that is shorter
+        const int64_t first = nl0 - buf + 1;
+        int64_t W = len;
+        if (max_rows < len / first) { W = first * max_rows; W += W / 4 + 4096; if (W > len) W = len; }
+        const char *wend = buf + W;
+        std::vector<int64_t> cnt((size_t)T, 0);
+        auto piece = [&](int t) { return buf + (int64_t)((__int128)W * t / T); };
+        host_pool().run(T, T, [&](int64_t t) { cnt[(size_t)t] = count_newlines(piece((int)t), piece((int)t + 1)); });
+        int64_t total = 0;
+        for (int t = 0; t < T; t++) total += cnt[(size_t)t];
+        if (total >= max_rows) {
+            int64_t before = 0; int t = 0;
+            while (before + cnt[(size_t)t] < max_rows) before += cnt[(size_t)t++];
+            lim = after_kth_newline(piece(t), piece(t + 1), max_rows - before);
+            lines = max_rows;
+        } else if (total > 0) {
+            const char *q = wend;
+            while (q > buf && q[-1] != '\n') q--;             // (at most one line back)
+            lim = q; lines = total;
+        } else {
+            lim = buf;
+        }
+        (void)wend;
+        if (lines < 4 * T) T = 1;
+    }
     if (T == 1) {
         int64_t r = 0, bd = 0;
-        const char *p = parse_lines(buf, buf, end, max_rows, x_out, meta_out, &r, &bd);
+        const char *stop = lim ? lim : end;
+        const char *p = parse_lines(buf, buf, stop, max_rows, x_out, meta_out, &r, &bd);
         *consumed = p - buf; *nrows = r;
         if (nbad) *nbad = bd;
         return 0;
     }
-    // the byte range of the first max_rows lines, cut into T slices of equal line counts
-    std::vector<const char *> cut;
-    std::vector<int64_t> first_line;
-    {
-        std::vector<const char *> starts;
-        starts.reserve((size_t)(max_rows < (1 << 20) ? max_rows + 1 : (1 << 20)));
-        const char *p = buf;
-        int64_t lines = 0;
-        while (lines < max_rows) {
-            const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
-            if (!nl) break;
-            starts.push_back(p);
-            p = nl + 1;
-            lines++;
-        }
-        starts.push_back(p);                                  // end of the last whole line taken
-        if (lines < 4 * T) T = 1;
-        for (int t = 0; t <= T; t++) { first_line.push_back(lines * t / T); cut.push_back(starts[(size_t)(lines * t / T)]); }
+    // [buf, lim) = `lines` whole lines: T byte slices, each moved forward to the next line start
+    std::vector<const char *> cut((size_t)T + 1);
+    const int64_t span = lim - buf;
+    cut[0] = buf; cut[(size_t)T] = lim;
+    for (int t = 1; t < T; t++) {
+        const char *c = buf + (int64_t)((__int128)span * t / T);
+        if (c < cut[(size_t)t - 1]) c = cut[(size_t)t - 1];
+        const char *q = c > buf ? (const char *)memchr(c - 1, '\n', (size_t)(lim - (c - 1))) : nullptr;
+        cut[(size_t)t] = c == buf ? buf : (q ? q + 1 : lim);
     }
+    std::vector<int64_t> nline((size_t)T, 0), first_line((size_t)T + 1, 0);
+    host_pool().run(T, T, [&](int64_t t) { nline[(size_t)t] = count_newlines(cut[(size_t)t], cut[(size_t)t + 1]); });
+    for (int t = 0; t < T; t++) first_line[(size_t)t + 1] = first_line[(size_t)t] + nline[(size_t)t];
+    if (first_line[(size_t)T] != lines) { cv_set_error("cv_parse_tensor_text: line count mismatch (internal)"); return 1; }
     std::vector<int64_t> got((size_t)T, 0), bads((size_t)T, 0);
     host_pool().run(T, T, [&](int64_t t) {
-        parse_lines(buf, cut[(size_t)t], cut[(size_t)t + 1], first_line[(size_t)t + 1] - first_line[(size_t)t],
+        parse_lines(buf, cut[(size_t)t], cut[(size_t)t + 1], nline[(size_t)t],
                     x_out + (size_t)first_line[(size_t)t] * NV, meta_out + first_line[(size_t)t] * 6, &got[(size_t)t],
                     &bads[(size_t)t]);
     });
@@ -275,7 +363,7 @@ extern "C" int cv_parse_tensor_text(const char *buf, int64_t len, int64_t max_ro
         rows += got[(size_t)t];
         bd += bads[(size_t)t];
     }
-    *consumed = cut[(size_t)T] - buf;
+    *consumed = lim - buf;
     *nrows = rows;
     if (nbad) *nbad = bd;
     return 0;

@@ -21,8 +21,25 @@ def world():
     return 0, 1
 
 
+_suspended = [False]
+
+
+class exchange_suspended(object):
+    """`with parallel.exchange_suspended():` -- steps inside run WITHOUT the gradient exchange (every rank applies its own
+    shard's gradient: the replicas diverge).  Measurement only: bench.py times the compute part of a data-parallel step
+    with it, to say how much of the exchange the backward pass hides."""
+
+    def __enter__(self):
+        _suspended[0] = True
+
+    def __exit__(self, *exc):
+        _suspended[0] = False
+
+
 def _active():
     """collectives run when there is more than one rank (or when forced, to test them at N=1)"""
+    if _suspended[0]:
+        return False
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or bool(os.environ.get("CV_FORCE_DIST")))
 
 

@@ -13,6 +13,7 @@ depth ~ clip(Poisson(40), 4, 250); class ~ {ref .70, het-SNP .12, hom-SNP .08,
 INS .05, DEL .05}.  Written with torch ops so the same code fills HBM directly
 on an MI355X (bench) or runs on CPU (tests, fixtures).
 """
+import numpy as np
 import torch
 
 H, W, C = 33, 4, 4
@@ -107,3 +108,61 @@ def make_labels(cls, ref, alt, ilen):
     ln = torch.where(indel, ilen.clamp(max=5), torch.zeros_like(ilen))
     y[idx, 10 + ln] = 1.0
     return y
+
+
+# ---- seeded weights (bench / smoke / parity workload) ---------------------------------------------------------
+_TOPOLOGY = {   # kh, cout, pool, fc4, fc5: clairvoyante_v3.py:9-12 / clairvoyante_v3_slim.py:9-11
+    "full": ((1, 2, 3), (16, 32, 48), (5, 4, 3), 336, 168),
+    "slim": ((1, 3, 5), (8, 16, 32), (1, 1, 1), 36, 18),
+}
+
+
+def param_shapes(arch):
+    """TF variable name -> shape in TF layout (HWIO kernels, [in, out] dense), in checkpoint order."""
+    kh, cout, pool, fc4, fc5 = _TOPOLOGY[arch]
+    cin = (C, cout[0], cout[1])
+    h = H - sum(p - 1 for p in pool)
+    shapes = {}
+    for l in range(3):
+        shapes["conv%d/kernel" % (l + 1)] = (kh[l], W, cin[l], cout[l])
+        shapes["conv%d/bias" % (l + 1)] = (cout[l],)
+    shapes.update({"fc4/kernel": (h * W * cout[2], fc4), "fc4/bias": (fc4,), "fc5/kernel": (fc4, fc5), "fc5/bias": (fc5,),
+                   "YBaseChangeSigmoid/kernel": (fc4, 4), "YBaseChangeSigmoid/bias": (4,),
+                   "YZygosityFC/kernel": (fc5, 2), "YZygosityFC/bias": (2,),
+                   "YVarTypeFC/kernel": (fc5, 4), "YVarTypeFC/bias": (4,),
+                   "YIndelLengthFC/kernel": (fc5, 6), "YIndelLengthFC/bias": (6,)})
+    return shapes
+
+
+def seeded_params(arch, seed=0, bias_scale=0.0):
+    """Weights drawn with the reference's initialisers from a seeded numpy stream: truncated normal with sigma
+    sqrt(1.3 * 2 / fan_in) cut at 2 sigma for conv / fc4 / fc5 (variance_scaling_initializer, clairvoyante_v3.py:57),
+    glorot-uniform heads (tf.layers.dense default, v3.py:125-135); biases zero, or N(0, bias_scale^2) so that the
+    bias path carries values."""
+    rng = np.random.RandomState(seed)
+    out = {}
+    for name, shp in param_shapes(arch).items():
+        if name.endswith("bias"):
+            out[name] = (bias_scale * rng.standard_normal(shp)).astype(np.float32)
+            continue
+        fan_in, fan_out = int(np.prod(shp[:-1])), shp[-1]
+        if name.startswith("Y"):
+            lim = np.sqrt(6.0 / (fan_in + fan_out))
+            out[name] = rng.uniform(-lim, lim, shp).astype(np.float32)
+            continue
+        v = rng.standard_normal(shp)
+        bad = np.abs(v) > 2.0
+        while bad.any():
+            v[bad] = rng.standard_normal(int(bad.sum()))
+            bad = np.abs(v) > 2.0
+        out[name] = (v * np.sqrt(1.3 * 2.0 / fan_in)).astype(np.float32)
+    return out
+
+
+def bench_params(arch, seed=1):
+    """The weight set of bench.py, smoke() and the parity tests: seeded_params with conv1 scaled by 1/32 so that
+    count-valued inputs give O(1) logits (un-scaled He-initialised weights saturate every softmax),
+    and non-zero biases."""
+    P = seeded_params(arch, seed=seed, bias_scale=0.05)
+    P["conv1/kernel"] = (P["conv1/kernel"] * np.float32(1.0 / 32.0)).astype(np.float32)
+    return P

@@ -177,10 +177,95 @@ def GetTensorFiles(files, num, rank, ws):
             yield k, c, X, pos
 
 
+def _map_plain_text(tensor_fn):
+    """-> read-only uint8 array over the memory-mapped file when `tensor_fn` is a regular, non-empty file that is NOT
+    gzip-compressed (the reference pipes everything through `gzip -fdc`, which passes plain text through unchanged,
+    utils_v2.py:25); None otherwise (PIPE, .gz, FIFOs: the stream path)."""
+    import mmap
+    import stat
+    if tensor_fn == "PIPE":
+        return None
+    try:
+        st = os.stat(tensor_fn)
+        if not stat.S_ISREG(st.st_mode) or st.st_size == 0:
+            return None
+        with open(tensor_fn, "rb") as fh:
+            if fh.read(2) == b"\x1f\x8b":
+                return None
+            mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+    except OSError:
+        return None
+    if hasattr(mm, "madvise") and hasattr(mmap, "MADV_SEQUENTIAL"):
+        mm.madvise(mmap.MADV_SEQUENTIAL)
+    return np.frombuffer(mm, dtype=np.uint8)
+
+
+def _get_tensor_mapped(data, num, log):
+    """GetTensor over a memory-mapped plain-text file: the parser threads read the lines where the page cache holds them
+    (no pipe, no copies; cv_parse_tensor_text sizes its own window), the position fields of a batch stay views of the map."""
+    lib = _lib.load()
+    n = int(data.shape[0])
+    base = data.ctypes.data
+    shape = (2 * param.flankingBaseNum + 1, 4, param.matrixNum)
+    consumed = ctypes.c_int64(); nrows = ctypes.c_int64(); nbad = ctypes.c_int64()
+    total, off = 0, 0
+    tail = None                      # a last line without newline: parsed from a copy that has one
+    if data[n - 1] != 10:
+        last_nl = n - 1
+        while last_nl >= 0 and data[last_nl] != 10:
+            last_nl -= 1
+        tail = bytes(data[last_nl + 1:]) + b"\n"
+        n = last_nl + 1
+    rows = _pinned.empty((num, _NV), np.float32)
+    meta = np.empty((num, 6), dtype=np.int64)
+    c, bufs = 0, []
+
+    def parse(ptr, length, view):
+        nonlocal c
+        _lib.check(lib.cv_parse_tensor_text(ctypes.c_void_p(ptr), length, num - c,
+                                            rows[c:].ctypes.data_as(ctypes.c_void_p), meta[c:].ctypes.data_as(ctypes.c_void_p),
+                                            ctypes.byref(consumed), ctypes.byref(nrows), ctypes.byref(nbad)))
+        if nbad.value:
+            print("UnpackATensorRecord Failure (%d malformed rows skipped)" % nbad.value, file=sys.stderr)
+        if nrows.value:
+            bufs.append((view(consumed.value), meta[c:c + nrows.value].copy()))
+        c += nrows.value
+        return consumed.value
+
+    while off < n or tail is not None:
+        if off < n:
+            o = off
+            used = parse(base + off, n - off, lambda k: data[o:o + k])
+            off += used
+            if used == 0:
+                off = n
+        else:
+            keep = np.frombuffer(tail, dtype=np.uint8)
+            parse(keep.ctypes.data, len(tail), lambda k: keep[:k])
+            tail = None
+        if c == num:
+            total += c
+            if log:
+                print("Processed %d tensors" % total, file=sys.stderr)
+            yield 0, c, rows.reshape((num,) + shape), _join_pos(bufs)
+            rows = _pinned.empty((num, _NV), np.float32)
+            meta = np.empty((num, 6), dtype=np.int64)
+            c, bufs = 0, []
+    total += c
+    if log:
+        print("Processed %d tensors" % total, file=sys.stderr)
+    yield 1, c, rows[:c].reshape((c,) + shape), _join_pos(bufs)
+
+
 def GetTensor(tensor_fn, num, log=True):
     """Generator over batches of `num` candidates: yields (endFlag, c, X, pos) exactly like
     utils_v2.py:23-59 -- X [c,33,4,4] fp32 with matrices 1..3 minus matrix 0, rows whose
     centre base is not ACGT dropped, a final (possibly empty) batch with endFlag 1."""
+    mapped = _map_plain_text(tensor_fn)
+    if mapped is not None:
+        for item in _get_tensor_mapped(mapped, num, log):
+            yield item
+        return
     lib = _lib.load()
     proc, fo = _open_tensor_stream(tensor_fn)
     total = 0
@@ -197,18 +282,18 @@ def GetTensor(tensor_fn, num, log=True):
             eof = True
             if pending and not pending.endswith(b"\n"):
                 pending += b"\n"
-        data = pending + chunk
+        data = pending + chunk if pending else chunk
+        arr = np.frombuffer(data, dtype=np.uint8)          # addresses into the bytes object: no slice copies
         off = 0
         while off < len(data):
-            view = data[off:]
-            _lib.check(lib.cv_parse_tensor_text(view, len(view), num - c,
+            _lib.check(lib.cv_parse_tensor_text(ctypes.c_void_p(arr.ctypes.data + off), len(data) - off, num - c,
                                                 rows[c:].ctypes.data_as(ctypes.c_void_p),
                                                 meta[c:].ctypes.data_as(ctypes.c_void_p),
                                                 ctypes.byref(consumed), ctypes.byref(nrows), ctypes.byref(nbad)))
             if nbad.value:
                 print("UnpackATensorRecord Failure (%d malformed rows skipped)" % nbad.value, file=sys.stderr)
             if nrows.value:
-                bufs.append((view, meta[c:c + nrows.value].copy()))
+                bufs.append((arr[off:off + consumed.value], meta[c:c + nrows.value].copy()))
             c += nrows.value
             off += consumed.value
             if c == num:
@@ -332,23 +417,34 @@ def _scan_block_list(mm, pos):
     import struct
     n = len(mm)
     index = []
-    while pos < n:
-        op = mm[pos]
-        if op == 0x80: pos += 2                                    # PROTO
-        elif op == 0x95: pos += 9                                  # FRAME
-        elif op in (0x5d, 0x28, 0x94, 0x65, 0x61): pos += 1        # EMPTY_LIST, MARK, MEMOIZE, APPENDS, APPEND
-        elif op == 0x71: pos += 2                                  # BINPUT
-        elif op == 0x72: pos += 5                                  # LONG_BINPUT
-        elif op in (0x43, 0x55):                                   # SHORT_BINBYTES, SHORT_BINSTRING
-            ln = mm[pos + 1]; index.append((pos + 2, ln)); pos += 2 + ln
-        elif op in (0x42, 0x54):                                   # BINBYTES, BINSTRING
-            ln = struct.unpack_from("<I", mm, pos + 1)[0]; index.append((pos + 5, ln)); pos += 5 + ln
-        elif op == 0x8e:                                           # BINBYTES8
-            ln = struct.unpack_from("<Q", mm, pos + 1)[0]; index.append((pos + 9, ln)); pos += 9 + ln
-        elif op == 0x2e:                                           # STOP
-            return index, pos + 1
-        else:
-            return None
+
+    def block(hdr, ln):
+        # a block that would run past the end of the file (truncated / corrupt .bin): no index, the caller un-pickles
+        # and reports the damage in pickle's own words
+        if pos + hdr + ln > n:
+            raise IndexError("block past the end of the file")
+        index.append((pos + hdr, ln))
+        return pos + hdr + ln
+    try:
+        while pos < n:
+            op = mm[pos]
+            if op == 0x80: pos += 2                                    # PROTO
+            elif op == 0x95: pos += 9                                  # FRAME
+            elif op in (0x5d, 0x28, 0x94, 0x65, 0x61): pos += 1        # EMPTY_LIST, MARK, MEMOIZE, APPENDS, APPEND
+            elif op == 0x71: pos += 2                                  # BINPUT
+            elif op == 0x72: pos += 5                                  # LONG_BINPUT
+            elif op in (0x43, 0x55):                                   # SHORT_BINBYTES, SHORT_BINSTRING
+                pos = block(2, mm[pos + 1])
+            elif op in (0x42, 0x54):                                   # BINBYTES, BINSTRING
+                pos = block(5, struct.unpack_from("<I", mm, pos + 1)[0])
+            elif op == 0x8e:                                           # BINBYTES8
+                pos = block(9, struct.unpack_from("<Q", mm, pos + 1)[0])
+            elif op == 0x2e:                                           # STOP
+                return index, pos + 1
+            else:
+                return None
+    except (IndexError, struct.error):
+        return None
     return None
 
 

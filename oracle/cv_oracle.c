@@ -462,17 +462,33 @@ double cvo_loss_grad(const cvo_arch *a, const float *const *P, const float *x, c
     int64_t psz[CVO_NPARAM]; cvo_param_sizes(a, psz);
     static const int hn[4] = {4, 2, 4, 6};
     static const int ho[4] = {0, 4, 6, 10};
-    double lsum[4] = {0, 0, 0, 0};
-    double *gacc[CVO_NPARAM];
-    for (int p = 0; p < CVO_NPARAM; p++) gacc[p] = grads ? (double *)calloc(psz[p], sizeof(double)) : NULL;
-
     const float ap = -1.7580993408473766f;
     float q = 1.0f - rate4;
     float aa = mask4 ? sqrtf(1.0f / (q * ((1.0f - q) * (ap * ap) + 1.0f))) : 1.0f;
 
+    /* Candidates are independent: every thread walks ONE contiguous range of the batch with its own double
+     * accumulators (losses and all 18 gradients); the ranges are added in thread order afterwards, so a result
+     * depends on the thread count only in the last bits of a double (far below the float it is rounded to).   */
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+    if ((int64_t)nthreads > n) nthreads = n > 0 ? (int)n : 1;
+#endif
+    double (*lsum_t)[4] = (double (*)[4])calloc(nthreads, sizeof(double[4]));
+    double **gacc_t = (double **)calloc((size_t)nthreads * CVO_NPARAM, sizeof(double *));
+#pragma omp parallel num_threads(nthreads)
+    {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    double *lsum = lsum_t[tid];
+    double **gacc = gacc_t + (size_t)tid * CVO_NPARAM;
+    for (int p = 0; p < CVO_NPARAM; p++) gacc[p] = grads ? (double *)calloc(psz[p], sizeof(double)) : NULL;
     float *rec = (float *)malloc(sizeof(float) * L.total);
     float *g = (float *)calloc(L.total, sizeof(float));   /* gradient record, same layout */
-    for (int64_t i = 0; i < n; i++) {
+    const int64_t i_lo = n * tid / nthreads, i_hi = n * (tid + 1) / nthreads;
+    for (int64_t i = i_lo; i < i_hi; i++) {
         const float *xi = x + (size_t)i * CVO_H * CVO_W * CVO_CIN;
         const float *yi = y + (size_t)i * CVO_NOUT;
         const float *mi = mask4 ? mask4 + (size_t)i * a->fc4 : NULL;
@@ -596,6 +612,22 @@ double cvo_loss_grad(const cvo_arch *a, const float *const *P, const float *x, c
         }
     }
     free(rec); free(g);
+    }   /* omp parallel */
+    double lsum[4] = {0, 0, 0, 0};
+    double **gacc = gacc_t;                      /* thread 0's buffers receive the sum, threads ascending */
+    for (int t = 0; t < nthreads; t++)
+        for (int k = 0; k < 4; k++) lsum[k] += lsum_t[t][k];
+    if (grads)
+        for (int p = 0; p < CVO_NPARAM; p++) {
+            double *dst = gacc[p];
+#pragma omp parallel for schedule(static)
+            for (int64_t k = 0; k < psz[p]; k++) {
+                double v = dst[k];
+                for (int t = 1; t < nthreads; t++) v += gacc_t[(size_t)t * CVO_NPARAM + p][k];
+                dst[k] = v;
+            }
+            for (int t = 1; t < nthreads; t++) free(gacc_t[(size_t)t * CVO_NPARAM + p]);
+        }
     /* L2 (v3.py:150): lambda * sum over non-bias variables of sum(w^2)/2 */
     double l2 = 0;
     for (int p = 0; p < CVO_NPARAM; p += 2) {
@@ -615,7 +647,9 @@ double cvo_loss_grad(const cvo_arch *a, const float *const *P, const float *x, c
         }
     }
     if (losses) { for (int k = 0; k < 4; k++) losses[k] = lsum[k]; losses[4] = l2; }
-    return lsum[0] + lsum[1] + lsum[2] + lsum[3] + l2;
+    double total = lsum[0] + lsum[1] + lsum[2] + lsum[3] + l2;
+    free(lsum_t); free(gacc_t);
+    return total;
 }
 
 /* TF1 AdamOptimizer step (beta1 .9, beta2 .999, eps 1e-8, "epsilon hat" form):

@@ -162,8 +162,7 @@ def test_side_stream_weight_gradients_give_the_same_bits(oracle, arch, n):
     assert np.isfinite(a[1]).all()
 
 
-@pytest.mark.parametrize("arch,n", [("full", 1250), ("slim", 1250), ("full", 83), ("full", 2560), ("full", 10000),
-                                    ("slim", 10000), ("full", 20000)])
+@pytest.mark.parametrize("arch,n", [("full", 1250), ("slim", 1250), ("full", 83), ("full", 2560), ("slim", 2560), ("full", 17)])
 def test_tiny_batch_kernel_variants_give_the_same_bits(oracle, arch, n):
     """batches of few groups (a rank's share of train.py's batch) split the serial loops of the training step over
     more waves: position ranges in the convolutions (pooled layers recompute the window overlap), one thread per
@@ -172,6 +171,9 @@ def test_tiny_batch_kernel_variants_give_the_same_bits(oracle, arch, n):
     pre-activations are eight partial sums added in order and the step stays within rounding of it"""
     import torch
     from clairvoyante_amd import synth
+    # only sizes where the switch changes the path: above 160 groups both settings run the regular kernels (those sizes
+    # are compared with the oracle in tests/test_gpu_train_parity.py)
+    assert (n + 15) // 16 <= 160
     xt, cls, rf, alt, il = synth.make_candidates(n, seed=43, device="cuda", return_class=True)
     y = synth.make_labels(cls, rf, alt, il)
     P = common.bench_params(oracle, arch)
@@ -308,15 +310,19 @@ def _spawn(fn, args, nprocs=2):
     mp.spawn(fn, args=(nprocs, port) + tuple(args), nprocs=nprocs, join=True)
 
 
-@pytest.mark.parametrize("arch,n", [("full", 10000), ("slim", 4001)])
-def test_two_rank_data_parallel_step_equals_the_single_process_step(oracle, arch, n, tmp_path):
+@pytest.mark.parametrize("arch,n,ws", [("full", 10000, 2), ("slim", 4001, 2), ("full", 10000, 8), ("slim", 4001, 3)])
+def test_data_parallel_step_equals_the_single_process_step(oracle, arch, n, ws, tmp_path):
+    """("full", 10000, 8) is BASELINE config 4 as it runs: train.py's batch of 10 000 split over 8 ranks = 1 250
+    candidates (79 groups, ragged) per rank, here as 8 processes on the one GPU (backend gloo)"""
     steps = 3
-    _spawn(_dp_worker, (str(tmp_path), arch, n, steps, 0.0))
-    r0 = np.load(str(tmp_path / "rank0.npz")); r1 = np.load(str(tmp_path / "rank1.npz"))
+    _spawn(_dp_worker, (str(tmp_path), arch, n, steps, 0.0), nprocs=ws)
+    r0 = np.load(str(tmp_path / "rank0.npz"))
     # identical replicas: every rank applied the same update to the same weights
-    for k in ("w", "am", "av", "g"):
-        assert np.array_equal(r0[k].view(np.uint32), r1[k].view(np.uint32)), k
-    assert np.array_equal(r0["losses"], r1["losses"])
+    for r in range(1, ws):
+        r1 = np.load(str(tmp_path / ("rank%d.npz" % r)))
+        for k in ("w", "am", "av", "g"):
+            assert np.array_equal(r0[k].view(np.uint32), r1[k].view(np.uint32)), (k, r)
+        assert np.array_equal(r0["losses"], r1["losses"])
     # one process on the whole batch
     m = _model(arch); m.setParameters(common.bench_params(oracle, arch, seed=1))
     m.dropoutRateFC4Val = 0.0; m.setLearningRate(1e-3); m.setL2RegularizationLambda(0.01)
@@ -351,16 +357,19 @@ def test_two_rank_data_parallel_step_equals_the_single_process_step(oracle, arch
     m.close()
 
 
-def test_two_rank_step_with_an_empty_shard(oracle, tmp_path):
-    """a global batch smaller than the rank count leaves a rank without candidates: it still takes part in the
+@pytest.mark.parametrize("ws,n", [(2, 1), (8, 3)])
+def test_step_with_empty_shards(oracle, tmp_path, ws, n):
+    """a global batch smaller than the rank count leaves ranks without candidates: they still take part in the
     exchange (zero gradient, zero losses) and every rank applies the same update"""
-    _spawn(_dp_worker, (str(tmp_path), "slim", 1, 2, 0.0))
-    r0 = np.load(str(tmp_path / "rank0.npz")); r1 = np.load(str(tmp_path / "rank1.npz"))
-    for k in ("w", "am", "av", "g"):
-        assert np.array_equal(r0[k].view(np.uint32), r1[k].view(np.uint32)), k
+    _spawn(_dp_worker, (str(tmp_path), "slim", n, 2, 0.0), nprocs=ws)
+    r0 = np.load(str(tmp_path / "rank0.npz"))
+    for r in range(1, ws):
+        r1 = np.load(str(tmp_path / ("rank%d.npz" % r)))
+        for k in ("w", "am", "av", "g"):
+            assert np.array_equal(r0[k].view(np.uint32), r1[k].view(np.uint32)), (k, r)
     m = _model("slim"); m.setParameters(common.bench_params(oracle, "slim", seed=1))
     m.dropoutRateFC4Val = 0.0; m.setLearningRate(1e-3); m.setL2RegularizationLambda(0.01)
-    x, y = _data(1, seed=60)
+    x, y = _data(n, seed=60)
     loss, summ = m.train(x, y)
     assert abs(r0["losses"][0][5] - summ["loss"]) <= 1e-6 * abs(summ["loss"])
     assert np.abs(r0["g1"] - _flat(m, 1)).max() <= 1e-6 * np.abs(r0["g1"]).max()
@@ -423,8 +432,9 @@ def _epoch_worker(rank, ws, port, tmp, binfn, n):
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_epoch_equals_the_single_process_epoch(oracle, tmp_path, monkeypatch):
-    """train.run_epoch under two ranks: every rank walks the same schedule on its slice of each batch; training sums
+@pytest.mark.parametrize("ws", [2, 8])
+def test_data_parallel_epoch_equals_the_single_process_epoch(oracle, tmp_path, monkeypatch, ws):
+    """train.run_epoch under two / eight ranks: every rank walks the same schedule on its slice of each batch; training sums
     come out of the exchanged loss header, validation sums through parallel.allreduce_scalar (train.py:113-123)"""
     from clairvoyante_amd import param, train, utils_v2
     n = 26000
@@ -435,9 +445,11 @@ def test_two_rank_epoch_equals_the_single_process_epoch(oracle, tmp_path, monkey
     binfn = str(tmp_path / "dp.bin")
     with open(binfn, "wb") as fh:
         pickle.dump(n, fh); pickle.dump(XC, fh); pickle.dump(YC, fh); pickle.dump([], fh)
-    _spawn(_epoch_worker, (str(tmp_path), binfn, n))
-    e0 = np.load(str(tmp_path / "epoch0.npz")); e1 = np.load(str(tmp_path / "epoch1.npz"))
-    assert np.array_equal(e0["sums"], e1["sums"]) and np.array_equal(e0["w"].view(np.uint32), e1["w"].view(np.uint32))
+    _spawn(_epoch_worker, (str(tmp_path), binfn, n), nprocs=ws)
+    e0 = np.load(str(tmp_path / "epoch0.npz"))
+    for r in range(1, ws):
+        e1 = np.load(str(tmp_path / ("epoch%d.npz" % r)))
+        assert np.array_equal(e0["sums"], e1["sums"]) and np.array_equal(e0["w"].view(np.uint32), e1["w"].view(np.uint32))
     m = _model("slim"); m.setParameters(common.bench_params(oracle, "slim", seed=1))
     m.dropoutRateFC4Val = 0.0; m.setLearningRate(1e-3); m.setL2RegularizationLambda(1e-3)
     vstart = int(n * param.trainingDatasetPercentage) + 1
@@ -480,9 +492,12 @@ def test_callvar_command_line_under_two_ranks_writes_the_single_rank_vcf(oracle,
     assert not [f for f in os.listdir(str(tmp_path)) if ".rank" in f]
 
 
-def test_callvar_command_line_under_two_ranks_over_a_list_of_files(oracle, tmp_path):
-    """--tensor_fn a.gz,b.gz,c.gz under two ranks: file k belongs to rank k % 2 -- the form that scales (no rank inflates
-    input it does not call); the VCF equals the concatenation of the three single-process runs (bodies in list order)"""
+@pytest.mark.parametrize("ws,sizes", [(2, (1500, 20000, 700)), (8, (1500, 20000, 700, 90, 0, 2500, 33, 1200, 640, 17, 3100))])
+def test_callvar_command_line_under_several_ranks_over_a_list_of_files(oracle, tmp_path, ws, sizes):
+    """--tensor_fn a.gz,b.gz,c.gz,... under two / eight ranks: file k belongs to rank k % ws -- the form that scales (no
+    rank inflates input it does not call; the reference's own recipe is one job per chunk, README.md:184-202); the VCF
+    equals the concatenation of the single-process runs (bodies in list order).  Eight ranks over 11 files: ranks with one
+    and with two files, an empty file."""
     import subprocess
     import test_gpu_pipeline as tp
     P = common.bench_params(oracle, "full")
@@ -490,9 +505,9 @@ def test_callvar_command_line_under_two_ranks_over_a_list_of_files(oracle, tmp_p
     prefix = str(tmp_path / "model")
     m.saveParameters(prefix); m.close()
     files = []
-    for k, n in enumerate((1500, 20000, 700)):           # the second file spans two reader batches of 16 384 rows
+    for k, n in enumerate(sizes):           # the second file spans two reader batches of 16 384 rows
         fn = str(tmp_path / ("t%d.gz" % k))
-        tp._write_text_tensors(fn, common.inputs(n, seed=50 + k))
+        tp._write_text_tensors(fn, common.inputs(max(n, 1), seed=50 + k)[:n])
         files.append(fn)
     env = dict(os.environ, PYTHONPATH=ROOT)
     base = [sys.executable, "-m", "clairvoyante_amd.callVar", "--chkpnt_fn", prefix, "--sampleName", "NA12878"]
@@ -506,11 +521,11 @@ def test_callvar_command_line_under_two_ranks_over_a_list_of_files(oracle, tmp_p
     two = str(tmp_path / "two.vcf")
     port = 29300 + os.getpid() % 500
     procs = []
-    for r in range(2):
-        e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for r in range(ws):
+        e = dict(env, RANK=str(r), WORLD_SIZE=str(ws), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                  CV_DIST_BACKEND="gloo")
         procs.append(subprocess.Popen(base + ["--tensor_fn", ",".join(files), "--call_fn", two], env=e, cwd=ROOT))
-    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    assert [p.wait(timeout=600) for p in procs] == [0] * ws
     assert open(two).read() == "".join(header + bodies) and len(bodies) > 500
 
 
@@ -590,3 +605,28 @@ def test_bench_line_under_two_ranks_sharing_the_gpu(tmp_path):
     assert set(b["train"]) == {"10000", "10000_per_rank", "slim_10000"}
     assert b["train"]["10000"]["per_rank_batch"] == 5000 and b["train"]["10000_per_rank"]["per_rank_batch"] == 10000
     assert all(np.isfinite(v["final_loss"]) for v in b["train"].values())
+
+
+@pytest.mark.parametrize("mode", ["infer", "train"])
+def test_bench_line_under_eight_ranks_sharing_the_gpu(mode):
+    """the driver's 8-GPU command, functionally: `python bench.py --gpus 8` with eight real ranks on the one GPU (backend
+    gloo, CV_SHARE_DEVICES) -- one line, n_gpus = rccl_ranks = 8; in train mode the line separates the exchange from the
+    compute (exchange_ms, compute_ms_per_step, exchange_hidden_frac)"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CV_SHARE_DEVICES="1", CV_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+    extra = ["--mode", "train"] if mode == "train" else ["--no-extras"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu"] + extra,
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    b = lines[0]
+    assert b["n_gpus"] == 8 and b["rccl_ranks"] == 8 and b["backend"] == "gloo" and b["value"] > 1e5
+    if mode == "train":
+        assert b["config"]["global_batch"] == 10000 and b["scaling"] == "strong"
+        assert b["exchange_ms"] > 0 and b["compute_ms_per_step"] > 0 and 0.0 <= b["exchange_hidden_frac"] <= 1.0
+        assert b["exchange_bytes"] == 4 * (1631496 + 16) and np.isfinite(b["final_loss"])
+    else:
+        assert b["scaling"] == "weak" and b["config"]["batch"] == 65536

@@ -218,8 +218,9 @@ def test_training_reduces_the_loss_and_keeps_predictions_finite():
 
 @pytest.mark.gpu
 def test_loss_and_gradient_are_additive_over_the_batch_at_scale(oracle):
-    """size-independent property at a size the oracle cannot reach: the loss is a SUM over candidates (v3.py:140-151),
-    so loss and data gradients of 40 000 candidates (three internal slices) equal those of two halves added up"""
+    """size-independent property: the loss is a SUM over candidates (v3.py:140-151), so loss and data gradients of
+    40 000 candidates equal those of two halves added up.  (The comparison of steps of this size with the ORACLE is
+    tests/test_gpu_train_parity.py; this one only checks additivity, which any per-candidate error would pass.)"""
     import torch
     from clairvoyante_amd import _lib, synth
     m = _model("full")

@@ -1,0 +1,123 @@
+"""The training step against the ORACLE at the sizes it is used and benchmarked at (SURVEY 8 a9, a10, a12;
+clairvoyante_v3.py:140-152, 174, 183-227 at param.trainBatchSize = 10 000, train.py:95-102).
+
+Above 160 groups of 16 candidates the library chooses kernels and schedules by SIZE that the small oracle tests
+(tests/test_gpu_dp.py n <= 1 000, tests/test_gpu_pipeline.py n <= 83) never reach: flat (group, row) ranges, the
+two-group fc4 data gradient fused with conv3's unpool, the three-slab fc4 forward with the dropout on its store,
+the tile unpool kernels, the second side stream, the two-groups-per-wave fc4 forward above 2 048 groups, several
+slices above 65 536 candidates.  Here every one of them runs with DEFAULT options and is compared with
+oracle/cv_oracle.c (cvo_loss_grad: OpenMP over candidates, double accumulators) under the keep mask the device
+drew: the five loss parts, the dropout output, all 18 gradients, and weights + both Adam slots after the update;
+getLoss (phase False: no dropout, lambda 0) on the same batch.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+LOSS_KEYS = ("loss1", "loss2", "loss3", "loss4", "lossL2")
+
+
+def _model(arch):
+    from clairvoyante_amd import clairvoyante_v3, clairvoyante_v3_slim
+    return clairvoyante_v3.Clairvoyante() if arch == "full" else clairvoyante_v3_slim.Clairvoyante()
+
+
+def _flat(m, which):
+    import torch
+    from clairvoyante_amd import _lib
+    t = torch.empty(m.numParameters, device="cuda")
+    _lib.check(m._lib.cv_flat_copy(m._h, which, ctypes.c_void_p(t.data_ptr()), 0, None))
+    torch.cuda.synchronize()
+    return t.cpu().numpy().copy()
+
+
+def _data(n, seed):
+    from clairvoyante_amd import synth
+    xt, cls, rf, alt, il = synth.make_candidates(n, seed=seed, return_class=True)
+    return xt.numpy(), synth.make_labels(cls, rf, alt, il).numpy()
+
+
+def _split(flat, oracle, shapes):
+    out, off = {}, 0
+    for name in oracle.PARAM_NAMES:
+        sz = int(np.prod(shapes[name]))
+        out[name] = flat[off:off + sz].reshape(shapes[name]); off += sz
+    assert off == flat.size
+    return out
+
+
+def compare_step(oracle, arch, n, rate, lam, lr=1e-3, seed=9, check_mask_rows=True):
+    """One m.train(x, y) with default options vs the oracle; returns the measured distances (for the logs)."""
+    x, y = _data(n, seed=seed)
+    P = common.bench_params(oracle, arch)
+    m = _model(arch); m.setParameters(P)
+    m.dropoutRateFC4Val = rate; m.setL2RegularizationLambda(lam); m.setLearningRate(lr)
+    m._dropout_seed = 4242
+    # getLoss first (v3.py:207-216: phase False, dropout 0, lambda 0); it must not disturb the step that follows
+    l_eval = float(m.getLoss(x, y))
+    want_eval = oracle.loss_grad(arch, P, x, y, lam=0.0, want_grads=False)[0]
+    assert abs(l_eval - want_eval) <= 1e-5 * abs(want_eval), (l_eval, want_eval)
+
+    loss, summ = m.train(x, y)
+    keep = None
+    if rate > 0.0:
+        assert check_mask_rows, "the mask of a multi-slice step is only kept for its last slice"
+        amask = m.getActivation(6, n).cpu().numpy()
+        keep = (amask != 0).astype(np.float32)
+        assert abs(keep.mean() - (1.0 - rate)) <= 4 * 0.5 / np.sqrt(keep.size)
+        d4 = m.getActivation(7, n).cpu().numpy()
+        fa = oracle.forward_all(arch, P, x, mask4=keep, rate4=rate)
+        d4_err = float(np.abs(d4 - fa["d4"]).max())
+        assert d4_err <= 1e-6 * max(1.0, float(np.abs(fa["d4"]).max())), d4_err
+        del fa
+    l_or, parts, g_or = oracle.loss_grad(arch, P, x, y, lam=lam, mask4=keep, rate4=rate)
+    rel = {"loss": abs(float(loss) - l_or) / abs(l_or)}
+    assert rel["loss"] <= 1e-5, (loss, l_or)
+    for k, ref in zip(LOSS_KEYS, parts):
+        rel[k] = abs(summ[k] - ref) / max(1.0, abs(ref))
+        assert rel[k] <= 1e-5, (k, summ[k], ref)
+    shapes = m.paramShapes()
+    g_dev = _split(_flat(m, 1), oracle, shapes)
+    w_dev, m_dev, v_dev = (_split(_flat(m, w), oracle, shapes) for w in (0, 2, 3))
+    worst = 0.0
+    for name in oracle.PARAM_NAMES:
+        l2 = lam * P[name] if "bias" not in name else 0
+        gref = g_or[name] - l2                                              # the bucket holds the data terms
+        err = float(np.abs(g_dev[name] - gref).max() / (np.abs(gref).max() + 1e-30))
+        worst = max(worst, err)
+        assert np.abs(g_dev[name] - gref).max() <= 2e-5 * np.abs(gref).max() + 1e-7, (name, err)
+        # the optimizer on the DEVICE's gradient (+ lambda w): TF1 Adam, step 1 (v3.py:174)
+        w = P[name].copy().ravel(); mm = np.zeros_like(w); vv = np.zeros_like(w)
+        gfull = np.ascontiguousarray((g_dev[name] + l2).astype(np.float32).ravel())
+        oracle.adam_step(w, mm, vv, gfull, lr, 1)
+        assert np.abs(w_dev[name].ravel() - w).max() <= 1e-6, name
+        assert np.abs(m_dev[name].ravel() - mm).max() <= 1e-6 * max(1.0, float(np.abs(mm).max())), name
+        assert np.abs(v_dev[name].ravel() - vv).max() <= 1e-6 * max(1.0, float(np.abs(vv).max())), name
+    m.close()
+    rel["grad_worst_rel_to_max"] = worst
+    return rel
+
+
+@pytest.mark.parametrize("arch", ["full", "slim"])
+@pytest.mark.parametrize("n", [2561, 10000, 20000, 40010])
+def test_training_step_matches_oracle_at_training_sizes(oracle, arch, n):
+    """2 561 = the first size past the tiny-batch regime (161 groups, ragged last group); 10 000 = train.py's batch
+    (the benchmarked step); 20 000 = two ranks' worth; 40 010 = 2 501 groups (> 2 048: the fc4 forward changes kernel),
+    ragged.  The reference's training defaults: dropout 0.5 on fc4, lambda from param.py."""
+    from clairvoyante_amd import param
+    r = compare_step(oracle, arch, n, rate=param.dropoutRateFC4, lam=param.l2RegularizationLambda)
+    print("train parity %s n=%d: %s" % (arch, n, {k: "%.2e" % v for k, v in r.items()}))
+
+
+@pytest.mark.parametrize("arch", ["full", "slim"])
+def test_training_step_over_several_slices_matches_oracle(oracle, arch):
+    """above 65 536 candidates a step runs as equal slices whose gradients and losses accumulate on the device;
+    dropout off (the keep mask is only kept for the last slice)"""
+    n = 70001
+    r = compare_step(oracle, arch, n, rate=0.0, lam=1e-3)
+    print("train parity %s n=%d (2 slices): %s" % (arch, n, {k: "%.2e" % v for k, v in r.items()}))

@@ -69,6 +69,55 @@ def test_gettensor_odd_batch_sizes():
         assert np.array_equal(np.concatenate(Xs), d["X"]) and poss == [str(s) for s in d["pos"]]
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("strip_last_newline", [False, True])
+def test_gettensor_plain_text_through_the_memory_map(tag, strip_last_newline, tmp_path):
+    """the same rows in an UNCOMPRESSED file (the reference's `gzip -fdc` passes plain text through, utils_v2.py:25):
+    read through the memory map instead of a pipe -- the reference's batches, whatever the batch size, also when the
+    last line has no newline, and with 1 or several parser threads (the large copy crosses the 1 MiB threshold above
+    which cv_parse_tensor_text splits its input)"""
+    import gzip
+    from clairvoyante_amd import _lib, utils_v2
+    d = np.load(os.path.join(G, "gettensor_%s.npz" % tag))
+    text = gzip.open(os.path.join(G, "gettensor_%s.txt.gz" % tag), "rb").read()
+    if strip_last_newline:
+        text = text.rstrip(b"\n")
+    fn = str(tmp_path / "plain.txt")
+    open(fn, "wb").write(text)
+    assert utils_v2._map_plain_text(fn) is not None and utils_v2._map_plain_text(os.path.join(G, "gettensor_a.txt.gz")) is None
+    for num in (int(d["num"]), 1, 43, 1000):
+        ends, nums, Xs, poss = [], [], [], []
+        for end, c, x, pos in utils_v2.GetTensor(fn, num, log=False):
+            assert x.shape == (c, 33, 4, 4) and x.dtype == np.float32 and len(pos) == c
+            ends.append(end); nums.append(c); Xs.append(np.array(x)); poss += list(pos)
+        if num == int(d["num"]):
+            assert ends == list(d["ends"]) and nums == list(d["nums"])
+        assert ends[-1] == 1 and sum(ends) == 1
+        assert np.array_equal(np.concatenate(Xs), d["X"]) and poss == [str(s) for s in d["pos"]]
+    # many copies: > 1 MiB, parsed by several threads (slices cut at arbitrary bytes, moved to line starts)
+    reps = (3 << 20) // len(text) + 2
+    body = text if text.endswith(b"\n") else text + b"\n"
+    big = str(tmp_path / "big.txt")
+    open(big, "wb").write(body * reps if not strip_last_newline else (body * reps).rstrip(b"\n"))
+    lib = _lib.load()
+    try:
+        for threads in (1, 3, 8):
+            lib.cv_set_host_threads(threads)
+            for num in (997, 100000):
+                got = [np.array(x) for _e, _c, x, _p in utils_v2.GetTensor(big, num, log=False)]
+                assert all(len(g) == num for g in got[:-1])
+                got = np.concatenate(got)
+                assert got.shape[0] == reps * d["X"].shape[0]
+                assert np.array_equal(got.reshape((reps,) + d["X"].shape), np.broadcast_to(d["X"], (reps,) + d["X"].shape))
+        last = None
+        for _e, c, _x, pos in utils_v2.GetTensor(big, 100000, log=False):
+            if c:
+                last = pos[c - 1]
+        assert last == str(d["pos"][-1])
+    finally:
+        lib.cv_set_host_threads(min(_lib.usable_cores(), 16))
+
+
 def test_training_array_matches_reference():
     from clairvoyante_amd import utils_v2
     d = np.load(os.path.join(G, "trainarray.npz"))
@@ -113,6 +162,29 @@ def test_bin_file_blocks_written_by_c_blosc(fn, lazy):
         assert (n2, e2) == (nn, ef) and np.array_equal(np.asarray(a, dtype=np.float32), dc["x%d" % k])
         k += 1
     assert k >= 10
+
+
+def test_lazy_scan_of_a_truncated_bin_gives_up_instead_of_raising(tmp_path):
+    """a .bin cut inside a block header / inside a block: the opcode scan returns None (no index of blocks that are not
+    all there), so LoadBin(lazy=True) takes the un-pickling path, whose error names the damage"""
+    import mmap
+    import pickle
+    from clairvoyante_amd import utils_v2
+    raw = open(os.path.join(G, "mini.bin"), "rb").read()
+    with open(os.path.join(G, "mini.bin"), "rb") as fh:
+        pickle.load(fh); start = fh.tell()
+    whole = utils_v2._scan_block_list(raw, start)
+    assert whole is not None and len(whole[0]) >= 1
+    first_off, first_len = whole[0][0]
+    for cut in (first_off - 2, first_off + first_len // 2, whole[1] - 1, start + 1):
+        fn = str(tmp_path / ("cut%d.bin" % cut))
+        open(fn, "wb").write(raw[:cut])
+        with open(fn, "rb") as fh:
+            mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+            assert utils_v2._scan_block_list(mm, start) is None
+            mm.close()
+        with pytest.raises((EOFError, pickle.UnpicklingError)):
+            utils_v2.LoadBin(fn, lazy=True)
 
 
 def test_blosc_roundtrip_and_edge_sizes():

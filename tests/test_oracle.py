@@ -12,6 +12,7 @@ import common
 import torch_ref
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("arch", ["full", "slim"])
@@ -130,3 +131,36 @@ def test_selu_is_monotone_over_every_negative_float(oracle):
     x.sort()
     y = np.array([oracle.lib().cvo_selu_scalar(v) for v in x], dtype=np.float32)
     assert (np.diff(y) >= 0).all()
+
+
+def test_seeded_weights_of_the_product_are_the_oracle_initialiser(oracle):
+    """bench.py and smoke() draw their weights from clairvoyante_amd/synth.py (nothing from oracle/ inside the timed
+    function); it is the same seeded stream as the oracle's own initialiser, so fixtures made with either agree"""
+    from clairvoyante_amd import synth
+    for arch in ("full", "slim"):
+        assert synth.param_shapes(arch) == oracle.param_shapes(arch)
+        for seed in (0, 1, 7):
+            a = oracle.init_params(arch, seed=seed, bias_scale=0.05)
+            b = synth.seeded_params(arch, seed=seed, bias_scale=0.05)
+            assert list(a) == list(b) == oracle.PARAM_NAMES
+            assert all(np.array_equal(a[k], b[k]) for k in a)
+
+
+def test_loss_grad_does_not_depend_on_the_thread_count(oracle):
+    """cvo_loss_grad walks contiguous candidate ranges on OpenMP threads with double accumulators added in thread order:
+    the float results are the single-thread ones (tests/test_gpu_train_parity.py leans on it at 10 000+ candidates)"""
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import common\nfrom oracle import cv_oracle as O\nfrom clairvoyante_amd import synth\n"
+            "xt, c, r, a, l = synth.make_candidates(300, seed=3, return_class=True)\n"
+            "y = synth.make_labels(c, r, a, l).numpy(); P = common.bench_params(O, 'slim')\n"
+            "L, parts, g = O.loss_grad('slim', P, xt.numpy(), y, lam=0.01)\n"
+            "np.save(sys.argv[1], np.concatenate([g[k].ravel() for k in O.PARAM_NAMES] + [np.float32(parts)]))\n") % (
+                ROOT, os.path.join(ROOT, "tests"))
+    outs = []
+    for nt in ("1", "5"):
+        fn = os.path.join(os.environ.get("TMPDIR", "/tmp"), "cvo_lg_%s_%d.npy" % (nt, os.getpid()))
+        subprocess.check_call([sys.executable, "-c", code, fn], env=dict(os.environ, OMP_NUM_THREADS=nt))
+        outs.append(np.load(fn)); os.remove(fn)
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))

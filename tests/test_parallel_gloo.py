@@ -1,5 +1,6 @@
-"""world_size-2 `gloo` tests of the N>1 path on CPU: contiguous candidate shards need no
-collective for inference; training = one all-reduce(SUM) of the flat gradient per step."""
+"""`gloo` tests of the N>1 path on CPU at world sizes 2, 3 and 8 (8 = the node BASELINE.json names; 3 = a size that
+divides nothing): contiguous candidate shards need no collective for inference; training = one all-reduce(SUM) of
+the flat gradient per step.  Sizes below the world size give ranks with EMPTY shards."""
 import os
 import sys
 
@@ -23,10 +24,11 @@ def test_shard_ranges_cover_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _worker(rank, ws, port, tmp):
+def _worker(rank, ws, port, tmp, n):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws),
-                      LOCAL_RANK=str(rank))
+                      LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
+    torch.set_num_threads(1)
     from clairvoyante_amd import parallel, synth
     from oracle import cv_oracle as O
     import common
@@ -34,7 +36,6 @@ def _worker(rank, ws, port, tmp):
     assert (r, w) == (rank, ws)
     arch = "slim"
     P = common.bench_params(O, arch)
-    n = 22
     xt, cls, rf, alt, il = synth.make_candidates(n, seed=4, return_class=True)
     y = synth.make_labels(cls, rf, alt, il).numpy(); x = xt.numpy()
     lo, hi = parallel.shard_range(n, rank, ws)
@@ -70,16 +71,19 @@ def _worker(rank, ws, port, tmp):
     assert np.abs(got[16:] - ref).max() <= 1e-4 * np.abs(ref).max()      # shard gradients sum to the whole-batch gradient
     dec = [float(got[2 * k]) + float(got[2 * k + 1]) for k in range(5)]
     assert np.allclose(dec[0:4], parts_all[0:4], rtol=1e-7)
-    assert got[10] == ws and abs(dec[4] / got[10] - l2) <= 1e-7 * l2
+    assert got[10] == ws and abs(dec[4] / got[10] - l2) <= 5e-7 * l2      # fp32 sum of ws equal (hi, lo) pairs: exact at powers of two only
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
 
 
-def test_two_rank_gloo_shards_and_gradient_allreduce(tmp_path, oracle):
-    port = 29600 + os.getpid() % 300
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+@pytest.mark.parametrize("ws,n", [(2, 22), (3, 22), (8, 22), (8, 5), (3, 1)])
+def test_gloo_shards_and_gradient_allreduce(tmp_path, oracle, ws, n):
+    """(8, 5) and (3, 1): more ranks than candidates -- the ranks with an empty shard contribute a zero gradient and
+    zero losses and still take part in both collectives"""
+    port = 29600 + (os.getpid() + 31 * ws + n) % 300
+    mp.spawn(_worker, args=(ws, port, str(tmp_path), n), nprocs=ws, join=True)
+    assert all((tmp_path / ("ok%d" % r)).exists() for r in range(ws))
 
 
 # ---- callVar under two ranks: block-cyclic split of the input lines, per-rank record fragments, merge -------------
@@ -102,7 +106,8 @@ def _write_tensor_text(path, x, seed=3, bad_every=97):
 def _callvar_worker(rank, ws, port, tmp, tfn, block_lines):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws),
-                      LOCAL_RANK=str(rank))
+                      LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
+    torch.set_num_threads(1)
     import io
     import types
     from clairvoyante_amd import callVar, parallel, utils_v2
@@ -140,8 +145,9 @@ def _callvar_worker(rank, ws, port, tmp, tfn, block_lines):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,block_lines", [(700, 64), (130, 64), (64, 64), (5, 64), (300, 1000)])
-def test_two_rank_callvar_split_and_merge_equals_one_process(oracle, tmp_path, n, block_lines):
+@pytest.mark.parametrize("ws,n,block_lines", [(2, 700, 64), (2, 130, 64), (2, 64, 64), (2, 5, 64), (2, 300, 1000),
+                                              (3, 700, 64), (8, 700, 64), (8, 130, 64), (8, 5, 64), (3, 64, 64)])
+def test_callvar_split_and_merge_equals_one_process(oracle, tmp_path, ws, n, block_lines):
     """the sharding / merge logic of callVar.TestSharded with the oracle in the model's place (no GPU here): every
     rank parses only its blocks of input lines, formats its records, rank 0 joins the fragments in input order --
     the file must equal the single-process VCF byte for byte, whatever the number of blocks (fewer blocks than
@@ -153,8 +159,8 @@ def test_two_rank_callvar_split_and_merge_equals_one_process(oracle, tmp_path, n
     x = common.inputs(n, seed=23)
     tfn = str(tmp_path / "t.gz")
     _write_tensor_text(tfn, x)
-    port = 29700 + (os.getpid() + n) % 200
-    mp.spawn(_callvar_worker, args=(2, port, str(tmp_path), tfn, block_lines), nprocs=2, join=True)
+    port = 29700 + (os.getpid() + n + 17 * ws) % 200
+    mp.spawn(_callvar_worker, args=(ws, port, str(tmp_path), tfn, block_lines), nprocs=ws, join=True)
     got = open(str(tmp_path / "calls.vcf")).read()
     args = types.SimpleNamespace(v2=False, v3=True, showRef=False, qual=30, ref_fn=None, sampleName="S")
     P = common.bench_params(oracle, "slim")
@@ -169,9 +175,10 @@ def test_two_rank_callvar_split_and_merge_equals_one_process(oracle, tmp_path, n
     assert not [f for f in os.listdir(str(tmp_path)) if ".rank" in f]          # fragments are removed
 
 
-@pytest.mark.parametrize("sizes", [(120, 0, 75), (40,), (30, 50, 20, 10, 60)])
-def test_two_rank_callvar_over_a_list_of_files_equals_one_process_per_file(oracle, tmp_path, sizes):
-    """--tensor_fn a.gz,b.gz,...: file k belongs to rank k % 2 (no rank inflates another rank's file); the merged VCF is
+@pytest.mark.parametrize("ws,sizes", [(2, (120, 0, 75)), (2, (40,)), (2, (30, 50, 20, 10, 60)),
+                                      (3, (30, 50, 20, 10, 60)), (8, (40, 12, 0, 33, 25, 18, 7, 21, 9, 30, 14)), (8, (40, 9))])
+def test_callvar_over_a_list_of_files_equals_one_process_per_file(oracle, tmp_path, ws, sizes):
+    """--tensor_fn a.gz,b.gz,...: file k belongs to rank k % ws (no rank inflates another rank's file); the merged VCF is
     the concatenation, in list order, of what one process writes for each file (an empty file, fewer files than ranks)"""
     import io
     import types
@@ -182,8 +189,8 @@ def test_two_rank_callvar_over_a_list_of_files_equals_one_process_per_file(oracl
         fn = str(tmp_path / ("t%d.gz" % k))
         _write_tensor_text(fn, common.inputs(max(n, 1), seed=31 + k)[:n], seed=5 + k)
         files.append(fn)
-    port = 29750 + (os.getpid() + len(sizes) * 7) % 200
-    mp.spawn(_callvar_worker, args=(2, port, str(tmp_path), ",".join(files), 64), nprocs=2, join=True)
+    port = 29750 + (os.getpid() + len(sizes) * 7 + 17 * ws) % 200
+    mp.spawn(_callvar_worker, args=(ws, port, str(tmp_path), ",".join(files), 64), nprocs=ws, join=True)
     got = open(str(tmp_path / "calls.vcf")).read()
     args = types.SimpleNamespace(v2=False, v3=True, showRef=False, qual=30, ref_fn=None, sampleName="S")
     P = common.bench_params(oracle, "slim")
