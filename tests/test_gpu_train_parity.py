@@ -73,7 +73,11 @@ def compare_step(oracle, arch, n, rate, lam, lr=1e-3, seed=9, check_mask_rows=Tr
         d4 = m.getActivation(7, n).cpu().numpy()
         fa = oracle.forward_all(arch, P, x, mask4=keep, rate4=rate)
         d4_err = float(np.abs(d4 - fa["d4"]).max())
-        assert d4_err <= 1e-6 * max(1.0, float(np.abs(fa["d4"]).max())), d4_err
+        # full: fc4 of a training pass above the tiny-batch range is the oracle's single ascending-k chain.  slim: its
+        # fc4 forward runs as EIGHT k ranges added in order at every batch size (reproducible, never used by
+        # cv_forward) -- the same sum in another fp32 order, 396 terms: a few 1e-6 of the largest value
+        tol = 1e-6 if arch == "full" else 5e-6
+        assert d4_err <= tol * max(1.0, float(np.abs(fa["d4"]).max())), d4_err
         del fa
     l_or, parts, g_or = oracle.loss_grad(arch, P, x, y, lam=lam, mask4=keep, rate4=rate)
     rel = {"loss": abs(float(loss) - l_or) / abs(l_or)}

@@ -42,7 +42,7 @@ o = sys.argv[1]
 b = json.load(open(os.path.join(o, "bench.json")))
 print("bench: %.2f M cand/s, dominant %.3f, whole path %.3f; slim %.2f M/s; train %s" % (
     b["value"] / 1e6, b["roofline"]["frac"], b["roofline"]["whole_path_frac"], b["slim"]["value"] / 1e6,
-    {k: "%.3f ms (%.3f)" % (v["ms_per_step"], v["roofline"]["frac"]) for k, v in b["train"].items()}))
+    {k: "%.3f ms (%.3f)" % (v["ms_per_step"], v["roofline"]["frac"]) for k, v in b["train"].items() if k != "parity"}))
 print("parity:", b.get("parity"))
 for l in open(os.path.join(o, "bench_train.jsonl")):
     r = json.loads(l)
