@@ -159,6 +159,8 @@ extern "C" int cv_destroy(cv_model *m)
         if (b) hipFree(b);
     if (m->tail_dev) hipFree(m->tail_dev);
     if (m->loss_acc) hipFree(m->loss_acc);
+    if (m->loss_rows) hipFree(m->loss_rows);
+    if (m->l2_rows) hipFree(m->l2_rows);
     if (m->tr_side) {
         (void)hipStreamSynchronize(m->tr_side);
         (void)hipStreamDestroy(m->tr_side);
@@ -241,6 +243,7 @@ extern "C" int cv_set_option(cv_model *m, const char *key, int64_t value)
         return 0;
     }
     if (!strcmp(key, "profile")) { m->profile = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "keep_activations")) { m->keep_act = value ? 1 : 0; return 0; }
     if (!strcmp(key, "train_overlap")) { m->train_overlap = value ? 1 : 0; return 0; }
     if (!strcmp(key, "train_ksplit")) { m->train_ksplit = value ? 1 : 0; return 0; }
     if (!strcmp(key, "train_side_streams")) { m->train_sides = value < 1 ? 1 : (value > 3 ? 3 : (int)value); return 0; }
@@ -262,6 +265,7 @@ extern "C" int cv_get_option(const cv_model *m, const char *key, int64_t *value)
     if (!strcmp(key, "impl")) { *value = m->impl; return 0; }
     if (!strcmp(key, "chunk")) { *value = m->chunk; return 0; }
     if (!strcmp(key, "profile")) { *value = m->profile; return 0; }
+    if (!strcmp(key, "keep_activations")) { *value = m->keep_act; return 0; }
     if (!strcmp(key, "train_overlap")) { *value = m->train_overlap; return 0; }
     if (!strcmp(key, "train_ksplit")) { *value = m->train_ksplit; return 0; }
     if (!strcmp(key, "train_side_streams")) { *value = m->train_sides; return 0; }
@@ -332,6 +336,11 @@ extern "C" int cv_get_activation(cv_model *m, int layer, float *dst_dev, int64_t
     if (layer == 3 && m->last_impl == 1 && m->stage_kernel[2] && !m->stage_kernel[3]) {
         cv_set_error("layer 3 is not materialised while conv3 and fc4 run as one kernel (option variant bit 8); "
                      "clear the bit to inspect it");
+        return 1;
+    }
+    if (layer >= 4 && m->last_impl == 1 && !m->last_maps) {
+        cv_set_error("layers 4 / 5 are not materialised while fc5 and the heads ride on the fc4 kernel (option variant bit 10) "
+                     "unless option keep_activations is set before the pass");
         return 1;
     }
     if (layer <= 3) {

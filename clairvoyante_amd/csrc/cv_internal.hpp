@@ -86,12 +86,19 @@ struct cv_model {
     int64_t last_n;      // candidates of the last chunk (for cv_get_activation)
     int last_impl;
     int last_variant;
+    int keep_act;        // option "keep_activations" (default 0): a pass whose fc5 + heads ride on the fc4 kernel also stores the
+                         // fc4 / fc5 maps that only cv_get_activation reads (68 % of that kernel's writes)
+    int last_maps;       // the last pass left the fc4 / fc5 maps in memory
     // training workspaces
     int64_t tr_cap;
     float *t_buf;        // one slab, carved by the training code
     size_t t_bytes;
     double *loss_dev;    // 8 doubles: losses of the current pass (inside the grads_own allocation, behind the gradients)
     double *loss_acc;    // 8 doubles: losses accumulated over steps (cv_loss_accumulate / cv_loss_read)
+    // fixed-order loss sums of the tile path: per-block rows of the heads kernel (4 doubles each, slice after slice) and
+    // the per-block sums of the L2 kernel ([kernel][256]); t_loss_finish adds them into loss_dev in a fixed order
+    double *loss_rows; int64_t loss_rows_cap, loss_rows_used;
+    double *l2_rows;
     float *grads_own;    // the library's own gradient bucket (CV_GRAD_HEADER + count floats); `grads` points
                          // CV_GRAD_HEADER floats into it, or into the caller's bucket (cv_bind_grad_bucket)
     // training step: side stream of the weight-gradient kernels, fork / join events, "dense gradients final"

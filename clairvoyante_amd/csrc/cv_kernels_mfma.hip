@@ -21,6 +21,7 @@
 #include "cv_math.hpp"
 #include "cv_unpool.hpp"
 #include <type_traits>
+#include <atomic>
 #include <string.h>
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -1295,7 +1296,9 @@ struct heads_args {
     const f4 *dact = nullptr;            // EPI 1 only: the output is multiplied by selu'-from-output of this map (same layout)
     // EPI 3 only (fc4 with fc5 and the heads on its tail): fc5's weights in k PAIRS [kp][24][64] (pack_dense_kpairs),
     // its bias / width, and where its output goes (kept for cv_get_activation and the parity tests)
-    const f4 *wp5p = nullptr; const float *bias5 = nullptr; int nout5 = 0; f4 *h5_out = nullptr;
+    const f4 *wp5p = nullptr; const float *bias5 = nullptr; int nout5 = 0;
+    int keep = 0;                        // option keep_activations: also store the maps only cv_get_activation reads
+    f4 *h5_out = nullptr;
     // EPI 3: the kernel reads all of the above from this DEVICE copy on its tail, so that the two dozen scalars stay out
     // of the main loop's register budget (by value they are loaded at kernel entry and live across the whole kernel)
     const heads_args *tail = nullptr;
@@ -1455,8 +1458,9 @@ __global__ __launch_bounds__(512, 2) void conv3fc4_slim(const f4 *__restrict__ i
     if (!live) return;
     f4 *op = out_h4 + (size_t)g * NB4 * 64 + lane;
     f4 h4[NB4];
+    const bool store_maps = !tail || tail->keep;           // with the tail below the maps are for cv_get_activation only
 #pragma unroll
-    for (int ob = 0; ob < NB4; ob++) { h4[ob] = selu4(acc4[ob] + load_bias4(bias4, ob, q, nout4)); op[ob * 64] = h4[ob]; }
+    for (int ob = 0; ob < NB4; ob++) { h4[ob] = selu4(acc4[ob] + load_bias4(bias4, ob, q, nout4)); if (store_maps) op[ob * 64] = h4[ob]; }
     if (!tail) return;
     const heads_args hd = *tail;
     constexpr int NB5 = 2, NBP5 = 4;                       // fc5's packed weights: [kb][4][64] (two real tiles)
@@ -1471,7 +1475,7 @@ __global__ __launch_bounds__(512, 2) void conv3fc4_slim(const f4 *__restrict__ i
             for (int s4 = 0; s4 < 4; s4++) a = mfma4(A[s4], h4[kb][s4], a);
         }
         h5[ob] = selu4(a + load_bias4(hd.bias5, ob, q, hd.nout5));
-        hd.h5_out[((size_t)g * NB5 + ob) * 64 + lane] = h5[ob];
+        if (hd.keep) hd.h5_out[((size_t)g * NB5 + ob) * 64 + lane] = h5[ob];
     }
 #pragma unroll
     for (int kb = 0; kb < NB4; kb++) {                     // base head over the fc4 output
@@ -1505,7 +1509,13 @@ __global__ __launch_bounds__(512, 2) void conv3fc4_slim(const f4 *__restrict__ i
 // per k step + 4 per output tile, then heads_finish.  No separate heads launch, the fc5 output is not re-read.
 // GR = groups per wave (1 or 2): with 2 a wave keeps two sets of accumulator tiles and every weight fragment read
 // from LDS feeds both -- twice the MFMA work per barrier and per LDS read, at 2 waves per SIMD.
-template <int NB, int WAVES, int EPI = 0, int GR = 1>
+// PRE = 1 (fc4 of a training pass, where the registers allow it): a FOUR-slot ring filled three k steps ahead.  A wave
+// then may read the first NPRE weight fragments of step k + 1 while it still multiplies step k -- the barrier that ended
+// step k - 1 already published them -- and carries them across the barrier in registers: its first MFMAs behind a
+// barrier wait for nothing (with three slots every wave of the workgroup opens a step with an LDS round trip while the
+// matrix pipe idles: ~10 % of a 28-MFMA step), and this step's loads / DMA pieces go out behind that first block.
+// Same fragments, same order per accumulator: same bits.
+template <int NB, int WAVES, int EPI = 0, int GR = 1, int PRE = 0>
 __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_tm(const f4 *__restrict__ in_tm, int KB,
                                                         const f4 *__restrict__ wp_all,
                                                         const float *__restrict__ bias, int nout,
@@ -1513,6 +1523,9 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
                                                         heads_args hd = heads_args())
 {
     static_assert(EPI != 2 || GR == 1, "the fused heads keep one group per wave");
+    static_assert(!PRE || (GR == 1 && (EPI == 0 || EPI == 1)), "the pre-read ring is written for one group per wave, no fused tail");
+    constexpr int SLOTS = PRE ? 4 : 3, AHEAD = SLOTS - 1;
+    constexpr int NPRE = PRE ? (NB < 2 ? NB : 2) : 0;
     static_assert(EPI != 3 || (GR == 2 && NB == 21 && WAVES == 8), "the fc5 + heads tail is written for the full topology's fc4");
     // The packed weight matrix holds NBP = roundup(NB, WAVES) fragments per k step (the pad
     // fragments are zero and never multiplied), so every thread stages exactly PER 16-byte
@@ -1582,6 +1595,7 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
     };
     stage_async(0, 0);
     stage_async(KB > 1 ? 1 : 0, 1);
+    if constexpr (PRE) stage_async(KB > 2 ? 2 : KB - 1, 2);
     f4 hacc0 = zero, hA = zero;                 // EPI 2: base-head tile and its weight fragment of the current k step
     if constexpr (EPI == 2) hA = load_frag(hd.wp0 + lane);
     f4 B[GR];
@@ -1592,26 +1606,48 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
     if constexpr (EPI == 2) asm volatile("" : "+v"(hA) : : "memory");
     __syncthreads();
     int slot = 0;
+    f4 Apre[NPRE > 0 ? NPRE : 1];               // PRE: the first weight fragments of the coming step, read one step early
+    if constexpr (PRE) {
+#pragma unroll
+        for (int j = 0; j < NPRE; j++) Apre[j] = ring[j * 64 + lane];
+    }
 #pragma unroll 1
     for (int kb = 0; kb < KB; kb++) {
         // stage kb+2 and activation fragment kb+1 (indices clamped: the surplus loads of the
         // last two steps re-read valid data and land in ring slots nobody reads again)
-        const int ks = kb + 2 < KB ? kb + 2 : KB - 1;
+        const int ks = kb + AHEAD < KB ? kb + AHEAD : KB - 1;
         const int kn = kb + 1 < KB ? kb + 1 : KB - 1;
-        int wslot = slot + 2; if (wslot >= 3) wslot -= 3;
+        int wslot = slot + AHEAD; if (wslot >= SLOTS) wslot -= SLOTS;
         f4 Bn[GR];
-#pragma unroll
-        for (int r = 0; r < GR; r++) Bn[r] = load_frag_off(bo[r] + (unsigned)kn * 1024u);
         f4 hAn = zero;
-        if constexpr (EPI == 2) hAn = load_frag(hd.wp0 + (size_t)kn * 64 + lane);      // issued before this step's DMA pieces
-        stage_async(ks, wslot);          // slot (kb+2)%3 was last read in step kb-1 (barrier passed)
+        if constexpr (!PRE) {
+#pragma unroll
+            for (int r = 0; r < GR; r++) Bn[r] = load_frag_off(bo[r] + (unsigned)kn * 1024u);
+            if constexpr (EPI == 2) hAn = load_frag(hd.wp0 + (size_t)kn * 64 + lane);      // issued before this step's DMA pieces
+            stage_async(ks, wslot);          // slot (kb+2)%3 was last read in step kb-1 (barrier passed)
+        }
         // (measured, round 3: these loads and pieces issued one per MFMA block instead of here -- what helped the
         // convolution kernels -- makes this ring slower: training step 2.15 -> 2.21 ms, inference 18.41 -> 18.28 M/s on
         // one box; a wave issues at most 5 of them per step, and the barrier needs them early)
         const f4 *wl = ring + slot * STAGE + lane;
         constexpr int AB = EPI == 3 ? 2 : 3;      // weight fragments read ahead of their MFMAs (EPI 3 is short of 4 VGPRs)
+        if constexpr (PRE) {
+            // the fragments carried across the barrier: multiplied at once; this step's loads and DMA pieces (slot
+            // (kb+3)%4, last read in step kb-1) go out behind them, then the first fragments of step kb+1 are fetched
 #pragma unroll
-        for (int ob = 0; ob < NB; ob += AB) {
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int j = 0; j < NPRE; j++) acc[0][j] = mfma4(Apre[j][s], B[0][s], acc[0][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            Bn[0] = load_frag_off(bo[0] + (unsigned)kn * 1024u);
+            stage_async(ks, wslot);
+            int nslot = slot + 1; if (nslot >= SLOTS) nslot -= SLOTS;
+            const f4 *wn = ring + nslot * STAGE + lane;
+#pragma unroll
+            for (int j = 0; j < NPRE; j++) Apre[j] = wn[j * 64];
+        }
+#pragma unroll
+        for (int ob = NPRE; ob < NB; ob += AB) {
             f4 A[AB];
 #pragma unroll
             for (int j = 0; j < AB; j++)
@@ -1638,10 +1674,14 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(Bn[0]) : : "memory");
         if constexpr (GR == 2) asm volatile("" : "+v"(Bn[1]) : : "memory");      // the same wait covers the second fragment
         if constexpr (EPI == 2) { asm volatile("" : "+v"(hAn) : : "memory"); hA = hAn; }
+        if constexpr (PRE) {                      // the pre-read fragments are in their registers before the barrier
+#pragma unroll
+            for (int j = 0; j < NPRE; j++) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Apre[j]) : : "memory");
+        }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < GR; r++) B[r] = Bn[r];
-        slot = slot + 1 == 3 ? 0 : slot + 1;
+        slot = slot + 1 == SLOTS ? 0 : slot + 1;
     }
     CV_STAMP_END(NB == 7 && EPI == 0, 3);
     const int q = lane >> 4;
@@ -1669,7 +1709,9 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
                 // (nout == 16 NB here -- checked by the launcher --, so no bounds test per lane: 168 predicates less)
                 const float *bq = bias + 16 * ob + q_t;
                 acc[r][ob] = selu4(acc[r][ob] + (f4){bq[0], bq[4], bq[8], bq[12]});
-                if (g + r < G) out_tm[((size_t)(g + r) * NBT + ob) * 64 + lane_t] = acc[r][ob];
+                // the second group's fragments are parked in the fc4 map while the first group's tail runs (re-read
+                // below); the first group's are stored for cv_get_activation only (option keep_activations)
+                if (g + r < G && (r > 0 || hd.keep)) out_tm[((size_t)(g + r) * NBT + ob) * 64 + lane_t] = acc[r][ob];
             }
         f4 hacc0[GR], hacc1[GR];
 #pragma unroll
@@ -1751,7 +1793,7 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
 #pragma unroll
             for (int ob = 0; ob < NB5; ob++) {
                 const f4 h = selu4(acc5[ob] + load_bias4(hd.bias5, ob, q_t, hd.nout5));
-                if (g + r < G) hd.h5_out[((size_t)(g + r) * NB5 + ob) * 64 + lane_t] = h;
+                if (hd.keep && g + r < G) hd.h5_out[((size_t)(g + r) * NB5 + ob) * 64 + lane_t] = h;
                 const f4 W = hd.wp1[(size_t)ob * 64 + lane_t];
 #pragma unroll
                 for (int s = 0; s < 4; s++) hacc1[r] = mfma4(W[s], h[s], hacc1[r]);
@@ -2249,10 +2291,10 @@ __global__ __launch_bounds__(256) void heads_train_tm(const f4 *__restrict__ d4,
                                                        const float *__restrict__ wz, const float *__restrict__ wt,
                                                        const float *__restrict__ wl, int K5, const float *__restrict__ y,
                                                        int64_t n, int want_grad, float *__restrict__ g16,
-                                                       f4 *__restrict__ g5pre_tm, double *__restrict__ loss, int G)
+                                                       f4 *__restrict__ g5pre_tm, double *__restrict__ loss_rows, int G)
 {
     __shared__ float sh[4][16][17];
-    __shared__ double part[4];
+    __shared__ double part[4][4];          // [wave][head]: the four loss sums of a wave's 16 candidates
     __shared__ __attribute__((aligned(16))) float shw[NB5 * 16][12];   // fc5-side head weights of a unit side by side: zygosity 2 | type 4 | length 6
     if (g5pre_tm && want_grad) {
         for (int i = threadIdx.x; i < NB5 * 16 * 12; i += 256) {
@@ -2298,16 +2340,15 @@ __global__ __launch_bounds__(256) void heads_train_tm(const f4 *__restrict__ d4,
     } else {
         S[c][14] = a1[0] + bl[4]; S[c][15] = a1[1] + bl[5];
     }
-    if (threadIdx.x < 4) part[threadIdx.x] = 0.0;
     __syncthreads();
     {   // losses and gradients: lane -> (candidate lane >> 2 of the group, head lane & 3)
         const int cc = lane >> 2, j = lane & 3;
         const int64_t cand = (int64_t)g * 16 + cc;
+        double l = 0.0;
         if (live && cand < n) {
             const float *yi = y + (size_t)cand * 16;
             float *gl = S[cc];
             float *go = g16 + (size_t)cand * 16;
-            double l = 0.0;
             if (j == 0) {
                 float v[4];
                 for (int k = 0; k < 4; k++) v[k] = gl[k];
@@ -2331,11 +2372,17 @@ __global__ __launch_bounds__(256) void heads_train_tm(const f4 *__restrict__ d4,
                     if (want_grad) { const float gr = (p[k] / se * ysum - yi[off + k]) * cvm::selu_grad(v[k]); gl[off + k] = gr; go[off + k] = gr; }
                 }
             }
-            atomicAdd(&part[j], l);
         }
+        // No atomics: the 16 candidates of a wave are added in a fixed tree (lanes with the same head: xor 4, 8, 16, 32),
+        // the four waves of the block in order, and the block's four sums go to ITS row of loss_rows -- t_loss_finish adds
+        // the rows in a fixed order.  The loss sums of a step are the same bits from run to run, like its gradients.
+#pragma unroll
+        for (int d = 4; d < 64; d <<= 1) l += __shfl_xor(l, d);
+        if (lane < 4) part[wave][lane] = l;
     }
     __syncthreads();
-    if (threadIdx.x < 4) atomicAdd(&loss[threadIdx.x], part[threadIdx.x]);
+    if (threadIdx.x < 4)
+        loss_rows[(size_t)blockIdx.x * 4 + threadIdx.x] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
     if (!g5pre_tm || !want_grad || !live) return;
     // fc5-side head data gradients (zygosity, type, length; k = fc5 unit), times selu'(fc5 output)
     const bool cand_ok = (int64_t)g * 16 + c < n;
@@ -2390,11 +2437,18 @@ int launch_conv(const float *in, const float *x, int64_t n, const float *wp1, co
     if constexpr (HSPLIT == 0) {
         // flat ranges: one round of equal waves.  slots = resident waves of this kernel (4-wave workgroups per CU by its
         // registers and LDS, asked once); at least 4 output rows per wave (a pooled layer recomputes POOL - 1 per segment).
-        static int slots = 0;
+        // (cached per DEVICE of this template instance, written once with an atomic store: the range boundaries -- and with
+        // them the summation order of the weight gradients -- depend on this value, so it must be the calling device's own)
+        static std::atomic<int> slots_by_dev[64];
+        int dev = 0;
+        CV_HIP(hipGetDevice(&dev));
+        int slots = slots_by_dev[dev & 63].load(std::memory_order_relaxed);
         if (slots == 0) {
-            int nb = 0;
+            int nb = 0, cus = 0;
             CV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), 256, lds));
-            slots = (nb > 0 ? nb : 2) * 4 * 256;
+            CV_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            slots = (nb > 0 ? nb : 2) * 4 * (cus > 0 ? cus : 256);
+            slots_by_dev[dev & 63].store(slots, std::memory_order_relaxed);
         }
         const int64_t rows = (int64_t)G * (HIN - POOL + 1);
         const int per_tile = slots / NT;
@@ -2477,13 +2531,13 @@ int launch_conv3_rot(const float *in, const float *wp, const float *bias, int co
     return 0;
 }
 
-template <int NB, int WAVES, int EPI = 0, int GR = 1>
+template <int NB, int WAVES, int EPI = 0, int GR = 1, int PRE = 0>
 int launch_dense(const float *in, int KB, const float *wp, const float *bias, int nout, float *out, int G,
                  hipStream_t st, int slabs = 1, int ksplit = 1, float *part = nullptr, heads_args hd = heads_args(),
                  cv_dropout_args dr = cv_dropout_args())
 {
-    auto k = dense_tm<NB, WAVES, EPI, GR>;
-    size_t lds = (size_t)3 * ((NB + WAVES - 1) / WAVES * WAVES) * 1024;
+    auto k = dense_tm<NB, WAVES, EPI, GR, PRE>;
+    size_t lds = (size_t)(PRE ? 4 : 3) * ((NB + WAVES - 1) / WAVES * WAVES) * 1024;
     if (EPI == 3) lds = (size_t)3 * 48 * 1024;          // the tail streams fc5 in stages of 4 k fragments x 12 output fragments
     if (set_lds(k, lds)) return 1;
     if (ksplit > 1) {       // partial sums per k range, then dense_ksum (EPI 0 layers only)
@@ -2705,7 +2759,7 @@ static int tail_args_refresh(cv_model *m, heads_args h, hipStream_t st, const he
     memset(clean, 0, sizeof(clean));
     heads_args *c = reinterpret_cast<heads_args *>(clean);
     c->wp0 = h.wp0; c->wp1 = h.wp1; c->bb = h.bb; c->bz = h.bz; c->bt = h.bt; c->bl = h.bl;
-    c->wp5p = h.wp5p; c->bias5 = h.bias5; c->nout5 = h.nout5; c->h5_out = h.h5_out;
+    c->wp5p = h.wp5p; c->bias5 = h.bias5; c->nout5 = h.nout5; c->h5_out = h.h5_out; c->keep = h.keep;
     if (!m->tail_dev) CV_HIP(hipMalloc(&m->tail_dev, sizeof(heads_args)));
     if (memcmp(m->tail_host, clean, sizeof(heads_args)) != 0) {
         CV_HIP(hipStreamSynchronize(st));               // no kernel in flight reads the old copy
@@ -2729,6 +2783,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
     }
     if (mfma_alloc(m, n)) return 1;
     for (int i = 0; i < CV_NUM_STAGES; i++) m->stage_kernel[i] = nullptr;
+    m->last_maps = 1;
     if (m->packed_dirty && cv_pack_weights(m, st)) return 1;
     const float *P = m->params;
     const int64_t *o = m->poff;
@@ -2795,6 +2850,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             m->stage_kernel[3] = "dense_tm<21, 8, 3, 2>";
             heads_args h3 = hd;
             h3.wp5p = (const f4 *)m->wp5p_fc5; h3.bias5 = P + o[9]; h3.nout5 = a.fc5; h3.h5_out = (f4 *)m->tm_h5;
+            h3.keep = m->keep_act;
             if (a.fc4 != 16 * s.nb4) { cv_set_error("fused fc4 tail: fc4 width must be a whole number of tiles"); return 1; }
             heads_args hk;                           // by value: the pointer to the device copy + what changes per call
             if (tail_args_refresh(m, h3, st, &hk.tail)) return 1;
@@ -2809,7 +2865,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         if (tail_done) {
             if (rc) return 1;
             CV_HIP(hipGetLastError());
-            m->last_n = n; m->last_impl = 1; m->last_variant = m->variant;
+            m->last_n = n; m->last_impl = 1; m->last_variant = m->variant; m->last_maps = m->keep_act;
             return 0;
         }
         cv_prof_begin(m, 4, st);
@@ -2851,6 +2907,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
                 if (m->variant & 1024) {            // fc5 + heads on the kernel's tail: arguments through a device copy
                     heads_args h3 = hd;
                     h3.wp5p = (const f4 *)m->wp_fc5; h3.bias5 = P + o[9]; h3.nout5 = a.fc5; h3.h5_out = (f4 *)m->tm_h5;
+                    h3.keep = m->keep_act;
                     if (tail_args_refresh(m, h3, st, &tail)) return 1;
                     tail_done = true;
                 }
@@ -2861,7 +2918,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             if (tail_done) {
                 if (rc) return 1;
                 CV_HIP(hipGetLastError());
-                m->last_n = n; m->last_impl = 1; m->last_variant = m->variant;
+                m->last_n = n; m->last_impl = 1; m->last_variant = m->variant; m->last_maps = m->keep_act;
                 return 0;
             }
         } else {
@@ -3133,7 +3190,14 @@ __global__ void wgrad_dense_reduce(const f4 *__restrict__ part, int splits, int 
     }
     f4 v = part[t];
     int sidx = 1;
-    for (; sidx + 4 <= splits; sidx += 4) {      // four loads in flight, added in split order
+    for (; sidx + 8 <= splits; sidx += 8) {      // eight loads in flight, added in split order
+        f4 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) w[u] = part[(size_t)(sidx + u) * per + t];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v += w[u];
+    }
+    for (; sidx + 4 <= splits; sidx += 4) {
         f4 w[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) w[u] = part[(size_t)(sidx + u) * per + t];
@@ -3566,7 +3630,10 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
                     hd.drop.seed = drop->seed; hd.drop.step = drop->step; hd.drop.cand0 = drop->cand0;
                     *drop_done = true;
                 }
-                return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3, 1, nullptr, hd);
+                // four-slot ring with the first fragments of a step read one step early (dense_tm PRE); dbg3 = 2: the
+                // three-slot ring of the inference pass -- same bits
+                if (m->dbg[3] == 2) return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3, 1, nullptr, hd);
+                return launch_dense<7, 8, 0, 1, 1>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3, 1, nullptr, hd);
             }
             return launch_dense<21, 8, 0, 2>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);      // slices of more than 2 048 groups: the inference kernel
         }
@@ -3720,7 +3787,12 @@ int cv_tile_heads_train(cv_model *m, const float *d4_tm, const float *h5_tm, con
     if (G <= 0) return 0;
 #define CV_HT(NB5) heads_train_tm<NB5><<<nblk(G, 4), 256, 0, st>>>((const f4 *)d4_tm, (const f4 *)h5_tm, s.nb4, (const f4 *)m->wp_heads0, \
         (const f4 *)m->wp_heads1, P + o[11], P + o[13], P + o[15], P + o[17], P + o[12], P + o[14], P + o[16], a.fc5, y, n, want_grad, \
-        g16, (f4 *)g5pre_tm, m->loss_dev, G)
+        g16, (f4 *)g5pre_tm, rows, G)
+    // the block sums of this slice: rows [loss_rows_used, + blocks) of the step's row buffer (cv_train.hip t_loss_finish)
+    const int64_t blocks = nblk(G, 4);
+    if (m->loss_rows_used + blocks > m->loss_rows_cap) { cv_set_error("heads_train_tm: loss row buffer too small (internal)"); return 1; }
+    double *rows = m->loss_rows + (size_t)m->loss_rows_used * 4;
+    m->loss_rows_used += blocks;
     if (s.nb5 == 11) CV_HT(11);
     else if (s.nb5 == 2) CV_HT(2);
     else { cv_set_error("heads_train_tm: %d fc5 fragments not instantiated", s.nb5); return 1; }

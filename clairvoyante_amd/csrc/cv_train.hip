@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void t_heads(
 struct l2_args { const float *w[CV_NUM_PARAMS / 2]; int64_t count[CV_NUM_PARAMS / 2]; };
 
 // sum of squares / 2 of every kernel (blockIdx.y), one launch
-__global__ void t_l2(l2_args a, double *__restrict__ out)
+__global__ void t_l2(l2_args a, double *__restrict__ out, double *__restrict__ rows)
 {
     __shared__ double sh[256];
     const float *__restrict__ w = a.w[blockIdx.y];
@@ -199,7 +199,12 @@ __global__ void t_l2(l2_args a, double *__restrict__ out)
         if (threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
         __syncthreads();
     }
-    if (threadIdx.x == 0 && sh[0] != 0.0) atomicAdd(out, sh[0] * 0.5);
+    // rows != NULL (tile path): this block's sum to its own slot [kernel][block] -- t_loss_finish adds the slots in a
+    // fixed order; else one atomic per block (the all-plain fallback path)
+    if (threadIdx.x == 0) {
+        if (rows) rows[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = sh[0] * 0.5;
+        else if (sh[0] != 0.0) atomicAdd(out, sh[0] * 0.5);
+    }
 }
 
 // ---- backward pieces -------------------------------------------------------------
@@ -774,14 +779,41 @@ static int train_slice(cv_model *m, const float *x, const float *y, int64_t n, i
 // loss k (k = 0..3: base, zygosity, type, length) of this pass as a (hi, lo) pair of floats whose sum is the
 // double the kernels accumulated; slots 8, 9 = lambda * sum(w^2)/2 likewise; slot 10 = 1 (counts the ranks when
 // the bucket is all-reduced); the rest 0.  A SUM all-reduce of the header therefore keeps ~48 bits of every loss.
-__global__ void t_loss_header(const double *__restrict__ loss, double lambda, float *__restrict__ hdr)
+//
+// Before that the kernel (one block of 256 threads) finishes the loss sums of the tile path in a FIXED order, so that a
+// step's losses are the same bits from run to run: thread t adds the heads kernel's block rows t, t + 256, ... (4 doubles
+// each, `nrows` rows, slice after slice) and, when l2_rows is given, the L2 kernel's block sums [kernel][t] over the
+// kernels; a fixed binary tree over the threads follows; the results are ADDED to loss[0..3] / loss[4] (which hold what
+// the all-plain fallback path accumulated, normally 0).  hdr == NULL (cv_loss): the sums only.
+__global__ __launch_bounds__(256) void t_loss_header(double *__restrict__ loss, double lambda, float *__restrict__ hdr,
+                                                     const double *__restrict__ rows, int64_t nrows,
+                                                     const double *__restrict__ l2_rows, int l2_kernels)
 {
+    __shared__ double sh[5][256];
     const int t = threadIdx.x;
-    if (t >= 16) return;
+    double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int64_t r = t; r < nrows; r += 256)
+#pragma unroll
+        for (int j = 0; j < 4; j++) a[j] += rows[r * 4 + j];
+    if (l2_rows)
+        for (int p = 0; p < l2_kernels; p++) a[4] += l2_rows[(size_t)p * 256 + t];
+#pragma unroll
+    for (int j = 0; j < 5; j++) sh[j][t] = a[j];
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (t < k)
+#pragma unroll
+            for (int j = 0; j < 5; j++) sh[j][t] += sh[j][t + k];
+        __syncthreads();
+    }
+    if (t < 5) loss[t] += sh[t][0];
+    __syncthreads();
+    if (t >= 16 || !hdr) return;
+    __threadfence_block();
     float v = 0.0f;
     if (t < 10) {
         const int k = t >> 1;
-        const double d = k < 4 ? loss[k] : loss[4] * lambda;
+        const double d = k < 4 ? loss[k] : loss[4] * lambda;        // (written above by threads of this block, behind the barrier)
         const float hi = (float)d;
         v = (t & 1) ? (float)(d - (double)hi) : hi;
     } else if (t == 10) v = 1.0f;
@@ -813,6 +845,17 @@ static int train_workspace(cv_model *m, int64_t n, int64_t *slice_out)
         CV_HIP(hipMalloc(&m->t_buf, need));
         m->t_bytes = need;
     }
+    // block rows of the heads kernel: 4 groups per block, slice after slice
+    const int64_t rows_need = nslice * ((slice / 16 + 3) / 4 + 1);
+    if (m->loss_rows_cap < rows_need) {
+        CV_HIP(hipDeviceSynchronize());
+        if (m->loss_rows) CV_HIP(hipFree(m->loss_rows));
+        m->loss_rows = nullptr; m->loss_rows_cap = 0;
+        CV_HIP(hipMalloc(&m->loss_rows, sizeof(double) * 4 * (size_t)rows_need));
+        m->loss_rows_cap = rows_need;
+    }
+    if (!m->l2_rows) CV_HIP(hipMalloc(&m->l2_rows, sizeof(double) * 256 * (CV_NUM_PARAMS / 2)));
+    m->loss_rows_used = 0;
     if (!m->tr_side) {
         CV_HIP(hipStreamCreateWithFlags(&m->tr_side, hipStreamNonBlocking));
         for (int i = 0; i < 2; i++) CV_HIP(hipStreamCreateWithFlags(&m->tr_side_more[i], hipStreamNonBlocking));
@@ -859,7 +902,7 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
         CV_HIP(hipStreamWaitEvent(sw, m->tr_ev[CV_TR_EVENTS - 1], 0));
         l2_args la;
         for (int p = 0; p < CV_NUM_PARAMS; p += 2) { la.w[p / 2] = m->params + m->poff[p]; la.count[p / 2] = m->psize[p]; }
-        t_l2<<<dim3(256, CV_NUM_PARAMS / 2), 256, 0, sw>>>(la, m->loss_dev + 4);
+        t_l2<<<dim3(256, CV_NUM_PARAMS / 2), 256, 0, sw>>>(la, m->loss_dev + 4, tile_path ? m->l2_rows : nullptr);
         l2_done = true;
     }
     bool recorded = false;
@@ -877,9 +920,11 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
     if (lambda != 0.0f && !l2_done) {
         l2_args la;
         for (int p = 0; p < CV_NUM_PARAMS; p += 2) { la.w[p / 2] = m->params + m->poff[p]; la.count[p / 2] = m->psize[p]; }
-        t_l2<<<dim3(256, CV_NUM_PARAMS / 2), 256, 0, st>>>(la, m->loss_dev + 4);
+        t_l2<<<dim3(256, CV_NUM_PARAMS / 2), 256, 0, st>>>(la, m->loss_dev + 4, tile_path ? m->l2_rows : nullptr);
     }
-    if (backward) t_loss_header<<<1, 64, 0, st>>>(m->loss_dev, (double)lambda, m->grads - CV_GRAD_HEADER);
+    // the fixed-order loss sums (and, for a training step, the header of the gradient bucket)
+    t_loss_header<<<1, 256, 0, st>>>(m->loss_dev, (double)lambda, backward ? m->grads - CV_GRAD_HEADER : nullptr, m->loss_rows,
+                                     m->loss_rows_used, (lambda != 0.0f && tile_path) ? m->l2_rows : nullptr, CV_NUM_PARAMS / 2);
     CV_HIP(hipGetLastError());
     return 0;
 }

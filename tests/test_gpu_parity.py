@@ -26,6 +26,7 @@ def setup(request, oracle):
     P = common.bench_params(oracle, arch)
     m = _model(arch)
     m.setParameters(P)
+    m.setOption("keep_activations", 1)       # the tests below read the fc4 / fc5 maps also behind the fused tails
     x = common.inputs(1000, stress=24)
     ref = oracle.forward_all(arch, P, x)
     yield arch, P, m, x, ref
@@ -199,6 +200,7 @@ def test_hip_path_matches_committed_float64_fixture_directly(oracle, arch):
     m = _model(arch)
     try:
         m.setParameters(P)
+        m.setOption("keep_activations", 1)
         x = d["x"].astype(np.float32)
         n = x.shape[0]
         for variant in (common.DEFAULT_VARIANT, 0):       # pass-size default kernels, and the unfused set that keeps pool3
@@ -215,5 +217,36 @@ def test_hip_path_matches_committed_float64_fixture_directly(oracle, arch):
         k = d["pool3_64"].shape[0]
         pool3 = m.getActivation(3, n).cpu().numpy()[:k]          # variant 0: conv3's map is in HBM for both topologies
         assert np.abs(pool3 - d["pool3_64"]).max() <= 2e-5 * np.abs(d["pool3_64"]).max()
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("arch", ["full", "slim"])
+def test_fused_tail_writes_no_maps_unless_asked(oracle, arch):
+    """with fc5 and the heads on the tail of the fc4 kernel the fc4 / fc5 maps have no reader but cv_get_activation: by
+    default they are not written (option keep_activations 0) and asking for them says so; the 16 outputs are the same
+    bits either way"""
+    import torch
+    from clairvoyante_amd import _lib, synth
+    n = 40010
+    xd = synth.make_candidates(n, seed=78, device="cuda")
+    m = _model(arch); m.setParameters(common.bench_params(oracle, arch))
+    try:
+        lean = m.predict_device(xd).cpu().numpy()
+        with pytest.raises(_lib.CvError, match="keep_activations"):
+            m.getActivation(5, n)
+        m.getActivation(2, n)                                     # maps of the layers in front are untouched by the option
+        m.setOption("keep_activations", 1)
+        kept = m.predict_device(xd).cpu().numpy()
+        assert np.array_equal(lean.view(np.uint32), kept.view(np.uint32))
+        fc5 = m.getActivation(5, n).cpu().numpy()
+        want = oracle.forward_all(arch, common.bench_params(oracle, arch), xd[:512].cpu().numpy())
+        assert np.array_equal(fc5[:512].view(np.uint32), want["fc5"].view(np.uint32))
+        assert np.array_equal(lean[:512].view(np.uint32), want["out"].view(np.uint32))
+        small = m.predict_device(xd[:1000].contiguous())           # a pass on separate kernels always leaves its maps
+        m.setOption("keep_activations", 0)
+        small = m.predict_device(xd[:1000].contiguous())
+        if arch == "full":
+            m.getActivation(4, 1000)
     finally:
         m.close()
