@@ -1509,13 +1509,12 @@ __global__ __launch_bounds__(512, 2) void conv3fc4_slim(const f4 *__restrict__ i
 // per k step + 4 per output tile, then heads_finish.  No separate heads launch, the fc5 output is not re-read.
 // GR = groups per wave (1 or 2): with 2 a wave keeps two sets of accumulator tiles and every weight fragment read
 // from LDS feeds both -- twice the MFMA work per barrier and per LDS read, at 2 waves per SIMD.
-// PRE = 1 (fc4 of a training pass, where the registers allow it): a FOUR-slot ring filled three k steps ahead.  A wave
-// then may read the first NPRE weight fragments of step k + 1 while it still multiplies step k -- the barrier that ended
-// step k - 1 already published them -- and carries them across the barrier in registers: its first MFMAs behind a
-// barrier wait for nothing (with three slots every wave of the workgroup opens a step with an LDS round trip while the
-// matrix pipe idles: ~10 % of a 28-MFMA step), and this step's loads / DMA pieces go out behind that first block.
-// Same fragments, same order per accumulator: same bits.
-template <int NB, int WAVES, int EPI = 0, int GR = 1, int PRE = 0>
+// (measured, round 4: a FOUR-slot ring filled three k steps ahead, so that a wave reads the first two weight fragments of
+// step k + 1 while it still multiplies step k, carries them across the barrier in registers and issues this step's loads /
+// DMA pieces behind its first MFMA block -- no LDS round trip between a barrier and the first MFMA.  Bit-identical; the
+// training step did not move: 2.1163 against 2.1167 ms at 10 000, three alternating runs each on one box,
+// profiles/r04/train_ab_fc4_forward_ring.txt.  The step behind a barrier is not what the kernel waits for; removed.)
+template <int NB, int WAVES, int EPI = 0, int GR = 1>
 __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_tm(const f4 *__restrict__ in_tm, int KB,
                                                         const f4 *__restrict__ wp_all,
                                                         const float *__restrict__ bias, int nout,
@@ -1523,9 +1522,6 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
                                                         heads_args hd = heads_args())
 {
     static_assert(EPI != 2 || GR == 1, "the fused heads keep one group per wave");
-    static_assert(!PRE || (GR == 1 && (EPI == 0 || EPI == 1)), "the pre-read ring is written for one group per wave, no fused tail");
-    constexpr int SLOTS = PRE ? 4 : 3, AHEAD = SLOTS - 1;
-    constexpr int NPRE = PRE ? (NB < 2 ? NB : 2) : 0;
     static_assert(EPI != 3 || (GR == 2 && NB == 21 && WAVES == 8), "the fc5 + heads tail is written for the full topology's fc4");
     // The packed weight matrix holds NBP = roundup(NB, WAVES) fragments per k step (the pad
     // fragments are zero and never multiplied), so every thread stages exactly PER 16-byte
@@ -1595,7 +1591,6 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
     };
     stage_async(0, 0);
     stage_async(KB > 1 ? 1 : 0, 1);
-    if constexpr (PRE) stage_async(KB > 2 ? 2 : KB - 1, 2);
     f4 hacc0 = zero, hA = zero;                 // EPI 2: base-head tile and its weight fragment of the current k step
     if constexpr (EPI == 2) hA = load_frag(hd.wp0 + lane);
     f4 B[GR];
@@ -1606,48 +1601,26 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
     if constexpr (EPI == 2) asm volatile("" : "+v"(hA) : : "memory");
     __syncthreads();
     int slot = 0;
-    f4 Apre[NPRE > 0 ? NPRE : 1];               // PRE: the first weight fragments of the coming step, read one step early
-    if constexpr (PRE) {
-#pragma unroll
-        for (int j = 0; j < NPRE; j++) Apre[j] = ring[j * 64 + lane];
-    }
 #pragma unroll 1
     for (int kb = 0; kb < KB; kb++) {
         // stage kb+2 and activation fragment kb+1 (indices clamped: the surplus loads of the
         // last two steps re-read valid data and land in ring slots nobody reads again)
-        const int ks = kb + AHEAD < KB ? kb + AHEAD : KB - 1;
+        const int ks = kb + 2 < KB ? kb + 2 : KB - 1;
         const int kn = kb + 1 < KB ? kb + 1 : KB - 1;
-        int wslot = slot + AHEAD; if (wslot >= SLOTS) wslot -= SLOTS;
+        int wslot = slot + 2; if (wslot >= 3) wslot -= 3;
         f4 Bn[GR];
-        f4 hAn = zero;
-        if constexpr (!PRE) {
 #pragma unroll
-            for (int r = 0; r < GR; r++) Bn[r] = load_frag_off(bo[r] + (unsigned)kn * 1024u);
-            if constexpr (EPI == 2) hAn = load_frag(hd.wp0 + (size_t)kn * 64 + lane);      // issued before this step's DMA pieces
-            stage_async(ks, wslot);          // slot (kb+2)%3 was last read in step kb-1 (barrier passed)
-        }
+        for (int r = 0; r < GR; r++) Bn[r] = load_frag_off(bo[r] + (unsigned)kn * 1024u);
+        f4 hAn = zero;
+        if constexpr (EPI == 2) hAn = load_frag(hd.wp0 + (size_t)kn * 64 + lane);      // issued before this step's DMA pieces
+        stage_async(ks, wslot);          // slot (kb+2)%3 was last read in step kb-1 (barrier passed)
         // (measured, round 3: these loads and pieces issued one per MFMA block instead of here -- what helped the
         // convolution kernels -- makes this ring slower: training step 2.15 -> 2.21 ms, inference 18.41 -> 18.28 M/s on
         // one box; a wave issues at most 5 of them per step, and the barrier needs them early)
         const f4 *wl = ring + slot * STAGE + lane;
         constexpr int AB = EPI == 3 ? 2 : 3;      // weight fragments read ahead of their MFMAs (EPI 3 is short of 4 VGPRs)
-        if constexpr (PRE) {
-            // the fragments carried across the barrier: multiplied at once; this step's loads and DMA pieces (slot
-            // (kb+3)%4, last read in step kb-1) go out behind them, then the first fragments of step kb+1 are fetched
 #pragma unroll
-            for (int s = 0; s < 4; s++)
-#pragma unroll
-                for (int j = 0; j < NPRE; j++) acc[0][j] = mfma4(Apre[j][s], B[0][s], acc[0][j]);
-            __builtin_amdgcn_sched_barrier(0);
-            Bn[0] = load_frag_off(bo[0] + (unsigned)kn * 1024u);
-            stage_async(ks, wslot);
-            int nslot = slot + 1; if (nslot >= SLOTS) nslot -= SLOTS;
-            const f4 *wn = ring + nslot * STAGE + lane;
-#pragma unroll
-            for (int j = 0; j < NPRE; j++) Apre[j] = wn[j * 64];
-        }
-#pragma unroll
-        for (int ob = NPRE; ob < NB; ob += AB) {
+        for (int ob = 0; ob < NB; ob += AB) {
             f4 A[AB];
 #pragma unroll
             for (int j = 0; j < AB; j++)
@@ -1674,14 +1647,10 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(Bn[0]) : : "memory");
         if constexpr (GR == 2) asm volatile("" : "+v"(Bn[1]) : : "memory");      // the same wait covers the second fragment
         if constexpr (EPI == 2) { asm volatile("" : "+v"(hAn) : : "memory"); hA = hAn; }
-        if constexpr (PRE) {                      // the pre-read fragments are in their registers before the barrier
-#pragma unroll
-            for (int j = 0; j < NPRE; j++) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Apre[j]) : : "memory");
-        }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < GR; r++) B[r] = Bn[r];
-        slot = slot + 1 == SLOTS ? 0 : slot + 1;
+        slot = slot + 1 == 3 ? 0 : slot + 1;
     }
     CV_STAMP_END(NB == 7 && EPI == 0, 3);
     const int q = lane >> 4;
@@ -2531,13 +2500,13 @@ int launch_conv3_rot(const float *in, const float *wp, const float *bias, int co
     return 0;
 }
 
-template <int NB, int WAVES, int EPI = 0, int GR = 1, int PRE = 0>
+template <int NB, int WAVES, int EPI = 0, int GR = 1>
 int launch_dense(const float *in, int KB, const float *wp, const float *bias, int nout, float *out, int G,
                  hipStream_t st, int slabs = 1, int ksplit = 1, float *part = nullptr, heads_args hd = heads_args(),
                  cv_dropout_args dr = cv_dropout_args())
 {
-    auto k = dense_tm<NB, WAVES, EPI, GR, PRE>;
-    size_t lds = (size_t)(PRE ? 4 : 3) * ((NB + WAVES - 1) / WAVES * WAVES) * 1024;
+    auto k = dense_tm<NB, WAVES, EPI, GR>;
+    size_t lds = (size_t)3 * ((NB + WAVES - 1) / WAVES * WAVES) * 1024;
     if (EPI == 3) lds = (size_t)3 * 48 * 1024;          // the tail streams fc5 in stages of 4 k fragments x 12 output fragments
     if (set_lds(k, lds)) return 1;
     if (ksplit > 1) {       // partial sums per k range, then dense_ksum (EPI 0 layers only)
@@ -3630,10 +3599,7 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
                     hd.drop.seed = drop->seed; hd.drop.step = drop->step; hd.drop.cand0 = drop->cand0;
                     *drop_done = true;
                 }
-                // four-slot ring with the first fragments of a step read one step early (dense_tm PRE); dbg3 = 2: the
-                // three-slot ring of the inference pass -- same bits
-                if (m->dbg[3] == 2) return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3, 1, nullptr, hd);
-                return launch_dense<7, 8, 0, 1, 1>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3, 1, nullptr, hd);
+                return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3, 1, nullptr, hd);
             }
             return launch_dense<21, 8, 0, 2>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);      // slices of more than 2 048 groups: the inference kernel
         }
