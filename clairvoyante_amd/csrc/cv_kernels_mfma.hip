@@ -1036,7 +1036,19 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
     for (int i = threadIdx.x; i < NFRAG * 64; i += WAVES * 64) ldsw[i] = wp[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    int gX = -1;
+    if (!(SAVE && rows_per > 0) && gridDim.x >= 16) {
+        // XCD-aware mapping (workgroup b runs on XCD b % 8, each XCD has its own L2): the NT waves of a group read the
+        // same input map, and with WAVES = 4, NT = 3 every other group has its waves in two consecutive workgroups =
+        // two XCDs, which then both fetch the map from HBM (measured: 1.44 x the input per launch).  Here XCD x owns
+        // the groups g = x (mod 8): the waves of the workgroups b = x, x + 8, x + 16, ... are numbered in that order,
+        // so a group's waves sit in workgroups of ONE XCD.  A speed-only assumption: the values do not depend on it.
+        const int x = blockIdx.x & 7;
+        const int lw = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * WAVES + (threadIdx.x >> 6));
+        gX = (lw / NT) * 8 + x;
+        wv = gX * NT + lw % NT;
+    }
     const int nt = wv % NT;
     // rows_per == 0: one wave per (group, tile), all HIN positions.  rows_per > 0 (training forward, larger batches):
     // the wave owns the POOLED rows [r0, r1) of the flat (group, row) sequence of its tile, so that a launch is one round
@@ -2487,6 +2499,7 @@ int launch_conv3_rot(const float *in, const float *wp, const float *bias, int co
     size_t lds = (size_t)NT * 3 * 4 * CINB * 1024;
     if (set_lds(k, lds)) return 1;
     unsigned grid = nblk((int64_t)G * NT, WAVES);
+    if (grid >= 16) grid = 8 * nblk((int64_t)((G + 7) / 8) * NT, WAVES);      // per-XCD wave numbering (see the kernel)
     int rows_per = 0;
     if (SAVE && flat_slots > 0) {            // training forward: one round of equal waves (see launch_conv)
         const int64_t rows = (int64_t)G * (HIN - 2);

@@ -94,9 +94,14 @@ def compare_step(oracle, arch, n, rate, lam, lr=1e-3, seed=9, check_mask_rows=Tr
         gref = g_or[name] - l2                                              # the bucket holds the data terms
         err = float(np.abs(g_dev[name] - gref).max() / (np.abs(gref).max() + 1e-30))
         worst = max(worst, err)
-        # 2e-5 of the largest entry at train.py's batch; a gradient is an fp32 sum over all candidates of the batch, whose
-        # rounding grows like the square root of the number of terms (measured: 3.7e-6 / 2.3e-5 worst at 10 000 / 20 000)
-        assert np.abs(g_dev[name] - gref).max() <= 2e-5 * max(1.0, np.sqrt(n / 10000.0)) * np.abs(gref).max() + 1e-7, (name, err)
+        # full: 2e-5 of the largest entry at train.py's batch; a gradient is an fp32 sum over all candidates of the batch,
+        # whose rounding grows like the square root of the number of terms (measured worst: 3.7e-6 at 10 000, 6.6e-6 at
+        # 40 010).  slim: 1e-4, the bound tests/test_gpu_dp.py uses for a k-split fc4 forward -- selu' jumps from 1.05 to
+        # 1.76 at 0, so a pre-activation within rounding of 0 whose eight partial sums come out on the other side than the
+        # oracle's single chain changes one candidate's contribution to a whole column of dW (seen at 20 000: one column
+        # of fc4/kernel off by 4e-5 of the largest entry, every other entry at 1e-7)
+        tol_g = 2e-5 * max(1.0, np.sqrt(n / 10000.0)) if arch == "full" else 1e-4
+        assert np.abs(g_dev[name] - gref).max() <= tol_g * np.abs(gref).max() + 1e-7, (name, err)
         # the optimizer on the DEVICE's gradient (+ lambda w): TF1 Adam, step 1 (v3.py:174)
         w = P[name].copy().ravel(); mm = np.zeros_like(w); vv = np.zeros_like(w)
         gfull = np.ascontiguousarray((g_dev[name] + l2).astype(np.float32).ravel())
