@@ -529,8 +529,11 @@ def Test(args, m, utils):
 
     def reader():
         try:
-            for fn in files:                     # a list of files is called in list order (one VCF, like TestSharded)
-                for item in utils.GetTensor(fn, batch):
+            if len(files) > 1:                   # a list of files is called in list order (one VCF, like TestSharded);
+                for _k, c, X, pos in utils.GetTensorFiles(files, batch, 0, 1):      # compressed files are read ahead, several at a time
+                    q_in.put((0, c, X, pos))
+            else:
+                for item in utils.GetTensor(files[0], batch):
                     q_in.put(item)
         except BaseException as e:   # surfaced on the consumer side (the reference loses it)
             q_in.put(e)

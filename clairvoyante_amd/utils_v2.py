@@ -165,16 +165,74 @@ def GetTensorBlocks(tensor_fn, block_lines, rank, ws):
     proc.wait()
 
 
-def GetTensorFiles(files, num, rank, ws):
-    """Sharding of callVar under torchrun that SCALES: one tensor file per chunk of the genome (the reference's own
-    recipe is one callVarBam / callVar job per chunk, README.md:184-202), file k belongs to rank k % ws -- a rank only
-    ever opens (and inflates) its own files.  Yields (file index, c, X, pos) batches of <= num rows, at least one
-    per owned file."""
-    for k, fn in enumerate(files):
-        if k % ws != rank:
-            continue
-        for _end, c, X, pos in GetTensor(fn, num, log=False):
-            yield k, c, X, pos
+def _default_readers(nfiles):
+    """concurrent file readers of one process: a compressed tensor file arrives at ONE core's inflate rate (~0.15 M
+    rows/s), so several files are inflated side by side (each `gzip -dc` is its own process) while the parser threads
+    serve whichever batch is complete; bounded by the cores this rank may use and by 8"""
+    lws = max(int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))), 1)
+    return max(1, min(nfiles, _lib.usable_cores() // (2 * lws), 8))
+
+
+def GetTensorFiles(files, num, rank, ws, readers=None, depth=2):
+    """One tensor file per chunk of the genome (the reference's own recipe is one callVarBam / callVar job per chunk,
+    README.md:184-202): file k belongs to rank k % ws -- a rank only ever opens (and inflates) its own files -- and is
+    yielded in list order as (file index, c, X, pos) batches of <= num rows, at least one per owned file.
+    Compressed files are read AHEAD: up to `readers` of the rank's files are inflated and parsed concurrently by reader
+    threads (each holds at most `depth` finished batches), the consumer still sees file after file, batch after batch
+    -- the same sequence as reading them one by one.  An error in a reader is raised where its file is consumed."""
+    import threading
+    from queue import Queue
+    owned = [(k, fn) for k, fn in enumerate(files) if k % ws == rank]
+    if readers is None:
+        compressed = bool(owned) and all(_map_plain_text(fn) is None for _k, fn in owned[:1])
+        readers = _default_readers(len(owned)) if compressed else 1
+    if readers <= 1 or len(owned) <= 1:
+        for k, fn in owned:
+            for _end, c, X, pos in GetTensor(fn, num, log=False):
+                yield k, c, X, pos
+        return
+    queues = [Queue(maxsize=depth) for _ in owned]
+    slots = threading.Semaphore(readers)
+    stop = threading.Event()
+
+    def read(i):
+        q = queues[i]
+        try:
+            for _end, c, X, pos in GetTensor(owned[i][1], num, log=False):
+                while not stop.is_set():
+                    try:
+                        q.put((c, X, pos), timeout=0.2)
+                        break
+                    except Exception:                      # queue.Full: the consumer is still on an earlier file
+                        continue
+                if stop.is_set():
+                    return
+            q.put(None)
+        except BaseException as e:                         # surfaced where the file is consumed
+            q.put(e)
+        finally:
+            slots.release()
+
+    def launch():
+        for i in range(len(owned)):                        # files start in list order, `readers` at a time
+            slots.acquire()
+            if stop.is_set():
+                slots.release()
+                return
+            threading.Thread(target=read, args=(i,), daemon=True).start()
+
+    threading.Thread(target=launch, daemon=True).start()
+    try:
+        for i, (k, _fn) in enumerate(owned):
+            while True:
+                item = queues[i].get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                yield (k,) + item
+    finally:
+        stop.set()
 
 
 def _map_plain_text(tensor_fn):
@@ -312,7 +370,9 @@ def GetTensor(tensor_fn, num, log=True):
             break
     if proc is not None:
         fo.close()
-        proc.wait()
+        if proc.wait() == 1:          # gzip: 1 = error (missing / unreadable / corrupt file), 2 = warning.  The reference
+            # reads on with whatever arrived (utils_v2.py:25 never looks at the exit status): a truncated call set
+            raise _lib.CvError("gzip -fdc %s failed (exit status 1): the tensor stream is incomplete" % tensor_fn)
     total += c
     if log:
         print("Processed %d tensors" % total, file=sys.stderr)

@@ -118,6 +118,45 @@ def test_gettensor_plain_text_through_the_memory_map(tag, strip_last_newline, tm
         lib.cv_set_host_threads(min(_lib.usable_cores(), 16))
 
 
+def test_list_of_compressed_files_read_ahead_gives_the_sequential_batches(tmp_path):
+    """GetTensorFiles with several reader threads (a list of .gz files, inflated side by side) yields exactly what reading
+    the files one after the other yields -- order of files, batch boundaries, rows, positions --, for every rank's share;
+    an unreadable file raises where it is consumed, after the batches of the files in front of it"""
+    import gzip
+    import shutil
+    from clairvoyante_amd import utils_v2
+    srcs = [os.path.join(G, "gettensor_a.txt.gz"), os.path.join(G, "gettensor_b.txt.gz")]
+    files = []
+    for i in range(7):
+        fn = str(tmp_path / ("f%d.gz" % i))
+        if i == 3:
+            gzip.open(fn, "wb").close()                       # an empty chunk
+        else:
+            shutil.copy(srcs[i % 2], fn)
+        files.append(fn)
+
+    def flat(it):
+        return [(k, c, np.array(X), list(pos)) for k, c, X, pos in it]
+    for rank, ws in ((0, 1), (1, 2), (2, 3)):
+        for num in (16, 1000):
+            want = flat(utils_v2.GetTensorFiles(files, num, rank, ws, readers=1))
+            got = flat(utils_v2.GetTensorFiles(files, num, rank, ws, readers=4, depth=1))
+            assert [k for k, _c, _x, _p in want] == [k for k, _c, _x, _p in got] and len(want) >= len(files[rank::ws])
+            for a, b in zip(want, got):
+                assert a[1] == b[1] and np.array_equal(a[2], b[2]) and a[3] == b[3]
+    assert utils_v2._default_readers(5) >= 1
+    # a consumer that stops early leaves no reader stuck (the generator's finally tells them)
+    it = utils_v2.GetTensorFiles(files, 16, 0, 1, readers=3, depth=1)
+    next(it); it.close()
+    broken = files[:2] + [str(tmp_path / "missing.gz")] + files[2:3]
+    it = utils_v2.GetTensorFiles(broken, 1000, 0, 1, readers=4)
+    seen = []
+    with pytest.raises(Exception):
+        for k, c, _x, _p in it:
+            seen.append(k)
+    assert set(seen) <= {0, 1, 2} and {0, 1} <= set(seen)
+
+
 def test_training_array_matches_reference():
     from clairvoyante_amd import utils_v2
     d = np.load(os.path.join(G, "trainarray.npz"))
