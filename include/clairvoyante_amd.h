@@ -113,7 +113,9 @@ int cv_format_vcf(const int32_t *call, const float *qual, int64_t n, const float
  * layer 6 / 7 refer to the last cv_grad / cv_loss slice instead: 6 = the alpha-dropout
  * keep mask of fc4 times its affine factor a (selu.py:53-62; 0 where a unit was
  * dropped, a where kept, 1 everywhere at rate 0), 7 = dropout4, the layer's output
- * [n, fc4] -- what the parity tests feed to / compare with the oracle.            */
+ * [n, fc4] -- what the parity tests feed to / compare with the oracle.
+ * Layers 4 / 5 of a pass that ran fc5 and the heads on the tail of the fc4 kernel exist only with option
+ * "keep_activations" set before the pass (error otherwise).                        */
 int cv_get_activation(cv_model *m, int layer, float *dst_dev, int64_t n, void *stream);
 
 /* debug / parity: the device's SELU (csrc/cv_math.hpp, selu.py:21-25) evaluated on every fp32 bit pattern in
@@ -125,7 +127,10 @@ int cv_get_activation(cv_model *m, int layer, float *dst_dev, int64_t n, void *s
 int cv_selu_sweep(int device, uint32_t lo_bits, uint32_t hi_bits, uint64_t *violations, uint64_t *checksum);
 
 /* knobs: "impl" (0 = plain one-thread-per-output kernels, 1 = MFMA tile kernels),
- * "chunk" (candidates per internal pass), "profile" (0/1, see cv_kernel_times), "train_overlap" (0/1: weight
+ * "chunk" (candidates per internal pass), "profile" (0/1, see cv_kernel_times), "keep_activations" (0/1, default 0:
+ * a pass whose fc5 + heads ride on the tail of the fc4 kernel -- variant bit 10 -- also stores the fc4 / fc5 maps,
+ * which then only cv_get_activation layers 4 / 5 read; off, those layers report an error after such a pass and the
+ * kernel writes a third of the bytes), "train_overlap" (0/1: weight
  * gradients of the training step on a side stream next to the data-gradient chain; default 1, same bits),
  * "train_tiny_groups" (0..160, default 160: training batches of up to that many groups of 16 candidates split the
  * serial loops of their layers over more waves -- same bits), "train_ksplit" (0/1, default 1: at such batches

@@ -32,7 +32,9 @@ for b in 10000 1250; do
 done
 python tools/vcf_format_probe.py 2000000 16 > $OUT/vcf_format_probe.txt 2>&1
 python tools/vcf_format_probe.py 2000000 1 >> $OUT/vcf_format_probe.txt 2>&1
-timeout 600 python tools/gpu_callvar_text_probe.py 200000 > $OUT/callvar_text_probe.txt 2>&1
+timeout 900 python tools/gpu_callvar_text_probe.py > $OUT/callvar_text_probe.txt 2>&1
+# the RCCL branch of the training line with ONE rank (exchange timing keys, RCCL log summary)
+CV_FORCE_DIST=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 python bench.py --mode train --steps 20 --warmup 3 > $OUT/bench_train_rccl_one_rank.json 2>> $OUT/bench.err
 timeout 600 python tools/gpu_e2e_bam.py > $OUT/e2e_bam.txt 2>&1
 timeout 300 python tools/gpu_small_batch_probe.py > $OUT/small_batch.txt 2>&1
 tail -3 $OUT/pytest_gpu.log; tail -3 $OUT/smoke.log; cat $OUT/status.txt
