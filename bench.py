@@ -91,39 +91,77 @@ def relaunch_under_torchrun(args, argv):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-_RCCL_LOG = [None]
+_REAL_STDOUT = [None]      # the process's real stdout: ONLY the JSON line goes there
+_CAPTURE = [None]          # what libraries write to file descriptor 1 meanwhile (RCCL's banner and INFO log) lands here
+
+
+def protect_stdout():
+    """The driver reads ONE JSON line from rank 0's stdout.  Libraries write there too (RCCL prints its version banner
+    and, at NCCL_DEBUG=INFO, its log to fd 1), so fd 1 is pointed at a scratch file for the whole run: emit() writes the
+    line to the saved descriptor, release_stdout() forwards the captured chatter to stderr."""
+    import tempfile
+    if _REAL_STDOUT[0] is not None:
+        return
+    sys.stdout.flush()
+    real = os.dup(1)
+    cap = tempfile.NamedTemporaryFile(prefix="cv_bench_fd1_", suffix=".log", delete=False)
+    os.dup2(cap.fileno(), 1)
+    cap.close()
+    _REAL_STDOUT[0] = os.fdopen(real, "w")
+    _CAPTURE[0] = cap.name
+
+
+def emit(line):
+    out = _REAL_STDOUT[0] or sys.stdout
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+
+
+def release_stdout():
+    fn = _CAPTURE[0]
+    if not fn:
+        return
+    try:
+        sys.stdout.flush()
+        with open(fn, errors="replace") as f:
+            text = f.read()
+        if text.strip():
+            sys.stderr.write(text if len(text) < 20000 else text[:20000] + "\n[... %d more bytes of library output]\n" % (len(text) - 20000))
+        os.remove(fn)
+    except OSError:
+        pass
+    _CAPTURE[0] = None
 
 
 def rccl_logging():
-    """Before the process group exists: have RCCL write its INFO log (init, topology graph, per-collective algorithm /
-    protocol choice) to a file per process, so that rank 0 can say ONCE in the line what the exchange ran on.  Nothing is
-    touched when the user set NCCL_DEBUG, the backend is not RCCL, or there is one rank."""
+    """Before the process group exists: ask RCCL for its INFO log (init, topology graph, per-collective algorithm /
+    protocol choice); it arrives on fd 1, i.e. in the capture file, and rank 0 says ONCE in the line what the exchange
+    ran on (rccl_summary).  Nothing is touched when the user set NCCL_DEBUG, the backend is not RCCL, or there is one rank."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     if (ws <= 1 and not os.environ.get("CV_FORCE_DIST")) or "NCCL_DEBUG" in os.environ:
         return
     if (os.environ.get("CV_DIST_BACKEND") or "nccl") != "nccl":
         return
-    import tempfile
-    tmpl = os.path.join(tempfile.gettempdir(), "cv_rccl_%s_%%p.log" % os.environ.get("MASTER_PORT", "0"))
     os.environ["NCCL_DEBUG"] = "INFO"
     os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,TUNING"
-    os.environ["NCCL_DEBUG_FILE"] = tmpl
-    _RCCL_LOG[0] = tmpl.replace("%p", str(os.getpid()))
 
 
 def rccl_summary(max_lines=8):
     """-> dict from this process's RCCL INFO log (None if there is none): library version, channel counts, transports
     between peers, and the distinct (collective, bytes, algorithm, protocol) choices it logged."""
     import re
-    fn = _RCCL_LOG[0]
+    fn = _CAPTURE[0]
     if not fn or not os.path.exists(fn):
         return None
     try:
+        sys.stdout.flush()
         text = open(fn, errors="replace").read()
     except OSError:
         return None
+    if "NCCL" not in text and "RCCL" not in text:
+        return None
     out = {"log_bytes": len(text)}
-    mo = re.search(r"(RCCL|NCCL) version[ :]*([^\n]+)", text)
+    mo = re.search(r"(RCCL|NCCL) version\s*:?\s*([^\n]+)", text)
     if mo:
         out["version"] = mo.group(0).strip()[:120]
     mo = re.search(r"(\d+) coll channels[^\n]*", text)
@@ -199,7 +237,7 @@ def dry_main(args):
     if rank == 0:
         line = {"dry": True, "mode": args.mode, "n_gpus": ws, "counted_ranks": n}
         line.update(rank_info(ws))
-        print(json.dumps(line), flush=True)
+        emit(line)
     finish_ranks()
 
 
@@ -297,7 +335,7 @@ def pileup_main(args):
             cpu = {"value": len(lines) * read_len / cs, "unit": "alignment columns/s", "cores": 1, "kind": "port",
                    "sample": "first %d reads of the timed set through oracle/extract_candidates.py + oracle/create_tensor.py "
                              "(CPython restatement of the reference scripts), %.1f s" % (len(lines), cs)}
-        print(json.dumps({"rccl_ranks": rank_info(ws)["rccl_ranks"], "backend": rank_info(ws)["backend"],
+        emit({"rccl_ranks": rank_info(ws)["rccl_ranks"], "backend": rank_info(ws)["backend"],
                           "metric": "alignment columns/sec (candidates + tensors)", "value": ws * steps * columns / dt,
                           "unit": "columns/s", "n_gpus": ws, "steps": steps, "warmup": args.warmup,
                           "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -308,7 +346,7 @@ def pileup_main(args):
                           "roofline": roof, "cpu_baseline": cpu,
                           "host_inclusive": {"seconds": host_s, "sam_MB_per_s": len(text) / host_s / 1e6,
                                              "columns_per_s": columns / host_s},
-                          "parity": {"repeat_passes_identical": bool(same)}}), flush=True)
+                          "parity": {"repeat_passes_identical": bool(same)}})
     pl.close()
     finish_ranks()
 
@@ -486,7 +524,7 @@ def train_main(args):
             if k in r:
                 line[k] = r[k]
         line.update(rank_info(ws))
-        print(json.dumps(line), flush=True)
+        emit(line)
     finish_ranks()
 
 
@@ -638,6 +676,9 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args, sys.argv[1:])          # does not return
+    protect_stdout()          # from here on only emit() reaches the real stdout
+    import atexit
+    atexit.register(release_stdout)
     if args.dry:
         return dry_main(args)
     if args.mode == "train":
@@ -711,7 +752,7 @@ def main():
             except Exception as e:
                 line["parity"]["max_abs_dprob_vs_float64"] = None
                 line["parity"]["float64_error"] = str(e)
-        print(json.dumps(line), flush=True)
+        emit(line)
     m.close()
     finish_ranks()
 

@@ -434,13 +434,29 @@ def TestSharded(args, m, utils, rank, ws):
 
     def reader():
         try:
-            src = utils.GetTensorFiles(files, max(param.predictBatchSize, 16384), rank, ws) if len(files) > 1 else \
-                utils.GetTensorBlocks(files[0], SHARD_BLOCK_LINES, rank, ws)
-            for item in src:
-                q_in.put(item)
+            if len(files) > 1:       # this rank's files, compressed ones several at a time, batches as they complete
+                for item in utils.GetTensorFiles(files, max(param.predictBatchSize, 16384), rank, ws, ordered=False):
+                    q_in.put(item)
+            else:                    # one batch per owned block of lines
+                for block, num, X, pos in utils.GetTensorBlocks(files[0], SHARD_BLOCK_LINES, rank, ws):
+                    q_in.put((block, num, X, pos))
+                    q_in.put((block, None, None, None))
         except BaseException as e:
             q_in.put(e)
         q_in.put(None)
+
+    # the fragment holds this rank's blocks / files in ascending order (merge_fragments walks k = 0, 1, 2, ...): text that
+    # is ready before its turn waits in memory (_OrderedWriter); one index entry per block that was seen
+    seen = set()
+
+    def write(k, text):
+        frag.write(text)
+        if index and index[-1][0] == k:
+            index[-1] = (k, index[-1][1] + len(text))
+        else:
+            index.append((k, len(text)))
+
+    out = _OrderedWriter(write, first=rank, step=ws)
 
     rt = Thread(target=reader, daemon=True)
     rt.start()
@@ -453,29 +469,24 @@ def TestSharded(args, m, utils, rank, ws):
                 if isinstance(item, BaseException):
                     raise item
                 nxt = None
-                if item is not None:
+                if item is not None and item[1] is not None and item[1] > 0:
                     block, num, X, pos = item
-                    call = qual = None
-                    ev = None
-                    if num > 0:
-                        xd = torch.from_numpy(X).to(m.device, non_blocking=True)
-                        call, qual = predict_and_reduce(m, xd)
-                        ev = fetcher.mark()
-                    nxt = (block, num, X, pos, call, qual, ev)
+                    xd = torch.from_numpy(X).to(m.device, non_blocking=True)
+                    call, qual = predict_and_reduce(m, xd)
+                    nxt = (block, num, X, pos, call, qual, fetcher.mark())
                 if pending is not None:
                     pblock, pnum, pX, ppos, pcall, pqual, pev = pending
-                    text = b""
-                    if pnum > 0:
-                        hcall, hqual = fetcher.fetch(pev, pcall, pqual)
-                        text = format_records(args, pnum, pX, ppos, hcall, hqual)
-                    frag.write(text)
-                    if index and index[-1][0] == pblock:          # further batches of the same block (a whole file)
-                        index[-1] = (pblock, index[-1][1] + len(text))
-                    else:
-                        index.append((pblock, len(text)))
+                    hcall, hqual = fetcher.fetch(pev, pcall, pqual)
+                    out.add(pblock, format_records(args, pnum, pX, ppos, hcall, hqual))
                 pending = nxt
+                if item is not None and item[1] is None:      # block / file complete (its last batch was formatted above)
+                    seen.add(item[0])
+                    out.end(item[0])
                 if item is None:
                     break
+        # every block this rank owns gets an index entry, also one without records (merge_fragments counts them)
+        have = dict(index)
+        index = [(k, have.get(k, 0)) for k in sorted(seen)]
         frag.close()
         with open(frag_fn + ".idx", "w") as f:
             f.write("".join("%d %d\n" % e for e in index))
@@ -510,10 +521,36 @@ def TestSharded(args, m, utils, rank, ws):
     dist.barrier()
 
 
+class _OrderedWriter(object):
+    """VCF text of several input files, produced in any order, written in LIST order: the text of the file whose turn
+    it is goes straight to the output, that of files further down the list waits in memory (records only -- a few per
+    cent of the input rows) until the files in front of them are complete."""
+
+    def __init__(self, write, first=0, step=1):
+        self.write, self.next, self.step = write, first, step
+        self.held, self.done = {}, set()
+
+    def add(self, k, text):
+        if not text:
+            return
+        if k == self.next:
+            self.write(k, text)
+        else:
+            self.held.setdefault(k, []).append(text)
+
+    def end(self, k):
+        self.done.add(k)
+        while self.next in self.done:
+            self.done.discard(self.next)
+            self.next += self.step
+            for text in self.held.pop(self.next, []):
+                self.write(self.next, text)
+
+
 def Test(args, m, utils):
-    """callVar.py:180-216 re-cut for the GPU: reader thread (parse) || GPU (predict + per-
-    candidate reductions) || writer (format); batches stay in order, so the VCF is the
-    reference's record for record."""
+    """callVar.py:180-216 re-cut for the GPU: reader thread(s) (inflate, parse) || GPU (predict + per-candidate
+    reductions) || writer (format); the records of a file stay in the order of its rows, files in list order, so the VCF
+    is the reference's record for record."""
     import torch
     from . import _lib
     call_fh = open(args.call_fn, "w")
@@ -529,19 +566,21 @@ def Test(args, m, utils):
 
     def reader():
         try:
-            if len(files) > 1:                   # a list of files is called in list order (one VCF, like TestSharded);
-                for _k, c, X, pos in utils.GetTensorFiles(files, batch, 0, 1):      # compressed files are read ahead, several at a time
-                    q_in.put((0, c, X, pos))
-            else:
-                for item in utils.GetTensor(files[0], batch):
+            if len(files) > 1:                   # a list of files: compressed ones are inflated several at a time and their
+                for item in utils.GetTensorFiles(files, batch, 0, 1, ordered=False):     # batches taken as they complete
                     q_in.put(item)
+            else:
+                for _end, c, X, pos in utils.GetTensor(files[0], batch):
+                    q_in.put((0, c, X, pos))
+                q_in.put((0, None, None, None))
         except BaseException as e:   # surfaced on the consumer side (the reference loses it)
             q_in.put(e)
         q_in.put(None)
 
     rt = Thread(target=reader, daemon=True)
     rt.start()
-    pending = None                   # (num, X, pos, call_dev, qual_dev, event)
+    out = _OrderedWriter(lambda _k, text: call_fh.write(text.decode("ascii")))
+    pending = None                   # (file, num, X, pos, call_dev, qual_dev, event)
     with torch.cuda.device(m.device):
         fetcher = ResultFetcher(m)
         while True:
@@ -549,17 +588,18 @@ def Test(args, m, utils):
             if isinstance(item, BaseException):
                 raise item
             nxt = None
-            if item is not None:
-                end, num, X, pos = item
-                if num > 0:
-                    xd = torch.from_numpy(X).to(m.device, non_blocking=True)
-                    call, qual = predict_and_reduce(m, xd)
-                    nxt = (num, X, pos, call, qual, fetcher.mark())
-            if pending is not None:      # format batch k while the GPU works on batch k+1
-                pnum, pX, ppos, pcall, pqual, pev = pending
+            if item is not None and item[1] is not None and item[1] > 0:
+                k, num, X, pos = item
+                xd = torch.from_numpy(X).to(m.device, non_blocking=True)
+                call, qual = predict_and_reduce(m, xd)
+                nxt = (k, num, X, pos, call, qual, fetcher.mark())
+            if pending is not None:      # format batch j while the GPU works on batch j+1
+                pk, pnum, pX, ppos, pcall, pqual, pev = pending
                 hcall, hqual = fetcher.fetch(pev, pcall, pqual)
-                OutputFromDevice(args, call_fh, pnum, pX, ppos, hcall, hqual)
+                out.add(pk, format_records(args, pnum, pX, ppos, hcall, hqual))
             pending = nxt
+            if item is not None and item[1] is None:      # end of file k (its last batch was formatted just above)
+                out.end(item[0])
             if item is None:
                 break
     call_fh.close()

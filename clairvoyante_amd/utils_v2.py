@@ -173,15 +173,21 @@ def _default_readers(nfiles):
     return max(1, min(nfiles, _lib.usable_cores() // (2 * lws), 8))
 
 
-def GetTensorFiles(files, num, rank, ws, readers=None, depth=2):
+def GetTensorFiles(files, num, rank, ws, readers=None, depth=2, ordered=True):
     """One tensor file per chunk of the genome (the reference's own recipe is one callVarBam / callVar job per chunk,
-    README.md:184-202): file k belongs to rank k % ws -- a rank only ever opens (and inflates) its own files -- and is
-    yielded in list order as (file index, c, X, pos) batches of <= num rows, at least one per owned file.
-    Compressed files are read AHEAD: up to `readers` of the rank's files are inflated and parsed concurrently by reader
-    threads (each holds at most `depth` finished batches), the consumer still sees file after file, batch after batch
-    -- the same sequence as reading them one by one.  An error in a reader is raised where its file is consumed."""
+    README.md:184-202): file k belongs to rank k % ws -- a rank only ever opens (and inflates) its own files.  Yields
+    (file index, c, X, pos) batches of <= num rows, at least one per owned file.
+    Compressed files arrive at ONE core's inflate rate each, so up to `readers` of the rank's files are inflated and
+    parsed concurrently by reader threads (started in list order, `depth` finished batches per reader in flight):
+      ordered=True   the consumer sees file after file, batch after batch -- the sequence of reading them one by one
+                     (a reader that runs ahead waits with `depth` batches until its file's turn comes);
+      ordered=False  batches are handed over as they complete, whichever file they belong to (the batches of ONE file
+                     still in order), and (file index, None, None, None) follows the last batch of a file: for a
+                     consumer that keeps the per-file results apart and joins them in list order itself (callVar) --
+                     all readers stay busy, `readers` x the rate of one file.
+    An error in a reader is raised in the consumer."""
     import threading
-    from queue import Queue
+    from queue import Queue, Full
     owned = [(k, fn) for k, fn in enumerate(files) if k % ws == rank]
     if readers is None:
         compressed = bool(owned) and all(_map_plain_text(fn) is None for _k, fn in owned[:1])
@@ -190,26 +196,31 @@ def GetTensorFiles(files, num, rank, ws, readers=None, depth=2):
         for k, fn in owned:
             for _end, c, X, pos in GetTensor(fn, num, log=False):
                 yield k, c, X, pos
+            if not ordered:
+                yield k, None, None, None
         return
-    queues = [Queue(maxsize=depth) for _ in owned]
+    queues = [Queue(maxsize=depth) for _ in owned] if ordered else [Queue(maxsize=depth * readers)] * len(owned)
     slots = threading.Semaphore(readers)
     stop = threading.Event()
+
+    def put(q, item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.2)
+                return True
+            except Full:                                   # the consumer is busy elsewhere: look at `stop` and wait on
+                continue
+        return False
 
     def read(i):
         q = queues[i]
         try:
             for _end, c, X, pos in GetTensor(owned[i][1], num, log=False):
-                while not stop.is_set():
-                    try:
-                        q.put((c, X, pos), timeout=0.2)
-                        break
-                    except Exception:                      # queue.Full: the consumer is still on an earlier file
-                        continue
-                if stop.is_set():
+                if not put(q, (i, c, X, pos)):
                     return
-            q.put(None)
-        except BaseException as e:                         # surfaced where the file is consumed
-            q.put(e)
+            put(q, (i, None, None, None))
+        except BaseException as e:                         # surfaced in the consumer
+            put(q, (i, e, None, None))
         finally:
             slots.release()
 
@@ -223,14 +234,24 @@ def GetTensorFiles(files, num, rank, ws, readers=None, depth=2):
 
     threading.Thread(target=launch, daemon=True).start()
     try:
-        for i, (k, _fn) in enumerate(owned):
-            while True:
-                item = queues[i].get()
-                if item is None:
-                    break
-                if isinstance(item, BaseException):
-                    raise item
-                yield (k,) + item
+        if ordered:
+            for i, (k, _fn) in enumerate(owned):
+                while True:
+                    _i, c, X, pos = queues[i].get()
+                    if c is None:
+                        break
+                    if isinstance(c, BaseException):
+                        raise c
+                    yield k, c, X, pos
+        else:
+            left = len(owned)
+            while left:
+                i, c, X, pos = queues[0].get()
+                if isinstance(c, BaseException):
+                    raise c
+                if c is None:
+                    left -= 1
+                yield owned[i][0], c, X, pos
     finally:
         stop.set()
 

@@ -144,6 +144,21 @@ def test_list_of_compressed_files_read_ahead_gives_the_sequential_batches(tmp_pa
             assert [k for k, _c, _x, _p in want] == [k for k, _c, _x, _p in got] and len(want) >= len(files[rank::ws])
             for a, b in zip(want, got):
                 assert a[1] == b[1] and np.array_equal(a[2], b[2]) and a[3] == b[3]
+    # unordered hand-over: per file the same batches in the same order, an end marker behind each file's last batch
+    for readers in (1, 4):
+        per_file, ended = {}, []
+        for k, c, X, pos in utils_v2.GetTensorFiles(files, 16, 0, 1, readers=readers, ordered=False):
+            if c is None:
+                ended.append(k)
+            else:
+                assert k not in ended
+                per_file.setdefault(k, []).append((k, c, np.array(X), list(pos)))
+        assert sorted(ended) == list(range(len(files)))
+        want = flat(utils_v2.GetTensorFiles(files, 16, 0, 1, readers=1))
+        got = [b for k in range(len(files)) for b in per_file.get(k, [])]
+        assert len(want) == len(got)
+        for a, b in zip(want, got):
+            assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and a[3] == b[3]
     assert utils_v2._default_readers(5) >= 1
     # a consumer that stops early leaves no reader stuck (the generator's finally tells them)
     it = utils_v2.GetTensorFiles(files, 16, 0, 1, readers=3, depth=1)
