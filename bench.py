@@ -111,6 +111,14 @@ def protect_stdout():
     _CAPTURE[0] = cap.name
 
 
+def _flush_c_stdio():
+    """RCCL prints through C stdio, which buffers fully when fd 1 is a file: push it out before the capture is read"""
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def emit(line):
     out = _REAL_STDOUT[0] or sys.stdout
     out.write(json.dumps(line) + "\n")
@@ -123,6 +131,7 @@ def release_stdout():
         return
     try:
         sys.stdout.flush()
+        _flush_c_stdio()
         with open(fn, errors="replace") as f:
             text = f.read()
         if text.strip():
@@ -155,6 +164,7 @@ def rccl_summary(max_lines=8):
         return None
     try:
         sys.stdout.flush()
+        _flush_c_stdio()
         text = open(fn, errors="replace").read()
     except OSError:
         return None
