@@ -56,9 +56,23 @@ struct cv_stamp {
 };
 #define CV_STAMP_BEGIN const cv_stamp cv_st;
 #define CV_STAMP_END(cond, kid) do { if (cond) cv_st.end(kid); } while (0)
+// -DCV_ROW_PHASES on top: where the cycles of a barrier-ring loop go, per wave (record id 7: cycles up to the end of the
+// iteration's instruction issue / waiting for its own memory operations / waiting at the barrier, summed over the loop;
+// the fourth word is the wave's index in its workgroup).  tools/gpu_row_phases.py prints the shares.
+#ifdef CV_ROW_PHASES
+#define CV_PHASE_BEGIN unsigned long long cv_ph[3] = {0, 0, 0}; unsigned long long cv_pt = __builtin_amdgcn_s_memtime();
+#define CV_PHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cv_ph[i] += t_ - cv_pt; cv_pt = t_; } while (0)
+#define CV_PHASE_END(cond, w) do { if ((cond) && (threadIdx.x & 63) == 0) { const unsigned i_ = atomicAdd(&cv_wg_stamp_n[7], 1u) & 4095u; \
+    unsigned long long *o_ = cv_wg_stamp + ((size_t)7 * 4096 + i_) * 4; o_[0] = cv_ph[0]; o_[1] = cv_ph[1]; o_[2] = cv_ph[2]; o_[3] = (unsigned long long)(w); } } while (0)
+#endif
 #else
 #define CV_STAMP_BEGIN
 #define CV_STAMP_END(cond, kid) do { } while (0)
+#endif
+#ifndef CV_PHASE_BEGIN
+#define CV_PHASE_BEGIN
+#define CV_PHASE(i) do { } while (0)
+#define CV_PHASE_END(cond, w) do { } while (0)
 #endif
 
 namespace {
@@ -1979,6 +1993,9 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_unpool(const f4 *__restrict
 // dense_tm EPI 1.  Loads and DMA from inline asm; per iteration: GR stores (row r-1), 2 GR loads (pooled output and codes
 // of row r), PER DMA pieces (weights of row r+2), one counted wait that leaves only the DMA pieces in flight.
 // ---------------------------------------------------------------------------
+#ifndef CV_DGRAD_KLATE
+#define CV_DGRAD_KLATE 9            // head length of the second wave of a SIMD (measured: 9 against 15, step 2.109 against 2.115 ms)
+#endif
 template <int NB, int P, int WAVES, int GR>
 __global__ __launch_bounds__(WAVES * 64, 2) void dense_dgrad_unpool(const f4 *__restrict__ g_tm, const f4 *__restrict__ wpr,
                                                                   const f4 *__restrict__ pooled, const u32x2 *__restrict__ codes,
@@ -2013,10 +2030,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void dense_dgrad_unpool(const f4 *__
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
         return v;
     };
-    auto load_u2 = [&](const u32x2 *ptr) {
-        u32x2 v;
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    // per-row traffic of the unpool window: SCALAR base addresses (group, column and row are wave-uniform) + one lane
+    // offset for everything -- no 64-bit vector pointers live across the loop.  The kernel sits at the 256-register limit
+    // of two waves per SIMD; with twelve registers of addresses more, hipcc had the two accumulators of a wave hop between
+    // register quads to make room for the next weight fragment's LDS read, and every hop is an MFMA -> ds_read hazard it
+    // pads with s_nop 7 / s_nop 4 in front of dependent MFMAs (38 instead of 32 cycles per MFMA, measured per wave).
+    const unsigned lane16 = (unsigned)lane * 16u, lane8 = (unsigned)lane * 8u;
+    auto load_f4_s = [&](const f4 *sbase) {
+        f4 v;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(lane16), "s"(sbase) : "memory");
         return v;
+    };
+    auto load_u1_s = [&](const unsigned *sbase) {          // one dword of every lane's 8-byte code word
+        unsigned v;
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(lane8), "s"(sbase) : "memory");
+        return v;
+    };
+    auto store_f4_s = [&](f4 *sbase, f4 v) {
+        asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(lane16), "v"(v), "s"(sbase) : "memory");
     };
     int gl[GR]; bool live[GR];
 #pragma unroll
@@ -2041,55 +2072,88 @@ __global__ __launch_bounds__(WAVES * 64, 2) void dense_dgrad_unpool(const f4 *__
         for (int kb = 0; kb < NB; kb++) asm volatile("" : "+v"(B[r][kb]));
     __syncthreads();
     unpool_col<P> U[GR];
-    const f4 *pp[GR]; const u32x2 *cp[GR]; f4 *op[GR];
 #pragma unroll
-    for (int r = 0; r < GR; r++) {
-        U[r].init();
-        pp[r] = pooled + ((size_t)gl[r] * HO * NCOL + col) * 64 + lane;
-        cp[r] = codes + ((size_t)gl[r] * HO * NT + nt) * 64 + lane;
-        op[r] = gpre + ((size_t)gl[r] * (HO + P - 1) * NCOL + col) * 64 + lane;
-    }
-    f4 acc[GR], yv[GR]; u32x2 cv[GR];
+    for (int r = 0; r < GR; r++) U[r].init();
+    // lane 0's element of (group r, this column, row): scalar pointers
+    auto pooled_at = [&](int r, int row) { return pooled + ((size_t)gl[r] * HO * NCOL + col + (size_t)row * NCOL) * 64; };
+    auto gpre_at = [&](int r, int row) { return gpre + ((size_t)gl[r] * (HO + P - 1) * NCOL + col + (size_t)row * NCOL) * 64; };
+    auto code_at = [&](int r, int row) {                   // the dword that holds base w's 16 code bits (cv_code16)
+        return reinterpret_cast<const unsigned *>(codes + ((size_t)gl[r] * HO * NT + nt + (size_t)row * NT) * 64) + (w >> 1);
+    };
+    f4 acc[GR], yv[GR]; unsigned cv[GR];
 #pragma unroll
-    for (int r = 0; r < GR; r++) { acc[r] = zero; yv[r] = zero; cv[r] = (u32x2){0u, 0u}; }
-    // row `row` leaves the accumulators: into the unpool window, one finished row out
-    auto finish_row = [&](int row) {
+    for (int r = 0; r < GR; r++) { acc[r] = zero; yv[r] = zero; cv[r] = 0u; }
+    // row `row` leaves the accumulators (a copy: the next row is already being multiplied): into the unpool window, one
+    // finished row out
+    auto finish_row = [&](int row, const f4 (&done)[GR]) {
 #pragma unroll
         for (int r = 0; r < GR; r++) {
-            U[r].push(acc[r], yv[r], cv_code16(cv[r][0], cv[r][1], w));
+            U[r].push(done[r], yv[r], (cv[r] >> (16 * (w & 1))) & 0xFFFFu);
             const f4 o = U[r].emit();
-            if (live[r] && row >= pa) op[r][(size_t)row * NCOL * 64] = o;      // (a plain store: older than the DMA pieces the counted wait leaves in flight)
+            if (live[r] && row >= pa) store_f4_s(gpre_at(r, row), o);      // (older than the DMA pieces the counted wait leaves in flight)
         }
     };
-    int slot = 0;
-#pragma unroll 1
-    for (int row = lo; row <= hi; row++) {
-        if (row > lo) finish_row(row - 1);
+    // the MFMAs of the k fragments [k0, k1) of the current row
+    // the MFMAs of the k fragments [k0, k1) of the current row.  (Measured, round 4: the reads of fragments kb + 2, kb + 3
+    // issued from inline asm BEFORE the MFMAs of kb, kb + 1 with counted lgkmcnt waits -- hipcc sinks every ds_read to
+    // just in front of its MFMAs, "2 reads, wait, 8 MFMAs, wait, 8 MFMAs" -- changed nothing: 295.1 -> 294.1 us, the
+    // partner wave covers the LDS round trips; profiles/r04/lib_ab_dgrad_lds_read_ahead.txt.  Nor do the register hops
+    // hipcc makes the two accumulators take (destination quad != addend quad, padded with s_nop 4..7 in front of the
+    // next LDS read) cost anything measurable: with the MFMAs issued from inline asm on tied registers the stream is
+    // clean and the kernel no faster, 292 against 287 us -- and wrong, the compiler no longer pads the hazards around
+    // instructions it cannot see.)
+    auto multiply = [&](const f4 *wl, int k0, int k1) {
 #pragma unroll
-        for (int r = 0; r < GR; r++) {
-            yv[r] = load_f4(pp[r] + (size_t)row * NCOL * 64);
-            cv[r] = load_u2(cp[r] + (size_t)row * NT * 64);
-            acc[r] = zero;
-        }
-        const int rs = row + 2 <= hi ? row + 2 : hi;
-        int wslot = slot + 2; if (wslot >= 3) wslot -= 3;
-        stage_async(rs, wslot);
-        const f4 *wl = ring + slot * STAGE + lane;
-#pragma unroll
-        for (int kb = 0; kb < NB; kb += 3) {
+        for (int kb = k0; kb < k1; kb += 3) {
             f4 A[3];
 #pragma unroll
             for (int j = 0; j < 3; j++)
-                if (kb + j < NB) A[j] = wl[(kb + j) * 64];
+                if (kb + j < k1) A[j] = wl[(kb + j) * 64];
 #pragma unroll
             for (int j = 0; j < 3; j++)
 #pragma unroll
                 for (int s4 = 0; s4 < 4; s4++)
 #pragma unroll
                     for (int r = 0; r < GR; r++)
-                        if (kb + j < NB) acc[r] = mfma4(A[j][s4], B[r][kb + j][s4], acc[r]);
+                        if (kb + j < k1) acc[r] = mfma4(A[j][s4], B[r][kb + j][s4], acc[r]);
         }
+    };
+    // A row opens with MFMAs, not with the bookkeeping of the row before: behind a barrier both waves of a SIMD are at
+    // the same place, and ~150 vector / scalar / memory instructions each (unpool window, store, this row's loads, the
+    // DMA pieces) in front of the first MFMA left the matrix pipe idle for about a tenth of a row.  Now a wave multiplies
+    // a HEAD of the row's fragments first; the finished row of the previous iteration (its accumulators live on in
+    // `done`), this row's loads and the DMA pieces follow in that order -- the order the counted wait below relies on --,
+    // then the rest of the fragments.  The two waves that share a SIMD (waves w and w + WAVES/2 of a workgroup) take
+    // heads of different length, 3 and 9 of the 21 fragments, so that one of them always has MFMAs for the pipe while the
+    // other does its bookkeeping.  Same chain per value.
+    constexpr int KEARLY = NB >= 6 ? 3 : NB, KLATE = NB >= 18 ? CV_DGRAD_KLATE : KEARLY;
+    const bool late = wid >= WAVES / 2;
+    int slot = 0;
+    CV_PHASE_BEGIN
+#pragma unroll 1
+    for (int row = lo; row <= hi; row++) {
+        f4 done[GR];
+#pragma unroll
+        for (int r = 0; r < GR; r++) { done[r] = acc[r]; acc[r] = zero; }
+        const f4 *wl = ring + slot * STAGE + lane;
+        const int rs = row + 2 <= hi ? row + 2 : hi;
+        int wslot = slot + 2; if (wslot >= 3) wslot -= 3;
+        auto bookkeeping = [&]() {
+            if (row > lo) finish_row(row - 1, done);
+#pragma unroll
+            for (int r = 0; r < GR; r++) {
+                yv[r] = load_f4_s(pooled_at(r, row));
+                cv[r] = load_u1_s(code_at(r, row));
+            }
+            stage_async(rs, wslot);
+        };
+        multiply(wl, 0, KEARLY);
+        if (!late) bookkeeping();
+        if constexpr (KLATE > KEARLY) multiply(wl, KEARLY, KLATE);
+        if (late) bookkeeping();
+        multiply(wl, KLATE, NB);
         __builtin_amdgcn_sched_barrier(0);
+        CV_PHASE(0);                                        // (development probe: cycles up to here = issue of the row's work)
         // counted wait: only this iteration's PER DMA pieces (weights of row + 2) stay in flight -- VMEM operations
         // complete in order, and the pieces are the newest ones; the loads of this row and the store of the previous
         // one are done.  The barrier then publishes the weights of row + 1.
@@ -2098,21 +2162,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void dense_dgrad_unpool(const f4 *__
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int r = 0; r < GR; r++) { asm volatile("" : "+v"(yv[r])); asm volatile("" : "+v"(cv[r])); }
+        CV_PHASE(1);                                        // ... waiting for this wave's loads / the DMA pieces of the next row
         __syncthreads();
+        CV_PHASE(2);                                        // ... waiting for the other waves at the barrier
         slot = slot + 1 == 3 ? 0 : slot + 1;
     }
-    finish_row(hi);
+    CV_PHASE_END(GR == 2, wid);
+    finish_row(hi, acc);
     if (hi == HO - 1) {                                    // the last P - 1 output rows start no window
         for (int row = HO; row < pb; row++) {
 #pragma unroll
             for (int r = 0; r < GR; r++) {
                 U[r].push_none();
                 const f4 o = U[r].emit();
-                if (live[r] && row >= pa) op[r][(size_t)row * NCOL * 64] = o;
+                if (live[r] && row >= pa) store_f4_s(gpre_at(r, row), o);
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // surplus DMA pieces of the last rows
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // surplus DMA pieces of the last rows, the stores
     CV_STAMP_END(true, 4);
 }
 
