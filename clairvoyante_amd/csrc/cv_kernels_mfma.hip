@@ -2030,24 +2030,32 @@ __global__ __launch_bounds__(WAVES * 64, 2) void dense_dgrad_unpool(const f4 *__
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
         return v;
     };
-    // per-row traffic of the unpool window: SCALAR base addresses (group, column and row are wave-uniform) + one lane
-    // offset for everything -- no 64-bit vector pointers live across the loop.  The kernel sits at the 256-register limit
-    // of two waves per SIMD; with twelve registers of addresses more, hipcc had the two accumulators of a wave hop between
-    // register quads to make room for the next weight fragment's LDS read, and every hop is an MFMA -> ds_read hazard it
-    // pads with s_nop 7 / s_nop 4 in front of dependent MFMAs (38 instead of 32 cycles per MFMA, measured per wave).
+    // per-row traffic of the unpool window with SCALAR base addresses (group, column and row are wave-uniform) + one lane
+    // offset for everything -- no 64-bit vector pointers live across the loop (used with one group per wave, see below).
+    // (The bases are recomputed by scalar instructions right in front of these statements, and the compiler cannot see
+    // that the asm is a memory instruction: the wait states it would insert are written out -- 5 between a scalar write
+    // of an SGPR and a vector-memory instruction that uses it as address, 2 (gfx940 and later; 1 before) behind a store of
+    // more than 8 bytes before its data registers may be overwritten.  With one wait state behind the store the very next
+    // instruction -- the unpool arithmetic of the wave's second group -- rewrote half of the stored fragment: the step was
+    // wrong, differently from run to run, and only tests/test_gpu_train_parity.py at 10 000+ candidates said so.)
     const unsigned lane16 = (unsigned)lane * 16u, lane8 = (unsigned)lane * 8u;
     auto load_f4_s = [&](const f4 *sbase) {
         f4 v;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(lane16), "s"(sbase) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(lane16), "s"(sbase) : "memory");
         return v;
     };
     auto load_u1_s = [&](const unsigned *sbase) {          // one dword of every lane's 8-byte code word
         unsigned v;
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(lane8), "s"(sbase) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(v) : "v"(lane8), "s"(sbase) : "memory");
         return v;
     };
     auto store_f4_s = [&](f4 *sbase, f4 v) {
-        asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(lane16), "v"(v), "s"(sbase) : "memory");
+        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(lane16), "v"(v), "s"(sbase) : "memory");
+    };
+    auto load_u2 = [&](const u32x2 *ptr) {
+        u32x2 v;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+        return v;
     };
     int gl[GR]; bool live[GR];
 #pragma unroll
@@ -2074,23 +2082,43 @@ __global__ __launch_bounds__(WAVES * 64, 2) void dense_dgrad_unpool(const f4 *__
     unpool_col<P> U[GR];
 #pragma unroll
     for (int r = 0; r < GR; r++) U[r].init();
+    // Two groups per wave keep the round-3 form of this traffic: 64-bit vector pointers, the whole code word, a
+    // compiler-visible store.  With the scalar bases below the kernel needs 232 registers instead of 244 and is 9 us faster
+    // on its own (296 -> 287 us), but the STEP is 45 us slower (2.16 against 2.11 ms, same box, profiles/r04/
+    // train_10000_timeline_{r03_head,scalar_addressing}.txt): at 232 registers the small kernels at the head of the side
+    // stream fit next to this kernel's workgroups on a CU instead of queueing behind it, the side stream runs ahead, fc4's
+    // weight gradient arrives before conv3's data gradient and takes the CUs from the data-gradient chain.  (Side-stream
+    // priorities and three other enqueue orders did not restore the old schedule.)  One group per wave (small batches,
+    // nothing to compete with): the scalar form, 0.606 -> 0.592 ms per step at 1 250.
+    constexpr bool SCALAR_ADDR = GR == 1;
+    const f4 *pp[GR]; const u32x2 *cp[GR]; f4 *op[GR];
+#pragma unroll
+    for (int r = 0; r < GR; r++) {
+        pp[r] = pooled + ((size_t)gl[r] * HO * NCOL + col) * 64 + lane;
+        cp[r] = codes + ((size_t)gl[r] * HO * NT + nt) * 64 + lane;
+        op[r] = gpre + ((size_t)gl[r] * (HO + P - 1) * NCOL + col) * 64 + lane;
+    }
     // lane 0's element of (group r, this column, row): scalar pointers
     auto pooled_at = [&](int r, int row) { return pooled + ((size_t)gl[r] * HO * NCOL + col + (size_t)row * NCOL) * 64; };
     auto gpre_at = [&](int r, int row) { return gpre + ((size_t)gl[r] * (HO + P - 1) * NCOL + col + (size_t)row * NCOL) * 64; };
     auto code_at = [&](int r, int row) {                   // the dword that holds base w's 16 code bits (cv_code16)
         return reinterpret_cast<const unsigned *>(codes + ((size_t)gl[r] * HO * NT + nt + (size_t)row * NT) * 64) + (w >> 1);
     };
-    f4 acc[GR], yv[GR]; unsigned cv[GR];
+    f4 acc[GR], yv[GR]; u32x2 cv[GR]; unsigned cs[GR];      // code words: whole (vector form) / the dword of base w (scalar form)
 #pragma unroll
-    for (int r = 0; r < GR; r++) { acc[r] = zero; yv[r] = zero; cv[r] = 0u; }
+    for (int r = 0; r < GR; r++) { acc[r] = zero; yv[r] = zero; cv[r] = (u32x2){0u, 0u}; cs[r] = 0u; }
     // row `row` leaves the accumulators (a copy: the next row is already being multiplied): into the unpool window, one
     // finished row out
     auto finish_row = [&](int row, const f4 (&done)[GR]) {
 #pragma unroll
         for (int r = 0; r < GR; r++) {
-            U[r].push(done[r], yv[r], (cv[r] >> (16 * (w & 1))) & 0xFFFFu);
+            const unsigned cw = SCALAR_ADDR ? cs[r] : (w < 2 ? cv[r][0] : cv[r][1]);      // (read here, behind the counted wait)
+            U[r].push(done[r], yv[r], (cw >> (16 * (w & 1))) & 0xFFFFu);
             const f4 o = U[r].emit();
-            if (live[r] && row >= pa) store_f4_s(gpre_at(r, row), o);      // (older than the DMA pieces the counted wait leaves in flight)
+            if (live[r] && row >= pa) {                  // (older than the DMA pieces the counted wait leaves in flight)
+                if constexpr (SCALAR_ADDR) store_f4_s(gpre_at(r, row), o);
+                else op[r][(size_t)row * NCOL * 64] = o;
+            }
         }
     };
     // the MFMAs of the k fragments [k0, k1) of the current row
@@ -2142,8 +2170,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void dense_dgrad_unpool(const f4 *__
             if (row > lo) finish_row(row - 1, done);
 #pragma unroll
             for (int r = 0; r < GR; r++) {
-                yv[r] = load_f4_s(pooled_at(r, row));
-                cv[r] = load_u1_s(code_at(r, row));
+                if constexpr (SCALAR_ADDR) {
+                    yv[r] = load_f4_s(pooled_at(r, row));
+                    cs[r] = load_u1_s(code_at(r, row));
+                } else {
+                    yv[r] = load_f4(pp[r] + (size_t)row * NCOL * 64);
+                    cv[r] = load_u2(cp[r] + (size_t)row * NT * 64);
+                }
             }
             stage_async(rs, wslot);
         };
@@ -2161,7 +2194,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void dense_dgrad_unpool(const f4 *__
         else if constexpr (PER == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < GR; r++) { asm volatile("" : "+v"(yv[r])); asm volatile("" : "+v"(cv[r])); }
+        for (int r = 0; r < GR; r++) { asm volatile("" : "+v"(yv[r])); asm volatile("" : "+v"(cv[r])); asm volatile("" : "+v"(cs[r])); }
         CV_PHASE(1);                                        // ... waiting for this wave's loads / the DMA pieces of the next row
         __syncthreads();
         CV_PHASE(2);                                        // ... waiting for the other waves at the barrier
@@ -2175,7 +2208,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void dense_dgrad_unpool(const f4 *__
             for (int r = 0; r < GR; r++) {
                 U[r].push_none();
                 const f4 o = U[r].emit();
-                if (live[r] && row >= pa) store_f4_s(gpre_at(r, row), o);
+                if (live[r] && row >= pa) {
+                    if constexpr (SCALAR_ADDR) store_f4_s(gpre_at(r, row), o);
+                    else op[r][(size_t)row * NCOL * 64] = o;
+                }
             }
         }
     }
