@@ -45,9 +45,9 @@ def main():
     l1, w1 = run()
     l2, w2 = run()
     same = np.array_equal(w1.view(np.uint32), w2.view(np.uint32))
-    print("%s%s: %d steps x 2 runs, last loss %.6g / %.6g, weights finite %s, bitwise equal %s" % (
-        arch, " (deferred)" if deferred else "", steps, l1, l2, bool(np.isfinite(w1).all()), same))
-    sys.exit(0 if same and np.isfinite(w1).all() else 1)
+    print("%s%s: %d steps x 2 runs, last loss %.17g / %.17g (equal: %s), weights finite %s, bitwise equal %s" % (
+        arch, " (deferred)" if deferred else "", steps, l1, l2, l1 == l2, bool(np.isfinite(w1).all()), same))
+    sys.exit(0 if same and l1 == l2 and np.isfinite(w1).all() else 1)
 
 
 if __name__ == "__main__":
