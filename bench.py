@@ -143,16 +143,19 @@ def release_stdout():
 
 
 def rccl_logging():
-    """Before the process group exists: ask RCCL for its INFO log (init, topology graph, per-collective algorithm /
-    protocol choice); it arrives on fd 1, i.e. in the capture file, and rank 0 says ONCE in the line what the exchange
-    ran on (rccl_summary).  Nothing is touched when the user set NCCL_DEBUG, the backend is not RCCL, or there is one rank."""
+    """Before the process group exists: ask RCCL for its INFO log (init, topology graph; with CV_RCCL_TUNING_LOG=1 also the
+    per-collective algorithm / protocol choice); it arrives on fd 1, i.e. in the capture file, and rank 0 says ONCE in
+    the line what the exchange ran on (rccl_summary).  Nothing is touched when the user set NCCL_DEBUG, the backend is not RCCL, or there is one rank."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     if (ws <= 1 and not os.environ.get("CV_FORCE_DIST")) or "NCCL_DEBUG" in os.environ:
         return
     if (os.environ.get("CV_DIST_BACKEND") or "nccl") != "nccl":
         return
     os.environ["NCCL_DEBUG"] = "INFO"
-    os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,TUNING"
+    # INIT + GRAPH are written once, when the communicator is built (version, channels, rings / trees, transports).  TUNING
+    # adds one line per collective CALL (algorithm / protocol / predicted time) -- inside the timed loop too, so it is
+    # opt-in: CV_RCCL_TUNING_LOG=1 for a run whose purpose is to read those choices, not to be timed.
+    os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,TUNING" if os.environ.get("CV_RCCL_TUNING_LOG") else "INIT,GRAPH"
 
 
 def rccl_summary(max_lines=8):
