@@ -130,6 +130,8 @@ _SIGS = {
                                              ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]),
     "cv_bam_record_cigar": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]),
     "cv_inflate_raw": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]),
+    "cv_inflate_stream": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p,
+                                           ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32)]),
     "cv_crc32_ieee": (ctypes.c_uint32, [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int64]),
     "cv_pileup_add_bam": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_int64)]),

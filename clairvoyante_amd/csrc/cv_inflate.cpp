@@ -110,7 +110,13 @@ inline uint64_t load64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return 
 // src[0, n): one complete raw-DEFLATE stream, followed by at least 8 readable bytes (BGZF: the CRC-32 / ISIZE
 // trailer).  dst[0, cap): the output; the stream must produce exactly `cap` bytes.  Returns cap, or -1 if the
 // stream is malformed, too long or too short for `cap` (the caller falls back to zlib then).
-extern "C" int64_t cv_inflate_raw(const uint8_t *src, int64_t n, uint8_t *dst, int64_t cap)
+// The decoder.  Whole-stream mode (stream == nullptr): as described above.  Streaming mode (cv_inflate_stream): starts at
+// bit `stream->bitpos` of src, appends to dst behind `have` bytes of history (matches may reach back into them), and
+// returns at the first BLOCK boundary at which at least `want` bytes have been produced, or at the end of the stream.
+namespace {
+struct stream_io { int64_t bitpos; int64_t have; int64_t want; int final; };
+}
+static int64_t inflate_core(const uint8_t *src, int64_t n, uint8_t *dst, int64_t cap, stream_io *stream)
 {
     if (!src || n < 0 || cap < 0 || (cap > 0 && !dst)) return -1;
     static thread_local tables T;
@@ -118,13 +124,25 @@ extern "C" int64_t cv_inflate_raw(const uint8_t *src, int64_t n, uint8_t *dst, i
     uint8_t *out = dst, *const oend = dst + cap;
     uint64_t buf = 0;
     int cnt = 0;
+    if (stream) {
+        if (stream->bitpos < 0 || (stream->bitpos >> 3) > n || stream->have < 0 || stream->have > cap) return -1;
+        p = src + (stream->bitpos >> 3);
+        out = dst + stream->have;
+        stream->final = 0;
+    }
+    uint8_t *const out0 = out;
     // top the bit buffer up to 56..63 bits while there is input left (the load reads at most 7 bytes past pend:
     // allowed, see above).  Once every byte of the stream is in the buffer nothing is added; a valid stream never
     // asks for more bits than it has, an invalid one runs the count negative and is rejected.
 #define REFILL() do { if (cnt < 0) return -1; if (p <= pend) { buf |= load64(p) << cnt; p += (63 - cnt) >> 3; cnt |= 56; } } while (0)
 #define DROP(k) do { buf >>= (k); cnt -= (int)(k); } while (0)
     bool last = false;
+    if (stream && (stream->bitpos & 7)) { REFILL(); DROP(stream->bitpos & 7); }
     while (!last) {
+        if (stream && out - out0 >= stream->want) {             // a block boundary with enough output: hand over
+            stream->bitpos = (int64_t)(p - src) * 8 - cnt;
+            return out - out0;
+        }
         REFILL();
         last = buf & 1;
         const int type = (int)((buf >> 1) & 3);
@@ -262,7 +280,36 @@ extern "C" int64_t cv_inflate_raw(const uint8_t *src, int64_t n, uint8_t *dst, i
     }
 #undef REFILL
 #undef DROP
+    if (stream) {
+        if (cnt < 0) return -1;
+        stream->bitpos = (int64_t)(p - src) * 8 - cnt;
+        stream->final = 1;
+        return out - out0;
+    }
     return (out == oend && cnt >= 0) ? cap : -1;
+}
+
+extern "C" int64_t cv_inflate_raw(const uint8_t *src, int64_t n, uint8_t *dst, int64_t cap)
+{
+    return inflate_core(src, n, dst, cap, nullptr);
+}
+
+// Streaming form for a gzip member that does not fit in memory at once (the text-tensor files of utils_v2.GetTensor):
+// src[0, n) = the raw-DEFLATE data from its first byte on (the caller has skipped the gzip header), followed by at
+// least 8 readable bytes (the member's CRC-32 / ISIZE trailer); *bitpos = where to go on (0 at the start).  dst[0, have)
+// holds the output produced last (at least the last 32 768 bytes of it, or all of it if less); new output is appended at
+// dst + have, at most up to dst + cap.  Returns when a block ends with >= want new bytes, or at the end of the stream
+// (*final = 1; *bitpos then points behind the last block: the trailer starts at the next byte boundary).  Returns the
+// number of new bytes, or -1 (malformed, or a block that does not fit: cap - have must leave room for want plus the
+// largest block -- the caller falls back to an external gzip).
+extern "C" int64_t cv_inflate_stream(const uint8_t *src, int64_t n, int64_t *bitpos, uint8_t *dst, int64_t have, int64_t cap,
+                                     int64_t want, int32_t *final)
+{
+    if (!bitpos || !final) return -1;
+    stream_io io{*bitpos, have, want, 0};
+    const int64_t got = inflate_core(src, n, dst, cap, &io);
+    if (got >= 0) { *bitpos = io.bitpos; *final = io.final; }
+    return got;
 }
 
 // CRC-32 of the gzip / BGZF trailer (polynomial 0xEDB88320, reflected), sixteen bytes per step through sixteen

@@ -388,6 +388,14 @@ int cv_bam_record_cigar(const uint8_t *rec, const uint8_t **ops, int64_t *n);
  * followed by 8 readable bytes, the stream must produce exactly cap bytes; returns cap or -1.  And the CRC-32 of
  * the gzip trailer (start with crc = 0).                                                                 */
 int64_t cv_inflate_raw(const uint8_t *src, int64_t n, uint8_t *dst, int64_t cap);
+/* The same decoder over a gzip member too large to inflate at once (text-tensor files, utils_v2.GetTensor -- the
+ * reference pipes them through `gzip -fdc`, utils_v2.py:25): src[0, n) = the raw-DEFLATE data behind the gzip header,
+ * followed by >= 8 readable bytes; *bitpos = bit offset to go on from (0 first); dst[0, have) = the output produced
+ * last (>= its last 32 768 bytes), new output is appended at dst + have up to dst + cap.  Returns at the first block
+ * boundary with >= want new bytes or at the end of the stream (*final = 1; the CRC-32 / ISIZE trailer starts at the
+ * byte boundary behind *bitpos): the number of new bytes, or -1 (malformed / a block that does not fit).          */
+int64_t cv_inflate_stream(const uint8_t *src, int64_t n, int64_t *bitpos, uint8_t *dst, int64_t have, int64_t cap,
+                          int64_t want, int32_t *final);
 uint32_t cv_crc32_ieee(uint32_t crc, const uint8_t *p, int64_t n);
 
 #ifdef __cplusplus

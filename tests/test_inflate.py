@@ -3,6 +3,7 @@ compression level and strategy (stored, fixed and dynamic codes, long and short 
 stream, empty and 64 KiB outputs), and malformed input: truncated, bit-flipped and random streams must be rejected or
 at worst decode to something else -- never write outside the output buffer."""
 import ctypes
+import gzip
 import os
 import sys
 import zlib
@@ -146,3 +147,79 @@ def test_decoder_equals_zlib_on_generated_inputs(lib):
         rc, out, intact = inflate(lib, comp, len(data))
         assert intact and rc == len(data) and out == data
     check()
+
+
+# ---- the same decoder streaming over gzip files too large to inflate at once (utils_v2._GzipFile) --------------------
+
+def _read_all(g, piece):
+    out = []
+    while True:
+        c = g.read(piece)
+        if not c:
+            return b"".join(out)
+        out.append(c)
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_gzip_file_reader_equals_gzip(tmp_path, level, monkeypatch):
+    """utils_v2._GzipFile (memory-mapped file, RFC 1952 header by hand, cv_inflate_stream block by block into a window buffer,
+    CRC-32 + length of every member checked) hands out the bytes `gzip -dc` does: small and empty files, stored blocks
+    (incompressible data), a file whose output crosses several decoder calls, several members, zero padding at the end"""
+    from clairvoyante_amd import utils_v2
+    monkeypatch.setattr(utils_v2._GzipFile, "WANT", 1 << 20)          # many decoder calls on modest data
+    monkeypatch.setattr(utils_v2._GzipFile, "CAP", 32768 + (1 << 20) + (8 << 20))
+    rng = np.random.RandomState(level)
+    row = b"chr1 12345 ACGTACGTACGTACGTACGTACGTACGTACGTA " + b" ".join(b"%d.0" % v for v in rng.randint(0, 60, 528)) + b"\n"
+    texts = [b"", b"x", b"hello\nworld\n" * 1000, rng.bytes(700000),
+             b"".join(row[:40] + b" ".join(b"%d.0" % v for v in rng.randint(0, 60, 528)) + b"\n" for _ in range(3000))]
+    for i, t in enumerate(texts):
+        fn = str(tmp_path / ("t%d.gz" % i))
+        with gzip.open(fn, "wb", compresslevel=level) as f:
+            f.write(t)
+        g = utils_v2._GzipFile(fn)
+        assert _read_all(g, 333333) == t
+        g.close()
+    multi = str(tmp_path / "multi.gz")
+    with open(multi, "wb") as f:
+        for t in texts[2:]:
+            f.write(gzip.compress(t, compresslevel=level))
+        f.write(b"\0" * 11)
+    g = utils_v2._GzipFile(multi)
+    assert _read_all(g, 1 << 22) == b"".join(texts[2:])
+    g.close()
+
+
+def test_gzip_file_reader_refuses_what_it_cannot_vouch_for(tmp_path, monkeypatch):
+    """damage found before the first byte is handed out sends the file to the external gzip (_GzipFallback); damage found
+    later raises CvError -- a call set must not end early in silence; GetTensor gives the rows of the reference's pipe
+    through either decoder"""
+    from clairvoyante_amd import _lib, utils_v2
+    rng = np.random.RandomState(3)
+    text = b"".join(b"line %d " % i + rng.bytes(40).hex().encode() + b"\n" for i in range(60000))
+    good = gzip.compress(text, compresslevel=6)
+    bad_crc = bytearray(good); bad_crc[-6] ^= 0xff
+    fn = str(tmp_path / "bad_crc.gz"); open(fn, "wb").write(bytes(bad_crc))
+    with pytest.raises(utils_v2._GzipFallback):
+        utils_v2._GzipFile(fn).read(10)
+    monkeypatch.setattr(utils_v2._GzipFile, "WANT", 1 << 18)
+    g = utils_v2._GzipFile(fn)                       # with small pieces the first bytes leave before the trailer is seen
+    assert g.read(1000) == text[:1000]
+    with pytest.raises(_lib.CvError, match="broke off"):
+        _read_all(g, 1 << 20)
+    cut = str(tmp_path / "cut.gz"); open(cut, "wb").write(good[:len(good) // 2])
+    g = utils_v2._GzipFile(cut)
+    with pytest.raises((_lib.CvError, utils_v2._GzipFallback)):
+        _read_all(g, 1 << 20)
+    notgz = str(tmp_path / "plain.txt.gz"); open(notgz, "wb").write(text[:5000])
+    with pytest.raises(utils_v2._GzipFallback):
+        utils_v2._GzipFile(notgz)
+    # GetTensor: same batches through the in-process decoder and through the gzip child process
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    src = os.path.join(G, "gettensor_b.txt.gz")
+
+    def rows():
+        return [(e, c, np.array(x), list(p)) for e, c, x, p in utils_v2.GetTensor(src, 43, log=False)]
+    a = rows()
+    monkeypatch.setenv("CV_GZIP", "external")
+    b = rows()
+    assert len(a) == len(b) and all(u[0] == v[0] and u[1] == v[1] and np.array_equal(u[2], v[2]) and u[3] == v[3] for u, v in zip(a, b))
