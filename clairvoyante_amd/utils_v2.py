@@ -222,20 +222,64 @@ class _GzipFallback(Exception):
 
 def _open_tensor_stream(tensor_fn):
     """-> (child process or None, file object with read(n)): the reference's `gzip -fdc FILE` pipe (utils_v2.py:25), or
-    for a regular gzip file the in-process decoder; CV_GZIP=external forces the child process."""
+    for a regular file the in-process decoder (which hands the file over to that pipe if it meets anything it cannot
+    decode or vouch for); CV_GZIP=external forces the child process."""
     if tensor_fn != "PIPE":
         if os.environ.get("CV_GZIP") != "external" and os.path.isfile(tensor_fn):
-            try:
-                g = _GzipFile(tensor_fn)
-                head = g.read(1)                 # a file the decoder cannot start on goes to gzip (which also takes .Z, plain text)
-                if head:
-                    return None, _Prefixed(head, g)
-                g.close()
-            except (_GzipFallback, OSError, ValueError, IndexError):
-                pass
+            return None, _GzipOrPipe(tensor_fn)
         f = subprocess.Popen(shlex.split("gzip -fdc %s" % (tensor_fn)), stdout=subprocess.PIPE, bufsize=8388608)
         return f, f.stdout
     return None, sys.stdin.buffer
+
+
+class _GzipOrPipe(object):
+    """read(n) over a tensor file: the in-process decoder while it is sure of itself; at its first doubt -- a file that is
+    not gzip (the reference's `gzip -fdc` also passes plain text and .Z through), a construct it does not take, a member
+    whose check fails -- the reference's own `gzip -fdc` child process takes over FROM THE BYTE the caller has reached
+    (what was handed out already is read from the pipe and dropped), so the caller sees exactly the reference's stream,
+    and an error (exit status 1, raised by close()) where the reference's decompressor reports one."""
+
+    def __init__(self, fn):
+        self.fn, self.g, self.proc, self.out = fn, None, None, 0
+        try:
+            self.g = _GzipFile(fn)
+        except (_GzipFallback, OSError, ValueError, IndexError):
+            self._to_pipe()
+
+    def _to_pipe(self):
+        if self.g is not None:
+            self.g.close()
+            self.g = None
+        self.proc = subprocess.Popen(shlex.split("gzip -fdc %s" % (self.fn)), stdout=subprocess.PIPE, bufsize=8388608)
+        skip = self.out
+        while skip > 0:
+            c = self.proc.stdout.read(min(skip, 1 << 24))
+            if not c:
+                break
+            skip -= len(c)
+
+    def read(self, n=-1):
+        if self.g is not None:
+            try:
+                c = self.g.read(n)
+                self.out += len(c)
+                return c
+            except (_GzipFallback, _lib.CvError, OSError, ValueError, IndexError):
+                self._to_pipe()
+        c = self.proc.stdout.read(n)
+        self.out += len(c)
+        return c
+
+    def close(self):
+        if self.g is not None:
+            self.g.close()
+            self.g = None
+        if self.proc is not None:
+            self.proc.stdout.close()
+            rc = self.proc.wait()
+            self.proc = None
+            if rc == 1:
+                raise _lib.CvError("gzip -fdc %s failed (exit status 1): the tensor stream is incomplete" % self.fn)
 
 
 def _close_tensor_stream(proc, fo, tensor_fn):

@@ -213,6 +213,20 @@ def test_gzip_file_reader_refuses_what_it_cannot_vouch_for(tmp_path, monkeypatch
     notgz = str(tmp_path / "plain.txt.gz"); open(notgz, "wb").write(text[:5000])
     with pytest.raises(utils_v2._GzipFallback):
         utils_v2._GzipFile(notgz)
+    # the reader GetTensor uses: the decoder's doubts end in the reference's pipe, at the byte the caller had reached
+    f = utils_v2._GzipOrPipe(fn)                                   # bad CRC: gzip itself writes the data, then reports the error
+    assert _read_all(f, 1 << 18) == text
+    with pytest.raises(_lib.CvError, match="exit status 1"):
+        f.close()
+    f = utils_v2._GzipOrPipe(notgz)                                # plain text under a .gz name: `gzip -fdc` passes it through
+    assert _read_all(f, 999) == text[:5000]
+    f.close()
+    whole = str(tmp_path / "good.gz"); open(whole, "wb").write(good)
+    monkeypatch.setattr(utils_v2._GzipFile, "CAP", 32768 + (1 << 18) + 4096)      # a window too small for a block: hand-over mid-stream
+    f = utils_v2._GzipOrPipe(whole)
+    assert _read_all(f, 77777) == text
+    f.close()
+    monkeypatch.undo()
     # GetTensor: same batches through the in-process decoder and through the gzip child process
     G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     src = os.path.join(G, "gettensor_b.txt.gz")
