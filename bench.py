@@ -379,6 +379,7 @@ def run_train(arch, gb, steps, warmup, rank, ws, dev, sync_loss=False, options=N
     xt, cls, rf, alt, il = synth.make_candidates(gb, seed=synth.BASE_SEED, device=dev, return_class=True)
     y = synth.make_labels(cls, rf, alt, il)[lo:hi].contiguous(); x = xt[lo:hi].contiguous()
     use_dist = dist.is_initialized()
+    exchange_plan = parallel.plan_exchange(m, gb) if use_dist else None      # what train.run_epoch does
     for k, v in (options or {}).items():
         if v is not None:
             m.setOption(k, v)
@@ -414,14 +415,16 @@ def run_train(arch, gb, steps, warmup, rank, ws, dev, sync_loss=False, options=N
            "global_batch": gb, "per_rank_batch": hi - lo, "roofline": roof, "final_loss": float(loss)}
     if exchange:
         res.update(exchange)
+        res["exchange_plan"] = exchange_plan
     return res
 
 
 def exchange_timing(m, step, x, y, steps, step_ms, dev):
     """What the gradient exchange costs and how much of it the backward pass hides, measured AFTER the timed region on
     the same model (N > 1 only):
-      exchange_ms          the two in-place bucket all-reduces of one step alone (parallel.exchange_bucket: the dense
-                           95 % on the communication stream, the rest in stream order), 20 iterations, no compute;
+      exchange_ms          the in-place bucket all-reduce(s) of one step alone (parallel.exchange_bucket as planned for
+                           this batch: one collective, or the dense 95 % on the communication stream + the rest in
+                           stream order), 20 iterations, no compute;
       compute_ms_per_step  the same optimizer steps with the exchange suspended (every rank applies its own shard's
                            gradient -- measurement only, the replicas diverge, the model is closed afterwards);
       exchange_hidden_frac 1 - (ms_per_step - compute_ms_per_step) / exchange_ms, clipped to [0, 1].
@@ -533,7 +536,7 @@ def train_main(args):
                            "dbg": args.dbg + (" sides=%d" % args.sides if args.sides is not None else "") +
                                   (" ksplit=%d" % args.ksplit if args.ksplit is not None else "")},
                 "roofline": r["roofline"], "final_loss": r["final_loss"]}
-        for k in ("exchange_ms", "compute_ms_per_step", "exchange_hidden_frac", "exchange_bytes"):
+        for k in ("exchange_ms", "compute_ms_per_step", "exchange_hidden_frac", "exchange_bytes", "exchange_plan"):
             if k in r:
                 line[k] = r[k]
         line.update(rank_info(ws))

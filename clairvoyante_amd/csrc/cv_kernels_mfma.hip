@@ -58,12 +58,15 @@ struct cv_stamp {
 #define CV_STAMP_END(cond, kid) do { if (cond) cv_st.end(kid); } while (0)
 // -DCV_ROW_PHASES on top: where the cycles of a barrier-ring loop go, per wave (record id 7: cycles up to the end of the
 // iteration's instruction issue / waiting for its own memory operations / waiting at the barrier, summed over the loop;
-// the fourth word is the wave's index in its workgroup).  tools/gpu_row_phases.py prints the shares.
+// the fourth word is the wave's index in its workgroup in its low byte and a fourth phase above it).  front2_tm (an
+// inference pass never runs dense_dgrad_unpool, so the record id is free): producer half / conv2 over the chunk /
+// both barriers / waiting for the raw X rows.  tools/gpu_row_phases.py prints the shares.
 #ifdef CV_ROW_PHASES
-#define CV_PHASE_BEGIN unsigned long long cv_ph[3] = {0, 0, 0}; unsigned long long cv_pt = __builtin_amdgcn_s_memtime();
+#define CV_PHASE_BEGIN unsigned long long cv_ph[4] = {0, 0, 0, 0}; unsigned long long cv_pt = __builtin_amdgcn_s_memtime();
 #define CV_PHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cv_ph[i] += t_ - cv_pt; cv_pt = t_; } while (0)
 #define CV_PHASE_END(cond, w) do { if ((cond) && (threadIdx.x & 63) == 0) { const unsigned i_ = atomicAdd(&cv_wg_stamp_n[7], 1u) & 4095u; \
-    unsigned long long *o_ = cv_wg_stamp + ((size_t)7 * 4096 + i_) * 4; o_[0] = cv_ph[0]; o_[1] = cv_ph[1]; o_[2] = cv_ph[2]; o_[3] = (unsigned long long)(w); } } while (0)
+    unsigned long long *o_ = cv_wg_stamp + ((size_t)7 * 4096 + i_) * 4; o_[0] = cv_ph[0]; o_[1] = cv_ph[1]; o_[2] = cv_ph[2]; o_[3] = (unsigned long long)(w) | (cv_ph[3] << 8); } } while (0)
+#define CV_PHASE_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 #else
 #define CV_STAMP_BEGIN
@@ -73,6 +76,9 @@ struct cv_stamp {
 #define CV_PHASE_BEGIN
 #define CV_PHASE(i) do { } while (0)
 #define CV_PHASE_END(cond, w) do { } while (0)
+#endif
+#ifndef CV_PHASE_DRAIN
+#define CV_PHASE_DRAIN() do { } while (0)
 #endif
 
 namespace {
@@ -961,6 +967,7 @@ __global__ __launch_bounds__(256, 2) void front2_tm(const float *__restrict__ x,
     };
 
     __syncthreads();                                     // conv2 weights are in LDS
+    CV_PHASE_BEGIN
 #pragma unroll 1
     for (int c0 = 0; c0 < H1; c0 += CH) {
         const int cn = H1 - c0 < CH ? H1 - c0 : CH;
@@ -981,6 +988,9 @@ __global__ __launch_bounds__(256, 2) void front2_tm(const float *__restrict__ x,
 #pragma unroll
                 for (int w = 0; w < 4; w++) xr[r][w] = xp[rr * 16 + w * 4];
             }
+            CV_PHASE(0);
+            CV_PHASE_DRAIN();                            // (development probe: the raw rows' round trip on its own)
+            CV_PHASE(3);
             f4 t[NRAW][4];
 #pragma unroll
             for (int r = 0; r < NRAW; r++) {
@@ -1009,7 +1019,9 @@ __global__ __launch_bounds__(256, 2) void front2_tm(const float *__restrict__ x,
                 if (a0 + 2 < a1) myrows[(size_t)((a0 - c0 + 2) * 4 + w) * 64] = selu4(o2);
             }
         }
+        CV_PHASE(0);
         __syncthreads();
+        CV_PHASE(2);
         // ---- phase B: conv2 over the chunk's rows
 #pragma unroll 1
         for (int p = c0; p < c0 + cn; p++) {
@@ -1020,9 +1032,13 @@ __global__ __launch_bounds__(256, 2) void front2_tm(const float *__restrict__ x,
 #pragma unroll
             for (int w = 0; w < 4; w++) prev[w] = cur[w];
         }
+        CV_PHASE(1);
         __syncthreads();
+        CV_PHASE(2);
     }
     out_row(H1 - 1, prev, false);                        // the row below the last one is SAME padding
+    CV_PHASE(1);
+    CV_PHASE_END(true, wid);
 }
 
 // ---------------------------------------------------------------------------

@@ -909,14 +909,18 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
     for (int64_t off = 0; off < n; off += slice) {
         int64_t cn = n - off < slice ? n - off : slice;
         const bool last = off + slice >= n;
-        hipEvent_t ev = (backward && last) ? m->tr_dense_ready : nullptr;
+        // (no communication stream -- one rank, or the whole bucket exchanged behind the step: nobody waits for "dense
+        // gradients final", so the side streams are not gathered for it)
+        hipEvent_t ev = (backward && last && comm) ? m->tr_dense_ready : nullptr;
         if (train_slice(m, x + (size_t)off * (CV_INPUT_H * 16), y + (size_t)off * 16, cn, off, backward, drop4,
                         seed, step, st, sw, ev))
             return 1;
         recorded = recorded || ev != nullptr;
     }
-    if (backward && !recorded) CV_HIP(hipEventRecord(m->tr_dense_ready, st));      // empty batch
-    if (backward && comm) CV_HIP(hipStreamWaitEvent(comm, m->tr_dense_ready, 0));
+    if (backward && comm) {
+        if (!recorded) CV_HIP(hipEventRecord(m->tr_dense_ready, st));      // empty batch
+        CV_HIP(hipStreamWaitEvent(comm, m->tr_dense_ready, 0));
+    }
     if (lambda != 0.0f && !l2_done) {
         l2_args la;
         for (int p = 0; p < CV_NUM_PARAMS; p += 2) { la.w[p / 2] = m->params + m->poff[p]; la.count[p / 2] = m->psize[p]; }

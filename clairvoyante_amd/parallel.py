@@ -79,9 +79,11 @@ _host_staged = [None]      # gloo without device support: collectives of device 
 
 
 def _all_reduce(t, async_op=False):
-    """all-reduce(SUM) in place; RCCL ("nccl") reduces device tensors directly.  The gloo backend (CPU tests, and
-    the two-ranks-on-one-GPU tests: RCCL refuses two ranks on one device) may lack device support, in which case
-    the tensor is staged through the host -- decided once, identically on every rank."""
+    """all-reduce(SUM) in place; RCCL ("nccl") reduces device tensors directly.  A synchronous call (async_op False) is
+    enqueued by torch >= 2.8 on the CURRENT stream itself -- no trampoline stream, no event pair around the collective
+    -- which is what the step wants: the collective is one more kernel of the stream it belongs to.  The gloo backend
+    (CPU tests, and the several-ranks-on-one-GPU tests: RCCL refuses two ranks on one device) may lack device support,
+    in which case the tensor is staged through the host -- decided once, identically on every rank."""
     if t.is_cuda and dist.get_backend() == "gloo":
         if _host_staged[0] is None:
             try:
@@ -107,10 +109,41 @@ def _broadcast(t, src):
     dist.broadcast(t, src=src)
 
 
+# A rank's share of the batch at or below which the step exchanges its bucket in ONE collective (see plan_exchange):
+# 160 groups of 16 candidates, the same bound as the library's tiny-batch kernel choices (cv_model::tiny_g).
+TINY_SHARE = 2560
+
+
+def plan_exchange(model, global_batch):
+    """Choose how the optimizer steps of `model` exchange their gradient bucket, from the GLOBAL batch size (the same
+    number on every rank, so every rank chooses the same):
+      "split"  the dense 95 % of the bucket (fc4 / fc5 / heads: final before the convolution backward pass) on the
+               communication stream under the rest of the backward pass, the convolution part + loss header behind
+               it -- two collectives, one stream hand-over each way; pays when there is a backward pass long enough to
+               hide 6 MB of all-reduce (a rank's share of thousands of candidates);
+      "one"    the whole bucket in one collective on the step's own stream after the backward pass -- no second
+               stream, no events: at a share of ~1 000 candidates (train.py's batch of 10 000 over 8 GPUs) the
+               convolution backward pass is ~150 us, less than the fixed cost of the hand-overs it would hide under
+               (measured with one rank, where no byte moves: profiles/r05/exchange_fixed_cost.txt).
+    CV_EXCHANGE=one|split overrides.  Returns the mode."""
+    _rank, ws = world()
+    share = -(-int(global_batch) // max(ws, 1))
+    mode = os.environ.get("CV_EXCHANGE") or ("one" if share <= TINY_SHARE else "split")
+    if mode not in ("one", "split"):
+        raise ValueError("CV_EXCHANGE must be 'one' or 'split'")
+    model._exchange_mode = mode
+    return mode
+
+
+def exchange_mode(model):
+    """the plan of plan_exchange; a model nobody planned for exchanges in two pieces (correct at any size)"""
+    return getattr(model, "_exchange_mode", None) or os.environ.get("CV_EXCHANGE") or "split"
+
+
 def comm_stream(model):
-    """The stream the early part of the gradient exchange is enqueued on (one per model), or None when there
-    is nothing to exchange.  cv_grad_async makes it wait for the event "fc4 / fc5 / head gradients are final"."""
-    if not _active() or torch.device(model.device).type != "cuda":
+    """The stream the early part of a "split" exchange is enqueued on (one per model), or None when there is nothing
+    to exchange or the plan is "one".  cv_grad_async makes it wait for the event "fc4 / fc5 / head gradients are final"."""
+    if not _active() or torch.device(model.device).type != "cuda" or exchange_mode(model) == "one":
         return None
     st = getattr(model, "_comm_stream", None)
     if st is None:
@@ -119,25 +152,42 @@ def comm_stream(model):
 
 
 def exchange_bucket(model, comm=None):
-    """Gradient + loss exchange of one optimizer step, in place on the model's bucket (no staging copies, no
-    host synchronisation): all-reduce(SUM) of the dense part [dense_begin, end) -- 95 % of the bytes, final before
-    the convolution backward pass -- on `comm`, so that it runs under the rest of the backward pass, then
-    all-reduce(SUM) of [0, dense_begin) = loss header + convolution gradients in stream order.  The current
-    stream continues behind both (Adam follows).  The loss header sums to the global-batch losses; its L2 slot is
-    identical on every rank and is divided by the rank count when read (cv_loss_accumulate)."""
+    """Gradient + loss exchange of one optimizer step, in place on the model's bucket (no staging copies, no host
+    synchronisation), as planned by plan_exchange.  The loss header sums to the global-batch losses; its L2 slot is
+    identical on every rank and is divided by the rank count when read (cv_loss_accumulate).  Adam follows on the
+    current stream.
+
+    "one": all-reduce(SUM) of the whole bucket on the current stream.
+    "split": all-reduce(SUM) of the dense part [dense_begin, end) on `comm` (which cv_grad_async made wait for "dense
+    gradients final"), so that it runs under the rest of the backward pass; then [0, dense_begin) = loss header +
+    convolution gradients in stream order; the current stream continues behind both.  The collectives are synchronous
+    calls: enqueued on the stream that is current (see _all_reduce), so the only cross-stream edges of a step are
+    the event into `comm` and the join back.  CV_EXCHANGE_ASYNC=1 restores the round-4 form (async_op on torch's own
+    communication stream, three waits) for A/B runs."""
     if not _active():
         return
     b = model._bucket
+    if comm is None and exchange_mode(model) == "one":
+        _all_reduce(b)
+        return
     d = model._bucket_dense
-    if comm is not None:
-        with torch.cuda.stream(comm):
+    if os.environ.get("CV_EXCHANGE_ASYNC"):
+        if comm is not None:
+            with torch.cuda.stream(comm):
+                w1 = _all_reduce(b[d:], async_op=True)
+        else:
             w1 = _all_reduce(b[d:], async_op=True)
+        w2 = _all_reduce(b[:d], async_op=True)
+        for w in (w1, w2):
+            if w is not None:
+                w.wait()
     else:
-        w1 = _all_reduce(b[d:], async_op=True)
-    w2 = _all_reduce(b[:d], async_op=True)
-    for w in (w1, w2):
-        if w is not None:
-            w.wait()
+        if comm is not None:
+            with torch.cuda.stream(comm):
+                _all_reduce(b[d:])
+        else:
+            _all_reduce(b[d:])
+        _all_reduce(b[:d])
     if comm is not None:
         torch.cuda.current_stream(model.device).wait_stream(comm)
 

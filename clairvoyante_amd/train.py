@@ -297,6 +297,8 @@ def run_epoch(stream, m, rank, ws, writer, epoch, validationStart):
     train_sum = 0
     val_sum = 0
     stream.rewind()
+    if ws > 1 and hasattr(m, "_enqueue_step"):
+        parallel.plan_exchange(m, param.trainBatchSize)      # one collective per step when a rank's share is tiny
     # real models take batches that are already in HBM; mock / foreign model objects get the numpy arrays
     device = getattr(m, "device", None) if getattr(m, "accepts_device_batches", False) else None
     # the validation loss is a sum over candidates: a real model takes it in passes of 16 000 instead of the
