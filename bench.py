@@ -53,13 +53,16 @@ def cpu_baseline(arch, P, x_sample, target_s=12.0):
                       "%d OpenMP threads, %.1f s" % (passes, n, cores, total)}, out, n
 
 
-def cpu_torch_line(arch, P, x_sample, ref_out, target_s=6.0):
+def cpu_torch_line(arch, P, x_sample, ref_out, hip_out=None, target_s=6.0):
     """Second CPU line: the same network in stock torch CPU ops (oneDNN convolutions / GEMMs,
     fp32) -- the closest stand-in available here for the reference's TensorFlow-CPU kernels.  Not bit-identical
-    to the oracle (library summation order); its distance to the oracle is reported."""
+    to the oracle (library summation order); its distance to the oracle is reported, and -- the nearest thing to
+    north_star's "argmax agreement vs TF-CPU" this image allows -- the per-head argmax agreement of the HIP output
+    with THIS library's fp32 results (another summation order, as TF-Eigen's is).  -> (dict, its outputs)"""
     import numpy as np
     import torch
     import torch_ref
+    import common
     cores = usable_cores()
     torch.set_num_threads(cores)
     bs = 8192
@@ -72,9 +75,14 @@ def cpu_torch_line(arch, P, x_sample, ref_out, target_s=6.0):
         dt = time.time() - t0
     got = np.concatenate(outs)
     n = got.shape[0]
-    return {"value": n / dt, "unit": "candidates/s", "cores": cores, "kind": "torch CPU ops (oneDNN), fp32 -- a "
+    line = {"value": n / dt, "unit": "candidates/s", "cores": cores, "kind": "torch CPU ops (oneDNN), fp32 -- a "
             "stand-in for TF-CPU, not the reference", "sample": "first %d candidates of the timed set, %.1f s" % (n, dt),
             "max_abs_dprob_vs_oracle": float(np.abs(got - ref_out[:n]).max())}
+    if hip_out is not None:
+        line["n"] = n
+        line["argmax_match_per_head"] = common.argmax_match(hip_out[:n], got)      # HIP path vs this library, all n
+        line["max_abs_dprob_vs_hip"] = float(np.abs(got - hip_out[:n]).max())
+    return line, got
 
 
 def relaunch_under_torchrun(args, argv):
@@ -508,6 +516,78 @@ def train_traffic(arch, per_rank):
     return None, "profiles/pmc_traffic.json has no train entry for %s at %d candidates per rank" % (arch, per_rank)
 
 
+def exchange_main(args):
+    """--mode exchange: ONLY the gradient exchange of the data-parallel step -- in-place all-reduce(SUM) of the bucket
+    (loss header + 1 631 496 gradients = 6.5 MB) and of its pieces, no compute: what xGMI / RCCL deliver at these sizes.
+    A step = one all-reduce of the whole bucket; value = its bus bandwidth (algorithm bandwidth x 2 (N - 1) / N, the
+    figure rccl-tests quotes), per size also the time and algorithm bandwidth; `rccl_log` carries the algorithm /
+    protocol RCCL chose per size (NCCL_DEBUG_SUBSYS TUNING is switched on in this mode: reading those choices is its
+    purpose).  Runs on any backend (gloo: functional test) and with one rank under CV_FORCE_DIST=1."""
+    import torch
+    import torch.distributed as dist
+    from clairvoyante_amd import clairvoyante_v3
+    os.environ.setdefault("CV_RCCL_TUNING_LOG", "1")
+    rank, ws, local = init_ranks(args)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    m = clairvoyante_v3.Clairvoyante(); m.init()
+    bucket = m._ensure_bucket()
+    d = m._bucket_dense
+    m.close()
+    nfl = int(bucket.numel())
+    use_dist = dist.is_available() and dist.is_initialized()
+    staged = use_dist and dist.get_backend() == "gloo"
+    steps = args.steps if args.steps != 64 else 50
+    pieces = [("whole bucket (the tiny-share plan: one collective per step)", 0, nfl),
+              ("dense part: fc4 / fc5 / heads gradients (under the convolution backward pass)", d, nfl),
+              ("convolution gradients + loss header (behind the step)", 0, d),
+              ("a fifth of the bucket", 0, nfl // 5)]
+    buf = torch.zeros(nfl, dtype=torch.float32, device=dev)
+    rows = []
+    for label, lo, hi in pieces:
+        t = buf[lo:hi]
+
+        def one():
+            if not use_dist:
+                return
+            if staged:
+                h = t.cpu(); dist.all_reduce(h); t.copy_(h)
+            else:
+                dist.all_reduce(t)
+        for _ in range(max(args.warmup, 3)):
+            one()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if staged else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        nbytes = (hi - lo) * 4
+        alg = nbytes / (dt / steps) / 1e9
+        rows.append({"piece": label, "bytes": nbytes, "ms": dt / steps * 1e3, "algbw_GBps": alg,
+                     "busbw_GBps": alg * 2.0 * (ws - 1) / ws})
+    if rank == 0:
+        line = {"metric": "gradient bucket all-reduce bus bandwidth", "value": rows[0]["busbw_GBps"], "unit": "GB/s",
+                "n_gpus": ws, "steps": steps, "warmup": max(args.warmup, 3), "ms_per_step": rows[0]["ms"],
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "in-place all-reduce(SUM) of the training step's gradient bucket, %d bytes, no compute" % (nfl * 4),
+                           "parallelism": "dp%d" % ws},
+                "pieces": rows,
+                "xgmi_ring_ceiling_note": "a ring over point-to-point xGMI is bound by one link (~153 GB/s per direction): "
+                                          "busbw of a large message approaches that figure; at 6.5 MB latency dominates"}
+        line.update(rank_info(ws))
+        emit(line)
+    finish_ranks()
+
+
 def train_main(args):
     """--mode train: a step = one optimizer step (forward, backward, all-reduce, Adam) on a global batch of
     param.trainBatchSize = 10 000 synthetic labelled tensors (strong scaling: the batch is split)."""
@@ -580,10 +660,15 @@ def run_infer(arch, batch, steps, warmup, rank, ws, dev, variant=None, batches=N
     m.setOption("profile", 0)
     ms = (ctypes.c_double * 6)(); cnt = (ctypes.c_int64 * 6)()
     _lib.check(m._lib.cv_kernel_times(m._h, ms, cnt))
+    per_rank = None
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank's own time for its steps (min / max over ranks: a straggler is visible), then the MAX is the job's time
+        mine = torch.zeros(ws, dtype=torch.float64, device=dev)
+        mine[rank] = dt
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        allms = [float(v) / steps * 1e3 for v in mine.cpu()]
+        per_rank = {"min": min(allms), "max": max(allms), "argmax_rank": int(max(range(ws), key=lambda r: allms[r]))}
+        dt = max(float(v) for v in mine.cpu())
 
     value = steps * batch * ws / dt
     chunk = ctypes.c_int64(); _lib.check(m._lib.cv_get_option(m._h, b"chunk", ctypes.byref(chunk)))
@@ -644,27 +729,73 @@ def run_infer(arch, batch, steps, warmup, rank, ws, dev, variant=None, batches=N
                 "whole_path_frac": value / ws * FLOP_EXACT[arch] / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                 "hbm_frac_compulsory": value / ws * 2176 / 1e9 / PEAK_HBM_GBS}
     res = {"value": value, "unit": "candidates/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-           "roofline": roof, "kernels": stages}
+           "roofline": roof, "kernels": stages, "per_rank_ms": per_rank}
     return res, m, P, batches
 
 
-def float64_leg(arch, P, xs, got):
-    """The GPU output against the independent float64 torch formulation (tests/torch_ref.py; no oracle/ in the loop):
-    max |dp| over the 16 outputs and per-head argmax agreement where the float64 margin between the two best classes
-    exceeds 1e-5 (closer than that, fp32 and float64 may legitimately order them differently)."""
+def float64_outputs(arch, P, xs, dev=None, chunk=16384):
+    """The independent float64 torch formulation (tests/torch_ref.py; no oracle/ in the loop) over xs, with stock torch
+    ops on `dev` (the GPU: 262 144 candidates take a second or two) or, when the device refuses a float64 op, on the
+    host over the first 16 384.  -> float64 [m, 16], m <= len(xs)"""
     import numpy as np
     import torch
     import torch_ref
-    import common
     with torch.no_grad():
-        want = torch_ref.forward(arch, P, xs, dtype=torch.float64)["out"].numpy()
-    agree = []
+        if dev is not None:
+            try:
+                return np.concatenate([torch_ref.forward(arch, P, xs[i:i + chunk], dtype=torch.float64, device=dev)["out"].cpu().numpy()
+                                       for i in range(0, len(xs), chunk)])
+            except Exception as e:
+                print("bench.py: float64 formulation on %s failed (%s: %s); host, first 16 384 candidates" % (dev, type(e).__name__, e), file=sys.stderr)
+        return torch_ref.forward(arch, P, xs[:16384], dtype=torch.float64)["out"].numpy()
+
+
+def margin_mask(want64, eps=1e-5):
+    """-> bool [m, 4]: per head, the float64 margin between the two best classes is below eps -- where two correct fp32
+    implementations (each within ~5e-6 of float64 on every probability) may legitimately order the classes differently."""
+    import numpy as np
+    import common
+    close = []
     for lo, hi in common.HEADS:
-        w = want[:, lo:hi]
-        srt = np.sort(w, axis=1)
-        clear = (srt[:, -1] - srt[:, -2]) > 1e-5
-        agree.append(float(np.mean(np.argmax(got[:, lo:hi], 1)[clear] == np.argmax(w, 1)[clear])) if clear.any() else 1.0)
-    return float(np.abs(got.astype(np.float64) - want).max()), agree
+        srt = np.sort(want64[:, lo:hi], axis=1)
+        close.append((srt[:, -1] - srt[:, -2]) < eps)
+    return np.stack(close, 1)
+
+
+def order_sensitivity(got, want64, other=None):
+    """Summation-order sensitivity of the argmax, from the float64 formulation: `got` = HIP outputs [m, 16], `other` =
+    another fp32 implementation's outputs on the first len(other) of the same candidates.
+      margin_below_1e-5_frac          share of the candidates with a float64 top-2 margin < 1e-5 on ANY head = the upper
+                                      bound on argmax disagreement between the HIP path and any correct fp32 implementation
+                                      (TF-CPU included);
+      ..._per_head                    the same per head (base, zygosity, type, length);
+      argmax_match_vs_float64_where_margin_ge_1e-5   HIP vs float64 outside that set, per head (must be 1.0);
+      other_argmax_match_where_margin_ge_1e-5        HIP vs `other` outside that set, per head (must be 1.0);
+      other_argmax_mismatches_in_margin_set          candidates x heads inside the set where the two fp32 orders differ."""
+    import numpy as np
+    import common
+    m = want64.shape[0]
+    close = margin_mask(want64)
+    res = {"n": int(m), "margin_below_1e-5_frac": float(close.any(1).mean()),
+           "margin_below_1e-5_frac_per_head": [float(v) for v in close.mean(0)],
+           "max_abs_dprob_vs_float64": float(np.abs(got[:m].astype(np.float64) - want64).max())}
+    agree = []
+    for h, (lo, hi) in enumerate(common.HEADS):
+        ok = ~close[:, h]
+        agree.append(float(np.mean(np.argmax(got[:m, lo:hi], 1)[ok] == np.argmax(want64[:, lo:hi], 1)[ok])) if ok.any() else 1.0)
+    res["argmax_match_vs_float64_where_margin_ge_1e-5"] = agree
+    if other is not None:
+        k = min(m, other.shape[0])
+        out_ok, inside = [], 0
+        for h, (lo, hi) in enumerate(common.HEADS):
+            same = np.argmax(got[:k, lo:hi], 1) == np.argmax(other[:k, lo:hi], 1)
+            ok = ~close[:k, h]
+            out_ok.append(float(same[ok].mean()) if ok.any() else 1.0)
+            inside += int((~same[~ok]).sum())
+        res["other_n"] = int(k)
+        res["other_argmax_match_where_margin_ge_1e-5"] = out_ok
+        res["other_argmax_mismatches_in_margin_set"] = inside
+    return res
 
 
 def main():
@@ -684,11 +815,12 @@ def main():
     ap.add_argument("--ksplit", type=int, default=None, help="train mode: option train_ksplit (A/B)")
     ap.add_argument("--sides", type=int, default=None, help="train mode: option train_side_streams (A/B)")
     ap.add_argument("--dbg", default="", help="train mode: development switches, e.g. 0=3,2=1 sets options dbg0=3, dbg2=1")
-    ap.add_argument("--mode", default="infer", choices=["infer", "train", "pileup"],
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "pileup", "exchange"],
                     help="infer (default, the headline metric) or train: Adam steps on the reference's global "
                          "batch of 10 000 split over the ranks, one RCCL gradient all-reduce per step "
                          "(BASELINE.json configs[3]); pileup: candidate extraction + tensor generation over "
-                         "alignments resident in HBM (SURVEY.md 8f N4)")
+                         "alignments resident in HBM (SURVEY.md 8f N4); exchange: only the all-reduce of the step's "
+                         "gradient bucket and of its pieces (time, algorithm / bus bandwidth, RCCL's algorithm choice)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args, sys.argv[1:])          # does not return
@@ -701,6 +833,8 @@ def main():
         return train_main(args)
     if args.mode == "pileup":
         return pileup_main(args)
+    if args.mode == "exchange":
+        return exchange_main(args)
 
     import numpy as np
     import torch
@@ -720,6 +854,8 @@ def main():
                                    "batch %d x %d steps per GPU" % (args.arch, args.batch, args.steps),
                        "arch": args.arch, "batch": args.batch, "parallelism": "shard%d" % ws},
             "roofline": res["roofline"], "kernels": res["kernels"]}
+    if res.get("per_rank_ms"):
+        line["per_rank_ms"] = res["per_rank_ms"]          # ms per step of the fastest / slowest rank (N > 1)
     line.update(rank_info(ws))
 
     # Configs 5 and 4 under the same clock, OUTSIDE the headline's timed region: slim inference at the same batch, and
@@ -753,21 +889,43 @@ def main():
             cb, ref, n = cpu_baseline(args.arch, P, xs)
             got = m.predict_device(torch.from_numpy(xs[:n]).to(dev)).cpu().numpy()
             line["cpu_baseline"] = cb
+            got_t = None
             try:
-                line["cpu_baseline_torch"] = cpu_torch_line(args.arch, P, xs, ref)
+                line["cpu_baseline_torch"], got_t = cpu_torch_line(args.arch, P, xs, ref, hip_out=got)
             except Exception as e:      # informational only
                 line["cpu_baseline_torch"] = {"error": str(e)}
             line["parity"] = {"n": n, "argmax_match_per_head": common.argmax_match(got, ref),
                               "max_abs_dprob": float(np.abs(got - ref).max()),
                               "bitwise_equal_frac": common.bitwise_frac(got, ref)}
+            # Summation-order sensitivity (north_star: "100 % per-head argmax agreement vs TF-CPU"; TF cannot run here):
+            # the float64 formulation over ALL timed candidates of the sample bounds the set on which any two correct
+            # fp32 implementations may differ; outside it the HIP path must agree with float64 and with the oneDNN leg.
             try:
-                d64, am64 = float64_leg(args.arch, P, xs[:4096], got[:4096])
-                line["parity"]["max_abs_dprob_vs_float64"] = d64
-                line["parity"]["argmax_match_vs_float64_where_margin_gt_1e-5"] = am64
-                line["parity"]["float64_n"] = 4096
+                w64 = float64_outputs(args.arch, P, xs[:n], dev)
+                sens = order_sensitivity(got, w64, got_t)
+                line["parity"]["max_abs_dprob_vs_float64"] = sens.pop("max_abs_dprob_vs_float64")
+                line["parity"]["float64_n"] = sens.pop("n")
+                line["parity"]["margin_below_1e-5_frac"] = sens["margin_below_1e-5_frac"]
+                line["parity"]["margin_below_1e-5_frac_per_head"] = sens["margin_below_1e-5_frac_per_head"]
+                line["parity"]["argmax_match_vs_float64_where_margin_gt_1e-5"] = sens["argmax_match_vs_float64_where_margin_ge_1e-5"]
+                if "other_n" in sens and "error" not in line["cpu_baseline_torch"]:
+                    line["cpu_baseline_torch"]["argmax_match_where_float64_margin_ge_1e-5"] = sens["other_argmax_match_where_margin_ge_1e-5"]
+                    line["cpu_baseline_torch"]["argmax_mismatches_in_margin_set"] = sens["other_argmax_mismatches_in_margin_set"]
+                from clairvoyante_amd import synth
+                xst = (synth.make_stress(8192, seed=synth.BASE_SEED).numpy() * np.float32(0.25)).astype(np.float32)
+                gst = m.predict_device(torch.from_numpy(xst).to(dev)).cpu().numpy()
+                with torch.no_grad():
+                    import torch_ref
+                    tst = torch_ref.forward(args.arch, P, xst, dtype=torch.float32)["out"].numpy()
+                st = order_sensitivity(gst, float64_outputs(args.arch, P, xst, dev), tst)
+                line["parity"]["stress"] = {"n": st["n"], "margin_below_1e-5_frac": st["margin_below_1e-5_frac"],
+                                            "max_abs_dprob_vs_float64": st["max_abs_dprob_vs_float64"],
+                                            "argmax_match_vs_float64_where_margin_gt_1e-5": st["argmax_match_vs_float64_where_margin_ge_1e-5"],
+                                            "torch_fp32_argmax_match_where_margin_ge_1e-5": st["other_argmax_match_where_margin_ge_1e-5"],
+                                            "torch_fp32_argmax_mismatches_in_margin_set": st["other_argmax_mismatches_in_margin_set"]}
             except Exception as e:
                 line["parity"]["max_abs_dprob_vs_float64"] = None
-                line["parity"]["float64_error"] = str(e)
+                line["parity"]["float64_error"] = "%s: %s" % (type(e).__name__, e)
         emit(line)
     m.close()
     finish_ranks()

@@ -431,6 +431,11 @@ def TestSharded(args, m, utils, rank, ws):
     # a single file: its LINES are split block-cyclically (every rank inflates the whole stream -- the job is then
     # capped by one core's gzip rate whatever the number of GPUs)
     files = tensor_files(args.tensor_fn)
+    if len(files) == 1 and ws > 1 and rank == 0 and utils.is_compressed(files[0]):
+        logging.warning("callVar: ONE compressed tensor file under %d ranks -- every rank inflates the whole stream to find its "
+                        "line blocks, so the job runs at one core's inflate rate (~0.35 M rows/s) whatever the number of GPUs. "
+                        "Give --tensor_fn a comma-separated list (one file per chunk of the genome; file k goes to rank k mod N) "
+                        "or uncompressed text to scale." % ws)
 
     def reader():
         try:

@@ -143,7 +143,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
         cv_destroy(m);
         return 1;
     }
-    m->packed_dirty = true; m->packed_train_dirty = true;
+    cv_layouts_stale(m);
     *out = m;
     return 0;
 }
@@ -154,7 +154,7 @@ extern "C" int cv_destroy(cv_model *m)
     hipSetDevice(m->device);
     float *bufs[] = {m->params, m->grads_own, m->adam_m, m->adam_v, m->wp_conv1, m->wp_conv[1], m->wp_conv[2],
                      m->wp_fc4, m->wp_fc5, m->wp_heads0, m->wp_heads1, m->wpd_conv[1], m->wpd_conv[2], m->wpd_fc4, m->wpr_fc4, m->wpd_fc5, m->wps_fc4, m->wps7_fc4, m->wps3_fc5, m->wp5p_fc5, m->wg_part, m->tm_p1, m->tm_p2, m->tm_p3, m->tm_h4, m->tm_h5, m->r_a[0],
-                     m->r_a[1], m->r_a[2], m->r_p[0], m->r_p[1], m->r_p[2], m->r_h4, m->r_h5, m->t_buf};
+                     m->r_a[1], m->r_a[2], m->r_p[0], m->r_p[1], m->r_p[2], m->r_h4, m->r_h5, m->t_buf, m->tr_keep};
     for (float *b : bufs)
         if (b) hipFree(b);
     if (m->tail_dev) hipFree(m->tail_dev);
@@ -206,7 +206,7 @@ extern "C" int cv_set_param(cv_model *m, const char *tf_name, const float *src, 
     hipStream_t st = (hipStream_t)stream;
     CV_HIP(hipMemcpyAsync(m->params + m->poff[i], src, sizeof(float) * count, hipMemcpyHostToDevice, st));
     CV_HIP(hipStreamSynchronize(st));
-    m->packed_dirty = true; m->packed_train_dirty = true;
+    cv_layouts_stale(m);
     return 0;
 }
 
@@ -230,7 +230,7 @@ extern "C" int cv_get_param(cv_model *m, const char *tf_name, float *dst, int64_
 extern "C" int cv_params_changed(cv_model *m)
 {
     if (!m) { cv_set_error("null model"); return 1; }
-    m->packed_dirty = true; m->packed_train_dirty = true;
+    cv_layouts_stale(m);
     return 0;
 }
 
@@ -249,7 +249,7 @@ extern "C" int cv_set_option(cv_model *m, const char *key, int64_t value)
     if (!strcmp(key, "train_side_streams")) { m->train_sides = value < 1 ? 1 : (value > 3 ? 3 : (int)value); return 0; }
     if (!strcmp(key, "train_tiny_groups")) { m->tiny_g = value < 0 ? 0 : (value > 160 ? 160 : (int)value); return 0; }
     if (!strcmp(key, "variant")) { m->variant = (int)value; return 0; }
-    if (!strncmp(key, "dbg", 3) && key[3] >= '0' && key[3] <= '7' && !key[4]) { m->dbg[key[3] - '0'] = (int)value; m->packed_train_dirty = true; return 0; }
+    if (!strncmp(key, "dbg", 3) && key[3] >= '0' && key[3] <= '7' && !key[4]) { m->dbg[key[3] - '0'] = (int)value; cv_layouts_stale(m, CVL_BACKWARD); return 0; }
     if (!strcmp(key, "chunk")) {
         if (value < 16 || value > (1 << 22)) { cv_set_error("chunk must be in [16, 4194304]"); return 1; }
         m->chunk = (value + 15) / 16 * 16;

@@ -76,8 +76,11 @@ struct cv_model {
     float *wp_heads0;    // [nb4][64][4]  base head (rows 0..3)
     float *wp_heads1;    // [nb5][64][4]  zygosity / type / length heads
     int variant;         // kernel selection bits, see include/clairvoyante_amd.h (cv_set_option "variant")
-    bool packed_dirty;         // forward fragments are stale
-    bool packed_train_dirty;   // data-gradient fragments are stale
+    // Packed (MFMA fragment) copies of the weights that are CURRENT, one bit per layout (CVL_*).  A pass packs what its
+    // kernels will read and is not valid (a training step of G groups reads two of the four fc4 layouts: the others stay
+    // stale until a pass that reads them); every change of the weights clears the mask (cv_layouts_stale).  Consumers
+    // check the bit where they take the pointer (cv_layout_current): a mismatch is an error, never stale arithmetic.
+    unsigned packed_valid;
     // workspaces (allocated lazily for `ws_cap` candidates)
     int64_t ws_cap;      // MFMA path capacity (multiple of 16)
     float *tm_p1, *tm_p2, *tm_p3, *tm_h4, *tm_h5;
@@ -116,14 +119,19 @@ struct cv_model {
     const float *last_tr_d4, *last_tr_mask;
     int64_t last_tr_n;
     int last_tr_tile;    // 1: tile-major buffers, 0: natural [n, fc4]
+    // option keep_activations + a step of several slices: the two maps of EVERY slice, copied here slice after slice
+    // (mask first, dropout output behind it), so that cv_get_activation 6 / 7 covers the whole batch
+    float *tr_keep; size_t tr_keep_floats;
     // optional per-kernel timing (option "profile")
     // options "dbg0".."dbg7": development switches of the training step (A/B runs and variant tests; 0 = shipped path).
     //   dbg0 = n: position parts of the convolution data gradients      dbg1 = n: ... of the training-forward convolutions
     //        (n = 9: the batch-dependent number of parts instead of flat row ranges; n = 7: flat ranges for a small batch too;
     //         dbg1 = 8: conv2 forward on flat ranges too)
-    //   dbg2 = 1 / 2: unpool always thread-per-row / always streaming, 3: fc4's alpha-dropout as its own pass   dbg3 = 1: fc4 data gradient and conv3 unpool as two kernels
+    //   dbg2 = 1 / 2: unpool always thread-per-row / always streaming, 3: fc4's alpha-dropout as its own pass, 4: thread-per-row at tiny batches (default there: row segments)
+    //   dbg3 = 1: fc4 data gradient and conv3 unpool as two kernels
     //   dbg4 = 2: conv data gradients fused with the unpool below (conv_dgrad_unpool), 3: slim selu' as its own pass
-    //   dbg5 = 1: all weight packing in one launch in stream order      dbg6 = n: row parts of dense_dgrad_unpool (few groups)
+    //   dbg5 = 1: all weight packing in one launch in stream order, 2: conv1's weight gradient on a side stream at tiny batches too,
+    //          3: the loss header at the tail of the step                  dbg6 = n: row parts of dense_dgrad_unpool (few groups)
     //   dbg7 = 1: training-forward conv3 on conv_tm instead of conv3_rot
     int dbg[8];
     int profile;
@@ -137,6 +145,25 @@ void cv_prof_end(cv_model *m, int stage, hipStream_t st);
 void cv_prof_free(cv_model *m);
 
 void cv_set_error(const char *fmt, ...);
+
+// layouts of cv_model::packed_valid
+enum : unsigned {
+    CVL_CONV = 1u,      // wp_conv1, wp_conv[1..2]
+    CVL_FC4 = 2u,       // wp_fc4
+    CVL_FC5 = 4u,       // wp_fc5
+    CVL_FC5P = 8u,      // wp5p_fc5
+    CVL_FC4S3 = 16u,    // wps_fc4
+    CVL_FC5S3 = 32u,    // wps3_fc5
+    CVL_FC4S7 = 64u,    // wps7_fc4
+    CVL_HEADS = 128u,   // wp_heads0 / wp_heads1
+    CVL_DCONV = 256u,   // wpd_conv[1..2]
+    CVL_DFC4 = 512u,    // wpr_fc4 or wpd_fc4 (by dbg3)
+    CVL_DFC5 = 1024u,   // wpd_fc5
+    CVL_FORWARD = CVL_CONV | CVL_FC4 | CVL_FC5 | CVL_FC5P | CVL_FC4S3 | CVL_FC5S3 | CVL_FC4S7 | CVL_HEADS,
+    CVL_BACKWARD = CVL_DCONV | CVL_DFC4 | CVL_DFC5,
+};
+inline void cv_layouts_stale(cv_model *m, unsigned which = ~0u) { m->packed_valid &= ~which; }
+int cv_layout_current(const cv_model *m, unsigned layout, const char *who);    // 0 = current; else sets the error text
 
 #define CV_TR_EVENTS 16
 #define CV_WG_REGIONS 6
@@ -160,8 +187,9 @@ int cv_launch_heads(cv_model *m, const float *h4, const float *h5, int tm, int64
                     hipStream_t st);
 bool cv_tile_supported(const cv_model *m);
 int cv_pack_train_weights(cv_model *m, hipStream_t st);
-int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward, hipStream_t sw = nullptr, hipEvent_t fork = nullptr,
-                         hipEvent_t done = nullptr, bool *wait_before_dense = nullptr);   // whatever is stale
+// what a training pass over G groups will read and is stale; sw_ordered: sw already runs behind st (the caller forked)
+int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward, int G, hipStream_t sw = nullptr, hipEvent_t fork = nullptr,
+                         hipEvent_t done = nullptr, bool *wait_before_dense = nullptr, bool sw_ordered = false);
 int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float *a1, float *p2, float *a2,
                         float *p3, float *a3, hipStream_t st);
 #define CV_DENSE_KSPLIT 8      // k ranges of the fc4 training forward at tiny batches (cv_tile_dense_fwd)

@@ -2732,18 +2732,16 @@ struct pack_builder {
     }
 };
 
-// forward fragments (inference and training); with_train: also the transposed / flipped fragments of the
-// data-gradient kernels
-// part 0: all jobs; 1: only the convolution forward fragments (a few KB: what the first kernels of a pass need);
-// 2: everything else (the dense layers in all their slab forms, the heads, the data-gradient fragments: ~30 MB)
-static int pack_launch(cv_model *m, hipStream_t st, bool fwd, bool with_train, int part = 0)
+// Packs the layouts of `mask` (CVL_* bits; a layout the topology does not have is skipped) in ONE launch on `st` and
+// marks them current.
+static int pack_launch(cv_model *m, hipStream_t st, unsigned mask)
 {
     const float *P = m->params;
     const int64_t *o = m->poff;
     const cv_shapes &s = m->sh;
     const cv_arch &a = m->arch;
     pack_builder pb;
-    if (fwd && part != 2) {
+    if (mask & CVL_CONV) {
         { pack_job &J = pb.add(0, 256); J.src[0] = P + o[0]; J.dst[0] = m->wp_conv1; J.i[0] = a.cout[0]; }
         for (int l = 1; l < 3; l++) {
             pack_job &J = pb.add(1, (int64_t)s.ntile[l] * a.kh[l] * 4 * s.cinb[l] * 256);
@@ -2751,38 +2749,44 @@ static int pack_launch(cv_model *m, hipStream_t st, bool fwd, bool with_train, i
             J.i[0] = a.kh[l]; J.i[1] = s.cin[l]; J.i[2] = a.cout[l]; J.i[3] = s.cinb[l]; J.i[4] = s.ntile[l];
         }
     }
-    if (fwd && part != 1) {
-        const int nbp4 = (s.nb4 + 3) / 4 * 4, nbp5 = (s.nb5 + 3) / 4 * 4;   // launch_dense: WAVES = 4
-        { pack_job &J = pb.add(2, (int64_t)s.kb4 * nbp4 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wp_fc4;
-          J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = nbp4; }
-        { pack_job &J = pb.add(2, (int64_t)s.nb4 * nbp5 * 256); J.src[0] = P + o[8]; J.dst[0] = m->wp_fc5;
-          J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb4; J.i[3] = nbp5; }
-        if (m->wp5p_fc5) {      // full topology: fc5 in k pairs for the tail of the large-pass fc4 kernel (dense_tm EPI 3)
-            pack_job &J = pb.add(8, (int64_t)((s.nb4 + 3) / 4) * 48 * 256); J.src[0] = P + o[8]; J.dst[0] = m->wp5p_fc5;
-            J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb4; J.i[3] = 12; J.i[4] = 4;
-        }
-        if (m->wps_fc4) {       // full topology: fc4 in 3 slabs of 7 fragments for small batches
-            pack_job &J = pb.add(3, (int64_t)3 * s.kb4 * 8 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wps_fc4;
-            J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = 7; J.i[4] = 8; J.i[5] = 3;
-        }
-        if (m->wps3_fc5) {      // fc5 in 3 slabs of 4 fragments (11 -> 12, the last one zero) for dense_small
-            pack_job &J = pb.add(3, (int64_t)3 * s.nb4 * 4 * 256); J.src[0] = P + o[8]; J.dst[0] = m->wps3_fc5;
-            J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb4; J.i[3] = 4; J.i[4] = 4; J.i[5] = 3;
-        }
-        if (m->wps7_fc4) {      // ... and in 7 slabs of 3 fragments for the one-wave-per-slab kernel of very small batches
-            pack_job &J = pb.add(3, (int64_t)7 * s.kb4 * 3 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wps7_fc4;
-            J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = 3; J.i[4] = 3; J.i[5] = 7;
-        }
-        { pack_job &J = pb.add(6, (int64_t)(s.nb4 + s.nb5) * 256);
-          J.src[0] = P + o[10]; J.src[1] = P + o[12]; J.src[2] = P + o[14]; J.src[3] = P + o[16];
-          J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb4; J.i[3] = s.nb5; J.dst[0] = m->wp_heads0; J.dst[1] = m->wp_heads1; }
+    const int nbp4 = (s.nb4 + 3) / 4 * 4, nbp5 = (s.nb5 + 3) / 4 * 4;   // launch_dense: WAVES = 4
+    if (mask & CVL_FC4) {
+        pack_job &J = pb.add(2, (int64_t)s.kb4 * nbp4 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wp_fc4;
+        J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = nbp4;
     }
-    if (with_train && part != 1) {
+    if (mask & CVL_FC5) {
+        pack_job &J = pb.add(2, (int64_t)s.nb4 * nbp5 * 256); J.src[0] = P + o[8]; J.dst[0] = m->wp_fc5;
+        J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb4; J.i[3] = nbp5;
+    }
+    if ((mask & CVL_FC5P) && m->wp5p_fc5) {      // full topology: fc5 in k pairs for the tail of the large-pass fc4 kernel (dense_tm EPI 3)
+        pack_job &J = pb.add(8, (int64_t)((s.nb4 + 3) / 4) * 48 * 256); J.src[0] = P + o[8]; J.dst[0] = m->wp5p_fc5;
+        J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb4; J.i[3] = 12; J.i[4] = 4;
+    }
+    if ((mask & CVL_FC4S3) && m->wps_fc4) {      // full topology: fc4 in 3 slabs of 7 fragments for small batches
+        pack_job &J = pb.add(3, (int64_t)3 * s.kb4 * 8 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wps_fc4;
+        J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = 7; J.i[4] = 8; J.i[5] = 3;
+    }
+    if ((mask & CVL_FC5S3) && m->wps3_fc5) {     // fc5 in 3 slabs of 4 fragments (11 -> 12, the last one zero) for dense_small
+        pack_job &J = pb.add(3, (int64_t)3 * s.nb4 * 4 * 256); J.src[0] = P + o[8]; J.dst[0] = m->wps3_fc5;
+        J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb4; J.i[3] = 4; J.i[4] = 4; J.i[5] = 3;
+    }
+    if ((mask & CVL_FC4S7) && m->wps7_fc4) {     // ... and in 7 slabs of 3 fragments for the one-wave-per-slab kernel of very small batches
+        pack_job &J = pb.add(3, (int64_t)7 * s.kb4 * 3 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wps7_fc4;
+        J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = 3; J.i[4] = 3; J.i[5] = 7;
+    }
+    if (mask & CVL_HEADS) {
+        pack_job &J = pb.add(6, (int64_t)(s.nb4 + s.nb5) * 256);
+        J.src[0] = P + o[10]; J.src[1] = P + o[12]; J.src[2] = P + o[14]; J.src[3] = P + o[16];
+        J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb4; J.i[3] = s.nb5; J.dst[0] = m->wp_heads0; J.dst[1] = m->wp_heads1;
+    }
+    if (mask & CVL_DCONV) {
         for (int l = 1; l < 3; l++) {
             pack_job &J = pb.add(5, (int64_t)s.cinb[l] * a.kh[l] * 4 * s.ntile[l] * 256);
             J.src[0] = P + o[2 * l]; J.dst[0] = m->wpd_conv[l];
             J.i[0] = a.kh[l]; J.i[1] = s.cin[l]; J.i[2] = a.cout[l]; J.i[3] = s.ntile[l]; J.i[4] = s.cinb[l];
         }
+    }
+    if (mask & CVL_DFC4) {
         if (m->wpr_fc4 && m->dbg[3] != 1) {     // full: by column and pooled row, for dense_dgrad_unpool
             const int ncol = 4 * s.ntile[2];
             pack_job &J = pb.add(7, (int64_t)ncol * s.hp[2] * 24 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wpr_fc4;
@@ -2791,46 +2795,72 @@ static int pack_launch(cv_model *m, hipStream_t st, bool fwd, bool with_train, i
             pack_job &J = pb.add(4, (int64_t)(s.kb4 / 24) * s.nb4 * 24 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wpd_fc4;
             J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.nb4; J.i[3] = 24; J.i[4] = s.kb4 / 24; J.i[5] = 24;
         }
-        {   // fc5: full = 3 slabs of 7 fragments (stride 8 = dense_tm<7, 8>'s padded count), slim = one slab of 3 (stride 4)
-            const int nbs = is_full(a) ? 7 : s.nb4, nbsp = is_full(a) ? 8 : 4, nslab = is_full(a) ? 3 : 1;
-            pack_job &J = pb.add(4, (int64_t)nslab * s.nb5 * nbsp * 256); J.src[0] = P + o[8]; J.dst[0] = m->wpd_fc5;
-            J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb5; J.i[3] = nbs; J.i[4] = nslab; J.i[5] = nbsp;
-        }
     }
+    if (mask & CVL_DFC5) {   // fc5: full = 3 slabs of 7 fragments (stride 8 = dense_tm<7, 8>'s padded count), slim = one slab of 3 (stride 4)
+        const int nbs = is_full(a) ? 7 : s.nb4, nbsp = is_full(a) ? 8 : 4, nslab = is_full(a) ? 3 : 1;
+        pack_job &J = pb.add(4, (int64_t)nslab * s.nb5 * nbsp * 256); J.src[0] = P + o[8]; J.dst[0] = m->wpd_fc5;
+        J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb5; J.i[3] = nbs; J.i[4] = nslab; J.i[5] = nbsp;
+    }
+    m->packed_valid |= mask;
     if (pb.blocks == 0) return 0;
     pack_all<<<pb.blocks, 256, 0, st>>>(pb.tab);
     CV_HIP(hipGetLastError());
     return 0;
 }
 
-int cv_pack_weights(cv_model *m, hipStream_t st)
+int cv_layout_current(const cv_model *m, unsigned layout, const char *who)
 {
-    if (pack_launch(m, st, true, false)) return 1;
-    m->packed_dirty = false;
-    return 0;
+    if ((m->packed_valid & layout) == layout) return 0;
+    cv_set_error("%s: packed weight layout 0x%x is stale (0x%x current) -- internal: the pass did not pack what it reads", who, layout, m->packed_valid);
+    return 1;
 }
 
-// training step: whatever is stale.  One launch on `st`; or, with a side stream, the convolution fragments on `st`
-// (the first kernels need them) and the 30 MB of dense / data-gradient fragments on `sw` next to the convolution
-// forward pass -- *wait_before_dense is then the event `st` has to wait for before the first dense layer.
-int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward, hipStream_t sw, hipEvent_t fork, hipEvent_t done,
-                         bool *wait_before_dense)
+// inference: every forward layout that is stale
+int cv_pack_weights(cv_model *m, hipStream_t st)
+{
+    return pack_launch(m, st, CVL_FORWARD & ~m->packed_valid);
+}
+
+// Which packed layout the fc4 / fc5 of a TRAINING pass over G groups read: cv_tile_dense_fwd takes its kernel from
+// these, and cv_pack_for_training packs by them.
+static unsigned fc4_train_layout(const cv_model *m, int G)
+{
+    if (!is_full(m->arch)) return CVL_FC4;
+    if (m->train_ksplit && G <= m->tiny_g) return CVL_FC4S3;          // eight k ranges of the 3-slab form
+    if (G <= m->tiny_g && (m->variant & 128)) return CVL_FC4S7;       // one wave per (group, slab of 3)
+    if (G <= CV_FC4_SLAB_MAX_G) return CVL_FC4S3;
+    return CVL_FC4;
+}
+static unsigned fc5_train_layout(const cv_model *m, int G)
+{
+    if (!is_full(m->arch)) return CVL_FC5;
+    return (G <= CV_FC4_SLAB_MAX_G && (m->variant & 128)) ? CVL_FC5S3 : CVL_FC5;
+}
+
+// Training pass over G groups: the layouts ITS kernels read and that are stale -- two of the four fc4 layouts, one of
+// the three fc5 layouts (round 5: all of them were re-packed every step, 30 MB; a step now packs ~14 MB and an
+// inference pass that follows packs what it reads).  One launch on `st`; or, with a side stream, the convolution
+// fragments on `st` (the first kernels need them) and the dense / data-gradient fragments on `sw` next to the
+// convolution forward pass -- *wait_before_dense is then the event `st` has to wait for before the first dense layer.
+int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward, int G, hipStream_t sw, hipEvent_t fork, hipEvent_t done,
+                         bool *wait_before_dense, bool sw_ordered)
 {
     if (wait_before_dense) *wait_before_dense = false;
-    const bool fwd = m->packed_dirty, tr = backward && m->packed_train_dirty;
-    if (!fwd && !tr) return 0;
-    if (sw == st || !sw || !wait_before_dense) {
-        if (pack_launch(m, st, fwd, tr)) return 1;
-    } else {
+    unsigned need = CVL_CONV | CVL_HEADS | fc4_train_layout(m, G) | fc5_train_layout(m, G);
+    if (backward) need |= CVL_BACKWARD;
+    const unsigned todo = need & ~m->packed_valid;
+    if (!todo) return 0;
+    if (sw == st || !sw || !wait_before_dense) return pack_launch(m, st, todo);
+    if (!sw_ordered) {
         CV_HIP(hipEventRecord(fork, st));              // behind the optimizer update of the previous step
         CV_HIP(hipStreamWaitEvent(sw, fork, 0));
-        if (pack_launch(m, st, fwd, tr, 1)) return 1;
-        if (pack_launch(m, sw, fwd, tr, 2)) return 1;
+    }
+    if (pack_launch(m, st, todo & CVL_CONV)) return 1;
+    if (todo & ~CVL_CONV) {
+        if (pack_launch(m, sw, todo & ~CVL_CONV)) return 1;
         CV_HIP(hipEventRecord(done, sw));
         *wait_before_dense = true;
     }
-    if (fwd) m->packed_dirty = false;
-    if (tr) m->packed_train_dirty = false;
     return 0;
 }
 
@@ -2885,7 +2915,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
     if (mfma_alloc(m, n)) return 1;
     for (int i = 0; i < CV_NUM_STAGES; i++) m->stage_kernel[i] = nullptr;
     m->last_maps = 1;
-    if (m->packed_dirty && cv_pack_weights(m, st)) return 1;
+    if (cv_pack_weights(m, st)) return 1;
     const float *P = m->params;
     const int64_t *o = m->poff;
     const int G = (int)((n + 15) / 16);
@@ -3647,9 +3677,7 @@ bool cv_tile_supported(const cv_model *m) { return is_full(m->arch) || is_slim(m
 
 int cv_pack_train_weights(cv_model *m, hipStream_t st)
 {
-    if (pack_launch(m, st, false, true)) return 1;
-    m->packed_train_dirty = false;
-    return 0;
+    return pack_launch(m, st, CVL_BACKWARD & ~m->packed_valid);
 }
 
 // conv1..conv3 (+pools) with the pre-pool activations kept; buffers are TM
@@ -3704,11 +3732,15 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
     const int64_t *o = m->poff;
     const cv_shapes &s = m->sh;
     const int G = (int)((n + 15) / 16);
+    // (the layout each branch reads is the one cv_pack_for_training packed for this G: fc4_train_layout / fc5_train_layout)
     if (is_full(a)) {
         if (layer == 4) {
+            const unsigned lay = fc4_train_layout(m, G);
+            if (cv_layout_current(m, lay, "fc4 forward (training pass)")) return 1;
             // tiny batches: 288 dependent k steps at ~0.9 us each are the longest kernel of the step; eight k ranges
             // (CV_DENSE_KSPLIT) run side by side instead and a second pass adds them up in order
-            if (part && G <= m->tiny_g) {
+            if (lay == CVL_FC4S3 && G <= m->tiny_g) {
+                if (!part) { cv_set_error("k-split fc4 forward without its scratch (internal)"); return 1; }
                 cv_dropout_args dr = cv_dropout_args();
                 if (drop && drop_done) {            // the alpha-dropout of fc4 rides on the second pass of the k-split
                     dr.d4 = drop->d4; dr.amask = drop->amask; dr.nunits = a.fc4; dr.rate = drop->rate; dr.seed = drop->seed;
@@ -3720,11 +3752,11 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
             }
             // (dense_small beyond the tiny range loses: at 625 groups its 4 375 waves re-read the weight matrix from L2
             // 7 x 625 times -- 2.63 against 2.41 ms per step)
-            if (G <= m->tiny_g && (m->variant & 128))
+            if (lay == CVL_FC4S7)
                 return launch_dense_small<3, 8>(in_tm, s.kb4, m->wps7_fc4, P + o[7], a.fc4, out_tm, G, 7, st);
             // (measured at train.py's batch of 10 000, no gain: two k ranges of the 3-slab form; 3 / 4 / 6 / 8 k ranges of the
             // two-groups-per-wave, all-21-tiles form -- 2.47 / 2.36 / 2.25 / 2.39 ms per step against 2.25)
-            if (G <= CV_FC4_SLAB_MAX_G) {
+            if (lay == CVL_FC4S3) {
                 heads_args hd = heads_args();
                 if (drop && drop_done && m->dbg[2] != 3) {      // the alpha-dropout rides on the kernel's store (dbg2 = 3: dropout_tm)
                     hd.drop.d4 = drop->d4; hd.drop.amask = drop->amask; hd.drop.nunits = a.fc4; hd.drop.rate = drop->rate;
@@ -3737,10 +3769,13 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
         }
         // fc5 (21 k fragments): one wave per (group, slab of 4 output fragments), no barriers, weights straight from L2 --
         // up to a slice of 2 048 groups (dense_tm<11, 4> with its 4-group workgroups took 25 us at 625 groups)
-        if (G <= CV_FC4_SLAB_MAX_G && (m->variant & 128))
+        const unsigned lay5 = fc5_train_layout(m, G);
+        if (cv_layout_current(m, lay5, "fc5 forward (training pass)")) return 1;
+        if (lay5 == CVL_FC5S3)
             return launch_dense_small<4, 7>(in_tm, s.nb4, m->wps3_fc5, P + o[9], a.fc5, out_tm, G, 3, st, s.nb5);
         return launch_dense<11, 4>(in_tm, s.nb4, m->wp_fc5, P + o[9], a.fc5, out_tm, G, st);
     }
+    if (cv_layout_current(m, layer == 4 ? CVL_FC4 : CVL_FC5, "dense forward (training pass)")) return 1;
     if (layer == 4) {
         // slim fc4 is 396 dependent k steps of 12 MFMAs on 4-wave workgroups, one barrier each: 133 us at 625 groups for
         // 40 us of matrix work, the longest kernel of the slim step.  With the k-split scratch (training passes, option
@@ -3770,6 +3805,7 @@ int cv_tile_fc4_dgrad_unpool(cv_model *m, const float *g_tm, const float *pooled
     const cv_shapes &s = m->sh;
     const int G = (int)((n + 15) / 16);
     if (!is_full(m->arch) || !m->wpr_fc4) { cv_set_error("cv_tile_fc4_dgrad_unpool: full topology only"); return 1; }
+    if (cv_layout_current(m, CVL_DFC4, "fc4 data gradient")) return 1;
     const size_t lds = (size_t)3 * 24 * 1024;
     const int HO = s.hp[2], NT = s.ntile[2];
     // (workgroup shape measured at 625 groups: 8 waves x 2 groups 298 us, 4 waves x 2 groups 298 us, 8 waves x 1 group 292 us)
@@ -3801,6 +3837,7 @@ int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, 
     const int G = (int)((n + 15) / 16);
     heads_args hd;
     hd.dact = (const f4 *)act_below;        // not null: the result is already the pre-activation gradient of conv3 (no pooling)
+    if (cv_layout_current(m, CVL_DFC4, "fc4 data gradient")) return 1;
     return launch_dense<24, 8, 1>(g_tm, s.nb4, m->wpd_fc4, nullptr, 0, gin_tm, G, st, s.kb4 / 24, 1, nullptr, hd);
 }
 
@@ -3809,6 +3846,7 @@ int cv_tile_fc5_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, 
 {
     const cv_shapes &s = m->sh;
     const int G = (int)((n + 15) / 16);
+    if (cv_layout_current(m, CVL_DFC5, "fc5 data gradient")) return 1;
     // full: three slabs of 7 output fragments -- as one workgroup per 8 groups with all 21 the kernel took 32 us at ANY
     // batch (2 waves x 11 k steps x 84 MFMAs per SIMD on 10 .. 79 CUs); the values do not depend on the slab width
     if (is_full(m->arch)) return launch_dense<7, 8, 1>(g_tm, s.nb5, m->wpd_fc5, nullptr, 0, gin_tm, G, st, 3);
@@ -3822,6 +3860,7 @@ int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm,
     const cv_arch &a = m->arch;
     const int G = (int)((n + 15) / 16);
     const float *W = m->wpd_conv[layer];
+    if (cv_layout_current(m, CVL_DCONV, "convolution data gradient")) return 1;
     if (is_full(a) && m->dbg[0] > 0 && m->dbg[0] < 7) {          // development: forced number of position parts
         if (layer == 2) return launch_conv_parts<3, 3, 2, 1, 26, 2>(m->dbg[0], g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);
         return launch_conv_parts<2, 2, 1, 1, 29, 2>(m->dbg[0], g_tm, nullptr, n, W, nullptr, 0, gin_tm, G, st);

@@ -187,7 +187,7 @@ extern "C" int cv_flat_copy(cv_model *m, int which, float *caller_dev, int to_mo
     size_t bytes = sizeof(float) * m->poff[CV_NUM_PARAMS];
     if (to_model) {
         CV_HIP(hipMemcpyAsync(bufs[which], caller_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-        if (which == 0) { m->packed_dirty = true; m->packed_train_dirty = true; }
+        if (which == 0) { cv_layouts_stale(m); }
     } else {
         CV_HIP(hipMemcpyAsync(caller_dev, bufs[which], bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
@@ -207,7 +207,7 @@ static int apply_adam(cv_model *m, float lr, float lambda, int64_t t, void *stre
                                                                              m->grads, offs, (float)lr_t, lambda,
                                                                              accumulate ? m->loss_acc : nullptr);
     CV_HIP(hipGetLastError());
-    m->packed_dirty = true; m->packed_train_dirty = true;
+    cv_layouts_stale(m);
     return 0;
 }
 

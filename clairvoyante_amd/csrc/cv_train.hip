@@ -425,6 +425,41 @@ __global__ void b_unpool_rows(const tf4 *__restrict__ gpool, const tf4 *__restri
     gpre[(size_t)(g * H + h) * cols + col] = acc;
 }
 
+// Between the two for batches of few groups: one thread per (group, column, SEGMENT of rows).  A segment walks its rows
+// with b_unpool_tm's register window after P - 1 warm-up windows that are pushed but emit nothing -- every value is read
+// (1 + (P - 1) NSEG / HO) times instead of P times and a thread has H / NSEG dependent steps instead of H.  Row for row
+// the terms and their order are b_unpool_tm's: same bits.  (79 groups, conv2's map: 61 us thread-per-row -> see
+// profiles/r05/train_1250_timeline_*.txt)
+template <int P, int NSEG>
+__global__ void b_unpool_seg(const tf4 *__restrict__ gpool, const tf4 *__restrict__ pooled, const uint2 *__restrict__ codes,
+                             tf4 *__restrict__ gpre, int64_t G, int HO, int NT)
+{
+    const int cols = 4 * NT * 64;
+    const int H = HO + P - 1;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= G * NSEG * cols) return;
+    const int col = (int)(t % cols);
+    const int seg = (int)((t / cols) % NSEG);
+    const int64_t g = t / ((int64_t)cols * NSEG);
+    const int lane = col & 63, nt = (col >> 6) % NT, w = (col >> 6) / NT;
+    const int h0 = H * seg / NSEG, h1 = H * (seg + 1) / NSEG;
+    const tf4 *gp = gpool + (size_t)g * HO * cols + col;
+    const tf4 *pp = pooled + (size_t)g * HO * cols + col;
+    const uint2 *cp = codes + ((size_t)g * HO * NT + nt) * 64 + lane;
+    tf4 *o = gpre + (size_t)g * H * cols + col;
+    unpool_col<P> U;
+    U.init();
+    for (int ho = h0 - (P - 1); ho < h1; ho++) {
+        if (ho >= 0 && ho < HO) {
+            const uint2 c = cp[(size_t)ho * NT * 64];
+            U.push(gp[(size_t)ho * cols], pp[(size_t)ho * cols], cv_code16(c.x, c.y, w));
+        } else {
+            U.push_none();
+        }
+        if (ho >= h0) o[(size_t)ho * cols] = U.emit();
+    }
+}
+
 // gpre = gact * selu'(act) for a layer without pooling (slim): act is the layer output
 __global__ void b_selu_out_tm(const tf4 *__restrict__ gact, const tf4 *__restrict__ act, tf4 *__restrict__ gpre, int64_t nf4)
 {
@@ -439,7 +474,7 @@ __global__ void b_selu_out_tm(const tf4 *__restrict__ gact, const tf4 *__restric
 
 // gpool / pooled: HO = H - p + 1 rows; gpre: H rows
 static int launch_unpool(const float *gpool, const float *pooled, const float *codes, float *gpre, int64_t G, int H, int NT,
-                         int p, hipStream_t st, int tiny_g)
+                         int p, hipStream_t st, int tiny_g, bool rows_form)
 {
     const tf4 *gi = (const tf4 *)gpool, *pi = (const tf4 *)pooled;
     const uint2 *ci = (const uint2 *)codes;
@@ -450,7 +485,17 @@ static int launch_unpool(const float *gpool, const float *pooled, const float *c
         return 0;
     }
     const int HO = H - p + 1;
-    if (G <= tiny_g) {       // tiny batches (cv_model::tiny_g)
+    if (G <= tiny_g && !rows_form) {       // tiny batches (cv_model::tiny_g): four row segments per column
+        const unsigned grid = (unsigned)((G * 4 * 4 * NT * 64 + 255) / 256);
+        switch (p) {
+        case 2: b_unpool_seg<2, 4><<<grid, 256, 0, st>>>(gi, pi, ci, go, G, HO, NT); return 0;
+        case 3: b_unpool_seg<3, 4><<<grid, 256, 0, st>>>(gi, pi, ci, go, G, HO, NT); return 0;
+        case 4: b_unpool_seg<4, 4><<<grid, 256, 0, st>>>(gi, pi, ci, go, G, HO, NT); return 0;
+        case 5: b_unpool_seg<5, 4><<<grid, 256, 0, st>>>(gi, pi, ci, go, G, HO, NT); return 0;
+        default: break;
+        }
+    }
+    if (G <= tiny_g) {       // (dbg2 = 1 / 4: one thread per row)
         const unsigned grid = (unsigned)((G * H * 4 * NT * 64 + 255) / 256);
         switch (p) {
         case 2: b_unpool_rows<2><<<grid, 256, 0, st>>>(gi, pi, ci, go, G, HO, NT); return 0;
@@ -619,20 +664,29 @@ struct tr_fork {
     cv_model *m; hipStream_t st; hipStream_t side[CV_TR_SIDES]; int nside; int k; bool used[CV_TR_SIDES];
     bool tail_only;        // large batches: the second side stream takes the launch sites from tail_first on (see train_slice_tile)
     int tail_first;
+    hipEvent_t mark;       // the newest marker recorded on st; mark_fresh: nothing was enqueued on st since
+    bool mark_fresh;
     hipEvent_t next_event() { return m->tr_ev[k++ % (CV_TR_EVENTS - 1)]; }
+    int side_of(int site) const { return tail_only ? (site >= tail_first && nside > 1 ? 1 : 0) : site % nside; }
     // side stream of launch site `site` (0 heads, 1 fc5, 2 fc4, 3 conv3, 4 conv2, 5 conv1), made to wait for
-    // everything enqueued on st so far; st itself when the step runs in stream order
-    int to_side(int site, hipStream_t *out)
+    // everything enqueued on st so far; st itself when the step runs in stream order.  A marker costs the main stream
+    // ~6 us (a barrier packet between two kernels: profiles/r05/train_1250_timeline_before.txt), so two launch sites with
+    // no kernel of st between them share one (`same_point`).
+    int to_side(int site, hipStream_t *out, bool same_point = false)
     {
         if (nside == 0) { *out = st; return 0; }
-        const int i = tail_only ? (site >= tail_first && nside > 1 ? 1 : 0) : site % nside;
-        hipEvent_t e = next_event();
-        CV_HIP(hipEventRecord(e, st));
-        CV_HIP(hipStreamWaitEvent(side[i], e, 0));
+        const int i = side_of(site);
+        if (!(same_point && mark_fresh)) {
+            mark = next_event();
+            CV_HIP(hipEventRecord(mark, st));
+            mark_fresh = true;
+        }
+        CV_HIP(hipStreamWaitEvent(side[i], mark, 0));
         used[i] = true;
         *out = side[i];
         return 0;
     }
+    void st_moved() { mark_fresh = false; }      // the caller enqueued something on st
     // stream `to` continues behind everything enqueued so far on the side streams other than `to`
     int gather(hipStream_t to)
     {
@@ -644,8 +698,24 @@ struct tr_fork {
         }
         return 0;
     }
-    int join() { return nside == 0 ? 0 : gather(st); }      // st continues behind all side streams
+    // st continues behind all side streams.  The side streams are chained among themselves first (the last used one
+    // waits for the others -- off the critical path), so that st takes ONE wait instead of one per side stream.
+    int join()
+    {
+        if (nside == 0) return 0;
+        int last = -1;
+        for (int i = 0; i < nside; i++) if (used[i]) last = i;
+        if (last < 0) return 0;
+        if (gather(side[last])) return 1;
+        hipEvent_t e = next_event();
+        CV_HIP(hipEventRecord(e, side[last]));
+        CV_HIP(hipStreamWaitEvent(st, e, 0));
+        return 0;
+    }
 };
+
+// the fixed-order loss sums + the bucket's loss header (t_loss_header, below) launched from inside a slice
+struct tr_header { double lambda; bool l2; };
 
 // forward (+ optional backward) of one slice of the batch on the tile kernels; every
 // intermediate stays tile-major, the only natural-layout tensors are X, Y and the 16 head
@@ -653,9 +723,16 @@ struct tr_fork {
 // gradients of fc4, fc5 and the heads -- the contiguous tail of the flat gradient buffer, 95 %
 // of its bytes -- are final, so that the caller's exchange of that part runs under the conv
 // backward pass.
+__global__ __launch_bounds__(256) void t_loss_header(double *__restrict__ loss, double lambda, float *__restrict__ hdr,
+                                                     const double *__restrict__ rows, int64_t nrows,
+                                                     const double *__restrict__ l2_rows, int l2_kernels, int overwrite);
+
+// hdr_now (single-slice step with side streams): the loss header is launched on the side stream of launch site 0 right
+// behind the heads kernel -- it needs the heads' block sums and the L2 sums (that stream carries t_l2), nothing of the
+// backward pass -- instead of at the tail of the step on st (8 us + a launch off the critical path).
 static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t n, int64_t cand0, bool backward,
                             float drop4, uint64_t seed, uint64_t step, hipStream_t st, hipStream_t sw,
-                            hipEvent_t dense_ready)
+                            hipEvent_t dense_ready, bool sw_ordered, const tr_header *hdr_now)
 {
     const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
     const float *P = m->params; const int64_t *o = m->poff;
@@ -676,7 +753,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     if (!ghpre || !kpart) { cv_set_error("training workspace too small"); return 1; }
     // ---- forward
     bool pack_wait = false;       // dbg5 = 1: all packing in one launch on st, as before
-    if (cv_pack_for_training(m, st, backward, m->dbg[5] == 1 ? st : sw, m->tr_pack_fork, m->tr_pack_done, &pack_wait)) return 1;
+    if (cv_pack_for_training(m, st, backward, (int)Gn, m->dbg[5] == 1 ? st : sw, m->tr_pack_fork, m->tr_pack_done, &pack_wait, sw_ordered)) return 1;
     if (cv_tile_train_convs(m, x, n, tp[0], ta[0], tp[1], ta[1], tp[2], ta[2], st)) return 1;
     if (pack_wait) CV_HIP(hipStreamWaitEvent(st, m->tr_pack_done, 0));
     const cv_train_dropout drop{td4, tmask, backward ? drop4 : 0.0f, seed, step, cand0};
@@ -698,6 +775,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     if (!tgin[2]) { cv_set_error("training workspace too small"); return 1; }
     tr_fork f;
     f.m = m; f.st = st; f.k = 0; f.nside = 0; f.tail_only = Gn > m->tiny_g; f.tail_first = m->wpr_fc4 ? 4 : 3;
+    f.mark = nullptr; f.mark_fresh = false;
     for (int i = 0; i < CV_TR_SIDES; i++) { f.side[i] = nullptr; f.used[i] = false; }
     if (sw != st) {
         f.side[f.nside++] = sw;
@@ -716,14 +794,19 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     // heads: weight gradients on the matrix cores (inputs tile-major, the 16 gradients as they lie), data
     // gradients written to TM, times selu'(h5)
     if (f.to_side(0, &sx)) return 1;
+    if (hdr_now && f.nside > 0 && sx == sw)        // (sw carries the L2 kernel of this step: stream order covers it)
+        t_loss_header<<<1, 256, 0, sx>>>(m->loss_dev, hdr_now->lambda, m->grads - CV_GRAD_HEADER, m->loss_rows, m->loss_rows_used,
+                                         hdr_now->l2 ? m->l2_rows : nullptr, CV_NUM_PARAMS / 2, 1);
     if (cv_tile_heads_wgrad(m, td4, th5, ghpre, n, sx)) return 1;
-    // fc5 (its pre-activation gradient came out of the heads kernel)
-    if (f.to_side(1, &sx)) return 1;
+    // fc5 (its pre-activation gradient came out of the heads kernel: the same point of st as the heads' launch site)
+    if (f.to_side(1, &sx, true)) return 1;
     if (cv_tile_dense_wgrad(m, 5, td4, tg5pre, n, sx)) return 1;
+    f.st_moved();
     if (cv_tile_fc5_dgrad(m, tg5pre, tgd4, n, st)) return 1;
     // + the base head's contribution, then dropout4 + selu' (h4 is the SELU output before dropout)
     b_head_dgrad_tm<<<nblk(Gn * s.nb4 * 256, 256), 256, 0, st>>>(ghpre, P + o[10], P + o[12], P + o[14], P + o[16], a.fc4,
                                                                s.nb4, n, Gn, 1, tgd4, th4, tmask, tg4pre);
+    f.st_moved();
     // fc4
     if (f.to_side(2, &sx)) return 1;
     if (cv_tile_dense_wgrad(m, 4, tp[2], tg4pre, n, sx)) return 1;
@@ -736,6 +819,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     // layers without pooling (slim): the selu' factor of the layer below rides on the data-gradient kernel's store
     // (dbg4 = 3: as a separate element-wise pass)
     const bool nopool_fused = a.pool[0] == 1 && a.pool[1] == 1 && a.pool[2] == 1 && m->dbg[4] != 3;
+    f.st_moved();
     if (fused3) { if (cv_tile_fc4_dgrad_unpool(m, tg4pre, tp[2], ta[2], tgpre[2], n, st)) return 1; }
     else if (nopool_fused) { if (cv_tile_fc4_dgrad(m, tg4pre, tgpre[2], n, st, tp[2])) return 1; }
     else if (cv_tile_fc4_dgrad(m, tg4pre, tgin[2], n, st)) return 1;
@@ -749,8 +833,13 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     for (int l = 2; l >= 0; l--) {
         const int H = s.hc[l], NT = s.ntile[l];
         const bool have_gpre = (l == 2 && fused3) || (l < 2 && fusedc) || nopool_fused;
-        if (!have_gpre && launch_unpool(tgin[l], tp[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st, m->dbg[2] == 1 ? (1 << 30) : (m->dbg[2] == 2 ? 0 : m->tiny_g))) return 1;
-        if (f.to_side(5 - l, &sx)) return 1;
+        if (!have_gpre && launch_unpool(tgin[l], tp[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st, m->dbg[2] == 1 ? (1 << 30) : (m->dbg[2] == 2 ? 0 : m->tiny_g), m->dbg[2] == 1 || m->dbg[2] == 4)) return 1;
+        f.st_moved();
+        // The first layer's weight gradient is the LAST work of the backward pass: nothing of st is left to run beside it.
+        // At tiny batches it stays on st (a marker, the hand-over to the side stream and the wait for it back cost ~25 us
+        // of an otherwise idle chip for a 17 us kernel); at large ones the side stream keeps it off the chain's tail.
+        if (l == 0 && Gn <= m->tiny_g && m->dbg[5] != 2) sx = st;
+        else if (f.to_side(5 - l, &sx)) return 1;
         if (l == 0) {        // first layer: X viewed as [33][16] fragments, read in place
             if (cv_tile_conv1_wgrad(m, x, tgpre[0], n, sx)) return 1;
         } else {
@@ -766,10 +855,11 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
 }
 
 static int train_slice(cv_model *m, const float *x, const float *y, int64_t n, int64_t cand0, bool backward,
-                       float drop4, uint64_t seed, uint64_t step, hipStream_t st, hipStream_t sw, hipEvent_t dense_ready)
+                       float drop4, uint64_t seed, uint64_t step, hipStream_t st, hipStream_t sw, hipEvent_t dense_ready,
+                       bool sw_ordered, const tr_header *hdr_now)
 {
     if (m->impl == 1 && cv_tile_supported(m))
-        return train_slice_tile(m, x, y, n, cand0, backward, drop4, seed, step, st, sw, dense_ready);
+        return train_slice_tile(m, x, y, n, cand0, backward, drop4, seed, step, st, sw, dense_ready, sw_ordered, hdr_now);
     if (train_slice_plain(m, x, y, n, cand0, backward, drop4, seed, step, st)) return 1;
     if (dense_ready) CV_HIP(hipEventRecord(dense_ready, st));
     return 0;
@@ -785,9 +875,10 @@ static int train_slice(cv_model *m, const float *x, const float *y, int64_t n, i
 // each, `nrows` rows, slice after slice) and, when l2_rows is given, the L2 kernel's block sums [kernel][t] over the
 // kernels; a fixed binary tree over the threads follows; the results are ADDED to loss[0..3] / loss[4] (which hold what
 // the all-plain fallback path accumulated, normally 0).  hdr == NULL (cv_loss): the sums only.
+// overwrite (tile path: nothing else accumulates into loss[]): the sums REPLACE loss[0..4] -- no memset of them needed.
 __global__ __launch_bounds__(256) void t_loss_header(double *__restrict__ loss, double lambda, float *__restrict__ hdr,
                                                      const double *__restrict__ rows, int64_t nrows,
-                                                     const double *__restrict__ l2_rows, int l2_kernels)
+                                                     const double *__restrict__ l2_rows, int l2_kernels, int overwrite)
 {
     __shared__ double sh[5][256];
     const int t = threadIdx.x;
@@ -806,7 +897,7 @@ __global__ __launch_bounds__(256) void t_loss_header(double *__restrict__ loss, 
             for (int j = 0; j < 5; j++) sh[j][t] += sh[j][t + k];
         __syncthreads();
     }
-    if (t < 5) loss[t] += sh[t][0];
+    if (t < 5) loss[t] = overwrite ? sh[t][0] : loss[t] + sh[t][0];
     __syncthreads();
     if (t >= 16 || !hdr) return;
     __threadfence_block();
@@ -891,19 +982,41 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
         const size_t bytes = (size_t)(reinterpret_cast<char *>(m->loss_dev + 8) - reinterpret_cast<char *>(m->grads));
         CV_HIP(hipMemsetAsync(m->grads, 0, bytes, st));
     } else {
-        CV_HIP(hipMemsetAsync(m->loss_dev, 0, sizeof(double) * 8, st));
+        // (tile path: t_loss_header REPLACES the loss sums, nothing accumulates into them -- no memset of their own)
+        if (!tile_path) CV_HIP(hipMemsetAsync(m->loss_dev, 0, sizeof(double) * 8, st));
         if (backward) CV_HIP(hipMemsetAsync(m->grads, 0, sizeof(float) * m->poff[CV_NUM_PARAMS], st));      // (a caller's bucket)
     }
-    // lambda * sum(w^2)/2 depends on the weights alone: with a side stream it runs there, next to the forward pass
-    // (the slices join the side stream before they return), instead of at the tail of the step
-    bool l2_done = false;
-    if (lambda != 0.0f && sw != st && n > 0) {
+    // ONE marker for everything the side stream does ahead of the backward pass -- the L2 term and the weight packing
+    // both depend on the weights alone, i.e. on the optimizer update of the previous step (cv_pack_for_training is
+    // told that sw is ordered already)
+    const bool sw_ordered = sw != st && n > 0;
+    if (sw_ordered) {
         CV_HIP(hipEventRecord(m->tr_ev[CV_TR_EVENTS - 1], st));
         CV_HIP(hipStreamWaitEvent(sw, m->tr_ev[CV_TR_EVENTS - 1], 0));
+    }
+    // lambda * sum(w^2)/2: with a side stream it runs there, next to the forward pass (the slices join the side stream
+    // before they return), instead of at the tail of the step
+    bool l2_done = false;
+    if (lambda != 0.0f && sw_ordered) {
         l2_args la;
         for (int p = 0; p < CV_NUM_PARAMS; p += 2) { la.w[p / 2] = m->params + m->poff[p]; la.count[p / 2] = m->psize[p]; }
         t_l2<<<dim3(256, CV_NUM_PARAMS / 2), 256, 0, sw>>>(la, m->loss_dev + 4, tile_path ? m->l2_rows : nullptr);
         l2_done = true;
+    }
+    // single-slice step on the tile path with side streams: the loss header rides behind the heads kernel on the side stream
+    const tr_header hdr_early{(double)lambda, lambda != 0.0f};
+    const bool early = backward && tile_path && sw_ordered && n <= slice && (l2_done || lambda == 0.0f) && m->dbg[5] != 3;
+    // option keep_activations and several slices: the dropout maps of every slice are kept (cv_get_activation 6 / 7 then
+    // covers the whole batch, and the oracle tests can feed a multi-slice step's own keep mask back); one slice: in place
+    const size_t keep_per = tile_path ? (size_t)m->sh.nb4 * 16 : (size_t)m->arch.fc4;       // floats per candidate of a map
+    const bool keep_all = m->keep_act && n > slice;
+    const size_t keep_half = keep_all ? (size_t)(n + 16) * keep_per : 0;
+    if (keep_all && m->tr_keep_floats < 2 * keep_half) {
+        CV_HIP(hipDeviceSynchronize());
+        if (m->tr_keep) CV_HIP(hipFree(m->tr_keep));
+        m->tr_keep = nullptr; m->tr_keep_floats = 0;
+        CV_HIP(hipMalloc(&m->tr_keep, sizeof(float) * 2 * keep_half));
+        m->tr_keep_floats = 2 * keep_half;
     }
     bool recorded = false;
     for (int64_t off = 0; off < n; off += slice) {
@@ -913,10 +1026,16 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
         // gradients final", so the side streams are not gathered for it)
         hipEvent_t ev = (backward && last && comm) ? m->tr_dense_ready : nullptr;
         if (train_slice(m, x + (size_t)off * (CV_INPUT_H * 16), y + (size_t)off * 16, cn, off, backward, drop4,
-                        seed, step, st, sw, ev))
+                        seed, step, st, sw, ev, sw_ordered, early ? &hdr_early : nullptr))
             return 1;
         recorded = recorded || ev != nullptr;
+        if (keep_all && m->last_tr_d4) {          // (slices are multiples of 16 candidates: the tile-major maps concatenate)
+            const size_t cnt = (size_t)(tile_path ? (cn + 15) / 16 * 16 : cn) * keep_per;
+            CV_HIP(hipMemcpyAsync(m->tr_keep + (size_t)off * keep_per, m->last_tr_mask, sizeof(float) * cnt, hipMemcpyDeviceToDevice, st));
+            CV_HIP(hipMemcpyAsync(m->tr_keep + keep_half + (size_t)off * keep_per, m->last_tr_d4, sizeof(float) * cnt, hipMemcpyDeviceToDevice, st));
+        }
     }
+    if (keep_all && m->last_tr_d4) { m->last_tr_mask = m->tr_keep; m->last_tr_d4 = m->tr_keep + keep_half; m->last_tr_n = n; }
     if (backward && comm) {
         if (!recorded) CV_HIP(hipEventRecord(m->tr_dense_ready, st));      // empty batch
         CV_HIP(hipStreamWaitEvent(comm, m->tr_dense_ready, 0));
@@ -926,9 +1045,11 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
         for (int p = 0; p < CV_NUM_PARAMS; p += 2) { la.w[p / 2] = m->params + m->poff[p]; la.count[p / 2] = m->psize[p]; }
         t_l2<<<dim3(256, CV_NUM_PARAMS / 2), 256, 0, st>>>(la, m->loss_dev + 4, tile_path ? m->l2_rows : nullptr);
     }
-    // the fixed-order loss sums (and, for a training step, the header of the gradient bucket)
-    t_loss_header<<<1, 256, 0, st>>>(m->loss_dev, (double)lambda, backward ? m->grads - CV_GRAD_HEADER : nullptr, m->loss_rows,
-                                     m->loss_rows_used, (lambda != 0.0f && tile_path) ? m->l2_rows : nullptr, CV_NUM_PARAMS / 2);
+    // the fixed-order loss sums (and, for a training step, the header of the gradient bucket) -- unless the slice launched them
+    if (!early)
+        t_loss_header<<<1, 256, 0, st>>>(m->loss_dev, (double)lambda, backward ? m->grads - CV_GRAD_HEADER : nullptr, m->loss_rows,
+                                         m->loss_rows_used, (lambda != 0.0f && tile_path) ? m->l2_rows : nullptr, CV_NUM_PARAMS / 2,
+                                         tile_path ? 1 : 0);
     CV_HIP(hipGetLastError());
     return 0;
 }

@@ -292,20 +292,17 @@ def _close_tensor_stream(proc, fo, tensor_fn):
         fo.close()
 
 
-class _Prefixed(object):
-    """file object whose first bytes were already read"""
-
-    def __init__(self, head, f):
-        self.head, self.f = head, f
-
-    def read(self, n=-1):
-        if self.head:
-            h, self.head = self.head, b""
-            return h + self.f.read(n - len(h) if n is not None and n >= 0 else n)
-        return self.f.read(n)
-
-    def close(self):
-        self.f.close()
+def _close_quietly_unless(done, proc, fo, tensor_fn):
+    """the `finally` of the stream generators: a generator that ran to its end closes its stream the loud way (a failed
+    `gzip -fdc` raises); one that is dropped early -- the consumer stopped, an error is already on its way up -- still
+    closes it (the child process is waited for, the window buffer and the map are released) but adds no second error"""
+    if done:
+        _close_tensor_stream(proc, fo, tensor_fn)
+        return
+    try:
+        _close_tensor_stream(proc, fo, tensor_fn)
+    except Exception:
+        pass
 
 
 def owned_line_blocks(fo, rank, ws, block_lines):
@@ -349,26 +346,30 @@ def GetTensorBlocks(tensor_fn, block_lines, rank, ws):
     lib = _lib.load()
     proc, fo = _open_tensor_stream(tensor_fn)
     consumed = ctypes.c_int64(); nrows = ctypes.c_int64(); nbad = ctypes.c_int64()
-    for block, data in owned_line_blocks(fo, rank, ws, block_lines):
-        rows = _pinned.empty((block_lines, _NV), np.float32)
-        meta = np.empty((block_lines, 6), dtype=np.int64)
-        c, off, bufs = 0, 0, []
-        while off < len(data):
-            view = data[off:] if off else data
-            _lib.check(lib.cv_parse_tensor_text(view, len(view), block_lines - c,
-                                                rows[c:].ctypes.data_as(ctypes.c_void_p),
-                                                meta[c:].ctypes.data_as(ctypes.c_void_p),
-                                                ctypes.byref(consumed), ctypes.byref(nrows), ctypes.byref(nbad)))
-            if nbad.value:
-                print("UnpackATensorRecord Failure (%d malformed rows skipped)" % nbad.value, file=sys.stderr)
-            if nrows.value:
-                bufs.append((view, meta[c:c + nrows.value].copy()))
-            c += nrows.value
-            off += consumed.value
-            if consumed.value == 0:
-                break
-        yield block, c, rows[:c].reshape((c, 2 * param.flankingBaseNum + 1, 4, param.matrixNum)), _join_pos(bufs)
-    _close_tensor_stream(proc, fo, tensor_fn)
+    done = False
+    try:
+        for block, data in owned_line_blocks(fo, rank, ws, block_lines):
+            rows = _pinned.empty((block_lines, _NV), np.float32)
+            meta = np.empty((block_lines, 6), dtype=np.int64)
+            c, off, bufs = 0, 0, []
+            while off < len(data):
+                view = data[off:] if off else data
+                _lib.check(lib.cv_parse_tensor_text(view, len(view), block_lines - c,
+                                                    rows[c:].ctypes.data_as(ctypes.c_void_p),
+                                                    meta[c:].ctypes.data_as(ctypes.c_void_p),
+                                                    ctypes.byref(consumed), ctypes.byref(nrows), ctypes.byref(nbad)))
+                if nbad.value:
+                    print("UnpackATensorRecord Failure (%d malformed rows skipped)" % nbad.value, file=sys.stderr)
+                if nrows.value:
+                    bufs.append((view, meta[c:c + nrows.value].copy()))
+                c += nrows.value
+                off += consumed.value
+                if consumed.value == 0:
+                    break
+            yield block, c, rows[:c].reshape((c, 2 * param.flankingBaseNum + 1, 4, param.matrixNum)), _join_pos(bufs)
+        done = True
+    finally:
+        _close_quietly_unless(done, proc, fo, tensor_fn)
 
 
 def _default_readers(nfiles):
@@ -396,7 +397,7 @@ def GetTensorFiles(files, num, rank, ws, readers=None, depth=2, ordered=True):
     from queue import Queue, Full
     owned = [(k, fn) for k, fn in enumerate(files) if k % ws == rank]
     if readers is None:
-        compressed = bool(owned) and all(_map_plain_text(fn) is None for _k, fn in owned[:1])
+        compressed = any(is_compressed(fn) for _k, fn in owned)       # (magic bytes only: nothing is mapped here)
         readers = _default_readers(len(owned)) if compressed else 1
     if readers <= 1 or len(owned) <= 1:
         for k, fn in owned:
@@ -420,14 +421,16 @@ def GetTensorFiles(files, num, rank, ws, readers=None, depth=2, ordered=True):
 
     def read(i):
         q = queues[i]
+        gen = GetTensor(owned[i][1], num, log=False)
         try:
-            for _end, c, X, pos in GetTensor(owned[i][1], num, log=False):
+            for _end, c, X, pos in gen:
                 if not put(q, (i, c, X, pos)):
                     return
             put(q, (i, None, None, None))
         except BaseException as e:                         # surfaced in the consumer
             put(q, (i, e, None, None))
         finally:
+            gen.close()                                    # a reader told to stop still closes its stream (child process, map)
             slots.release()
 
     def launch():
@@ -462,20 +465,39 @@ def GetTensorFiles(files, num, rank, ws, readers=None, depth=2, ordered=True):
         stop.set()
 
 
+def _gzip_would_decode(head):
+    """first bytes of a file `gzip -fdc` would DEcompress rather than pass through: gzip (1f 8b), compress .Z (1f 9d),
+    pack (1f 1e), lzh (1f a0) and a zip local header -- everything else it copies unchanged (gzip -f)"""
+    return head[:2] in (b"\x1f\x8b", b"\x1f\x9d", b"\x1f\x1e", b"\x1f\xa0") or head[:4] == b"PK\x03\x04"
+
+
+def is_compressed(tensor_fn):
+    """the file is in a format the reference's `gzip -fdc` pipe (utils_v2.py:25) decompresses"""
+    try:
+        with open(tensor_fn, "rb") as fh:
+            return _gzip_would_decode(fh.read(4))
+    except OSError:
+        return False
+
+
 def _map_plain_text(tensor_fn):
-    """-> read-only uint8 array over the memory-mapped file when `tensor_fn` is a regular, non-empty file that is NOT
-    gzip-compressed (the reference pipes everything through `gzip -fdc`, which passes plain text through unchanged,
-    utils_v2.py:25); None otherwise (PIPE, .gz, FIFOs: the stream path)."""
+    """-> read-only uint8 array over the memory-mapped file when `tensor_fn` is a regular, non-empty file that the
+    reference's `gzip -fdc` pipe (utils_v2.py:25) would pass through unchanged, i.e. that does not start with the magic
+    of a format gzip decodes (gzip, compress, pack, lzh, zip); None otherwise (PIPE, compressed files, FIFOs: the stream
+    path, where _GzipOrPipe hands everything but gzip to the pipe).  CV_TEXT=stream forces the stream path for plain
+    files too.  NOTE: the position fields of a batch stay views of the map until its VCF records are formatted -- a file
+    that is truncated or rewritten while callVar reads it ends the process with SIGBUS instead of an exception (the
+    stream path copies; use CV_TEXT=stream for inputs another process is still writing)."""
     import mmap
     import stat
-    if tensor_fn == "PIPE":
+    if tensor_fn == "PIPE" or os.environ.get("CV_TEXT") == "stream":
         return None
     try:
         st = os.stat(tensor_fn)
         if not stat.S_ISREG(st.st_mode) or st.st_size == 0:
             return None
         with open(tensor_fn, "rb") as fh:
-            if fh.read(2) == b"\x1f\x8b":
+            if _gzip_would_decode(fh.read(4)):
                 return None
             mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
     except OSError:
@@ -561,41 +583,45 @@ def GetTensor(tensor_fn, num, log=True):
     bufs = []          # (bytes, meta rows) pieces of the batch being filled
     consumed = ctypes.c_int64(); nrows = ctypes.c_int64(); nbad = ctypes.c_int64()
     eof = False
-    while True:
-        chunk = fo.read(1 << 24) if not eof else b""
-        if not chunk:
-            eof = True
-            if pending and not pending.endswith(b"\n"):
-                pending += b"\n"
-        data = pending + chunk if pending else chunk
-        arr = np.frombuffer(data, dtype=np.uint8)          # addresses into the bytes object: no slice copies
-        off = 0
-        while off < len(data):
-            _lib.check(lib.cv_parse_tensor_text(ctypes.c_void_p(arr.ctypes.data + off), len(data) - off, num - c,
-                                                rows[c:].ctypes.data_as(ctypes.c_void_p),
-                                                meta[c:].ctypes.data_as(ctypes.c_void_p),
-                                                ctypes.byref(consumed), ctypes.byref(nrows), ctypes.byref(nbad)))
-            if nbad.value:
-                print("UnpackATensorRecord Failure (%d malformed rows skipped)" % nbad.value, file=sys.stderr)
-            if nrows.value:
-                bufs.append((arr[off:off + consumed.value], meta[c:c + nrows.value].copy()))
-            c += nrows.value
-            off += consumed.value
-            if c == num:
-                total += c
-                if log:
-                    print("Processed %d tensors" % total, file=sys.stderr)
-                yield 0, c, rows.reshape((num, 2 * param.flankingBaseNum + 1, 4, param.matrixNum)), _join_pos(bufs)
-                rows = _pinned.empty((num, _NV), np.float32)      # page-locked when a GPU is present: the consumer copies it to HBM
-                meta = np.empty((num, 6), dtype=np.int64)
-                c = 0
-                bufs = []
-            elif consumed.value == 0:
+    done = False
+    try:
+        while True:
+            chunk = fo.read(1 << 24) if not eof else b""
+            if not chunk:
+                eof = True
+                if pending and not pending.endswith(b"\n"):
+                    pending += b"\n"
+            data = pending + chunk if pending else chunk
+            arr = np.frombuffer(data, dtype=np.uint8)          # addresses into the bytes object: no slice copies
+            off = 0
+            while off < len(data):
+                _lib.check(lib.cv_parse_tensor_text(ctypes.c_void_p(arr.ctypes.data + off), len(data) - off, num - c,
+                                                    rows[c:].ctypes.data_as(ctypes.c_void_p),
+                                                    meta[c:].ctypes.data_as(ctypes.c_void_p),
+                                                    ctypes.byref(consumed), ctypes.byref(nrows), ctypes.byref(nbad)))
+                if nbad.value:
+                    print("UnpackATensorRecord Failure (%d malformed rows skipped)" % nbad.value, file=sys.stderr)
+                if nrows.value:
+                    bufs.append((arr[off:off + consumed.value], meta[c:c + nrows.value].copy()))
+                c += nrows.value
+                off += consumed.value
+                if c == num:
+                    total += c
+                    if log:
+                        print("Processed %d tensors" % total, file=sys.stderr)
+                    yield 0, c, rows.reshape((num, 2 * param.flankingBaseNum + 1, 4, param.matrixNum)), _join_pos(bufs)
+                    rows = _pinned.empty((num, _NV), np.float32)      # page-locked when a GPU is present: the consumer copies it to HBM
+                    meta = np.empty((num, 6), dtype=np.int64)
+                    c = 0
+                    bufs = []
+                elif consumed.value == 0:
+                    break
+            pending = data[off:]
+            if eof:
                 break
-        pending = data[off:]
-        if eof:
-            break
-    _close_tensor_stream(proc, fo, tensor_fn)
+        done = True
+    finally:
+        _close_quietly_unless(done, proc, fo, tensor_fn)
     total += c
     if log:
         print("Processed %d tensors" % total, file=sys.stderr)
@@ -898,13 +924,16 @@ class _PinnedPool(object):
     MIN_BYTES, MAX_BYTES, KEEP = 1 << 18, 1 << 28, 6
 
     def __init__(self):
+        import threading
         self.free = {}
         self.enabled = None
+        self.lock = threading.Lock()      # GetTensorFiles takes buffers from up to 8 reader threads; finalizers give them back
 
     def _give(self, cls, t):
-        lst = self.free.setdefault(cls, [])
-        if len(lst) < self.KEEP:
-            lst.append(t)
+        with self.lock:
+            lst = self.free.setdefault(cls, [])
+            if len(lst) < self.KEEP:
+                lst.append(t)
 
     def empty(self, shape, dtype):
         nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
@@ -919,8 +948,11 @@ class _PinnedPool(object):
         import torch
         import weakref
         cls = (nbytes + (1 << 20) - 1) >> 20 << 20
-        lst = self.free.get(cls)
-        t = lst.pop() if lst else torch.empty(cls, dtype=torch.uint8, pin_memory=True)
+        with self.lock:
+            lst = self.free.get(cls)
+            t = lst.pop() if lst else None
+        if t is None:
+            t = torch.empty(cls, dtype=torch.uint8, pin_memory=True)
         root = t.numpy()
         weakref.finalize(root, self._give, cls, t)
         return root[:nbytes].view(dtype).reshape(shape)

@@ -224,15 +224,57 @@ def test_backward_kernel_variants_give_the_same_bits(oracle, arch, n):
         m.close()
         return out
     ref = run({})
+    # (round 5: dbg2 = 4 the thread-per-row unpool at tiny batches instead of row segments; dbg5 = 2 the first layer's weight
+    # gradient on a side stream also at tiny batches; dbg5 = 3 the loss header at the tail of the step instead of behind the
+    # heads kernel on the side stream)
     variants = ({"dbg3": 1}, {"dbg4": 2}, {"dbg4": 2, "dbg0": 3}, {"train_side_streams": 1}, {"dbg5": 1}, {"dbg6": 3}, {"dbg7": 1},
-                {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7}, {"dbg1": 8}, {"dbg2": 3}, {"dbg3": 1, "dbg4": 2, "train_overlap": 0}) if arch == "full" else \
+                {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7}, {"dbg1": 8}, {"dbg2": 3}, {"dbg3": 1, "dbg4": 2, "train_overlap": 0},
+                {"dbg2": 4}, {"dbg5": 2}, {"dbg5": 3}, {"dbg2": 1}, {"dbg2": 2}) if arch == "full" else \
                ({"dbg4": 3}, {"train_side_streams": 1}, {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7},
-                {"dbg5": 1, "dbg4": 3, "train_overlap": 0})
+                {"dbg5": 1, "dbg4": 3, "train_overlap": 0}, {"dbg5": 2}, {"dbg5": 3})
     for opts in variants:
         got = run(opts)
         assert ref[0] == got[0], opts
         assert np.array_equal(ref[1].view(np.uint32), got[1].view(np.uint32)), opts
         assert np.array_equal(ref[2].view(np.uint32), got[2].view(np.uint32)), opts
+
+
+@pytest.mark.parametrize("arch", ["full", "slim"])
+def test_packed_layouts_follow_the_weights_through_mixed_passes(oracle, arch):
+    """A pass packs only the MFMA layouts of the weights that ITS kernels read (a training step of 79 groups reads two of
+    the four fc4 layouts; an inference pass of 65 536 candidates another one) and leaves the rest stale until a pass
+    that reads them.  Through a sequence that mixes training steps, predict() and getLoss() at sizes that switch
+    kernels, every pass of the long-lived model must give the bits of a FRESH model that was handed its current
+    weights -- a stale layout would show as different outputs / gradients (or as the library's own "layout is stale"
+    error).  Dropout off, so a step's gradient is a function of weights and batch alone."""
+    import torch
+    from clairvoyante_amd import synth
+    P = common.bench_params(oracle, arch)
+    used = _model(arch); used.setParameters(P)
+    used.dropoutRateFC4Val = 0.0; used.setLearningRate(1e-3); used.setL2RegularizationLambda(1e-3)
+    plan = [("train", 1250), ("predict", 1000), ("train", 10000), ("predict", 40000), ("train", 40010), ("loss", 3000),
+            ("train", 83), ("predict", 300), ("train", 2561), ("predict", 65536), ("train", 1250)]
+    data = {}
+    for op, n in plan:
+        if n not in data:
+            xt, cls, rf, alt, il = synth.make_candidates(n, seed=100 + n, device="cuda", return_class=True)
+            data[n] = (xt, synth.make_labels(cls, rf, alt, il))
+        x, y = data[n]
+        fresh = _model(arch); fresh.setParameters(used.getParameters())
+        fresh.dropoutRateFC4Val = 0.0; fresh.setLearningRate(1e-3); fresh.setL2RegularizationLambda(1e-3)
+        try:
+            if op == "predict":
+                a = used.predict_device(x).cpu().numpy(); b = fresh.predict_device(x).cpu().numpy()
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (op, n)
+            elif op == "loss":
+                assert float(used.getLoss(x, y)) == float(fresh.getLoss(x, y)), (op, n)
+            else:
+                la, lb = float(used.train(x, y)[0]), float(fresh.train(x, y)[0])
+                assert la == lb, (op, n)
+                assert np.array_equal(_flat(used, 1).view(np.uint32), _flat(fresh, 1).view(np.uint32)), (op, n)
+        finally:
+            fresh.close()
+    used.close()
 
 
 def test_deferred_losses_sum_to_the_per_step_losses(oracle):

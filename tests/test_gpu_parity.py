@@ -250,3 +250,40 @@ def test_fused_tail_writes_no_maps_unless_asked(oracle, arch):
             m.getActivation(4, 1000)
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("flat_heads", [False, True])
+@pytest.mark.parametrize("arch", ["full", "slim"])
+def test_argmax_agrees_with_a_second_fp32_library_outside_the_float64_margin_set(oracle, arch, flat_heads):
+    """north_star asks for 100 % per-head argmax agreement with TF-CPU; TensorFlow cannot run here, and its Eigen
+    summation order is not the oracle's ascending-k chain anyway.  What can be shown: the float64 formulation bounds the
+    set of candidates on which two correct fp32 implementations may order the two best classes differently (top-2
+    margin < 1e-5 on a head), and OUTSIDE that set the HIP path agrees per head with float64 and with stock torch CPU
+    ops (oneDNN: another library's summation order) on every candidate -- also with head weights shrunk until a large
+    part of the candidates IS inside the set (flat_heads), where the two fp32 orders do differ.  bench.py reports the
+    same quantities over its 262 144 timed candidates (parity.margin_below_1e-5_frac, cpu_baseline_torch.*)."""
+    import torch
+    import bench
+    import torch_ref
+    P = dict(common.bench_params(oracle, arch))
+    if flat_heads:
+        for k in list(P):                                   # logits within ~1e-5 of each other: most candidates near a tie
+            if k.startswith("Y"):
+                P[k] = (P[k] * np.float32(3e-5 if k.endswith("kernel") else 0.0)).astype(np.float32)
+    x = common.inputs(8192, seed=11, stress=2048)
+    m = _model(arch)
+    try:
+        m.setParameters(P)
+        got = m.predict_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    finally:
+        m.close()
+    with torch.no_grad():
+        other = torch_ref.forward(arch, P, x, dtype=torch.float32)["out"].numpy()
+    s = bench.order_sensitivity(got, bench.float64_outputs(arch, P, x, None, chunk=4096)[:len(x)], other)
+    assert s["n"] == len(x) and s["max_abs_dprob_vs_float64"] <= 1e-5
+    assert s["argmax_match_vs_float64_where_margin_ge_1e-5"] == [1.0, 1.0, 1.0, 1.0]
+    assert s["other_argmax_match_where_margin_ge_1e-5"] == [1.0, 1.0, 1.0, 1.0]
+    if flat_heads:
+        assert s["margin_below_1e-5_frac"] > 0.3           # the set is far from empty here: the test has teeth
+    else:
+        assert s["margin_below_1e-5_frac"] < 0.01

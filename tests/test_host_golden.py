@@ -69,6 +69,43 @@ def test_gettensor_odd_batch_sizes():
         assert np.array_equal(np.concatenate(Xs), d["X"]) and poss == [str(s) for s in d["pos"]]
 
 
+def test_only_what_gzip_passes_through_is_memory_mapped(tmp_path, monkeypatch):
+    """`gzip -fdc` (utils_v2.py:25) also decompresses compress (.Z), pack, lzh and single-member zip input: such files go to
+    the stream path (where the pipe takes them), never to the text parser as raw bytes; CV_TEXT=stream sends plain text
+    there too; a list counts as compressed when ANY of its files is; a stream generator that is dropped early still closes
+    its stream (the `gzip` child is waited for)"""
+    import subprocess
+    from clairvoyante_amd import utils_v2
+    for name, head in (("a.Z", b"\x1f\x9d\x90"), ("a.pack", b"\x1f\x1e\x00"), ("a.lzh", b"\x1f\xa0\x00"), ("a.zip", b"PK\x03\x04\x14")):
+        fn = str(tmp_path / name)
+        open(fn, "wb").write(head + b"\x00" * 64)
+        assert utils_v2._map_plain_text(fn) is None and utils_v2.is_compressed(fn)
+    plain = str(tmp_path / "plain.txt")
+    import gzip
+    open(plain, "wb").write(gzip.open(os.path.join(G, "gettensor_a.txt.gz"), "rb").read())
+    assert utils_v2._map_plain_text(plain) is not None and not utils_v2.is_compressed(plain)
+    want = [np.array(x) for _e, _c, x, _p in utils_v2.GetTensor(plain, 1000, log=False)]
+    monkeypatch.setenv("CV_TEXT", "stream")
+    assert utils_v2._map_plain_text(plain) is None
+    got = [np.array(x) for _e, _c, x, _p in utils_v2.GetTensor(plain, 1000, log=False)]
+    assert all(np.array_equal(a, b) for a, b in zip(want, got)) and len(want) == len(got)
+    monkeypatch.delenv("CV_TEXT")
+    # dropped after the first batch, through the reference's pipe: the child process does not outlive the generator
+    monkeypatch.setenv("CV_GZIP", "external")
+    started = []
+    real = subprocess.Popen
+
+    def spy(*a, **k):
+        p = real(*a, **k)
+        started.append(p)
+        return p
+    monkeypatch.setattr(utils_v2.subprocess, "Popen", spy)
+    gen = utils_v2.GetTensor(os.path.join(G, "gettensor_a.txt.gz"), 3, log=False)
+    next(gen)
+    gen.close()
+    assert len(started) == 1 and started[0].returncode is not None
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 @pytest.mark.parametrize("strip_last_newline", [False, True])
 def test_gettensor_plain_text_through_the_memory_map(tag, strip_last_newline, tmp_path):

@@ -27,11 +27,12 @@ def same_pad(k):
     return before, total - before
 
 
-def forward(arch, params, x, dtype=torch.float64, mask4=None, rate4=0.0, want_logits=False):
-    """x [n,33,4,4] (NHWC) -> dict with out16 and intermediates (NHWC)."""
+def forward(arch, params, x, dtype=torch.float64, mask4=None, rate4=0.0, want_logits=False, device=None):
+    """x [n,33,4,4] (NHWC) -> dict with out16 and intermediates (NHWC).  device: where the torch ops run (default: CPU;
+    bench.py runs the float64 formulation over all timed candidates with stock torch ops on the GPU)."""
     cfg = CFG[arch]
-    p = {k: torch.as_tensor(v).to(dtype) for k, v in params.items()}
-    t = torch.as_tensor(x).to(dtype).permute(0, 3, 1, 2)  # NCHW: C=matrix, H=position, W=base
+    p = {k: torch.as_tensor(v).to(device=device, dtype=dtype) for k, v in params.items()}
+    t = torch.as_tensor(x).to(device=device, dtype=dtype).permute(0, 3, 1, 2)  # NCHW: C=matrix, H=position, W=base
     inter = {}
     for l in range(3):
         w = p["conv%d/kernel" % (l + 1)].permute(3, 2, 0, 1)  # HWIO -> OIHW
@@ -53,7 +54,7 @@ def forward(arch, params, x, dtype=torch.float64, mask4=None, rate4=0.0, want_lo
         q = 1.0 - rate4
         a = (1.0 / (q * ((1 - q) * ap * ap + 1.0))) ** 0.5
         b = -a * ((1 - q) * ap)
-        m = torch.as_tensor(mask4).to(dtype)
+        m = torch.as_tensor(mask4).to(device=device, dtype=dtype)
         d4 = a * (fc4 * m + ap * (1 - m)) + b
     inter["d4"] = d4
     fc5 = selu(d4 @ p["fc5/kernel"] + p["fc5/bias"])
