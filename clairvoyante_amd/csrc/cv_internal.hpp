@@ -127,7 +127,7 @@ struct cv_model {
     //   dbg0 = n: position parts of the convolution data gradients      dbg1 = n: ... of the training-forward convolutions
     //        (n = 9: the batch-dependent number of parts instead of flat row ranges; n = 7: flat ranges for a small batch too;
     //         dbg1 = 8: conv2 forward on flat ranges too)
-    //   dbg2 = 1 / 2: unpool always thread-per-row / always streaming, 3: fc4's alpha-dropout as its own pass, 4: thread-per-row at tiny batches (default there: row segments)
+    //   dbg2 = 1 / 2: unpool always thread-per-row / always streaming, 3: fc4's alpha-dropout as its own pass, 4: thread-per-row at tiny batches (default there: row segments), 5: the tail of the tiny-batch forward as three kernels
     //   dbg3 = 1: fc4 data gradient and conv3 unpool as two kernels
     //   dbg4 = 2: conv data gradients fused with the unpool below (conv_dgrad_unpool), 3: slim selu' as its own pass
     //   dbg5 = 1: all weight packing in one launch in stream order, 2: conv1's weight gradient on a side stream at tiny batches too,
@@ -199,6 +199,8 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
 struct cv_train_dropout { float *d4, *amask; float rate; uint64_t seed, step; int64_t cand0; };
 int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm, int64_t n, hipStream_t st,
                       float *part = nullptr, const cv_train_dropout *drop = nullptr, bool *drop_done = nullptr);
+int cv_tile_train_tail(cv_model *m, const float *p3_tm, float *h4_tm, float *h5_tm, const float *y, int64_t n, int want_grad,
+                       float *g16, float *g5pre_tm, float *part, const cv_train_dropout *drop, hipStream_t st, bool *done);
 int cv_tile_fc5_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
 // act_below (layers without pooling, slim): the layer-below output; the result is then times selu' = its pre-activation gradient
 int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st, const float *act_below = nullptr);

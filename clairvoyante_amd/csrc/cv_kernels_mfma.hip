@@ -2507,6 +2507,222 @@ __global__ __launch_bounds__(256) void heads_train_tm(const f4 *__restrict__ d4,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Tail of the TRAINING forward pass at tiny batches in one kernel (full topology; round 5): second pass of the k-split
+// fc4 (dense_ksum: partial sums added in order, bias, SELU, alpha-dropout), fc5 (dense_small<4, 7>), and the heads
+// of the training pass (heads_train_tm: products, losses, head gradients, fc5-side data gradient times selu').  As
+// three launches they were 8 + 12 + 28 us of a 14-kernel chain at 79 groups (a rank's share of train.py's batch on
+// 8 GPUs), each a latency chain of global loads on a fraction of the chip; here a workgroup of four waves owns one
+// group of 16 candidates and the operands of every step come from LDS or registers:
+//   1. wave w sums fragments w, w + 4, ... of the eight k ranges, + bias, SELU -> fc4 output (stored: the backward
+//      pass takes selu' from it), dropout -> d4 / mask (stored) and d4 into LDS;
+//   2. waves 0..2: one slab of 4 fc5 tiles each over the 21 d4 fragments (weights from L2 through a register ring,
+//      dense_small's loop), bias + SELU -> fc5 output (stored, LDS, and kept in registers); wave 3: the base head's
+//      product over the same fragments;
+//   3. wave 0: the other heads' product from LDS, then -- lane = (candidate, head) -- losses and head gradients;
+//   4. waves 0..2: the fc5-side data gradient of their own tiles times selu'(fc5 output) from the registers of step 2.
+// Arithmetic and order per value are those of the three kernels (same bits); the loss sums leave as ONE ROW PER GROUP
+// (heads_train_tm: one per four groups), which t_loss_header adds in its fixed order.
+// ---------------------------------------------------------------------------
+template <int NB4, int NB5>
+__global__ __launch_bounds__(256) void train_tail_tm(const f4 *__restrict__ part, int KS, int G, const float *__restrict__ bias4,
+                                                      int nout4, f4 *__restrict__ h4_out, cv_dropout_args dr,
+                                                      const f4 *__restrict__ w5s, const float *__restrict__ bias5, int nout5,
+                                                      f4 *__restrict__ h5_out, const f4 *__restrict__ wp0,
+                                                      const f4 *__restrict__ wp1, const float *__restrict__ bb,
+                                                      const float *__restrict__ bz, const float *__restrict__ bt,
+                                                      const float *__restrict__ bl, const float *__restrict__ wz,
+                                                      const float *__restrict__ wt, const float *__restrict__ wl,
+                                                      const float *__restrict__ y, int64_t n, int want_grad,
+                                                      float *__restrict__ g16, f4 *__restrict__ g5pre_tm,
+                                                      double *__restrict__ loss_rows)
+{
+    constexpr int NBW = 4, D = 7;                 // fc5 slab width and operand ring depth of dense_small<4, 7>
+    static_assert(NB4 % D == 0 && NB5 <= 3 * NBW, "three slabs of four fc5 tiles, 21 k fragments in rings of 7");
+    __shared__ __attribute__((aligned(16))) f4 sd4[NB4][64];
+    __shared__ __attribute__((aligned(16))) f4 sh5[NB5][64];
+    __shared__ __attribute__((aligned(16))) f4 sa0[64];
+    __shared__ float S[16][17];
+    __shared__ __attribute__((aligned(16))) float shw[NB5 * 16][12];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = blockIdx.x;
+    const int c = lane & 15, q = lane >> 4;
+    const int K5 = nout5;
+    const bool grads = g5pre_tm && want_grad;
+    if (grads) {
+        for (int i = threadIdx.x; i < NB5 * 16 * 12; i += 256) {
+            const int k = i / 12, jj = i % 12;
+            float v = 0.0f;
+            if (k < K5) v = jj < 2 ? wz[(size_t)k * 2 + jj] : (jj < 6 ? wt[(size_t)k * 4 + (jj - 2)] : wl[(size_t)k * 6 + (jj - 6)]);
+            shw[k][jj] = v;
+        }
+    }
+    // ---- 1. fc4: k ranges added in ascending order, + bias, SELU, alpha-dropout (dense_ksum)
+    const int64_t per = (int64_t)G * NB4 * 64;
+    for (int ob = wave; ob < NB4; ob += 4) {
+        const int64_t t = ((int64_t)g * NB4 + ob) * 64 + lane;
+        f4 v = part[t];
+        for (int z = 1; z < KS; z++) v += part[(size_t)z * per + t];
+        const f4 h = selu4(v + load_bias4(bias4, ob, q, nout4));
+        h4_out[t] = h;
+        f4 d, mk;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            float x = h[s4], k;
+            dropout_value(x, k, 16 * ob + 4 * s4 + q, dr.nunits, dr.cand0 + (int64_t)g * 16 + c, dr.rate, dr.seed, dr.step);
+            d[s4] = x; mk[s4] = k;
+        }
+        reinterpret_cast<f4 *>(dr.d4)[t] = d;
+        reinterpret_cast<f4 *>(dr.amask)[t] = mk;
+        sd4[ob][lane] = d;
+    }
+    __syncthreads();
+    // ---- 2. fc5 slabs (waves 0..2) and the base head (wave 3)
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 H5[NBW];                                   // this wave's fc5 output tiles (waves 0..2)
+#pragma unroll
+    for (int j = 0; j < NBW; j++) H5[j] = zero;
+    if (wave < 3) {
+        const int slab = wave;
+        const f4 *wp = w5s + (size_t)slab * NB4 * (NBW * 64) + lane;
+        f4 acc[NBW];
+#pragma unroll
+        for (int j = 0; j < NBW; j++) acc[j] = zero;
+        f4 A[D][NBW];
+        auto fetch = [&](const f4 *pw, int d) {
+#pragma unroll
+            for (int j = 0; j < NBW; j++) A[d][j] = pw[((size_t)d * NBW + j) * 64];
+        };
+        auto step = [&](int kb, int d) {
+            const f4 B = sd4[kb][lane];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+                for (int j = 0; j < NBW; j++) acc[j] = mfma4(A[d][j][s4], B[s4], acc[j]);
+        };
+#pragma unroll
+        for (int d = 0; d < D; d++) fetch(wp, d);
+#pragma unroll 1
+        for (int kb0 = D; kb0 < NB4; kb0 += D) {
+            wp += (size_t)D * NBW * 64;
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                step(kb0 - D + d, d);
+                fetch(wp, d);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; d++) step(NB4 - D + d, d);
+#pragma unroll
+        for (int j = 0; j < NBW; j++) {
+            const int ob = slab * NBW + j;
+            if (ob >= NB5) break;
+            H5[j] = selu4(acc[j] + load_bias4(bias5, ob, q, nout5));
+            h5_out[((size_t)g * NB5 + ob) * 64 + lane] = H5[j];
+            sh5[ob][lane] = H5[j];
+        }
+    } else {
+        f4 a0 = zero;
+#pragma unroll 3
+        for (int kb = 0; kb < NB4; kb++) {
+            const f4 B = sd4[kb][lane];
+            const f4 A = wp0[(size_t)kb * 64 + lane];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) a0 = mfma4(A[s4], B[s4], a0);
+        }
+        sa0[lane] = a0;
+    }
+    __syncthreads();
+    // ---- 3. the fc5-side heads' product, losses and head gradients (wave 0; heads_train_tm)
+    if (wave == 0) {
+        f4 a1 = zero;
+#pragma unroll
+        for (int kb = 0; kb < NB5; kb++) {
+            const f4 B = sh5[kb][lane];
+            const f4 A = wp1[(size_t)kb * 64 + lane];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) a1 = mfma4(A[s4], B[s4], a1);
+        }
+        const f4 a0 = sa0[lane];
+        // rows of the second tile: q 0 = zygosity (2), q 1 = type (4), q 2 = length 0..3, q 3 = length 4..5
+        if (q == 0) {
+            S[c][0] = a0[0] + bb[0]; S[c][1] = a0[1] + bb[1]; S[c][2] = a0[2] + bb[2]; S[c][3] = a0[3] + bb[3];
+            S[c][4] = a1[0] + bz[0]; S[c][5] = a1[1] + bz[1];
+        } else if (q == 1) {
+            S[c][6] = a1[0] + bt[0]; S[c][7] = a1[1] + bt[1]; S[c][8] = a1[2] + bt[2]; S[c][9] = a1[3] + bt[3];
+        } else if (q == 2) {
+            S[c][10] = a1[0] + bl[0]; S[c][11] = a1[1] + bl[1]; S[c][12] = a1[2] + bl[2]; S[c][13] = a1[3] + bl[3];
+        } else {
+            S[c][14] = a1[0] + bl[4]; S[c][15] = a1[1] + bl[5];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // losses and gradients: lane -> (candidate lane >> 2 of the group, head lane & 3)
+        const int cc = lane >> 2, j = lane & 3;
+        const int64_t cand = (int64_t)g * 16 + cc;
+        double l = 0.0;
+        if (cand < n) {
+            const float *yi = y + (size_t)cand * 16;
+            float *gl = S[cc];
+            float *go = g16 + (size_t)cand * 16;
+            if (j == 0) {
+                float v[4];
+                for (int k = 0; k < 4; k++) v[k] = gl[k];
+                for (int k = 0; k < 4; k++) {
+                    float sg = cvm::sigmoid(v[k]);
+                    float dd = sg - yi[k];
+                    l += (double)dd * dd;
+                    if (want_grad) { const float gr = 2.0f * dd * sg * (1.0f - sg); gl[k] = gr; go[k] = gr; }
+                }
+            } else {
+                const int off = j == 1 ? 4 : (j == 2 ? 6 : 10);
+                const int cnt = j == 1 ? 2 : (j == 2 ? 4 : 6);
+                float v[6], lg[6], p[6];
+                float mx = -__builtin_inff();
+                for (int k = 0; k < cnt; k++) { v[k] = gl[off + k]; lg[k] = cvm::selu(v[k]) + 1e-10f; mx = fmaxf(mx, lg[k]); }
+                float se = 0.0f, ysum = 0.0f;
+                for (int k = 0; k < cnt; k++) { p[k] = cvm::expf_fixed(lg[k] - mx); se += p[k]; ysum += yi[off + k]; }
+                float lse = mx + logf(se);
+                for (int k = 0; k < cnt; k++) {
+                    l += -(double)yi[off + k] * (double)(lg[k] - lse);
+                    if (want_grad) { const float gr = (p[k] / se * ysum - yi[off + k]) * cvm::selu_grad(v[k]); gl[off + k] = gr; go[off + k] = gr; }
+                }
+            }
+        }
+        // the 16 candidates of the group in heads_train_tm's fixed tree (lanes with the same head: xor 4, 8, 16, 32)
+#pragma unroll
+        for (int d = 4; d < 64; d <<= 1) l += __shfl_xor(l, d);
+        if (lane < 4) loss_rows[(size_t)g * 4 + lane] = l;
+    }
+    __syncthreads();
+    if (!grads || wave >= 3) return;
+    // ---- 4. fc5-side head data gradients (zygosity, type, length; k = fc5 unit), times selu'(fc5 output)
+    const bool cand_ok = (int64_t)g * 16 + c < n;
+    const float *gi = S[c];
+#pragma unroll
+    for (int j = 0; j < NBW; j++) {
+        const int kb = wave * NBW + j;
+        if (kb >= NB5) break;
+        f4 o;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            const int k = 16 * kb + 4 * s4 + q;
+            float acc = 0.0f;
+            if (cand_ok && k < K5) {
+                const f4 *wk4 = reinterpret_cast<const f4 *>(shw[k]);
+                const f4 w0 = wk4[0], w1 = wk4[1], w2 = wk4[2];
+                const float wk[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
+#pragma unroll
+                for (int jj = 0; jj < 12; jj++) acc = __builtin_fmaf(gi[4 + jj], wk[jj], acc);
+            }
+            o[s4] = acc * cv_selu_grad_from_out(H5[j][s4]);
+        }
+        g5pre_tm[((size_t)g * NB5 + kb) * 64 + lane] = o;
+    }
+}
+
 // up to this many groups (16 candidates each) fc4 runs as 3 output slabs per group block: 8-wave workgroups
 // x 3 slabs fill the 256 CUs from ~700 groups on; above the threshold one workgroup keeps all 21 tiles
 constexpr int CV_FC4_SLAB_MAX_G = 2048;
@@ -2847,6 +3063,7 @@ int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward, int G, hipS
 {
     if (wait_before_dense) *wait_before_dense = false;
     unsigned need = CVL_CONV | CVL_HEADS | fc4_train_layout(m, G) | fc5_train_layout(m, G);
+    if (m->dbg[5] == 4) need = CVL_FORWARD;            // development: every forward layout, as before round 5
     if (backward) need |= CVL_BACKWARD;
     const unsigned todo = need & ~m->packed_valid;
     if (!todo) return 0;
@@ -3794,6 +4011,41 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
         return launch_dense<3, 4>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);
     }
     return launch_dense<2, 4>(in_tm, s.nb4, m->wp_fc5, P + o[9], a.fc5, out_tm, G, st);
+}
+
+// Tiny batches of the full topology with the k-split fc4 forward: fc4's eight k ranges, then ONE kernel for their sum,
+// bias, SELU, alpha-dropout, fc5, the heads, the losses, the head gradients and the fc5-side data gradient
+// (train_tail_tm).  *done = false: not this regime (or dbg2 = 5) -- the caller runs the layers one by one.
+int cv_tile_train_tail(cv_model *m, const float *p3_tm, float *h4_tm, float *h5_tm, const float *y, int64_t n, int want_grad,
+                       float *g16, float *g5pre_tm, float *part, const cv_train_dropout *drop, hipStream_t st, bool *done)
+{
+    *done = false;
+    const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
+    const float *P = m->params; const int64_t *o = m->poff;
+    const int G = (int)((n + 15) / 16);
+    if (G <= 0 || !is_full(a) || !part || !drop || G > m->tiny_g || m->dbg[2] == 5) return 0;
+    if (fc4_train_layout(m, G) != CVL_FC4S3 || fc5_train_layout(m, G) != CVL_FC5S3 || s.nb4 != 21 || s.nb5 != 11) return 0;
+    if (cv_layout_current(m, CVL_FC4S3 | CVL_FC5S3 | CVL_HEADS, "training forward tail")) return 1;
+    if (m->loss_rows_used + G > m->loss_rows_cap) { cv_set_error("train_tail_tm: loss row buffer too small (internal)"); return 1; }
+    double *rows = m->loss_rows + (size_t)m->loss_rows_used * 4;
+    m->loss_rows_used += G;                       // one row per group (cv_train.hip t_loss_header adds the rows in order)
+    {
+        auto k = dense_tm<7, 8, 0, 1>;
+        const size_t lds = (size_t)3 * 8 * 1024;
+        if (set_lds(k, lds)) return 1;
+        k<<<dim3(nblk(G, 8), 3, CV_DENSE_KSPLIT), 512, lds, st>>>((const f4 *)p3_tm, s.kb4, (const f4 *)m->wps_fc4, P + o[7], a.fc4,
+                                                                   (f4 *)part, G, 21, heads_args());
+    }
+    cv_dropout_args dr = cv_dropout_args();
+    dr.d4 = drop->d4; dr.amask = drop->amask; dr.nunits = a.fc4; dr.rate = drop->rate; dr.seed = drop->seed;
+    dr.step = drop->step; dr.cand0 = drop->cand0;
+    train_tail_tm<21, 11><<<G, 256, 0, st>>>((const f4 *)part, CV_DENSE_KSPLIT, G, P + o[7], a.fc4, (f4 *)h4_tm, dr,
+                                             (const f4 *)m->wps3_fc5, P + o[9], a.fc5, (f4 *)h5_tm, (const f4 *)m->wp_heads0,
+                                             (const f4 *)m->wp_heads1, P + o[11], P + o[13], P + o[15], P + o[17], P + o[12], P + o[14],
+                                             P + o[16], y, n, want_grad, g16, (f4 *)g5pre_tm, rows);
+    CV_HIP(hipGetLastError());
+    *done = true;
+    return 0;
 }
 
 // full topology: fc4 data gradient + max-pool backward + SELU' of conv3 in one kernel (dense_dgrad_unpool):

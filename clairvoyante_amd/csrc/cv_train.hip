@@ -698,20 +698,11 @@ struct tr_fork {
         }
         return 0;
     }
-    // st continues behind all side streams.  The side streams are chained among themselves first (the last used one
-    // waits for the others -- off the critical path), so that st takes ONE wait instead of one per side stream.
-    int join()
-    {
-        if (nside == 0) return 0;
-        int last = -1;
-        for (int i = 0; i < nside; i++) if (used[i]) last = i;
-        if (last < 0) return 0;
-        if (gather(side[last])) return 1;
-        hipEvent_t e = next_event();
-        CV_HIP(hipEventRecord(e, side[last]));
-        CV_HIP(hipStreamWaitEvent(st, e, 0));
-        return 0;
-    }
+    // st continues behind all side streams: one wait per side stream ON st.  (Round 5 measured the alternative -- the side
+    // streams chained among themselves, one wait on st: when the last side stream finishes just ahead of st, as at
+    // train.py's batch, the chain puts two dependent hand-overs in series, 19 us against 11 at the tail of the step;
+    // a wait for an event that has already fired costs st next to nothing.)
+    int join() { return nside == 0 ? 0 : gather(st); }
 };
 
 // the fixed-order loss sums + the bucket's loss header (t_loss_header, below) launched from inside a slice
@@ -757,15 +748,21 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     if (cv_tile_train_convs(m, x, n, tp[0], ta[0], tp[1], ta[1], tp[2], ta[2], st)) return 1;
     if (pack_wait) CV_HIP(hipStreamWaitEvent(st, m->tr_pack_done, 0));
     const cv_train_dropout drop{td4, tmask, backward ? drop4 : 0.0f, seed, step, cand0};
-    bool drop_done = false;
-    if (cv_tile_dense_fwd(m, 4, tp[2], th4, n, st, m->train_ksplit ? kpart : nullptr, &drop, &drop_done)) return 1;
-    if (!drop_done && cv_dropout_tm(m, th4, td4, tmask, n, drop.rate, seed, step, cand0, st)) return 1;
-    m->last_tr_d4 = td4; m->last_tr_mask = tmask; m->last_tr_n = n; m->last_tr_tile = 1;
-    if (cv_tile_dense_fwd(m, 5, td4, th5, n, st)) return 1;
-    // heads: products, losses, head gradients and the fc5-side data gradient (times selu'(h5)) in one launch
     float *tg5pre = backward ? sb.take(np * f5u) : nullptr;
     if (backward && !tg5pre) { cv_set_error("training workspace too small"); return 1; }
-    if (cv_tile_heads_train(m, td4, th5, y, n, backward ? 1 : 0, ghpre, tg5pre, st)) return 1;
+    // tiny batches (full topology, k-split fc4): everything behind fc4's k ranges -- their sum, dropout, fc5, the heads,
+    // losses, head gradients, fc5-side data gradient -- is one kernel
+    bool tail_done = false;
+    if (cv_tile_train_tail(m, tp[2], th4, th5, y, n, backward ? 1 : 0, ghpre, tg5pre, m->train_ksplit ? kpart : nullptr, &drop, st, &tail_done)) return 1;
+    if (!tail_done) {
+        bool drop_done = false;
+        if (cv_tile_dense_fwd(m, 4, tp[2], th4, n, st, m->train_ksplit ? kpart : nullptr, &drop, &drop_done)) return 1;
+        if (!drop_done && cv_dropout_tm(m, th4, td4, tmask, n, drop.rate, seed, step, cand0, st)) return 1;
+        if (cv_tile_dense_fwd(m, 5, td4, th5, n, st)) return 1;
+        // heads: products, losses, head gradients and the fc5-side data gradient (times selu'(h5)) in one launch
+        if (cv_tile_heads_train(m, td4, th5, y, n, backward ? 1 : 0, ghpre, tg5pre, st)) return 1;
+    }
+    m->last_tr_d4 = td4; m->last_tr_mask = tmask; m->last_tr_n = n; m->last_tr_tile = 1;
     CV_HIP(hipGetLastError());
     if (!backward) return 0;
     // ---- backward buffers (TM gradients; the weight-gradient kernels transpose their operands on the way in)
@@ -937,7 +934,8 @@ static int train_workspace(cv_model *m, int64_t n, int64_t *slice_out)
         m->t_bytes = need;
     }
     // block rows of the heads kernel: 4 groups per block, slice after slice
-    const int64_t rows_need = nslice * ((slice / 16 + 3) / 4 + 1);
+    // (heads_train_tm: one row per four groups; train_tail_tm, tiny batches: one per group)
+    const int64_t rows_need = nslice * ((slice / 16 + 3) / 4 + 1) + 160;
     if (m->loss_rows_cap < rows_need) {
         CV_HIP(hipDeviceSynchronize());
         if (m->loss_rows) CV_HIP(hipFree(m->loss_rows));

@@ -178,9 +178,11 @@ def test_tiny_batch_kernel_variants_give_the_same_bits(oracle, arch, n):
     y = synth.make_labels(cls, rf, alt, il)
     P = common.bench_params(oracle, arch)
 
-    def run(tiny_groups, ksplit):
+    def run(tiny_groups, ksplit, **opts):
         m = _model(arch); m.setParameters(P)
         m.setOption("train_tiny_groups", tiny_groups); m.setOption("train_ksplit", ksplit)
+        for k, v in opts.items():
+            m.setOption(k, v)
         m._dropout_seed = 99; m.setLearningRate(1e-3); m.setL2RegularizationLambda(1e-3)
         losses = [float(m.train(xt, y)[0]) for _ in range(2)]
         out = (losses, _flat(m, 0), _flat(m, 1), float(m.getLoss(xt, y)))
@@ -196,6 +198,13 @@ def test_tiny_batch_kernel_variants_give_the_same_bits(oracle, arch, n):
     gmax = np.abs(regular[2]).max()
     assert np.abs(regular[2] - ks[2]).max() <= 1e-4 * gmax
     assert np.isfinite(ks[1]).all()
+    # full topology: everything behind fc4's k ranges as ONE kernel (train_tail_tm) or as three (dbg2 = 5): the same
+    # arithmetic per value -- weights and gradients bit for bit; the loss sums leave as one row per group instead of one
+    # per four groups, so the reported loss may differ in its last bits
+    three = run(160, 1, dbg2=5)
+    assert np.array_equal(ks[1].view(np.uint32), three[1].view(np.uint32))
+    assert np.array_equal(ks[2].view(np.uint32), three[2].view(np.uint32))
+    assert np.allclose(ks[0], three[0], rtol=1e-12, atol=0) and abs(ks[3] - three[3]) <= 1e-12 * abs(three[3])
 
 
 @pytest.mark.parametrize("arch,n", [("full", 1250), ("full", 83), ("full", 10000), ("slim", 1250), ("slim", 10000)])
