@@ -70,7 +70,7 @@ struct cv_model {
     float *wps7_fc4;     // ... and in 7 slabs [slab][kb][3][64][4] (dense_small: one wave per group and slab)
     float *wps3_fc5;     // fc5 in 3 slabs [slab][kb][4][64][4] (dense_small)
     void *tail_dev;      // device copy of the tail arguments of the fused fc4 + fc5 + heads kernel (dense_tm EPI 3)
-    unsigned char tail_host[160];   // what tail_dev holds
+    unsigned char tail_host[256];   // what tail_dev holds
     float *wp5p_fc5;     // fc5 in k pairs [kp][24][64][4] (tail of the large-pass fc4 kernel, dense_tm EPI 3; full topology)
     float *wpd_fc5;      // data-gradient weights of fc5 [jb][24 | 4][64][4]
     float *wp_heads0;    // [nb4][64][4]  base head (rows 0..3)
@@ -130,10 +130,20 @@ struct cv_model {
     //   dbg2 = 1 / 2: unpool always thread-per-row / always streaming, 3: fc4's alpha-dropout as its own pass, 4: thread-per-row at tiny batches (default there: row segments), 5: the tail of the tiny-batch forward as three kernels
     //   dbg3 = 1: fc4 data gradient and conv3 unpool as two kernels
     //   dbg4 = 2: conv data gradients fused with the unpool below (conv_dgrad_unpool), 3: slim selu' as its own pass
-    //   dbg5 = 1: all weight packing in one launch in stream order, 2: conv1's weight gradient on a side stream at tiny batches too,
-    //          3: the loss header at the tail of the step                  dbg6 = n: row parts of dense_dgrad_unpool (few groups)
+    //   dbg5 = 1: all weight packing in one launch in stream order      dbg6 = n: row parts of dense_dgrad_unpool (few groups)
     //   dbg7 = 1: training-forward conv3 on conv_tm instead of conv3_rot
     int dbg[8];
+    // option "train_sched": the round-5 re-cut of the step's schedule, one bit per change (all on by default; A/B runs and
+    // the variant tests switch them off one by one -- same arithmetic either way):
+    //   1  loss header behind the heads kernel on the side stream (tiny batches only) instead of at the tail of the step
+    //   2  conv1's weight gradient on the main stream at tiny batches instead of a side stream
+    //   4  ONE marker on the main stream for the L2 term and the weight packing instead of one each
+    //   8  launch sites at the same point of the main stream share a marker (not for the full topology above 512 groups:
+    //      at train.py's 625 the step is 39 us SLOWER with it, at 313 groups 50 us faster -- profiles/r05/step_ab_session4_sched_bits.txt)
+    //   16 a pass packs only the weight layouts its kernels read instead of every forward layout
+    //   32 the base head's data gradient, the dropout factor and selu'(fc4) on the store of fc5's data-gradient kernel
+    //      instead of a pass of their own
+    int sched;
     int profile;
     void *prof;          // cv_prof*, owned
     const char *stage_kernel[CV_NUM_STAGES];   // kernel (template instance) each stage of the last cv_forward chunk ran
@@ -201,7 +211,8 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
                       float *part = nullptr, const cv_train_dropout *drop = nullptr, bool *drop_done = nullptr);
 int cv_tile_train_tail(cv_model *m, const float *p3_tm, float *h4_tm, float *h5_tm, const float *y, int64_t n, int want_grad,
                        float *g16, float *g5pre_tm, float *part, const cv_train_dropout *drop, hipStream_t st, bool *done);
-int cv_tile_fc5_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st);
+int cv_tile_fc5_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st, const float *g16 = nullptr,
+                      const float *mask_tm = nullptr, const float *act_tm = nullptr);
 // act_below (layers without pooling, slim): the layer-below output; the result is then times selu' = its pre-activation gradient
 int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st, const float *act_below = nullptr);
 int cv_tile_fc4_dgrad_unpool(cv_model *m, const float *g_tm, const float *pooled, const float *codes, float *gpre, int64_t n,

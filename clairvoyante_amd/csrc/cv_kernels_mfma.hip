@@ -1336,6 +1336,11 @@ struct heads_args {
     int64_t n;
     float *out16;
     const f4 *dact = nullptr;            // EPI 1 only: the output is multiplied by selu'-from-output of this map (same layout)
+    // EPI 1, fc5's data gradient of a training pass (round 5): the base head's contribution, the dropout factor and
+    // selu'(fc4 output) follow on the store -- b_head_dgrad_tm's mode 1 arithmetic, one launch and one round trip of the
+    // map less.  hg_g16 == NULL: none.  g16 [n][16] head pre-activation gradients, wb [K][4] base-head weights,
+    // mask / act: tile-major maps in the output's layout.
+    const float *hg_g16 = nullptr, *hg_wb = nullptr; const f4 *hg_mask = nullptr, *hg_act = nullptr; int64_t hg_n = 0; int hg_K = 0;
     // EPI 3 only (fc4 with fc5 and the heads on its tail): fc5's weights in k PAIRS [kp][24][64] (pack_dense_kpairs),
     // its bias / width, and where its output goes (kept for cv_get_activation and the parity tests)
     const f4 *wp5p = nullptr; const float *bias5 = nullptr; int nout5 = 0;
@@ -1871,6 +1876,24 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
                     const f4 y = hd.dact[(op - out_tm) + ob * 64];
 #pragma unroll
                     for (int k = 0; k < 4; k++) v[k] *= cv_selu_grad_from_out(y[k]);
+                }
+                if (hd.hg_g16) {             // + base head, * dropout factor, * selu'(fc4 output): b_head_dgrad_tm mode 1
+                    const size_t t = (size_t)(op - out_tm) + ob * 64;
+                    const f4 mk = hd.hg_mask[t], y = hd.hg_act[t];
+                    const int64_t cand = (int64_t)(g + r) * 16 + (lane & 15);
+                    const float *gi = hd.hg_g16 + (size_t)(cand < hd.hg_n ? cand : 0) * 16;
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        const int k = 16 * ((int)blockIdx.y * NB + ob) + 4 * s + q;
+                        float a = 0.0f;
+                        if (cand < hd.hg_n && k < hd.hg_K) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) a = __builtin_fmaf(gi[j], hd.hg_wb[(size_t)k * 4 + j], a);
+                        }
+                        float gact = v[s] + a;
+                        gact *= mk[s];
+                        v[s] = gact * cv_selu_grad_from_out(y[s]);
+                    }
                 }
                 op[ob * 64] = v;
             }
@@ -3063,7 +3086,7 @@ int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward, int G, hipS
 {
     if (wait_before_dense) *wait_before_dense = false;
     unsigned need = CVL_CONV | CVL_HEADS | fc4_train_layout(m, G) | fc5_train_layout(m, G);
-    if (m->dbg[5] == 4) need = CVL_FORWARD;            // development: every forward layout, as before round 5
+    if (!(m->sched & 16)) need = CVL_FORWARD;          // every forward layout, as before round 5
     if (backward) need |= CVL_BACKWARD;
     const unsigned todo = need & ~m->packed_valid;
     if (!todo) return 0;
@@ -4094,15 +4117,23 @@ int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, 
 }
 
 // g(d4)[k] = sum_j g5pre[j] W5[k][j]  (input TM with nb5 fragments, output TM with nb4 fragments)
-int cv_tile_fc5_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st)
+// g16 != NULL: the result is already fc4's PRE-ACTIVATION gradient -- the base head's contribution (g16, the base head's
+// weights), the dropout factor (mask_tm) and selu'(fc4 output act_tm) ride on the store
+int cv_tile_fc5_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st, const float *g16,
+                      const float *mask_tm, const float *act_tm)
 {
     const cv_shapes &s = m->sh;
     const int G = (int)((n + 15) / 16);
     if (cv_layout_current(m, CVL_DFC5, "fc5 data gradient")) return 1;
+    heads_args hd;
+    if (g16) {
+        hd.hg_g16 = g16; hd.hg_wb = m->params + m->poff[10]; hd.hg_mask = (const f4 *)mask_tm; hd.hg_act = (const f4 *)act_tm;
+        hd.hg_n = n; hd.hg_K = m->arch.fc4;
+    }
     // full: three slabs of 7 output fragments -- as one workgroup per 8 groups with all 21 the kernel took 32 us at ANY
     // batch (2 waves x 11 k steps x 84 MFMAs per SIMD on 10 .. 79 CUs); the values do not depend on the slab width
-    if (is_full(m->arch)) return launch_dense<7, 8, 1>(g_tm, s.nb5, m->wpd_fc5, nullptr, 0, gin_tm, G, st, 3);
-    return launch_dense<3, 4, 1>(g_tm, s.nb5, m->wpd_fc5, nullptr, 0, gin_tm, G, st);
+    if (is_full(m->arch)) return launch_dense<7, 8, 1>(g_tm, s.nb5, m->wpd_fc5, nullptr, 0, gin_tm, G, st, 3, 1, nullptr, hd);
+    return launch_dense<3, 4, 1>(g_tm, s.nb5, m->wpd_fc5, nullptr, 0, gin_tm, G, st, 1, 1, nullptr, hd);
 }
 
 // layer 1 = conv2, 2 = conv3: gradient w.r.t. the layer input from the pre-activation gradient

@@ -666,6 +666,7 @@ struct tr_fork {
     int tail_first;
     hipEvent_t mark;       // the newest marker recorded on st; mark_fresh: nothing was enqueued on st since
     bool mark_fresh;
+    bool share;            // launch sites at the same point of st share a marker (train_sched bit 3; see cv_internal.hpp)
     hipEvent_t next_event() { return m->tr_ev[k++ % (CV_TR_EVENTS - 1)]; }
     int side_of(int site) const { return tail_only ? (site >= tail_first && nside > 1 ? 1 : 0) : site % nside; }
     // side stream of launch site `site` (0 heads, 1 fc5, 2 fc4, 3 conv3, 4 conv2, 5 conv1), made to wait for
@@ -676,7 +677,7 @@ struct tr_fork {
     {
         if (nside == 0) { *out = st; return 0; }
         const int i = side_of(site);
-        if (!(same_point && mark_fresh)) {
+        if (!(same_point && mark_fresh && share)) {
             mark = next_event();
             CV_HIP(hipEventRecord(mark, st));
             mark_fresh = true;
@@ -773,6 +774,10 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     tr_fork f;
     f.m = m; f.st = st; f.k = 0; f.nside = 0; f.tail_only = Gn > m->tiny_g; f.tail_first = m->wpr_fc4 ? 4 : 3;
     f.mark = nullptr; f.mark_fresh = false;
+    // (measured, one box, alternating: at 625 groups of the full topology a shared marker lets the main stream run 6 us
+    // ahead and the step comes out 39 us LONGER -- the weight gradients then meet the fc4 / conv3 data gradients on the
+    // CUs at another moment; 2 500 and 5 000 candidates and the slim topology gain with it)
+    f.share = (m->sched & 8) && (Gn <= 512 || !m->wpr_fc4);
     for (int i = 0; i < CV_TR_SIDES; i++) { f.side[i] = nullptr; f.used[i] = false; }
     if (sw != st) {
         f.side[f.nside++] = sw;
@@ -799,10 +804,15 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     if (f.to_side(1, &sx, true)) return 1;
     if (cv_tile_dense_wgrad(m, 5, td4, tg5pre, n, sx)) return 1;
     f.st_moved();
-    if (cv_tile_fc5_dgrad(m, tg5pre, tgd4, n, st)) return 1;
-    // + the base head's contribution, then dropout4 + selu' (h4 is the SELU output before dropout)
-    b_head_dgrad_tm<<<nblk(Gn * s.nb4 * 256, 256), 256, 0, st>>>(ghpre, P + o[10], P + o[12], P + o[14], P + o[16], a.fc4,
-                                                               s.nb4, n, Gn, 1, tgd4, th4, tmask, tg4pre);
+    // fc5's data gradient + the base head's contribution, then dropout4 + selu' (h4 is the SELU output before dropout): on
+    // the kernel's store, or (train_sched bit 5 off) as an element-wise pass behind it -- the same operations per value
+    if (m->sched & 32) {
+        if (cv_tile_fc5_dgrad(m, tg5pre, tg4pre, n, st, ghpre, tmask, th4)) return 1;
+    } else {
+        if (cv_tile_fc5_dgrad(m, tg5pre, tgd4, n, st)) return 1;
+        b_head_dgrad_tm<<<nblk(Gn * s.nb4 * 256, 256), 256, 0, st>>>(ghpre, P + o[10], P + o[12], P + o[14], P + o[16], a.fc4,
+                                                                   s.nb4, n, Gn, 1, tgd4, th4, tmask, tg4pre);
+    }
     f.st_moved();
     // fc4
     if (f.to_side(2, &sx)) return 1;
@@ -835,7 +845,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
         // The first layer's weight gradient is the LAST work of the backward pass: nothing of st is left to run beside it.
         // At tiny batches it stays on st (a marker, the hand-over to the side stream and the wait for it back cost ~25 us
         // of an otherwise idle chip for a 17 us kernel); at large ones the side stream keeps it off the chain's tail.
-        if (l == 0 && Gn <= m->tiny_g && m->dbg[5] != 2) sx = st;
+        if (l == 0 && Gn <= m->tiny_g && (m->sched & 2)) sx = st;
         else if (f.to_side(5 - l, &sx)) return 1;
         if (l == 0) {        // first layer: X viewed as [33][16] fragments, read in place
             if (cv_tile_conv1_wgrad(m, x, tgpre[0], n, sx)) return 1;
@@ -987,7 +997,8 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
     // ONE marker for everything the side stream does ahead of the backward pass -- the L2 term and the weight packing
     // both depend on the weights alone, i.e. on the optimizer update of the previous step (cv_pack_for_training is
     // told that sw is ordered already)
-    const bool sw_ordered = sw != st && n > 0;
+    const bool one_marker = (m->sched & 4) != 0;
+    const bool sw_ordered = sw != st && n > 0 && (one_marker || lambda != 0.0f);
     if (sw_ordered) {
         CV_HIP(hipEventRecord(m->tr_ev[CV_TR_EVENTS - 1], st));
         CV_HIP(hipStreamWaitEvent(sw, m->tr_ev[CV_TR_EVENTS - 1], 0));
@@ -1003,7 +1014,10 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
     }
     // single-slice step on the tile path with side streams: the loss header rides behind the heads kernel on the side stream
     const tr_header hdr_early{(double)lambda, lambda != 0.0f};
-    const bool early = backward && tile_path && sw_ordered && n <= slice && (l2_done || lambda == 0.0f) && m->dbg[5] != 3;
+    // (tiny batches only: at train.py's batch the side stream is as long as the main chain, and 14 us of header at its head
+    // made the step 33 us longer -- profiles/r05/step_ab_session3.txt)
+    const bool early = backward && tile_path && sw_ordered && n <= slice && (l2_done || lambda == 0.0f) && (m->sched & 1) &&
+                       (n + 15) / 16 <= m->tiny_g;
     // option keep_activations and several slices: the dropout maps of every slice are kept (cv_get_activation 6 / 7 then
     // covers the whole batch, and the oracle tests can feed a multi-slice step's own keep mask back); one slice: in place
     const size_t keep_per = tile_path ? (size_t)m->sh.nb4 * 16 : (size_t)m->arch.fc4;       // floats per candidate of a map
@@ -1024,7 +1038,7 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
         // gradients final", so the side streams are not gathered for it)
         hipEvent_t ev = (backward && last && comm) ? m->tr_dense_ready : nullptr;
         if (train_slice(m, x + (size_t)off * (CV_INPUT_H * 16), y + (size_t)off * 16, cn, off, backward, drop4,
-                        seed, step, st, sw, ev, sw_ordered, early ? &hdr_early : nullptr))
+                        seed, step, st, sw, ev, sw_ordered && one_marker, early ? &hdr_early : nullptr))
             return 1;
         recorded = recorded || ev != nullptr;
         if (keep_all && m->last_tr_d4) {          // (slices are multiples of 16 candidates: the tile-major maps concatenate)

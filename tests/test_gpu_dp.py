@@ -233,14 +233,14 @@ def test_backward_kernel_variants_give_the_same_bits(oracle, arch, n):
         m.close()
         return out
     ref = run({})
-    # (round 5: dbg2 = 4 the thread-per-row unpool at tiny batches instead of row segments; dbg5 = 2 the first layer's weight
-    # gradient on a side stream also at tiny batches; dbg5 = 3 the loss header at the tail of the step instead of behind the
-    # heads kernel on the side stream)
+    # (round 5: dbg2 = 4 the thread-per-row unpool at tiny batches instead of row segments; option train_sched: the bits of
+    # the re-cut schedule -- early loss header, conv1's weight gradient on the main stream, one fork marker, shared launch-site
+    # markers, per-layout packing -- switched off in groups)
     variants = ({"dbg3": 1}, {"dbg4": 2}, {"dbg4": 2, "dbg0": 3}, {"train_side_streams": 1}, {"dbg5": 1}, {"dbg6": 3}, {"dbg7": 1},
                 {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7}, {"dbg1": 8}, {"dbg2": 3}, {"dbg3": 1, "dbg4": 2, "train_overlap": 0},
-                {"dbg2": 4}, {"dbg5": 2}, {"dbg5": 3}, {"dbg2": 1}, {"dbg2": 2}) if arch == "full" else \
+                {"dbg2": 4}, {"train_sched": 0}, {"train_sched": 62}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 31}, {"dbg2": 1}, {"dbg2": 2}) if arch == "full" else \
                ({"dbg4": 3}, {"train_side_streams": 1}, {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7},
-                {"dbg5": 1, "dbg4": 3, "train_overlap": 0}, {"dbg5": 2}, {"dbg5": 3})
+                {"dbg5": 1, "dbg4": 3, "train_overlap": 0}, {"train_sched": 0}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 31})
     for opts in variants:
         got = run(opts)
         assert ref[0] == got[0], opts
