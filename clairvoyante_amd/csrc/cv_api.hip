@@ -121,7 +121,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     m->train_sides = 3;
     m->train_ksplit = 1;
     m->tiny_g = 160;
-    m->sched = 63;
+    m->sched = 127;
     alloc(&m->wp_conv1, 4 * 64);
     for (int l = 1; l < 3; l++) alloc(&m->wp_conv[l], (size_t)s.ntile[l] * arch->kh[l] * 4 * s.cinb[l] * 256);
     alloc(&m->wp_fc4, (size_t)s.kb4 * ((s.nb4 + 3) / 4 * 4) * 256);   // fragments padded to the wave count
@@ -250,7 +250,7 @@ extern "C" int cv_set_option(cv_model *m, const char *key, int64_t value)
     if (!strcmp(key, "train_side_streams")) { m->train_sides = value < 1 ? 1 : (value > 3 ? 3 : (int)value); return 0; }
     if (!strcmp(key, "train_tiny_groups")) { m->tiny_g = value < 0 ? 0 : (value > 160 ? 160 : (int)value); return 0; }
     if (!strcmp(key, "variant")) { m->variant = (int)value; return 0; }
-    if (!strcmp(key, "train_sched")) { m->sched = (int)value & 63; return 0; }
+    if (!strcmp(key, "train_sched")) { m->sched = (int)value & 127; return 0; }
     if (!strncmp(key, "dbg", 3) && key[3] >= '0' && key[3] <= '7' && !key[4]) { m->dbg[key[3] - '0'] = (int)value; cv_layouts_stale(m, CVL_BACKWARD); return 0; }
     if (!strcmp(key, "chunk")) {
         if (value < 16 || value > (1 << 22)) { cv_set_error("chunk must be in [16, 4194304]"); return 1; }

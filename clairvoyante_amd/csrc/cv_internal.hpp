@@ -122,6 +122,7 @@ struct cv_model {
     // option keep_activations + a step of several slices: the two maps of EVERY slice, copied here slice after slice
     // (mask first, dropout output behind it), so that cv_get_activation 6 / 7 covers the whole batch
     float *tr_keep; size_t tr_keep_floats;
+    int tr_accumulate;   // the weight-gradient second passes ADD to the gradient (1) or store 0 + sum (0: first slice of a step)
     // optional per-kernel timing (option "profile")
     // options "dbg0".."dbg7": development switches of the training step (A/B runs and variant tests; 0 = shipped path).
     //   dbg0 = n: position parts of the convolution data gradients      dbg1 = n: ... of the training-forward convolutions
@@ -143,6 +144,7 @@ struct cv_model {
     //   16 a pass packs only the weight layouts its kernels read instead of every forward layout
     //   32 the base head's data gradient, the dropout factor and selu'(fc4) on the store of fc5's data-gradient kernel
     //      instead of a pass of their own
+    //   64 no memset of the gradient at the head of a step: the second passes of the first slice store instead of adding
     int sched;
     int profile;
     void *prof;          // cv_prof*, owned

@@ -3545,8 +3545,10 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
 
 // second pass of the dense weight gradient: dW += sum over splits (ascending: a fixed summation order),
 // one thread per (kb, jb, lane) fragment element quadruple; the threads behind those sum the bias parts
+// acc (all four second passes): 1 = add to what the gradient holds (a later slice of the step), 0 = the first slice:
+// 0 + sum is STORED -- the bits a zeroed buffer would end up with, without the 6.5 MB memset at the head of every step.
 __global__ void wgrad_dense_reduce(const f4 *__restrict__ part, int splits, int KB, int NJB, int K, int N,
-                                   float *__restrict__ dw, float *__restrict__ db)
+                                   float *__restrict__ dw, float *__restrict__ db, int acc)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t per = (int64_t)KB * NJB * 64;
@@ -3556,7 +3558,7 @@ __global__ void wgrad_dense_reduce(const f4 *__restrict__ part, int splits, int 
         const float *bpart = (const float *)(part + (size_t)splits * per);
         float b = bpart[j];
         for (int sidx = 1; sidx < splits; sidx++) b += bpart[(size_t)sidx * NJB * 16 + j];
-        db[j] += b;
+        db[j] = (acc ? db[j] : 0.0f) + b;
         return;
     }
     f4 v = part[t];
@@ -3584,7 +3586,7 @@ __global__ void wgrad_dense_reduce(const f4 *__restrict__ part, int splits, int 
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int k = 16 * kb + 4 * q + r;
-        if (k < K) dw[(size_t)k * N + j] += v[r];
+        if (k < K) dw[(size_t)k * N + j] = (acc ? dw[(size_t)k * N + j] : 0.0f) + v[r];
     }
 }
 
@@ -3759,7 +3761,7 @@ __global__ __launch_bounds__(64) void wgrad_conv_cm(const f4 *__restrict__ in_tm
 // tile == TILES: CM bias sums, lane (f, rg) register t -> db[16 cob + f] (registers, then lanes rg).
 __global__ __launch_bounds__(1024) void wgrad_conv_reduce(const f4 *__restrict__ part, int splits, int NT, int TILES,
                                                           int CINB, int cin, int cout, float *__restrict__ dw,
-                                                          float *__restrict__ db)
+                                                          float *__restrict__ db, int acc)
 {
     __shared__ f4 sh[16][64];
     const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
@@ -3787,14 +3789,14 @@ __global__ __launch_bounds__(1024) void wgrad_conv_reduce(const f4 *__restrict__
         float b = (v[0] + v[1]) + (v[2] + v[3]);
         b += __shfl_xor(b, 16);
         b += __shfl_xor(b, 32);
-        if (lane < 16 && co < cout) db[co] += b;
+        if (lane < 16 && co < cout) db[co] = (acc ? db[co] : 0.0f) + b;
         return;
     }
     const int cb = tile % CINB, kk = tile / CINB;        // kk = kh * 4 + kw
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int ci = 16 * cb + 4 * q + r;
-        if (ci < cin && co < cout) dw[((size_t)kk * cin + ci) * cout + co] += v[r];
+        if (ci < cin && co < cout) dw[((size_t)kk * cin + ci) * cout + co] = (acc ? dw[((size_t)kk * cin + ci) * cout + co] : 0.0f) + v[r];
     }
 }
 
@@ -3861,7 +3863,7 @@ __global__ __launch_bounds__(64) void wgrad_conv1_cm(const float *__restrict__ x
 // that belong to its tap; workgroup 4 sums the bias fragment.  Fixed order: 16 strided partial sums over the
 // splits, those ascending, then wo ascending.
 __global__ __launch_bounds__(1024) void wgrad_conv1_reduce(const f4 *__restrict__ part, int splits, int cout,
-                                                           float *__restrict__ dw, float *__restrict__ db)
+                                                           float *__restrict__ dw, float *__restrict__ db, int acc)
 {
     __shared__ f4 sh[16][64];
     const int l = threadIdx.x & 63, j = threadIdx.x >> 6;
@@ -3892,7 +3894,7 @@ __global__ __launch_bounds__(1024) void wgrad_conv1_reduce(const f4 *__restrict_
         float b = (v[0] + v[1]) + (v[2] + v[3]);
         b += __shfl_xor(b, 16);
         b += __shfl_xor(b, 32);
-        if (l < 16 && l < cout) db[l] += b;
+        if (l < 16 && l < cout) db[l] = (acc ? db[l] : 0.0f) + b;
         return;
     }
     sh[0][l] = v;                   // wave 0 only from here on (its own earlier reads of sh are done)
@@ -3903,7 +3905,7 @@ __global__ __launch_bounds__(1024) void wgrad_conv1_reduce(const f4 *__restrict_
 #pragma unroll
         for (int w = 0; w < 4; w++) t += sh[0][w * 16 + l];     // invalid (wo, kw) pairs hold zeros
 #pragma unroll
-        for (int r = 0; r < 4; r++) dw[((size_t)kw * 4 + r) * cout + l] += t[r];
+        for (int r = 0; r < 4; r++) dw[((size_t)kw * 4 + r) * cout + l] = (acc ? dw[((size_t)kw * 4 + r) * cout + l] : 0.0f) + t[r];
     }
 }
 
@@ -4303,7 +4305,7 @@ static int dense_wgrad_launch(cv_model *m, int region, const float *x_tm, int KB
     wgrad_dense_cm<NJB><<<dim3(kblocks, splits), 512, lds, st>>>((const f4 *)x_tm, KB, (const f4 *)g_tm, G, 0,
                                                                  (f4 *)scratch);
     const int64_t per = (int64_t)KB * NJB * 64;
-    wgrad_dense_reduce<<<nblk(per + NJB * 16, 256), 256, 0, st>>>((const f4 *)scratch, splits, KB, NJB, K, N, dw, db);
+    wgrad_dense_reduce<<<nblk(per + NJB * 16, 256), 256, 0, st>>>((const f4 *)scratch, splits, KB, NJB, K, N, dw, db, m->tr_accumulate);
     CV_HIP(hipGetLastError());
     return 0;
 }
@@ -4327,7 +4329,7 @@ int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_tm, const float *
 struct head_cols { float *dw[4], *db[4]; int j0[4], N[4]; };
 
 __global__ void wgrad_heads_reduce(const f4 *__restrict__ part, int splits, int KB, int K, int j_lo, int j_hi,
-                                   head_cols hc)
+                                   head_cols hc, int acc)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t per = (int64_t)KB * 64;
@@ -4351,7 +4353,7 @@ __global__ void wgrad_heads_reduce(const f4 *__restrict__ part, int splits, int 
             for (int u = 0; u < 8; u++) b += w[u];
         }
         for (; sidx < splits; sidx++) b += bpart[(size_t)sidx * 16 + j];
-        hc.db[q][col] += b;
+        hc.db[q][col] = (acc ? hc.db[q][col] : 0.0f) + b;
         return;
     }
     f4 v = part[t];
@@ -4368,7 +4370,7 @@ __global__ void wgrad_heads_reduce(const f4 *__restrict__ part, int splits, int 
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int k = 16 * kb + 4 * qq + r;
-        if (k < K) hc.dw[q][(size_t)k * N + col] += v[r];
+        if (k < K) hc.dw[q][(size_t)k * N + col] = (acc ? hc.dw[q][(size_t)k * N + col] : 0.0f) + v[r];
     }
 }
 
@@ -4394,7 +4396,7 @@ int cv_tile_heads_wgrad(cv_model *m, const float *d4_tm, const float *h5_tm, con
         wgrad_dense_cm<1, true><<<dim3(kblocks, splits), 512, lds, st>>>((const f4 *)x_tm, KB, (const f4 *)g16, G, n,
                                                                           (f4 *)scratch);
         wgrad_heads_reduce<<<nblk((int64_t)KB * 64 + 16, 256), 256, 0, st>>>((const f4 *)scratch, splits, KB, K,
-                                                                             pass == 0 ? 0 : 4, pass == 0 ? 4 : 16, hc);
+                                                                             pass == 0 ? 0 : 4, pass == 0 ? 4 : 16, hc, m->tr_accumulate);
     }
     CV_HIP(hipGetLastError());
     return 0;
@@ -4420,7 +4422,7 @@ static int conv_wgrad_launch(cv_model *m, int region, const float *in_tm, const 
     if (wg_region(m, region, (size_t)used * NT * (TILES + 1) * 256 * sizeof(float), &scratch)) return 1;
     wgrad_conv_cm<KH, CINB, NT, HIN><<<8 * NT * ((used + 7) / 8), 64, (4 * CINB + 4) * 1024, st>>>(
         (const f4 *)in_tm, (const f4 *)g_tm, G, used, rows_per, (f4 *)scratch);
-    wgrad_conv_reduce<<<NT * (TILES + 1), 1024, 0, st>>>((const f4 *)scratch, used, NT, TILES, CINB, cin, cout, dw, db);
+    wgrad_conv_reduce<<<NT * (TILES + 1), 1024, 0, st>>>((const f4 *)scratch, used, NT, TILES, CINB, cin, cout, dw, db, m->tr_accumulate);
     CV_HIP(hipGetLastError());
     return 0;
 }
@@ -4453,7 +4455,7 @@ int cv_tile_conv1_wgrad(cv_model *m, const float *x, const float *g_tm, int64_t 
     if (wg_region(m, 5, (size_t)splits * 5 * 256 * sizeof(float), &scratch)) return 1;
     wgrad_conv1_cm<<<splits, 64, CV_WG1_RING * 5 * 1024, st>>>(x, n, (const f4 *)g_tm, G, (f4 *)scratch);
     wgrad_conv1_reduce<<<5, 1024, 0, st>>>((const f4 *)scratch, used, m->arch.cout[0], m->grads + m->poff[0],
-                                          m->grads + m->poff[1]);
+                                          m->grads + m->poff[1], m->tr_accumulate);
     CV_HIP(hipGetLastError());
     return 0;
 }

@@ -59,27 +59,52 @@ struct offs_t { int64_t o[CV_NUM_PARAMS + 1]; };
 // g + lambda*w for kernels (the l2 term of v3.py:150), g for biases.
 // acc != NULL (cv_apply_adam_accumulate): the first threads also add the loss header in front of the gradients to the
 // accumulator -- cv_loss_accumulate's arithmetic (cv_train.hip t_loss_accumulate) without its launch
+__device__ __forceinline__ void adam_one(float &wi, float &mi, float &vi, float gi, bool kernel, float lr_t, float lambda)
+{
+    if (kernel) gi = gi + lambda * wi;
+    const float m1 = mi + (gi - mi) * (1.0f - 0.9f);
+    const float v1 = vi + (gi * gi - vi) * (1.0f - 0.999f);
+    mi = m1; vi = v1;
+    wi = wi - (m1 * lr_t) / (sqrtf(v1) + 1e-8f);
+}
+
+// Four consecutive elements per thread through 16-byte loads / stores (the update moves 7 floats per element and is the
+// last kernel of every step: 13 us as one element per thread, HBM-bound at ~46 MB); whether an element belongs to a
+// kernel (lambda term) or a bias is decided per ELEMENT from the offsets, so the quadruples may straddle tensors.
 __global__ void adam_kernel(float *__restrict__ w, float *__restrict__ mm, float *__restrict__ vv,
                             const float *__restrict__ g, offs_t offs, float lr_t, float lambda, double *__restrict__ acc)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (acc && i < 7) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (acc && t < 7) {
         const float *hdr = g - CV_GRAD_HEADER;
-        const int t = (int)i;
-        if (t < 4) acc[t] += (double)hdr[2 * t] + (double)hdr[2 * t + 1];
-        else if (t == 4) acc[4] += ((double)hdr[8] + (double)hdr[9]) / (double)(hdr[10] > 0.5f ? hdr[10] : 1.0f);
-        else if (t == 6) acc[6] += 1.0;
+        const int k = (int)t;
+        if (k < 4) acc[k] += (double)hdr[2 * k] + (double)hdr[2 * k + 1];
+        else if (k == 4) acc[4] += ((double)hdr[8] + (double)hdr[9]) / (double)(hdr[10] > 0.5f ? hdr[10] : 1.0f);
+        else if (k == 6) acc[6] += 1.0;
     }
-    if (i >= offs.o[CV_NUM_PARAMS]) return;
+    const int64_t n = offs.o[CV_NUM_PARAMS];
+    const int64_t i = t * 4;
+    if (i >= n) return;
     int p = 0;
     while (i >= offs.o[p + 1]) p++;
-    float gi = g[i];
-    float wi = w[i];
-    if ((p & 1) == 0) gi = gi + lambda * wi;
-    float m1 = mm[i] + (gi - mm[i]) * (1.0f - 0.9f);
-    float v1 = vv[i] + (gi * gi - vv[i]) * (1.0f - 0.999f);
-    mm[i] = m1; vv[i] = v1;
-    w[i] = wi - (m1 * lr_t) / (sqrtf(v1) + 1e-8f);
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    if (i + 3 < n) {
+        v4 W = *reinterpret_cast<const v4 *>(w + i), M = *reinterpret_cast<const v4 *>(mm + i), V = *reinterpret_cast<const v4 *>(vv + i);
+        const v4 G = *reinterpret_cast<const v4 *>(g + i);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            while (i + e >= offs.o[p + 1]) p++;
+            float a = W[e], b = M[e], c = V[e];
+            adam_one(a, b, c, G[e], (p & 1) == 0, lr_t, lambda);
+            W[e] = a; M[e] = b; V[e] = c;
+        }
+        *reinterpret_cast<v4 *>(w + i) = W; *reinterpret_cast<v4 *>(mm + i) = M; *reinterpret_cast<v4 *>(vv + i) = V;
+        return;
+    }
+    for (int64_t j = i; j < n; j++) {
+        while (j >= offs.o[p + 1]) p++;
+        adam_one(w[j], mm[j], vv[j], g[j], (p & 1) == 0, lr_t, lambda);
+    }
 }
 
 // Exhaustive monotonicity sweep of the canonical SELU over the negative floats (bit patterns 0x80000000 .. -inf):
@@ -203,7 +228,7 @@ static int apply_adam(cv_model *m, float lr, float lambda, int64_t t, void *stre
     for (int i = 0; i <= CV_NUM_PARAMS; i++) offs.o[i] = m->poff[i];
     double lr_t = (double)lr * sqrt(1.0 - pow(0.999, (double)t)) / (1.0 - pow(0.9, (double)t));
     int64_t n = m->poff[CV_NUM_PARAMS];
-    adam_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(m->params, m->adam_m, m->adam_v,
+    adam_kernel<<<(unsigned)((n + 1023) / 1024), 256, 0, (hipStream_t)stream>>>(m->params, m->adam_m, m->adam_v,
                                                                              m->grads, offs, (float)lr_t, lambda,
                                                                              accumulate ? m->loss_acc : nullptr);
     CV_HIP(hipGetLastError());

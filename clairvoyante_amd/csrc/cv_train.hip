@@ -985,7 +985,15 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
     // all-plain path runs everything, the L2 term included, in stream order
     const bool tile_path = m->impl == 1 && cv_tile_supported(m);
     hipStream_t sw = (backward && m->train_overlap && tile_path) ? m->tr_side : st;
-    if (backward && m->grads == m->grads_own + CV_GRAD_HEADER) {
+    // Tile path: every gradient element is written by the second pass of its layer's weight gradient, which STORES for
+    // the first slice of a step and adds for the later ones (cv_model::tr_accumulate), and t_loss_header replaces the
+    // loss sums -- nothing needs zeroing (the 6.5 MB memset was the first 5-7 us of every step).  An empty batch (a rank
+    // without candidates) runs no kernel: its gradient is zeroed here.  All-plain path: atomics into zeroed buffers.
+    const bool no_memset = tile_path && backward && n > 0 && (m->sched & 64);
+    m->tr_accumulate = no_memset ? 0 : 1;
+    if (no_memset) {
+        /* nothing */
+    } else if (backward && m->grads == m->grads_own + CV_GRAD_HEADER) {
         // gradients and the loss sums behind them (cv_create) in one memset
         const size_t bytes = (size_t)(reinterpret_cast<char *>(m->loss_dev + 8) - reinterpret_cast<char *>(m->grads));
         CV_HIP(hipMemsetAsync(m->grads, 0, bytes, st));
@@ -1041,6 +1049,7 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
                         seed, step, st, sw, ev, sw_ordered && one_marker, early ? &hdr_early : nullptr))
             return 1;
         recorded = recorded || ev != nullptr;
+        m->tr_accumulate = 1;                     // the slices behind the first one add
         if (keep_all && m->last_tr_d4) {          // (slices are multiples of 16 candidates: the tile-major maps concatenate)
             const size_t cnt = (size_t)(tile_path ? (cn + 15) / 16 * 16 : cn) * keep_per;
             CV_HIP(hipMemcpyAsync(m->tr_keep + (size_t)off * keep_per, m->last_tr_mask, sizeof(float) * cnt, hipMemcpyDeviceToDevice, st));

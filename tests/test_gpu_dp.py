@@ -238,9 +238,9 @@ def test_backward_kernel_variants_give_the_same_bits(oracle, arch, n):
     # markers, per-layout packing -- switched off in groups)
     variants = ({"dbg3": 1}, {"dbg4": 2}, {"dbg4": 2, "dbg0": 3}, {"train_side_streams": 1}, {"dbg5": 1}, {"dbg6": 3}, {"dbg7": 1},
                 {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7}, {"dbg1": 8}, {"dbg2": 3}, {"dbg3": 1, "dbg4": 2, "train_overlap": 0},
-                {"dbg2": 4}, {"train_sched": 0}, {"train_sched": 62}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 31}, {"dbg2": 1}, {"dbg2": 2}) if arch == "full" else \
+                {"dbg2": 4}, {"train_sched": 0}, {"train_sched": 126}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 95}, {"train_sched": 63}, {"dbg2": 1}, {"dbg2": 2}) if arch == "full" else \
                ({"dbg4": 3}, {"train_side_streams": 1}, {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7},
-                {"dbg5": 1, "dbg4": 3, "train_overlap": 0}, {"train_sched": 0}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 31})
+                {"dbg5": 1, "dbg4": 3, "train_overlap": 0}, {"train_sched": 0}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 95}, {"train_sched": 63})
     for opts in variants:
         got = run(opts)
         assert ref[0] == got[0], opts
@@ -284,6 +284,31 @@ def test_packed_layouts_follow_the_weights_through_mixed_passes(oracle, arch):
         finally:
             fresh.close()
     used.close()
+
+
+@pytest.mark.parametrize("arch,n", [("full", 1250), ("full", 10000), ("slim", 3000), ("full", 70001)])
+def test_a_step_writes_every_gradient_element(oracle, arch, n):
+    """the step does not zero its gradient bucket (the second passes of the weight gradients STORE for the first slice of
+    a step): with the bucket full of NaN beforehand every element must come out finite and equal to the step that starts
+    from a zeroed bucket (train_sched bit 6 off) -- one slice, and two (the second one adds)"""
+    import torch
+    from clairvoyante_amd import synth
+    xt, cls, rf, alt, il = synth.make_candidates(n, seed=49, device="cuda", return_class=True)
+    y = synth.make_labels(cls, rf, alt, il)
+    P = common.bench_params(oracle, arch)
+    out = []
+    for sched in (127, 63):
+        m = _model(arch); m.setParameters(P); m.setOption("train_sched", sched)
+        m._dropout_seed = 7; m.setLearningRate(1e-3); m.setL2RegularizationLambda(1e-3)
+        m._ensure_bucket().fill_(float("nan"))
+        loss = float(m.train(xt, y)[0])
+        g = _flat(m, 1)
+        assert np.isfinite(g).all() and np.isfinite(loss)
+        out.append((loss, g, _flat(m, 0)))
+        m.close()
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    assert np.array_equal(out[0][2].view(np.uint32), out[1][2].view(np.uint32))
 
 
 def test_deferred_losses_sum_to_the_per_step_losses(oracle):
