@@ -121,7 +121,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     m->train_sides = 3;
     m->train_ksplit = 1;
     m->tiny_g = 160;
-    m->sched = 127;
+    m->sched = 255;
     alloc(&m->wp_conv1, 4 * 64);
     for (int l = 1; l < 3; l++) alloc(&m->wp_conv[l], (size_t)s.ntile[l] * arch->kh[l] * 4 * s.cinb[l] * 256);
     alloc(&m->wp_fc4, (size_t)s.kb4 * ((s.nb4 + 3) / 4 * 4) * 256);   // fragments padded to the wave count
@@ -136,6 +136,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     if (s.nb4 == 21 && s.nb5 == 11) alloc(&m->wp5p_fc5, (size_t)((s.nb4 + 3) / 4) * 48 * 256);
     alloc(&m->wp_heads0, (size_t)s.nb4 * 256);
     alloc(&m->wp_heads1, (size_t)s.nb5 * 256);
+    alloc(&m->wp_heads12, (size_t)s.nb5 * 16 * 12 + 16);
     m->variant = 1519;
     if (e == hipSuccess) e = hipMalloc(&m->loss_acc, sizeof(double) * 8);
     if (e == hipSuccess) e = hipMemset(m->loss_acc, 0, sizeof(double) * 8);
@@ -154,7 +155,7 @@ extern "C" int cv_destroy(cv_model *m)
     if (!m) return 0;
     hipSetDevice(m->device);
     float *bufs[] = {m->params, m->grads_own, m->adam_m, m->adam_v, m->wp_conv1, m->wp_conv[1], m->wp_conv[2],
-                     m->wp_fc4, m->wp_fc5, m->wp_heads0, m->wp_heads1, m->wpd_conv[1], m->wpd_conv[2], m->wpd_fc4, m->wpr_fc4, m->wpd_fc5, m->wps_fc4, m->wps7_fc4, m->wps3_fc5, m->wp5p_fc5, m->wg_part, m->tm_p1, m->tm_p2, m->tm_p3, m->tm_h4, m->tm_h5, m->r_a[0],
+                     m->wp_fc4, m->wp_fc5, m->wp_heads0, m->wp_heads1, m->wp_heads12, m->wpd_conv[1], m->wpd_conv[2], m->wpd_fc4, m->wpr_fc4, m->wpd_fc5, m->wps_fc4, m->wps7_fc4, m->wps3_fc5, m->wp5p_fc5, m->wg_part, m->tm_p1, m->tm_p2, m->tm_p3, m->tm_h4, m->tm_h5, m->r_a[0],
                      m->r_a[1], m->r_a[2], m->r_p[0], m->r_p[1], m->r_p[2], m->r_h4, m->r_h5, m->t_buf, m->tr_keep};
     for (float *b : bufs)
         if (b) hipFree(b);
@@ -250,7 +251,7 @@ extern "C" int cv_set_option(cv_model *m, const char *key, int64_t value)
     if (!strcmp(key, "train_side_streams")) { m->train_sides = value < 1 ? 1 : (value > 3 ? 3 : (int)value); return 0; }
     if (!strcmp(key, "train_tiny_groups")) { m->tiny_g = value < 0 ? 0 : (value > 160 ? 160 : (int)value); return 0; }
     if (!strcmp(key, "variant")) { m->variant = (int)value; return 0; }
-    if (!strcmp(key, "train_sched")) { m->sched = (int)value & 127; return 0; }
+    if (!strcmp(key, "train_sched")) { m->sched = (int)value & 255; return 0; }
     if (!strncmp(key, "dbg", 3) && key[3] >= '0' && key[3] <= '7' && !key[4]) { m->dbg[key[3] - '0'] = (int)value; cv_layouts_stale(m, CVL_BACKWARD); return 0; }
     if (!strcmp(key, "chunk")) {
         if (value < 16 || value > (1 << 22)) { cv_set_error("chunk must be in [16, 4194304]"); return 1; }

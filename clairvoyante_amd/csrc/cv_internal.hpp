@@ -75,6 +75,7 @@ struct cv_model {
     float *wpd_fc5;      // data-gradient weights of fc5 [jb][24 | 4][64][4]
     float *wp_heads0;    // [nb4][64][4]  base head (rows 0..3)
     float *wp_heads1;    // [nb5][64][4]  zygosity / type / length heads
+    float *wp_heads12;   // [nb5*16][12]  the same three heads' weights of an fc5 unit side by side (training heads: data gradient)
     int variant;         // kernel selection bits, see include/clairvoyante_amd.h (cv_set_option "variant")
     // Packed (MFMA fragment) copies of the weights that are CURRENT, one bit per layout (CVL_*).  A pass packs what its
     // kernels will read and is not valid (a training step of G groups reads two of the four fc4 layouts: the others stay
@@ -145,6 +146,8 @@ struct cv_model {
     //   32 the base head's data gradient, the dropout factor and selu'(fc4) on the store of fc5's data-gradient kernel
     //      instead of a pass of their own
     //   64 no memset of the gradient at the head of a step: the second passes of the first slice store instead of adding
+    //   128 tiny batches: fc4's weight gradient launched at conv3's marker (a marker less on the main stream), the side
+    //      streams chained before the ONE wait of the main stream at the end of the step
     int sched;
     int profile;
     void *prof;          // cv_prof*, owned

@@ -94,16 +94,6 @@ __device__ __forceinline__ f4 selu4(f4 v)
     f4 r;
     r[0] = cvm::selu(v[0]); r[1] = cvm::selu(v[1]); r[2] = cvm::selu(v[2]); r[3] = cvm::selu(v[3]);
     return r;
-#elif defined(CV_SELU_UNIFORM)             /* development: skip the negative branch when no lane of the wave needs it */
-    // Measured on the bench's synthetic set (profiles/r03/selu_wave_uniform.txt): 12 % of the first layer's pooled
-    // registers and 1.6 % of conv2's hold no negative value in any of the 64 lanes -- too few for the two extra
-    // instructions per pair (v_cmp + s_cbranch) to pay; kept as an A/B switch, off by default.
-    cvm::f2v a, b;
-    if (__builtin_amdgcn_ballot_w64(fminf(v[0], v[1]) < 0.0f) == 0) { a[0] = cvm::SELU_SCALE * v[0]; a[1] = cvm::SELU_SCALE * v[1]; }
-    else a = cvm::selu2((cvm::f2v){v[0], v[1]});
-    if (__builtin_amdgcn_ballot_w64(fminf(v[2], v[3]) < 0.0f) == 0) { b[0] = cvm::SELU_SCALE * v[2]; b[1] = cvm::SELU_SCALE * v[3]; }
-    else b = cvm::selu2((cvm::f2v){v[2], v[3]});
-    return (f4){a[0], a[1], b[0], b[1]};
 #else
     const cvm::f2v a = cvm::selu2((cvm::f2v){v[0], v[1]}), b = cvm::selu2((cvm::f2v){v[2], v[3]});
     return (f4){a[0], a[1], b[0], b[1]};
@@ -1222,9 +1212,18 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void pack_heads(int64_t t, const float *__restrict__ wb, const float *__restrict__ wz,
                            const float *__restrict__ wt, const float *__restrict__ wl, int K4, int K5,
-                           int NB4, int NB5, float *__restrict__ wp0, float *__restrict__ wp1)
+                           int NB4, int NB5, float *__restrict__ wp0, float *__restrict__ wp1, float *__restrict__ w12)
 {
     int tot0 = NB4 * 256, tot1 = NB5 * 256;
+    if (t >= tot0 + tot1) {          // the fc5-side head weights of a unit side by side [k][zygosity 2 | type 4 | length 6]: what the
+        const int u = (int)t - tot0 - tot1;      // training heads stage in LDS for their data gradient (one coalesced copy)
+        if (u >= NB5 * 16 * 12 || !w12) return;
+        const int k = u / 12, jj = u % 12;
+        float v = 0.0f;
+        if (k < K5) v = jj < 2 ? wz[(size_t)k * 2 + jj] : (jj < 6 ? wt[(size_t)k * 4 + (jj - 2)] : wl[(size_t)k * 6 + (jj - 6)]);
+        w12[u] = v;
+        return;
+    }
     if (t < tot0) {
         int s = t & 3, lane = (t >> 2) & 63, kb = t >> 8;
         int i = lane & 15, kq = lane >> 4, k = 16 * kb + 4 * s + kq;
@@ -2414,18 +2413,17 @@ __global__ __launch_bounds__(256) void heads_train_tm(const f4 *__restrict__ d4,
                                                        const float *__restrict__ wz, const float *__restrict__ wt,
                                                        const float *__restrict__ wl, int K5, const float *__restrict__ y,
                                                        int64_t n, int want_grad, float *__restrict__ g16,
-                                                       f4 *__restrict__ g5pre_tm, double *__restrict__ loss_rows, int G)
+                                                       f4 *__restrict__ g5pre_tm, double *__restrict__ loss_rows, int G,
+                                                       const float *__restrict__ w12)
 {
     __shared__ float sh[4][16][17];
     __shared__ double part[4][4];          // [wave][head]: the four loss sums of a wave's 16 candidates
     __shared__ __attribute__((aligned(16))) float shw[NB5 * 16][12];   // fc5-side head weights of a unit side by side: zygosity 2 | type 4 | length 6
     if (g5pre_tm && want_grad) {
-        for (int i = threadIdx.x; i < NB5 * 16 * 12; i += 256) {
-            const int k = i / 12, jj = i % 12;
-            float v = 0.0f;
-            if (k < K5) v = jj < 2 ? wz[(size_t)k * 2 + jj] : (jj < 6 ? wt[(size_t)k * 4 + (jj - 2)] : wl[(size_t)k * 6 + (jj - 6)]);
-            shw[k][jj] = v;
-        }
+        // (w12: the same [k][12] array packed once per weight change -- one coalesced copy instead of nine dependent
+        // strided loads per thread with a division each, which were ~10 us of this kernel at any batch)
+        for (int i = threadIdx.x; i < NB5 * 16 * 3; i += 256)
+            reinterpret_cast<f4 *>(&shw[0][0])[i] = reinterpret_cast<const f4 *>(w12)[i];
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = blockIdx.x * 4 + wave;
@@ -2558,7 +2556,7 @@ __global__ __launch_bounds__(256) void train_tail_tm(const f4 *__restrict__ part
                                                       const float *__restrict__ wt, const float *__restrict__ wl,
                                                       const float *__restrict__ y, int64_t n, int want_grad,
                                                       float *__restrict__ g16, f4 *__restrict__ g5pre_tm,
-                                                      double *__restrict__ loss_rows)
+                                                      double *__restrict__ loss_rows, const float *__restrict__ w12)
 {
     constexpr int NBW = 4, D = 7;                 // fc5 slab width and operand ring depth of dense_small<4, 7>
     static_assert(NB4 % D == 0 && NB5 <= 3 * NBW, "three slabs of four fc5 tiles, 21 k fragments in rings of 7");
@@ -2573,20 +2571,29 @@ __global__ __launch_bounds__(256) void train_tail_tm(const f4 *__restrict__ part
     const int c = lane & 15, q = lane >> 4;
     const int K5 = nout5;
     const bool grads = g5pre_tm && want_grad;
-    if (grads) {
-        for (int i = threadIdx.x; i < NB5 * 16 * 12; i += 256) {
-            const int k = i / 12, jj = i % 12;
-            float v = 0.0f;
-            if (k < K5) v = jj < 2 ? wz[(size_t)k * 2 + jj] : (jj < 6 ? wt[(size_t)k * 4 + (jj - 2)] : wl[(size_t)k * 6 + (jj - 6)]);
-            shw[k][jj] = v;
-        }
+    __shared__ float sy[16][16];                  // the group's label rows (one coalesced load)
+    {
+        const int64_t yc = (int64_t)g * 16 + (threadIdx.x >> 4);
+        sy[threadIdx.x >> 4][threadIdx.x & 15] = yc < n ? y[(size_t)yc * 16 + (threadIdx.x & 15)] : 0.0f;
     }
+    if (grads) {
+        for (int i = threadIdx.x; i < NB5 * 16 * 3; i += 256)
+            reinterpret_cast<f4 *>(&shw[0][0])[i] = reinterpret_cast<const f4 *>(w12)[i];
+    }
+    (void)wz; (void)wt; (void)wl;
     // ---- 1. fc4: k ranges added in ascending order, + bias, SELU, alpha-dropout (dense_ksum)
     const int64_t per = (int64_t)G * NB4 * 64;
     for (int ob = wave; ob < NB4; ob += 4) {
         const int64_t t = ((int64_t)g * NB4 + ob) * 64 + lane;
         f4 v = part[t];
-        for (int z = 1; z < KS; z++) v += part[(size_t)z * per + t];
+        if (KS == CV_DENSE_KSPLIT) {              // all ranges in flight, added in ascending order
+            f4 pz[CV_DENSE_KSPLIT - 1];
+#pragma unroll
+            for (int z = 1; z < CV_DENSE_KSPLIT; z++) pz[z - 1] = part[(size_t)z * per + t];
+#pragma unroll
+            for (int z = 1; z < CV_DENSE_KSPLIT; z++) v += pz[z - 1];
+        } else
+            for (int z = 1; z < KS; z++) v += part[(size_t)z * per + t];
         const f4 h = selu4(v + load_bias4(bias4, ob, q, nout4));
         h4_out[t] = h;
         f4 d, mk;
@@ -2687,7 +2694,7 @@ __global__ __launch_bounds__(256) void train_tail_tm(const f4 *__restrict__ part
         const int64_t cand = (int64_t)g * 16 + cc;
         double l = 0.0;
         if (cand < n) {
-            const float *yi = y + (size_t)cand * 16;
+            const float *yi = sy[cc];
             float *gl = S[cc];
             float *go = g16 + (size_t)cand * 16;
             if (j == 0) {
@@ -2932,7 +2939,7 @@ static bool is_full(const cv_arch &a);
 struct pack_job {
     int kind;                      // 0 conv1, 1 conv, 2 dense, 3 dense slabs, 4 dense dgrad, 5 conv dgrad, 6 heads, 7 dense dgrad by rows
     const float *src[4];
-    float *dst[2];
+    float *dst[3];
     int i[8];
     unsigned first;                // first block of the job
 };
@@ -2954,7 +2961,7 @@ __global__ __launch_bounds__(256) void pack_all(pack_tab tab)
     case 5: pack_conv_dgrad(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4]); break;
     case 7: pack_dense_dgrad_rows(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4], J.i[5]); break;
     case 8: pack_dense_kpairs(t, J.src[0], J.dst[0], J.i[0], J.i[1], J.i[2], J.i[3], J.i[4]); break;
-    default: pack_heads(t, J.src[0], J.src[1], J.src[2], J.src[3], J.i[0], J.i[1], J.i[2], J.i[3], J.dst[0], J.dst[1]); break;
+    default: pack_heads(t, J.src[0], J.src[1], J.src[2], J.src[3], J.i[0], J.i[1], J.i[2], J.i[3], J.dst[0], J.dst[1], J.dst[2]); break;
     }
 }
 
@@ -3014,9 +3021,10 @@ static int pack_launch(cv_model *m, hipStream_t st, unsigned mask)
         J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = 3; J.i[4] = 3; J.i[5] = 7;
     }
     if (mask & CVL_HEADS) {
-        pack_job &J = pb.add(6, (int64_t)(s.nb4 + s.nb5) * 256);
+        pack_job &J = pb.add(6, (int64_t)(s.nb4 + s.nb5) * 256 + (int64_t)s.nb5 * 16 * 12);
         J.src[0] = P + o[10]; J.src[1] = P + o[12]; J.src[2] = P + o[14]; J.src[3] = P + o[16];
         J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb4; J.i[3] = s.nb5; J.dst[0] = m->wp_heads0; J.dst[1] = m->wp_heads1;
+        J.dst[2] = m->wp_heads12;
     }
     if (mask & CVL_DCONV) {
         for (int l = 1; l < 3; l++) {
@@ -4067,7 +4075,7 @@ int cv_tile_train_tail(cv_model *m, const float *p3_tm, float *h4_tm, float *h5_
     train_tail_tm<21, 11><<<G, 256, 0, st>>>((const f4 *)part, CV_DENSE_KSPLIT, G, P + o[7], a.fc4, (f4 *)h4_tm, dr,
                                              (const f4 *)m->wps3_fc5, P + o[9], a.fc5, (f4 *)h5_tm, (const f4 *)m->wp_heads0,
                                              (const f4 *)m->wp_heads1, P + o[11], P + o[13], P + o[15], P + o[17], P + o[12], P + o[14],
-                                             P + o[16], y, n, want_grad, g16, (f4 *)g5pre_tm, rows);
+                                             P + o[16], y, n, want_grad, g16, (f4 *)g5pre_tm, rows, m->wp_heads12);
     CV_HIP(hipGetLastError());
     *done = true;
     return 0;
@@ -4209,7 +4217,7 @@ int cv_tile_heads_train(cv_model *m, const float *d4_tm, const float *h5_tm, con
     if (G <= 0) return 0;
 #define CV_HT(NB5) heads_train_tm<NB5><<<nblk(G, 4), 256, 0, st>>>((const f4 *)d4_tm, (const f4 *)h5_tm, s.nb4, (const f4 *)m->wp_heads0, \
         (const f4 *)m->wp_heads1, P + o[11], P + o[13], P + o[15], P + o[17], P + o[12], P + o[14], P + o[16], a.fc5, y, n, want_grad, \
-        g16, (f4 *)g5pre_tm, rows, G)
+        g16, (f4 *)g5pre_tm, rows, G, m->wp_heads12)
     // the block sums of this slice: rows [loss_rows_used, + blocks) of the step's row buffer (cv_train.hip t_loss_finish)
     const int64_t blocks = nblk(G, 4);
     if (m->loss_rows_used + blocks > m->loss_rows_cap) { cv_set_error("heads_train_tm: loss row buffer too small (internal)"); return 1; }

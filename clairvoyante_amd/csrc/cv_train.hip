@@ -704,6 +704,21 @@ struct tr_fork {
     // train.py's batch, the chain puts two dependent hand-overs in series, 19 us against 11 at the tail of the step;
     // a wait for an event that has already fired costs st next to nothing.)
     int join() { return nside == 0 ? 0 : gather(st); }
+    // Tiny batches, where the last kernels of the backward pass run on st itself: the side streams finished long before st
+    // gets here, so they are chained among themselves (off the critical path) and st takes ONE wait, for an event that has
+    // fired by then
+    int join_chained()
+    {
+        if (nside == 0) return 0;
+        int last = -1;
+        for (int i = 0; i < nside; i++) if (used[i]) last = i;
+        if (last < 0) return 0;
+        if (gather(side[last])) return 1;
+        hipEvent_t e = next_event();
+        CV_HIP(hipEventRecord(e, side[last]));
+        CV_HIP(hipStreamWaitEvent(st, e, 0));
+        return 0;
+    }
 };
 
 // the fixed-order loss sums + the bucket's loss header (t_loss_header, below) launched from inside a slice
@@ -814,15 +829,22 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
                                                                    s.nb4, n, Gn, 1, tgd4, th4, tmask, tg4pre);
     }
     f.st_moved();
-    // fc4
-    if (f.to_side(2, &sx)) return 1;
-    if (cv_tile_dense_wgrad(m, 4, tp[2], tg4pre, n, sx)) return 1;
-    if (dense_ready) {                       // heads, fc5 and fc4 gradients final: behind all three launch sites
-        if (f.nside > 0 && f.gather(sx)) return 1;
-        CV_HIP(hipEventRecord(dense_ready, sx));
-    }
     // fc4's data gradient; full topology: fused with conv3's max-pool backward + SELU' (dbg3 = 1: as two kernels)
     const bool fused3 = m->wpr_fc4 != nullptr && m->dbg[3] != 1;
+    // fc4's weight gradient.  Tiny batches with the fused data gradient (train_sched bit 7): launched one kernel LATER, at
+    // the marker of conv3's weight gradient -- it has 140 us of main chain left to hide its 70 us under, and the main stream
+    // has a marker less; otherwise here
+    const bool fc4_late = fused3 && Gn <= m->tiny_g && (m->sched & 128) && !dense_ready && f.nside > 1;
+    auto fc4_wgrad = [&](bool same_point) -> int {
+        if (f.to_side(2, &sx, same_point)) return 1;
+        if (cv_tile_dense_wgrad(m, 4, tp[2], tg4pre, n, sx)) return 1;
+        if (dense_ready) {                   // heads, fc5 and fc4 gradients final: behind all three launch sites
+            if (f.nside > 0 && f.gather(sx)) return 1;
+            CV_HIP(hipEventRecord(dense_ready, sx));
+        }
+        return 0;
+    };
+    if (!fc4_late && fc4_wgrad(false)) return 1;
     // layers without pooling (slim): the selu' factor of the layer below rides on the data-gradient kernel's store
     // (dbg4 = 3: as a separate element-wise pass)
     const bool nopool_fused = a.pool[0] == 1 && a.pool[1] == 1 && a.pool[2] == 1 && m->dbg[4] != 3;
@@ -846,7 +868,14 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
         // At tiny batches it stays on st (a marker, the hand-over to the side stream and the wait for it back cost ~25 us
         // of an otherwise idle chip for a 17 us kernel); at large ones the side stream keeps it off the chain's tail.
         if (l == 0 && Gn <= m->tiny_g && (m->sched & 2)) sx = st;
-        else if (f.to_side(5 - l, &sx)) return 1;
+        else {
+            if (f.to_side(5 - l, &sx)) return 1;
+            if (l == 2 && fc4_late) {            // the same marker serves fc4's weight gradient (another side stream)
+                hipStream_t s3 = sx;
+                if (fc4_wgrad(true)) return 1;
+                sx = s3;
+            }
+        }
         if (l == 0) {        // first layer: X viewed as [33][16] fragments, read in place
             if (cv_tile_conv1_wgrad(m, x, tgpre[0], n, sx)) return 1;
         } else {
@@ -856,7 +885,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
             else if (cv_tile_conv_dgrad(m, l, tgpre[l], tgin[l - 1], n, st)) return 1;
         }
     }
-    if (f.join()) return 1;
+    if ((Gn <= m->tiny_g && (m->sched & 2) && (m->sched & 128)) ? f.join_chained() : f.join()) return 1;
     CV_HIP(hipGetLastError());
     return 0;
 }

@@ -238,9 +238,9 @@ def test_backward_kernel_variants_give_the_same_bits(oracle, arch, n):
     # markers, per-layout packing -- switched off in groups)
     variants = ({"dbg3": 1}, {"dbg4": 2}, {"dbg4": 2, "dbg0": 3}, {"train_side_streams": 1}, {"dbg5": 1}, {"dbg6": 3}, {"dbg7": 1},
                 {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7}, {"dbg1": 8}, {"dbg2": 3}, {"dbg3": 1, "dbg4": 2, "train_overlap": 0},
-                {"dbg2": 4}, {"train_sched": 0}, {"train_sched": 126}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 95}, {"train_sched": 63}, {"dbg2": 1}, {"dbg2": 2}) if arch == "full" else \
+                {"dbg2": 4}, {"train_sched": 0}, {"train_sched": 254}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 223}, {"train_sched": 191}, {"train_sched": 127}, {"dbg2": 1}, {"dbg2": 2}) if arch == "full" else \
                ({"dbg4": 3}, {"train_side_streams": 1}, {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7},
-                {"dbg5": 1, "dbg4": 3, "train_overlap": 0}, {"train_sched": 0}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 95}, {"train_sched": 63})
+                {"dbg5": 1, "dbg4": 3, "train_overlap": 0}, {"train_sched": 0}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 223}, {"train_sched": 191}, {"train_sched": 127})
     for opts in variants:
         got = run(opts)
         assert ref[0] == got[0], opts
@@ -297,7 +297,7 @@ def test_a_step_writes_every_gradient_element(oracle, arch, n):
     y = synth.make_labels(cls, rf, alt, il)
     P = common.bench_params(oracle, arch)
     out = []
-    for sched in (127, 63):
+    for sched in (255, 191):
         m = _model(arch); m.setParameters(P); m.setOption("train_sched", sched)
         m._dropout_seed = 7; m.setLearningRate(1e-3); m.setL2RegularizationLambda(1e-3)
         m._ensure_bucket().fill_(float("nan"))
@@ -685,7 +685,7 @@ def test_bench_line_under_two_ranks_sharing_the_gpu(tmp_path):
     assert all(np.isfinite(v["final_loss"]) for v in b["train"].values())
 
 
-@pytest.mark.parametrize("mode", ["infer", "train"])
+@pytest.mark.parametrize("mode", ["infer", "train", "exchange"])
 def test_bench_line_under_eight_ranks_sharing_the_gpu(mode):
     """the driver's 8-GPU command, functionally: `python bench.py --gpus 8` with eight real ranks on the one GPU (backend
     gloo, CV_SHARE_DEVICES) -- one line, n_gpus = rccl_ranks = 8; in train mode the line separates the exchange from the
@@ -694,17 +694,26 @@ def test_bench_line_under_eight_ranks_sharing_the_gpu(mode):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(CV_SHARE_DEVICES="1", CV_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
-    extra = ["--mode", "train"] if mode == "train" else ["--no-extras"]
+    extra = ["--mode", mode] if mode != "infer" else ["--no-extras"]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu"] + extra,
                        env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     b = lines[0]
-    assert b["n_gpus"] == 8 and b["rccl_ranks"] == 8 and b["backend"] == "gloo" and b["value"] > 1e3     # functional: 8 ranks share one GPU, gloo through the host
+    assert b["n_gpus"] == 8 and b["rccl_ranks"] == 8 and b["backend"] == "gloo"
+    if mode == "exchange":       # only the bucket all-reduce: whole bucket, its two pieces, a fifth; time + bandwidths per piece
+        assert b["unit"] == "GB/s" and b["value"] > 0 and len(b["pieces"]) == 4
+        assert b["pieces"][0]["bytes"] == 4 * (1631496 + 16) and b["pieces"][1]["bytes"] + b["pieces"][2]["bytes"] == b["pieces"][0]["bytes"]
+        assert all(p["ms"] > 0 and abs(p["busbw_GBps"] - p["algbw_GBps"] * 2 * 7 / 8) < 1e-9 * max(1.0, p["busbw_GBps"]) for p in b["pieces"])
+        return
+    assert b["value"] > 1e3     # functional: 8 ranks share one GPU, gloo through the host
     if mode == "train":
         assert b["config"]["global_batch"] == 10000 and b["scaling"] == "strong"
         assert b["exchange_ms"] > 0 and b["compute_ms_per_step"] > 0 and 0.0 <= b["exchange_hidden_frac"] <= 1.0
         assert b["exchange_bytes"] == 4 * (1631496 + 16) and np.isfinite(b["final_loss"])
+        assert b["exchange_plan"] == "one"          # 1 250 candidates per rank: one collective per step
     else:
         assert b["scaling"] == "weak" and b["config"]["batch"] == 65536
+        pr = b["per_rank_ms"]                       # a straggler would show: slowest / fastest rank, ms per step
+        assert 0 < pr["min"] <= pr["max"] and 0 <= pr["argmax_rank"] < 8 and abs(pr["max"] - b["ms_per_step"]) < 1e-6 * pr["max"]

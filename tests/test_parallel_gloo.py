@@ -66,6 +66,10 @@ def _worker(rank, ws, port, tmp, n):
     m._bucket_header = 16
     m._bucket_dense = 16 + sum(P[k].size for k in O.PARAM_NAMES[:6])
     assert parallel.comm_stream(m) is None
+    if ws != 2:       # the plan for a tiny share: ONE collective over the whole bucket (ws == 2: the unplanned default, two pieces)
+        assert parallel.plan_exchange(m, n) == "one" and parallel.exchange_mode(m) == "one"
+    else:
+        assert parallel.exchange_mode(m) == "split"
     parallel.exchange_bucket(m, None)
     got = m._bucket.numpy()
     assert np.abs(got[16:] - ref).max() <= 1e-4 * np.abs(ref).max()      # shard gradients sum to the whole-batch gradient
