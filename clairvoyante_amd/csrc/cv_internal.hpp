@@ -114,6 +114,7 @@ struct cv_model {
     hipEvent_t tr_pack_fork, tr_pack_done;   // weight packing on the side stream (cv_pack_for_training)
     int train_overlap;   // option: weight gradients on the side stream (default 1)
     int train_ksplit;    // option: k-split fc4 forward at tiny batches (default 1)
+    int tail_kranges;    // option "train_kranges": k ranges of fc4 in front of the fused tail of a tiny-batch forward (8 or 16)
     int tiny_g;          // option "train_tiny_groups": batches of up to this many groups take the latency-oriented
                          // kernel variants of the training step (default 160; 0 = never)
     // fc4 dropout output / keep mask (a*keep) of the LAST training slice, for cv_get_activation 6 / 7
@@ -146,8 +147,8 @@ struct cv_model {
     //   32 the base head's data gradient, the dropout factor and selu'(fc4) on the store of fc5's data-gradient kernel
     //      instead of a pass of their own
     //   64 no memset of the gradient at the head of a step: the second passes of the first slice store instead of adding
-    //   128 tiny batches: fc4's weight gradient launched at conv3's marker (a marker less on the main stream), the side
-    //      streams chained before the ONE wait of the main stream at the end of the step
+    //   128 tiny batches: the side streams chained before the ONE wait of the main stream at the end of the step
+    //   256 (off by default) tiny batches: fc4's weight gradient launched at conv3's marker (a marker less on the main stream)
     int sched;
     int profile;
     void *prof;          // cv_prof*, owned
@@ -208,6 +209,7 @@ int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward, int G, hipS
 int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float *a1, float *p2, float *a2,
                         float *p3, float *a3, hipStream_t st);
 #define CV_DENSE_KSPLIT 8      // k ranges of the fc4 training forward at tiny batches (cv_tile_dense_fwd)
+#define CV_DENSE_KSPLIT_MAX 16 // ... of the fused tail's fc4 (option train_kranges): the scratch is sized for it
 // part: scratch of CV_DENSE_KSPLIT * groups * nb4 fragments, or NULL = always the single ascending-k chain
 // drop / drop_done (fc4 of a training pass): where the kernel set allows it the alpha-dropout is applied by the layer's
 // last kernel (*drop_done = true); otherwise the caller runs cv_dropout_tm

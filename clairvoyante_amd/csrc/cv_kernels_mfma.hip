@@ -2533,9 +2533,9 @@ __global__ __launch_bounds__(256) void heads_train_tm(const f4 *__restrict__ d4,
 // fc4 (dense_ksum: partial sums added in order, bias, SELU, alpha-dropout), fc5 (dense_small<4, 7>), and the heads
 // of the training pass (heads_train_tm: products, losses, head gradients, fc5-side data gradient times selu').  As
 // three launches they were 8 + 12 + 28 us of a 14-kernel chain at 79 groups (a rank's share of train.py's batch on
-// 8 GPUs), each a latency chain of global loads on a fraction of the chip; here a workgroup of four waves owns one
+// 8 GPUs), each a latency chain of global loads on a fraction of the chip; here a workgroup of eight waves owns one
 // group of 16 candidates and the operands of every step come from LDS or registers:
-//   1. wave w sums fragments w, w + 4, ... of the eight k ranges, + bias, SELU -> fc4 output (stored: the backward
+//   1. wave w sums fragments w, w + 8, w + 16 of the eight k ranges, + bias, SELU -> fc4 output (stored: the backward
 //      pass takes selu' from it), dropout -> d4 / mask (stored) and d4 into LDS;
 //   2. waves 0..2: one slab of 4 fc5 tiles each over the 21 d4 fragments (weights from L2 through a register ring,
 //      dense_small's loop), bias + SELU -> fc5 output (stored, LDS, and kept in registers); wave 3: the base head's
@@ -2545,8 +2545,8 @@ __global__ __launch_bounds__(256) void heads_train_tm(const f4 *__restrict__ d4,
 // Arithmetic and order per value are those of the three kernels (same bits); the loss sums leave as ONE ROW PER GROUP
 // (heads_train_tm: one per four groups), which t_loss_header adds in its fixed order.
 // ---------------------------------------------------------------------------
-template <int NB4, int NB5>
-__global__ __launch_bounds__(256) void train_tail_tm(const f4 *__restrict__ part, int KS, int G, const float *__restrict__ bias4,
+template <int NB4, int NB5, int KSF>
+__global__ __launch_bounds__(512) void train_tail_tm(const f4 *__restrict__ part, int KS, int G, const float *__restrict__ bias4,
                                                       int nout4, f4 *__restrict__ h4_out, cv_dropout_args dr,
                                                       const f4 *__restrict__ w5s, const float *__restrict__ bias5, int nout5,
                                                       f4 *__restrict__ h5_out, const f4 *__restrict__ wp0,
@@ -2572,28 +2572,54 @@ __global__ __launch_bounds__(256) void train_tail_tm(const f4 *__restrict__ part
     const int K5 = nout5;
     const bool grads = g5pre_tm && want_grad;
     __shared__ float sy[16][16];                  // the group's label rows (one coalesced load)
-    {
+    if (threadIdx.x < 256) {
         const int64_t yc = (int64_t)g * 16 + (threadIdx.x >> 4);
         sy[threadIdx.x >> 4][threadIdx.x & 15] = yc < n ? y[(size_t)yc * 16 + (threadIdx.x & 15)] : 0.0f;
     }
+    (void)wz; (void)wt; (void)wl;
+    // ---- 1. fc4: k ranges added in ascending order, + bias, SELU, alpha-dropout (dense_ksum).  Eight waves: at most
+    // three fragments each, the partial sums of all of them in flight at once (the step is a latency chain: 79 workgroups
+    // on 256 CUs)
+    constexpr int NW = 8, MAXF = (NB4 + NW - 1) / NW;
+    const int64_t per = (int64_t)G * NB4 * 64;
+    // KSF = the number of k ranges this instance keeps in flight per fragment; up to 8 ranges the partial sums of ALL of a
+    // wave's fragments are loaded up front, with 16 one fragment at a time (64 registers each)
+    constexpr bool ALL = KSF <= 8;
+    f4 pz[ALL ? MAXF : 1][KSF];
+    const bool fast = KS == KSF;
+    if (fast && ALL) {
+#pragma unroll
+        for (int i = 0; i < MAXF; i++) {
+            const int ob = wave + NW * i;
+            if (ob < NB4) {
+                const int64_t t = ((int64_t)g * NB4 + ob) * 64 + lane;
+#pragma unroll
+                for (int z = 0; z < KSF; z++) pz[i][z] = part[(size_t)z * per + t];
+            }
+        }
+    }
     if (grads) {
-        for (int i = threadIdx.x; i < NB5 * 16 * 3; i += 256)
+        for (int i = threadIdx.x; i < NB5 * 16 * 3; i += NW * 64)
             reinterpret_cast<f4 *>(&shw[0][0])[i] = reinterpret_cast<const f4 *>(w12)[i];
     }
-    (void)wz; (void)wt; (void)wl;
-    // ---- 1. fc4: k ranges added in ascending order, + bias, SELU, alpha-dropout (dense_ksum)
-    const int64_t per = (int64_t)G * NB4 * 64;
-    for (int ob = wave; ob < NB4; ob += 4) {
+#pragma unroll
+    for (int i = 0; i < MAXF; i++) {
+        const int ob = wave + NW * i;
+        if (ob >= NB4) break;
         const int64_t t = ((int64_t)g * NB4 + ob) * 64 + lane;
-        f4 v = part[t];
-        if (KS == CV_DENSE_KSPLIT) {              // all ranges in flight, added in ascending order
-            f4 pz[CV_DENSE_KSPLIT - 1];
+        f4 v;
+        if (fast) {
+            if constexpr (!ALL) {
 #pragma unroll
-            for (int z = 1; z < CV_DENSE_KSPLIT; z++) pz[z - 1] = part[(size_t)z * per + t];
+                for (int z = 0; z < KSF; z++) pz[0][z] = part[(size_t)z * per + t];
+            }
+            v = pz[ALL ? i : 0][0];
 #pragma unroll
-            for (int z = 1; z < CV_DENSE_KSPLIT; z++) v += pz[z - 1];
-        } else
+            for (int z = 1; z < KSF; z++) v += pz[ALL ? i : 0][z];
+        } else {
+            v = part[t];
             for (int z = 1; z < KS; z++) v += part[(size_t)z * per + t];
+        }
         const f4 h = selu4(v + load_bias4(bias4, ob, q, nout4));
         h4_out[t] = h;
         f4 d, mk;
@@ -2652,7 +2678,7 @@ __global__ __launch_bounds__(256) void train_tail_tm(const f4 *__restrict__ part
             h5_out[((size_t)g * NB5 + ob) * 64 + lane] = H5[j];
             sh5[ob][lane] = H5[j];
         }
-    } else {
+    } else if (wave == 3) {
         f4 a0 = zero;
 #pragma unroll 3
         for (int kb = 0; kb < NB4; kb++) {
@@ -4062,20 +4088,24 @@ int cv_tile_train_tail(cv_model *m, const float *p3_tm, float *h4_tm, float *h5_
     if (m->loss_rows_used + G > m->loss_rows_cap) { cv_set_error("train_tail_tm: loss row buffer too small (internal)"); return 1; }
     double *rows = m->loss_rows + (size_t)m->loss_rows_used * 4;
     m->loss_rows_used += G;                       // one row per group (cv_train.hip t_loss_header adds the rows in order)
+    // k ranges of fc4 (option train_kranges, 8 or 16): a range is a chain of KB / ranges barrier steps of ~1 us on a
+    // workgroup that holds 8 groups, so the number of ranges sets the length of the step's longest forward kernel
+    const int KR = m->tail_kranges == 16 ? 16 : CV_DENSE_KSPLIT;
     {
         auto k = dense_tm<7, 8, 0, 1>;
         const size_t lds = (size_t)3 * 8 * 1024;
         if (set_lds(k, lds)) return 1;
-        k<<<dim3(nblk(G, 8), 3, CV_DENSE_KSPLIT), 512, lds, st>>>((const f4 *)p3_tm, s.kb4, (const f4 *)m->wps_fc4, P + o[7], a.fc4,
-                                                                   (f4 *)part, G, 21, heads_args());
+        k<<<dim3(nblk(G, 8), 3, KR), 512, lds, st>>>((const f4 *)p3_tm, s.kb4, (const f4 *)m->wps_fc4, P + o[7], a.fc4,
+                                                      (f4 *)part, G, 21, heads_args());
     }
     cv_dropout_args dr = cv_dropout_args();
     dr.d4 = drop->d4; dr.amask = drop->amask; dr.nunits = a.fc4; dr.rate = drop->rate; dr.seed = drop->seed;
     dr.step = drop->step; dr.cand0 = drop->cand0;
-    train_tail_tm<21, 11><<<G, 256, 0, st>>>((const f4 *)part, CV_DENSE_KSPLIT, G, P + o[7], a.fc4, (f4 *)h4_tm, dr,
-                                             (const f4 *)m->wps3_fc5, P + o[9], a.fc5, (f4 *)h5_tm, (const f4 *)m->wp_heads0,
-                                             (const f4 *)m->wp_heads1, P + o[11], P + o[13], P + o[15], P + o[17], P + o[12], P + o[14],
-                                             P + o[16], y, n, want_grad, g16, (f4 *)g5pre_tm, rows, m->wp_heads12);
+#define CV_TAIL(KSF) train_tail_tm<21, 11, KSF><<<G, 512, 0, st>>>((const f4 *)part, KR, G, P + o[7], a.fc4, (f4 *)h4_tm, dr, \
+        (const f4 *)m->wps3_fc5, P + o[9], a.fc5, (f4 *)h5_tm, (const f4 *)m->wp_heads0, (const f4 *)m->wp_heads1, P + o[11], P + o[13], \
+        P + o[15], P + o[17], P + o[12], P + o[14], P + o[16], y, n, want_grad, g16, (f4 *)g5pre_tm, rows, m->wp_heads12)
+    if (KR == 16) CV_TAIL(16); else CV_TAIL(8);
+#undef CV_TAIL
     CV_HIP(hipGetLastError());
     *done = true;
     return 0;

@@ -570,7 +570,7 @@ static size_t train_floats_per_cand(const cv_model *m)
     // tile path: TM copies of activations, pre-pool activations and three gradient maps,
     // padded channel counts, plus the dense TM buffers
     for (int l = 0; l < 3; l++) f += (size_t)(2 * s.hc[l] + 2 * s.hp[l]) * 4 * s.ntile[l] * 16;
-    f += (6 + CV_DENSE_KSPLIT) * (size_t)s.nb4 * 16 + 2 * (size_t)s.nb5 * 16;
+    f += (6 + CV_DENSE_KSPLIT_MAX) * (size_t)s.nb4 * 16 + 2 * (size_t)s.nb5 * 16;
     return f + 64 * 80;
 }
 
@@ -756,7 +756,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     }
     float *th4 = sb.take(np * f4u), *td4 = sb.take(np * f4u), *tmask = sb.take(np * f4u), *th5 = sb.take(np * f5u);
     float *ghpre = sb.take((size_t)n * 16);
-    float *kpart = sb.take((size_t)CV_DENSE_KSPLIT * np * f4u);      // partial sums of the k-split fc4 forward
+    float *kpart = sb.take((size_t)CV_DENSE_KSPLIT_MAX * np * f4u);      // partial sums of the k-split fc4 forward
     if (!ghpre || !kpart) { cv_set_error("training workspace too small"); return 1; }
     // ---- forward
     bool pack_wait = false;       // dbg5 = 1: all packing in one launch on st, as before
@@ -831,10 +831,12 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     f.st_moved();
     // fc4's data gradient; full topology: fused with conv3's max-pool backward + SELU' (dbg3 = 1: as two kernels)
     const bool fused3 = m->wpr_fc4 != nullptr && m->dbg[3] != 1;
-    // fc4's weight gradient.  Tiny batches with the fused data gradient (train_sched bit 7): launched one kernel LATER, at
-    // the marker of conv3's weight gradient -- it has 140 us of main chain left to hide its 70 us under, and the main stream
-    // has a marker less; otherwise here
-    const bool fc4_late = fused3 && Gn <= m->tiny_g && (m->sched & 128) && !dense_ready && f.nside > 1;
+    // fc4's weight gradient.  train_sched bit 8 (OFF by default): at tiny batches launched one kernel LATER, at the marker of
+    // conv3's weight gradient -- a marker less on the main stream.  Measured with the chained join (one box, alternating,
+    // profiles/r05/step_ab_session6_sched_bit7.txt): 14 us SLOWER at 79 groups (the weight gradient fills the chip and then
+    // meets conv3's two gradient kernels instead of the fused fc4 data gradient, which leaves half the CUs free), 14 us
+    // faster at 157.  Here by default.
+    const bool fc4_late = fused3 && Gn <= m->tiny_g && (m->sched & 256) && !dense_ready && f.nside > 1;
     auto fc4_wgrad = [&](bool same_point) -> int {
         if (f.to_side(2, &sx, same_point)) return 1;
         if (cv_tile_dense_wgrad(m, 4, tp[2], tg4pre, n, sx)) return 1;

@@ -160,9 +160,9 @@ def exchange_bucket(model, comm=None):
     "one": all-reduce(SUM) of the whole bucket on the current stream.
     "split": all-reduce(SUM) of the dense part [dense_begin, end) on `comm` (which cv_grad_async made wait for "dense
     gradients final"), so that it runs under the rest of the backward pass; then [0, dense_begin) = loss header +
-    convolution gradients in stream order; the current stream continues behind both.  The collectives are synchronous
-    calls: enqueued on the stream that is current (see _all_reduce), so the only cross-stream edges of a step are
-    the event into `comm` and the join back.  CV_EXCHANGE_ASYNC=1 restores the round-4 form (async_op on torch's own
+    convolution gradients, also on `comm` once it has picked up the end of the backward pass; the current stream continues
+    behind both.  The collectives are synchronous calls: enqueued on the stream that is current (see _all_reduce), so the
+    cross-stream edges of a step are the event into `comm`, the pick-up and the join back.  CV_EXCHANGE_ASYNC=1 restores the round-4 form (async_op on torch's own
     communication stream, three waits) for A/B runs."""
     if not _active():
         return
@@ -181,12 +181,19 @@ def exchange_bucket(model, comm=None):
         for w in (w1, w2):
             if w is not None:
                 w.wait()
-    else:
-        if comm is not None:
-            with torch.cuda.stream(comm):
-                _all_reduce(b[d:])
-        else:
+    elif comm is not None:
+        # BOTH collectives on `comm`, in this order on every rank: one communicator is only ever driven from one stream at
+        # a time (two streams issuing on the same communicator would lean on RCCL's internal serialisation -- never
+        # exercised here with more than one rank).  comm already waits for "dense gradients final"; it picks up the end of
+        # the backward pass before the second piece.
+        cur = torch.cuda.current_stream(model.device)
+        with torch.cuda.stream(comm):
             _all_reduce(b[d:])
+        comm.wait_stream(cur)
+        with torch.cuda.stream(comm):
+            _all_reduce(b[:d])
+    else:
+        _all_reduce(b[d:])
         _all_reduce(b[:d])
     if comm is not None:
         torch.cuda.current_stream(model.device).wait_stream(comm)

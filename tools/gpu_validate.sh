@@ -2,7 +2,7 @@
 # Full validation on the GPU box (what profiles/rNN/ is made with): every GPU test, smoke(), the PMC passes of the
 # shipped kernels (inference: tools/gpu_pmc.sh; training step: tools/gpu_pmc_train.sh), the bench line, slim / training
 # lines, rocprofv3 kernel stats of the bench and of the training step, the host-side probes.
-#   gpurun --timeout 2400 -- 'bash tools/gpu_validate.sh TAG GITHEAD'
+#   gpurun --timeout 2400 -- 'bash tools/gpu_validate.sh TAG GITHEAD [host]'
 set -u
 OUT=gpurun_out/${1:-validate}
 HEAD=${2:-unknown}
@@ -30,13 +30,34 @@ for b in 10000 1250; do
   rocprofv3 --kernel-trace --output-format csv -d $OUT/tl_$b -o t -- python bench.py --mode train --batch $b --steps 12 --warmup 3 > /dev/null 2> $OUT/tl_$b.err
   f=$(find $OUT/tl_$b -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_timeline.py "$f" > $OUT/train_${b}_timeline.txt; rm -rf $OUT/tl_$b
 done
-python tools/vcf_format_probe.py 2000000 16 > $OUT/vcf_format_probe.txt 2>&1
-python tools/vcf_format_probe.py 2000000 1 >> $OUT/vcf_format_probe.txt 2>&1
-timeout 900 python tools/gpu_callvar_text_probe.py > $OUT/callvar_text_probe.txt 2>&1
-# the RCCL branch of the training line with ONE rank (exchange timing keys, RCCL log summary)
-CV_FORCE_DIST=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 python bench.py --mode train --steps 20 --warmup 3 > $OUT/bench_train_rccl_one_rank.json 2>> $OUT/bench.err
-timeout 600 python tools/gpu_e2e_bam.py > $OUT/e2e_bam.txt 2>&1
-timeout 300 python tools/gpu_small_batch_probe.py > $OUT/small_batch.txt 2>&1
+if [ "${3:-}" = "host" ]; then      # the loops around the kernels (unchanged code: not re-measured every round)
+  python tools/vcf_format_probe.py 2000000 16 > $OUT/vcf_format_probe.txt 2>&1
+  python tools/vcf_format_probe.py 2000000 1 >> $OUT/vcf_format_probe.txt 2>&1
+  timeout 900 python tools/gpu_callvar_text_probe.py > $OUT/callvar_text_probe.txt 2>&1
+  timeout 600 python tools/gpu_e2e_bam.py > $OUT/e2e_bam.txt 2>&1
+  timeout 300 python tools/gpu_small_batch_probe.py > $OUT/small_batch.txt 2>&1
+fi
+timeout 300 python tools/gpu_step_host_probe.py 1250 10000 > $OUT/step_host_probe.txt 2>&1
+# the RCCL branch with ONE rank (a sum over one rank moves no byte: what is measured is the machinery): the training lines
+# with their exchange keys, the exchange alone (--mode exchange), and the step by exchange form
+D="CV_FORCE_DIST=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517"
+for b in 10000 1250; do env $D python bench.py --mode train --batch $b --steps 40 --warmup 4 >> $OUT/bench_train_rccl_one_rank.jsonl 2>> $OUT/bench.err; done
+env $D python bench.py --mode exchange > $OUT/bench_exchange_rccl_one_rank.json 2>> $OUT/bench.err
+ex() {  # label, batch, env...
+  local label=$1 b=$2; shift 2
+  env "$@" python bench.py --mode train --batch $b --steps 40 --warmup 4 2>> $OUT/bench.err | LABEL="$label" python -c "
+import json,sys,os
+r=json.loads(sys.stdin.read()); print('batch %5d %-30s step %.3f ms  compute %s  exchange alone %s  plan %s' % (r['config']['global_batch'], os.environ['LABEL'], r['ms_per_step'], r.get('compute_ms_per_step'), r.get('exchange_ms'), r.get('exchange_plan')))" >> $OUT/exchange_fixed_cost.txt
+}
+for round in 1 2; do
+  for b in 1250 10000; do
+    ex "no process group" $b CV_NOTHING=1
+    ex "one collective" $b $D CV_EXCHANGE=one
+    ex "split, sync, both on the comm stream" $b $D CV_EXCHANGE=split
+    ex "split, async (round 4 form)" $b $D CV_EXCHANGE=split CV_EXCHANGE_ASYNC=1
+  done
+done
+sort -o $OUT/exchange_fixed_cost.txt $OUT/exchange_fixed_cost.txt
 tail -3 $OUT/pytest_gpu.log; tail -3 $OUT/smoke.log; cat $OUT/status.txt
 python - $OUT <<'PY'
 import json, sys, os
