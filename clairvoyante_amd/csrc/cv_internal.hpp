@@ -114,7 +114,6 @@ struct cv_model {
     hipEvent_t tr_pack_fork, tr_pack_done;   // weight packing on the side stream (cv_pack_for_training)
     int train_overlap;   // option: weight gradients on the side stream (default 1)
     int train_ksplit;    // option: k-split fc4 forward at tiny batches (default 1)
-    int tail_kranges;    // option "train_kranges": k ranges of fc4 in front of the fused tail of a tiny-batch forward (8 or 16)
     int tiny_g;          // option "train_tiny_groups": batches of up to this many groups take the latency-oriented
                          // kernel variants of the training step (default 160; 0 = never)
     // fc4 dropout output / keep mask (a*keep) of the LAST training slice, for cv_get_activation 6 / 7
@@ -132,7 +131,7 @@ struct cv_model {
     //         dbg1 = 8: conv2 forward on flat ranges too)
     //   dbg2 = 1 / 2: unpool always thread-per-row / always streaming, 3: fc4's alpha-dropout as its own pass, 4: thread-per-row at tiny batches (default there: row segments), 5: the tail of the tiny-batch forward as three kernels
     //   dbg3 = 1: fc4 data gradient and conv3 unpool as two kernels
-    //   dbg4 = 2: conv data gradients fused with the unpool below (conv_dgrad_unpool), 3: slim selu' as its own pass
+    //   dbg4 = 2: conv data gradients fused with the unpool below (conv_dgrad_unpool), 3: slim selu' as its own pass, 4: conv1's unpool and weight gradient as two kernels
     //   dbg5 = 1: all weight packing in one launch in stream order      dbg6 = n: row parts of dense_dgrad_unpool (few groups)
     //   dbg7 = 1: training-forward conv3 on conv_tm instead of conv3_rot
     int dbg[8];
@@ -149,6 +148,7 @@ struct cv_model {
     //   64 no memset of the gradient at the head of a step: the second passes of the first slice store instead of adding
     //   128 tiny batches: the side streams chained before the ONE wait of the main stream at the end of the step
     //   256 (off by default) tiny batches: fc4's weight gradient launched at conv3's marker (a marker less on the main stream)
+    //   512 (off by default) conv1's weight gradient on the main stream at EVERY batch size
     int sched;
     int profile;
     void *prof;          // cv_prof*, owned
@@ -209,7 +209,6 @@ int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward, int G, hipS
 int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float *a1, float *p2, float *a2,
                         float *p3, float *a3, hipStream_t st);
 #define CV_DENSE_KSPLIT 8      // k ranges of the fc4 training forward at tiny batches (cv_tile_dense_fwd)
-#define CV_DENSE_KSPLIT_MAX 16 // ... of the fused tail's fc4 (option train_kranges): the scratch is sized for it
 // part: scratch of CV_DENSE_KSPLIT * groups * nb4 fragments, or NULL = always the single ascending-k chain
 // drop / drop_done (fc4 of a training pass): where the kernel set allows it the alpha-dropout is applied by the layer's
 // last kernel (*drop_done = true); otherwise the caller runs cv_dropout_tm
@@ -231,6 +230,8 @@ int cv_tile_conv_dgrad_unpool(cv_model *m, int layer, const float *g_tm, const f
 int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_tm, const float *g_tm, int64_t n, hipStream_t st);
 int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_tm, const float *g_tm, int64_t n, hipStream_t st);
 int cv_tile_conv1_wgrad(cv_model *m, const float *x, const float *g_tm, int64_t n, hipStream_t st);
+int cv_tile_conv1_wgrad_unpool(cv_model *m, const float *x, const float *gpool, const float *pooled, const float *codes, int64_t n,
+                               hipStream_t st, bool *done);
 int cv_wgrad_scratch_reserve(cv_model *m);      // scratch of the weight-gradient kernels at its upper bound
 int cv_tile_heads_wgrad(cv_model *m, const float *d4_tm, const float *h5_tm, const float *g16, int64_t n, hipStream_t st);
 int cv_tile_heads_pre(cv_model *m, const float *d4_tm, const float *h5_tm, int64_t n, float *pre16, hipStream_t st);

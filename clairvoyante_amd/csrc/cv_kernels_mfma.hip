@@ -2545,7 +2545,7 @@ __global__ __launch_bounds__(256) void heads_train_tm(const f4 *__restrict__ d4,
 // Arithmetic and order per value are those of the three kernels (same bits); the loss sums leave as ONE ROW PER GROUP
 // (heads_train_tm: one per four groups), which t_loss_header adds in its fixed order.
 // ---------------------------------------------------------------------------
-template <int NB4, int NB5, int KSF>
+template <int NB4, int NB5>
 __global__ __launch_bounds__(512) void train_tail_tm(const f4 *__restrict__ part, int KS, int G, const float *__restrict__ bias4,
                                                       int nout4, f4 *__restrict__ h4_out, cv_dropout_args dr,
                                                       const f4 *__restrict__ w5s, const float *__restrict__ bias5, int nout5,
@@ -2582,12 +2582,12 @@ __global__ __launch_bounds__(512) void train_tail_tm(const f4 *__restrict__ part
     // on 256 CUs)
     constexpr int NW = 8, MAXF = (NB4 + NW - 1) / NW;
     const int64_t per = (int64_t)G * NB4 * 64;
-    // KSF = the number of k ranges this instance keeps in flight per fragment; up to 8 ranges the partial sums of ALL of a
-    // wave's fragments are loaded up front, with 16 one fragment at a time (64 registers each)
-    constexpr bool ALL = KSF <= 8;
-    f4 pz[ALL ? MAXF : 1][KSF];
+    // (sixteen ranges instead of eight were measured: the k-range kernel in front takes the same 40 us -- it is not bound by
+    // its number of barrier steps -- and the step does not move: profiles/r05/step_ab_session7_join_latefc4_kranges.txt)
+    constexpr int KSF = CV_DENSE_KSPLIT;
+    f4 pz[MAXF][KSF];
     const bool fast = KS == KSF;
-    if (fast && ALL) {
+    if (fast) {
 #pragma unroll
         for (int i = 0; i < MAXF; i++) {
             const int ob = wave + NW * i;
@@ -2597,6 +2597,24 @@ __global__ __launch_bounds__(512) void train_tail_tm(const f4 *__restrict__ part
                 for (int z = 0; z < KSF; z++) pz[i][z] = part[(size_t)z * per + t];
             }
         }
+    }
+    // Operands of step 2 that depend on nothing computed here are requested NOW, behind the partial sums: the first ring of
+    // fc5 weight fragments (waves 0..2), all of the base head's (wave 3), the other heads' (wave 0) -- they land while
+    // step 1 computes, instead of opening step 2 with a round trip to L2 each
+    // (ONE register array for both roles -- wave 3's 21 base-head fragments live where waves 0..2 keep their ring of
+    // 7 x 4: as two arrays the kernel spilled)
+    static_assert(NB4 <= D * NBW, "the base head's fragments fit the ring's registers");
+    const f4 *wp5 = w5s + (size_t)(wave < 3 ? wave : 0) * NB4 * (NBW * 64) + lane;
+    f4 A[D][NBW];
+    {
+        const f4 *src = wave == 3 ? wp0 + lane : wp5;
+#pragma unroll
+        for (int d = 0; d < D; d++)
+#pragma unroll
+            for (int j = 0; j < NBW; j++) {
+                const int f = d * NBW + j;
+                if (wave <= 3 && (wave < 3 || f < NB4)) A[d][j] = src[(size_t)f * 64];      // (wave-uniform)
+            }
     }
     if (grads) {
         for (int i = threadIdx.x; i < NB5 * 16 * 3; i += NW * 64)
@@ -2609,13 +2627,9 @@ __global__ __launch_bounds__(512) void train_tail_tm(const f4 *__restrict__ part
         const int64_t t = ((int64_t)g * NB4 + ob) * 64 + lane;
         f4 v;
         if (fast) {
-            if constexpr (!ALL) {
+            v = pz[i][0];
 #pragma unroll
-                for (int z = 0; z < KSF; z++) pz[0][z] = part[(size_t)z * per + t];
-            }
-            v = pz[ALL ? i : 0][0];
-#pragma unroll
-            for (int z = 1; z < KSF; z++) v += pz[ALL ? i : 0][z];
+            for (int z = 1; z < KSF; z++) v += pz[i][z];
         } else {
             v = part[t];
             for (int z = 1; z < KS; z++) v += part[(size_t)z * per + t];
@@ -2639,13 +2653,17 @@ __global__ __launch_bounds__(512) void train_tail_tm(const f4 *__restrict__ part
     f4 H5[NBW];                                   // this wave's fc5 output tiles (waves 0..2)
 #pragma unroll
     for (int j = 0; j < NBW; j++) H5[j] = zero;
+    f4 W1[NB5];                                   // wave 0: the fc5-side heads' fragments, landing under its fc5 slab
+    if (wave == 0) {
+#pragma unroll
+        for (int kb = 0; kb < NB5; kb++) W1[kb] = wp1[(size_t)kb * 64 + lane];
+    }
     if (wave < 3) {
         const int slab = wave;
-        const f4 *wp = w5s + (size_t)slab * NB4 * (NBW * 64) + lane;
+        const f4 *wp = wp5;
         f4 acc[NBW];
 #pragma unroll
         for (int j = 0; j < NBW; j++) acc[j] = zero;
-        f4 A[D][NBW];
         auto fetch = [&](const f4 *pw, int d) {
 #pragma unroll
             for (int j = 0; j < NBW; j++) A[d][j] = pw[((size_t)d * NBW + j) * 64];
@@ -2657,10 +2675,8 @@ __global__ __launch_bounds__(512) void train_tail_tm(const f4 *__restrict__ part
 #pragma unroll
                 for (int j = 0; j < NBW; j++) acc[j] = mfma4(A[d][j][s4], B[s4], acc[j]);
         };
-#pragma unroll
-        for (int d = 0; d < D; d++) fetch(wp, d);
 #pragma unroll 1
-        for (int kb0 = D; kb0 < NB4; kb0 += D) {
+        for (int kb0 = D; kb0 < NB4; kb0 += D) {          // (the first ring was requested at the top of the kernel)
             wp += (size_t)D * NBW * 64;
 #pragma unroll
             for (int d = 0; d < D; d++) {
@@ -2680,12 +2696,11 @@ __global__ __launch_bounds__(512) void train_tail_tm(const f4 *__restrict__ part
         }
     } else if (wave == 3) {
         f4 a0 = zero;
-#pragma unroll 3
+#pragma unroll
         for (int kb = 0; kb < NB4; kb++) {
             const f4 B = sd4[kb][lane];
-            const f4 A = wp0[(size_t)kb * 64 + lane];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; s4++) a0 = mfma4(A[s4], B[s4], a0);
+            for (int s4 = 0; s4 < 4; s4++) a0 = mfma4(A[kb / NBW][kb % NBW][s4], B[s4], a0);
         }
         sa0[lane] = a0;
     }
@@ -2696,9 +2711,8 @@ __global__ __launch_bounds__(512) void train_tail_tm(const f4 *__restrict__ part
 #pragma unroll
         for (int kb = 0; kb < NB5; kb++) {
             const f4 B = sh5[kb][lane];
-            const f4 A = wp1[(size_t)kb * 64 + lane];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; s4++) a1 = mfma4(A[s4], B[s4], a1);
+            for (int s4 = 0; s4 < 4; s4++) a1 = mfma4(W1[kb][s4], B[s4], a1);
         }
         const f4 a0 = sa0[lane];
         // rows of the second tile: q 0 = zygosity (2), q 1 = type (4), q 2 = length 0..3, q 3 = length 4..5
@@ -3851,7 +3865,7 @@ __global__ __launch_bounds__(64) void wgrad_conv1_cm(const float *__restrict__ x
     const int g0 = blockIdx.x * per, g1 = g0 + per < G ? g0 + per : G;
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
     f4 acc[4] = {zero, zero, zero, zero};
-    f4 bsum = zero;
+    f4 bsum[4] = {zero, zero, zero, zero};        // per base: the second pass adds the four (the fused kernel below makes them on four waves)
     // positions of consecutive groups are consecutive in both buffers: flat position i of this split
     const int total = (g1 > g0 ? g1 - g0 : 0) * HIN;
     const f4 *gp = g_tm + (size_t)g0 * HIN * 4 * 64;
@@ -3878,7 +3892,7 @@ __global__ __launch_bounds__(64) void wgrad_conv1_cm(const float *__restrict__ x
         fetch_pos(i + R, slot);
 #pragma unroll
         for (int wo = 0; wo < 4; wo++) {
-            bsum += Gf[wo];
+            bsum[wo] += Gf[wo];
 #pragma unroll
             for (int t = 0; t < 4; t++) acc[wo] = mfma4(X[t], Gf[wo][t], acc[wo]);
         }
@@ -3886,10 +3900,72 @@ __global__ __launch_bounds__(64) void wgrad_conv1_cm(const float *__restrict__ x
     }
     cm_stage::landed<0>();
     if (g0 >= g1) return;
-    f4 *pp = part + (size_t)blockIdx.x * 5 * 64 + lane;       // T_0..T_3 and the bias sums of this split
+    f4 *pp = part + (size_t)blockIdx.x * 8 * 64 + lane;       // T_0..T_3 and the four bias sums of this split
 #pragma unroll
-    for (int wo = 0; wo < 4; wo++) pp[wo * 64] = acc[wo];
-    pp[4 * 64] = bsum;
+    for (int wo = 0; wo < 4; wo++) { pp[wo * 64] = acc[wo]; pp[(4 + wo) * 64] = bsum[wo]; }
+}
+
+// The same FUSED with the max-pool backward + SELU' of the first layer (round 5).  A workgroup of four waves owns a
+// group; wave w owns BASE w: it makes that base's pre-activation gradient row on the spot from the pooled-map gradient,
+// the pooled output and the window-offset codes (cv_unpool.hpp: one unpool_col, rows in sequence -- b_unpool_tm's terms
+// and order), writes it to LDS at the positions cm_stage's DMA would have put it (fragment lane F at 16-byte position
+// (F >> 4) + 4 ((F >> 2) & 3) + 16 (F & 3)), reads it back candidate-major and contracts it with the position's X
+// fragment: T_w and the bias sum of base w.  The first layer's pre-activation gradient (33 rows x 4 KiB per group,
+// 74 MB at train.py's batch) has no other reader: it is never written, and the element-wise pass in front of the
+// weight gradient is gone (42 + 27 us at the tail of the 10 000 step, 13 + 16 us at 79 groups).  Per weight the same sum
+// over (group, position, candidate) in the same order, per bias the same four per-base sums: same bits as unpool +
+// wgrad_conv1_cm.  Plain loads with the next position's operands requested one position ahead; no DMA, no barrier.
+template <int P>
+__global__ __launch_bounds__(256) void wgrad_conv1_unpool_cm(const float *__restrict__ x, int64_t n, const f4 *__restrict__ gpool,
+                                                              const f4 *__restrict__ pooled, const u32x2 *__restrict__ codes,
+                                                              int G, f4 *__restrict__ part)
+{
+    __shared__ __attribute__((aligned(16))) float lds[4][2][256];      // per wave: the X fragment, the gradient fragment
+    constexpr int HIN = CV_INPUT_H, HO = HIN - P + 1;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const cm_stage S(&lds[w][0][0], lane);
+    const int per = (G + gridDim.x - 1) / gridDim.x;
+    const int g0 = blockIdx.x * per, g1 = g0 + per < G ? g0 + per : G;
+    if (g0 >= g1) return;
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 acc = zero, bsum = zero;
+    f4 *xslot = reinterpret_cast<f4 *>(&lds[w][0][0]) + lane;
+    f4 *gslot = reinterpret_cast<f4 *>(&lds[w][1][0]) + ((lane >> 4) + 4 * ((lane >> 2) & 3) + 16 * (lane & 3));
+#pragma unroll 1
+    for (int g = g0; g < g1; g++) {
+        const f4 *gp = gpool + ((size_t)g * HO * 4 + w) * 64 + lane;         // row ho: + ho * 256
+        const f4 *pp = pooled + ((size_t)g * HO * 4 + w) * 64 + lane;
+        const u32x2 *cp = codes + (size_t)g * HO * 64 + lane;                // row ho: + ho * 64
+        // X in natural order: LDS position `lane` holds quarter (lane & 3) of candidate 4 ((lane >> 2) & 3) + (lane >> 4)
+        int64_t cand = (int64_t)g * 16 + 4 * ((lane >> 2) & 3) + (lane >> 4);
+        if (cand >= n) cand = n - 1;
+        const f4 *xp = reinterpret_cast<const f4 *>(x + (size_t)cand * (HIN * 16) + 4 * (lane & 3));      // row h: + 4 h
+        unpool_col<P> U;
+        U.init();
+        f4 gv = gp[0], yv = pp[0], xv = xp[0];
+        u32x2 cv = cp[0];
+#pragma unroll 1
+        for (int h = 0; h < HIN; h++) {
+            const f4 xc = xv;
+            if (h < HO) U.push(gv, yv, cv_code16(cv[0], cv[1], w));
+            else U.push_none();
+            {   // the next position's operands (clamped: the last ones are re-read, unused)
+                const int hn = h + 1 < HO ? h + 1 : HO - 1, hx = h + 1 < HIN ? h + 1 : HIN - 1;
+                gv = gp[(size_t)hn * 256]; yv = pp[(size_t)hn * 256]; cv = cp[(size_t)hn * 64]; xv = xp[(size_t)hx * 4];
+            }
+            *gslot = U.emit();
+            *xslot = xc;
+            const f4 X = S.read_nat(0, lane);
+            const f4 Gf = S.read(1);
+            bsum += Gf;
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc = mfma4(X[t], Gf[t], acc);
+        }
+    }
+    f4 *po = part + (size_t)blockIdx.x * 8 * 64 + lane;
+    po[w * 64] = acc;
+    po[(4 + w) * 64] = bsum;
 }
 
 // second pass, first layer.  lane (co, q) register r of T_wo: row i = 4q + r = wi*4 + ci  =>  wi = q, ci = r, and
@@ -3906,18 +3982,23 @@ __global__ __launch_bounds__(1024) void wgrad_conv1_reduce(const f4 *__restrict_
     const int wi = wo + kw - 1;
     const bool bias = kw == 4;
     const bool valid = bias || (wi >= 0 && wi <= 3);
-    const int src = bias ? 4 * 64 + l : wo * 64 + wi * 16 + co;
     f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-    if (valid) {
-        int sp = j;
-        for (; sp + 48 < splits; sp += 64) {     // four loads in flight, added in split order
-            f4 w[4];
+    // (a split holds 8 fragments: T_0..T_3 and the bias sums of the four bases -- those are added base after base)
+    for (int bw = 0; bw < (bias ? 4 : 1); bw++) {
+        const int src = bias ? (4 + bw) * 64 + l : wo * 64 + wi * 16 + co;
+        f4 vb = (f4){0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            int sp = j;
+            for (; sp + 48 < splits; sp += 64) {     // four loads in flight, added in split order
+                f4 w[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) w[u] = part[(size_t)(sp + 16 * u) * 5 * 64 + src];
+                for (int u = 0; u < 4; u++) w[u] = part[(size_t)(sp + 16 * u) * 8 * 64 + src];
 #pragma unroll
-            for (int u = 0; u < 4; u++) v += w[u];
+                for (int u = 0; u < 4; u++) vb += w[u];
+            }
+            for (; sp < splits; sp += 16) vb += part[(size_t)sp * 8 * 64 + src];
         }
-        for (; sp < splits; sp += 16) v += part[(size_t)sp * 5 * 64 + src];
+        v = bw == 0 ? vb : v + vb;
     }
     sh[j][l] = v;
     __syncthreads();
@@ -4088,9 +4169,7 @@ int cv_tile_train_tail(cv_model *m, const float *p3_tm, float *h4_tm, float *h5_
     if (m->loss_rows_used + G > m->loss_rows_cap) { cv_set_error("train_tail_tm: loss row buffer too small (internal)"); return 1; }
     double *rows = m->loss_rows + (size_t)m->loss_rows_used * 4;
     m->loss_rows_used += G;                       // one row per group (cv_train.hip t_loss_header adds the rows in order)
-    // k ranges of fc4 (option train_kranges, 8 or 16): a range is a chain of KB / ranges barrier steps of ~1 us on a
-    // workgroup that holds 8 groups, so the number of ranges sets the length of the step's longest forward kernel
-    const int KR = m->tail_kranges == 16 ? 16 : CV_DENSE_KSPLIT;
+    const int KR = CV_DENSE_KSPLIT;
     {
         auto k = dense_tm<7, 8, 0, 1>;
         const size_t lds = (size_t)3 * 8 * 1024;
@@ -4101,11 +4180,10 @@ int cv_tile_train_tail(cv_model *m, const float *p3_tm, float *h4_tm, float *h5_
     cv_dropout_args dr = cv_dropout_args();
     dr.d4 = drop->d4; dr.amask = drop->amask; dr.nunits = a.fc4; dr.rate = drop->rate; dr.seed = drop->seed;
     dr.step = drop->step; dr.cand0 = drop->cand0;
-#define CV_TAIL(KSF) train_tail_tm<21, 11, KSF><<<G, 512, 0, st>>>((const f4 *)part, KR, G, P + o[7], a.fc4, (f4 *)h4_tm, dr, \
-        (const f4 *)m->wps3_fc5, P + o[9], a.fc5, (f4 *)h5_tm, (const f4 *)m->wp_heads0, (const f4 *)m->wp_heads1, P + o[11], P + o[13], \
-        P + o[15], P + o[17], P + o[12], P + o[14], P + o[16], y, n, want_grad, g16, (f4 *)g5pre_tm, rows, m->wp_heads12)
-    if (KR == 16) CV_TAIL(16); else CV_TAIL(8);
-#undef CV_TAIL
+    train_tail_tm<21, 11><<<G, 512, 0, st>>>((const f4 *)part, KR, G, P + o[7], a.fc4, (f4 *)h4_tm, dr, (const f4 *)m->wps3_fc5,
+                                             P + o[9], a.fc5, (f4 *)h5_tm, (const f4 *)m->wp_heads0, (const f4 *)m->wp_heads1, P + o[11],
+                                             P + o[13], P + o[15], P + o[17], P + o[12], P + o[14], P + o[16], y, n, want_grad, g16,
+                                             (f4 *)g5pre_tm, rows, m->wp_heads12);
     CV_HIP(hipGetLastError());
     *done = true;
     return 0;
@@ -4314,7 +4392,7 @@ int cv_wgrad_scratch_reserve(cv_model *m)
         const size_t NT = s.ntile[l], TILES = (size_t)a.kh[l] * 4 * s.cinb[l];
         sz[5 - l] = ((2048 + NT - 1) / NT) * NT * (TILES + 1) * 256;
     }
-    sz[5] = (size_t)1024 * 5 * 256;
+    sz[5] = (size_t)1024 * 8 * 256;
     size_t total = 0;
     for (int r = 0; r < CV_WG_REGIONS; r++) { sz[r] = (sz[r] + 63) / 64 * 64; total += sz[r]; }
     if (m->wg_part && m->wg_part_bytes >= total * sizeof(float)) return 0;
@@ -4482,6 +4560,28 @@ int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_tm, const float *
 
 // first layer: X as the caller holds it ([n][33 positions][16 = base*4 + matrix] floats, transposed by the
 // fetch), g = TM of its pre-activation gradient ([33*4] fragments per group)
+// first layer of a topology that pools it by 5 (full): max-pool backward + SELU' + weight gradient in one kernel
+// (wgrad_conv1_unpool_cm); gpool / pooled / codes as for the unpool pass.  *done = false: not this topology, or
+// dbg4 = 4 -- the caller unpools, then cv_tile_conv1_wgrad.
+int cv_tile_conv1_wgrad_unpool(cv_model *m, const float *x, const float *gpool, const float *pooled, const float *codes, int64_t n,
+                               hipStream_t st, bool *done)
+{
+    *done = false;
+    const int G = (int)((n + 15) / 16);
+    if (G <= 0 || m->arch.pool[0] != 5 || m->sh.ntile[0] != 1 || m->dbg[4] == 4) return 0;
+    const int splits = G < 1024 ? G : 1024;
+    const int per = (G + splits - 1) / splits;
+    const int used = (G + per - 1) / per;
+    float *scratch = nullptr;
+    if (wg_region(m, 5, (size_t)splits * 8 * 256 * sizeof(float), &scratch)) return 1;
+    wgrad_conv1_unpool_cm<5><<<splits, 256, 0, st>>>(x, n, (const f4 *)gpool, (const f4 *)pooled, (const u32x2 *)codes, G, (f4 *)scratch);
+    wgrad_conv1_reduce<<<5, 1024, 0, st>>>((const f4 *)scratch, used, m->arch.cout[0], m->grads + m->poff[0],
+                                          m->grads + m->poff[1], m->tr_accumulate);
+    CV_HIP(hipGetLastError());
+    *done = true;
+    return 0;
+}
+
 int cv_tile_conv1_wgrad(cv_model *m, const float *x, const float *g_tm, int64_t n, hipStream_t st)
 {
     const int G = (int)((n + 15) / 16);
@@ -4490,7 +4590,7 @@ int cv_tile_conv1_wgrad(cv_model *m, const float *x, const float *g_tm, int64_t 
     const int per = (G + splits - 1) / splits;
     const int used = (G + per - 1) / per;
     float *scratch = nullptr;
-    if (wg_region(m, 5, (size_t)splits * 5 * 256 * sizeof(float), &scratch)) return 1;
+    if (wg_region(m, 5, (size_t)splits * 8 * 256 * sizeof(float), &scratch)) return 1;
     wgrad_conv1_cm<<<splits, 64, CV_WG1_RING * 5 * 1024, st>>>(x, n, (const f4 *)g_tm, G, (f4 *)scratch);
     wgrad_conv1_reduce<<<5, 1024, 0, st>>>((const f4 *)scratch, used, m->arch.cout[0], m->grads + m->poff[0],
                                           m->grads + m->poff[1], m->tr_accumulate);

@@ -570,7 +570,7 @@ static size_t train_floats_per_cand(const cv_model *m)
     // tile path: TM copies of activations, pre-pool activations and three gradient maps,
     // padded channel counts, plus the dense TM buffers
     for (int l = 0; l < 3; l++) f += (size_t)(2 * s.hc[l] + 2 * s.hp[l]) * 4 * s.ntile[l] * 16;
-    f += (6 + CV_DENSE_KSPLIT_MAX) * (size_t)s.nb4 * 16 + 2 * (size_t)s.nb5 * 16;
+    f += (6 + CV_DENSE_KSPLIT) * (size_t)s.nb4 * 16 + 2 * (size_t)s.nb5 * 16;
     return f + 64 * 80;
 }
 
@@ -756,7 +756,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     }
     float *th4 = sb.take(np * f4u), *td4 = sb.take(np * f4u), *tmask = sb.take(np * f4u), *th5 = sb.take(np * f5u);
     float *ghpre = sb.take((size_t)n * 16);
-    float *kpart = sb.take((size_t)CV_DENSE_KSPLIT_MAX * np * f4u);      // partial sums of the k-split fc4 forward
+    float *kpart = sb.take((size_t)CV_DENSE_KSPLIT * np * f4u);      // partial sums of the k-split fc4 forward
     if (!ghpre || !kpart) { cv_set_error("training workspace too small"); return 1; }
     // ---- forward
     bool pack_wait = false;       // dbg5 = 1: all packing in one launch on st, as before
@@ -864,12 +864,14 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     for (int l = 2; l >= 0; l--) {
         const int H = s.hc[l], NT = s.ntile[l];
         const bool have_gpre = (l == 2 && fused3) || (l < 2 && fusedc) || nopool_fused;
-        if (!have_gpre && launch_unpool(tgin[l], tp[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st, m->dbg[2] == 1 ? (1 << 30) : (m->dbg[2] == 2 ? 0 : m->tiny_g), m->dbg[2] == 1 || m->dbg[2] == 4)) return 1;
+        // the first layer's unpool rides inside its weight-gradient kernel (its gradient map has no other reader)
+        const bool conv1_fused = l == 0 && !have_gpre && a.pool[0] == 5 && s.ntile[0] == 1 && m->dbg[4] != 4;
+        if (!have_gpre && !conv1_fused && launch_unpool(tgin[l], tp[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st, m->dbg[2] == 1 ? (1 << 30) : (m->dbg[2] == 2 ? 0 : m->tiny_g), m->dbg[2] == 1 || m->dbg[2] == 4)) return 1;
         f.st_moved();
         // The first layer's weight gradient is the LAST work of the backward pass: nothing of st is left to run beside it.
         // At tiny batches it stays on st (a marker, the hand-over to the side stream and the wait for it back cost ~25 us
         // of an otherwise idle chip for a 17 us kernel); at large ones the side stream keeps it off the chain's tail.
-        if (l == 0 && Gn <= m->tiny_g && (m->sched & 2)) sx = st;
+        if (l == 0 && ((Gn <= m->tiny_g && (m->sched & 2)) || (m->sched & 512))) sx = st;
         else {
             if (f.to_side(5 - l, &sx)) return 1;
             if (l == 2 && fc4_late) {            // the same marker serves fc4's weight gradient (another side stream)
@@ -879,7 +881,9 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
             }
         }
         if (l == 0) {        // first layer: X viewed as [33][16] fragments, read in place
-            if (cv_tile_conv1_wgrad(m, x, tgpre[0], n, sx)) return 1;
+            bool done1 = false;
+            if (conv1_fused && cv_tile_conv1_wgrad_unpool(m, x, tgin[0], tp[0], ta[0], n, sx, &done1)) return 1;
+            if (!done1 && cv_tile_conv1_wgrad(m, x, tgpre[0], n, sx)) return 1;
         } else {
             if (cv_tile_conv_wgrad(m, l, tp[l - 1], tgpre[l], n, sx)) return 1;
             if (fusedc) { if (cv_tile_conv_dgrad_unpool(m, l, tgpre[l], tp[l - 1], ta[l - 1], tgpre[l - 1], n, st)) return 1; }

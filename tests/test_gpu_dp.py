@@ -201,10 +201,6 @@ def test_tiny_batch_kernel_variants_give_the_same_bits(oracle, arch, n):
     # full topology: everything behind fc4's k ranges as ONE kernel (train_tail_tm) or as three (dbg2 = 5): the same
     # arithmetic per value -- weights and gradients bit for bit; the loss sums leave as one row per group instead of one
     # per four groups, so the reported loss may differ in its last bits
-    if arch == "full":           # sixteen k ranges instead of eight in front of the fused tail: another fixed order, same bounds
-        k16 = run(160, 1, train_kranges=16)
-        assert np.allclose(regular[0], k16[0], rtol=1e-6, atol=0)
-        assert np.abs(regular[2] - k16[2]).max() <= 1e-4 * gmax and np.isfinite(k16[1]).all()
     three = run(160, 1, dbg2=5)
     assert np.array_equal(ks[1].view(np.uint32), three[1].view(np.uint32))
     assert np.array_equal(ks[2].view(np.uint32), three[2].view(np.uint32))
@@ -242,7 +238,7 @@ def test_backward_kernel_variants_give_the_same_bits(oracle, arch, n):
     # markers, per-layout packing -- switched off in groups)
     variants = ({"dbg3": 1}, {"dbg4": 2}, {"dbg4": 2, "dbg0": 3}, {"train_side_streams": 1}, {"dbg5": 1}, {"dbg6": 3}, {"dbg7": 1},
                 {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7}, {"dbg1": 8}, {"dbg2": 3}, {"dbg3": 1, "dbg4": 2, "train_overlap": 0},
-                {"dbg2": 4}, {"train_sched": 0}, {"train_sched": 254}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 223}, {"train_sched": 191}, {"train_sched": 127}, {"train_sched": 511}, {"dbg2": 1}, {"dbg2": 2}) if arch == "full" else \
+                {"dbg2": 4}, {"train_sched": 0}, {"train_sched": 254}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 223}, {"train_sched": 191}, {"train_sched": 127}, {"train_sched": 511}, {"train_sched": 767}, {"dbg4": 4}, {"dbg2": 1}, {"dbg2": 2}) if arch == "full" else \
                ({"dbg4": 3}, {"train_side_streams": 1}, {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7},
                 {"dbg5": 1, "dbg4": 3, "train_overlap": 0}, {"train_sched": 0}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 223}, {"train_sched": 191}, {"train_sched": 127})
     for opts in variants:
