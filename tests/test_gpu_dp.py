@@ -238,9 +238,9 @@ def test_backward_kernel_variants_give_the_same_bits(oracle, arch, n):
     # markers, per-layout packing -- switched off in groups)
     variants = ({"dbg3": 1}, {"dbg4": 2}, {"dbg4": 2, "dbg0": 3}, {"train_side_streams": 1}, {"dbg5": 1}, {"dbg6": 3}, {"dbg7": 1},
                 {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7}, {"dbg1": 8}, {"dbg2": 3}, {"dbg3": 1, "dbg4": 2, "train_overlap": 0},
-                {"dbg2": 4}, {"train_sched": 0}, {"train_sched": 254}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 223}, {"train_sched": 191}, {"train_sched": 127}, {"train_sched": 511}, {"train_sched": 767}, {"dbg4": 4}, {"dbg2": 1}, {"dbg2": 2}) if arch == "full" else \
+                {"dbg2": 4}, {"train_sched": 0}, {"train_sched": 254}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 223}, {"train_sched": 191}, {"train_sched": 127}, {"train_sched": 511}, {"train_sched": 255}, {"train_sched": 1023}, {"dbg4": 4}, {"dbg2": 1}, {"dbg2": 2}) if arch == "full" else \
                ({"dbg4": 3}, {"train_side_streams": 1}, {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7},
-                {"dbg5": 1, "dbg4": 3, "train_overlap": 0}, {"train_sched": 0}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 223}, {"train_sched": 191}, {"train_sched": 127})
+                {"dbg5": 1, "dbg4": 3, "train_overlap": 0}, {"train_sched": 0}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 223}, {"train_sched": 191}, {"train_sched": 127}, {"train_sched": 255})
     for opts in variants:
         got = run(opts)
         assert ref[0] == got[0], opts
@@ -297,7 +297,7 @@ def test_a_step_writes_every_gradient_element(oracle, arch, n):
     y = synth.make_labels(cls, rf, alt, il)
     P = common.bench_params(oracle, arch)
     out = []
-    for sched in (255, 191):
+    for sched in (767, 703):
         m = _model(arch); m.setParameters(P); m.setOption("train_sched", sched)
         m._dropout_seed = 7; m.setLearningRate(1e-3); m.setL2RegularizationLambda(1e-3)
         m._ensure_bucket().fill_(float("nan"))
