@@ -460,9 +460,22 @@ def exchange_timing(m, step, x, y, steps, step_ms, dev):
         comp_ms = timed(lambda: step(x, y), steps)
     m.readLosses()
     hidden = 1.0 - (step_ms - comp_ms) / ex_ms if ex_ms > 0 else None
-    return {"exchange_ms": ex_ms, "compute_ms_per_step": comp_ms,
-            "exchange_hidden_frac": None if hidden is None else max(0.0, min(1.0, hidden)),
-            "exchange_bytes": int(m._bucket.numel()) * 4}
+    res = {"exchange_ms": ex_ms, "compute_ms_per_step": comp_ms,
+           "exchange_hidden_frac": None if hidden is None else max(0.0, min(1.0, hidden)),
+           "exchange_bytes": int(m._bucket.numel()) * 4}
+    # the same steps under the OTHER plan (one collective behind the step <-> the dense part under the backward pass), so
+    # that the first run on real links says which one the batch wants; the model's plan is restored afterwards
+    if not os.environ.get("CV_EXCHANGE"):
+        mine = parallel.exchange_mode(m)
+        other = "one" if mine == "split" else "split"
+        try:
+            m._exchange_mode = other
+            timed(lambda: step(x, y), 2)
+            res["other_plan"] = {"plan": other, "ms_per_step": timed(lambda: step(x, y), steps)}
+        finally:
+            m._exchange_mode = mine
+        m.readLosses()
+    return res
 
 
 def train_parity(arch, gb, dev):
@@ -616,7 +629,7 @@ def train_main(args):
                            "dbg": args.dbg + (" sides=%d" % args.sides if args.sides is not None else "") +
                                   (" ksplit=%d" % args.ksplit if args.ksplit is not None else "")},
                 "roofline": r["roofline"], "final_loss": r["final_loss"]}
-        for k in ("exchange_ms", "compute_ms_per_step", "exchange_hidden_frac", "exchange_bytes", "exchange_plan"):
+        for k in ("exchange_ms", "compute_ms_per_step", "exchange_hidden_frac", "exchange_bytes", "exchange_plan", "other_plan"):
             if k in r:
                 line[k] = r[k]
         line.update(rank_info(ws))

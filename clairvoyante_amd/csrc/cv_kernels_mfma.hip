@@ -3853,6 +3853,16 @@ __global__ __launch_bounds__(1024) void wgrad_conv_reduce(const f4 *__restrict__
 // dW[kw][ci][co] = sum_wo T_wo[(wo + kw - 1, ci)][co].  One wave per candidate-range split; a step is one
 // position (1 + 4 fragments, 16 MFMAs), so R = 6 steps are kept in flight (30 KiB of LDS per wave).
 constexpr int CV_WG1_RING = 6;
+// bias gradient of one base from a wave's candidate-major sum fragment: lane (co, q) register r -> the four registers, then
+// the four q rows; lanes 0..15 hold channel co.  (Done by the PRODUCER: a split then hands 64 floats of bias sums to the
+// second pass instead of four fragments -- at 625 splits the one workgroup that adds them was reading 2.5 MB.)
+__device__ __forceinline__ float conv1_bias_lanes(f4 v)
+{
+    float b = (v[0] + v[1]) + (v[2] + v[3]);
+    b += __shfl_xor(b, 16);
+    b += __shfl_xor(b, 32);
+    return b;
+}
 __global__ __launch_bounds__(64) void wgrad_conv1_cm(const float *__restrict__ x, int64_t n, const f4 *__restrict__ g_tm,
                                                       int G, f4 *__restrict__ part)
 {
@@ -3900,9 +3910,13 @@ __global__ __launch_bounds__(64) void wgrad_conv1_cm(const float *__restrict__ x
     }
     cm_stage::landed<0>();
     if (g0 >= g1) return;
-    f4 *pp = part + (size_t)blockIdx.x * 8 * 64 + lane;       // T_0..T_3 and the four bias sums of this split
+    f4 *pp = part + (size_t)blockIdx.x * 8 * 64 + lane;       // T_0..T_3, then the bias sums of this split: [base][16 channels]
 #pragma unroll
-    for (int wo = 0; wo < 4; wo++) { pp[wo * 64] = acc[wo]; pp[(4 + wo) * 64] = bsum[wo]; }
+    for (int wo = 0; wo < 4; wo++) {
+        pp[wo * 64] = acc[wo];
+        const float b = conv1_bias_lanes(bsum[wo]);
+        if (lane < 16) reinterpret_cast<float *>(part + ((size_t)blockIdx.x * 8 + 4) * 64)[wo * 16 + lane] = b;
+    }
 }
 
 // The same FUSED with the max-pool backward + SELU' of the first layer (round 5).  A workgroup of four waves owns a
@@ -3971,9 +3985,9 @@ __global__ __launch_bounds__(256) void wgrad_conv1_unpool_cm(const float *__rest
             }
         }
     }
-    f4 *po = part + (size_t)blockIdx.x * 8 * 64 + lane;
-    po[w * 64] = acc;
-    po[(4 + w) * 64] = bsum;
+    part[((size_t)blockIdx.x * 8 + w) * 64 + lane] = acc;
+    const float b = conv1_bias_lanes(bsum);
+    if (lane < 16) reinterpret_cast<float *>(part + ((size_t)blockIdx.x * 8 + 4) * 64)[w * 16 + lane] = b;
 }
 
 // second pass, first layer.  lane (co, q) register r of T_wo: row i = 4q + r = wi*4 + ci  =>  wi = q, ci = r, and
@@ -3991,27 +4005,27 @@ __global__ __launch_bounds__(1024) void wgrad_conv1_reduce(const f4 *__restrict_
     const bool bias = kw == 4;
     const bool valid = bias || (wi >= 0 && wi <= 3);
     f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-    // (a split holds 8 fragments: T_0..T_3 and the bias sums of the four bases; the bias workgroup walks the splits once
-    // with one accumulator per base -- each in split order -- and adds the four, base after base)
+    // (a split holds T_0..T_3 and, in its fifth fragment, 64 floats of bias sums [base][channel] the producer already
+    // added over its lanes; the bias workgroup adds them over the splits, then base after base)
     if (bias) {
-        f4 vb[4] = {v, v, v, v};
-        int sp = j;
-        for (; sp + 16 < splits; sp += 32) {     // two splits x four bases in flight
-            f4 w[2][4];
+        __shared__ float shb[16][64];
+        float vb = 0.0f;
+        for (int sp = j; sp < splits; sp += 16) vb += reinterpret_cast<const float *>(part + ((size_t)sp * 8 + 4) * 64)[l];
+        shb[j][l] = vb;
+        __syncthreads();
+        if (j != 0) return;
 #pragma unroll
-            for (int u = 0; u < 2; u++)
-#pragma unroll
-                for (int bw = 0; bw < 4; bw++) w[u][bw] = part[(size_t)(sp + 16 * u) * 8 * 64 + (4 + bw) * 64 + l];
-#pragma unroll
-            for (int u = 0; u < 2; u++)
-#pragma unroll
-                for (int bw = 0; bw < 4; bw++) vb[bw] += w[u][bw];
+        for (int k = 1; k < 16; k++) vb += shb[k][l];
+        shb[0][l] = vb;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (l < 16 && l < cout) {
+            const float b = ((shb[0][l] + shb[0][16 + l]) + shb[0][32 + l]) + shb[0][48 + l];
+            db[l] = (acc ? db[l] : 0.0f) + b;
         }
-        for (; sp < splits; sp += 16)
-#pragma unroll
-            for (int bw = 0; bw < 4; bw++) vb[bw] += part[(size_t)sp * 8 * 64 + (4 + bw) * 64 + l];
-        v = ((vb[0] + vb[1]) + vb[2]) + vb[3];
-    } else if (valid) {
+        return;
+    }
+    if (valid) {
         const int src = wo * 64 + wi * 16 + co;
         int sp = j;
         for (; sp + 48 < splits; sp += 64) {     // four loads in flight, added in split order
@@ -4028,13 +4042,6 @@ __global__ __launch_bounds__(1024) void wgrad_conv1_reduce(const f4 *__restrict_
     if (j != 0) return;
 #pragma unroll
     for (int k = 1; k < 16; k++) v += sh[k][l];
-    if (bias) {
-        float b = (v[0] + v[1]) + (v[2] + v[3]);
-        b += __shfl_xor(b, 16);
-        b += __shfl_xor(b, 32);
-        if (l < 16 && l < cout) db[l] = (acc ? db[l] : 0.0f) + b;
-        return;
-    }
     sh[0][l] = v;                   // wave 0 only from here on (its own earlier reads of sh are done)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

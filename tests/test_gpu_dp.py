@@ -713,6 +713,7 @@ def test_bench_line_under_eight_ranks_sharing_the_gpu(mode):
         assert b["exchange_ms"] > 0 and b["compute_ms_per_step"] > 0 and 0.0 <= b["exchange_hidden_frac"] <= 1.0
         assert b["exchange_bytes"] == 4 * (1631496 + 16) and np.isfinite(b["final_loss"])
         assert b["exchange_plan"] == "one"          # 1 250 candidates per rank: one collective per step
+        assert b["other_plan"]["plan"] == "split" and b["other_plan"]["ms_per_step"] > 0      # ... and the same steps under the other plan
     else:
         assert b["scaling"] == "weak" and b["config"]["batch"] == 65536
         pr = b["per_rank_ms"]                       # a straggler would show: slowest / fastest rank, ms per step
