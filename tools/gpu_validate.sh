@@ -17,6 +17,8 @@ cp $OUT/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null     # the bench b
 bash tools/gpu_pmc_train.sh $(basename $OUT)_t $HEAD > $OUT/pmc_train.log 2>&1
 cp gpurun_out/$(basename $OUT)_t/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
+# round 4's library against the in-tree one on this box (only if the base library was built and shipped)
+[ -f clairvoyante_amd/csrc/libclairvoyante_hip_base.so ] && bash tools/gpu_step_ab.sh $(basename $OUT)_ab "1250 10000" 2 > $OUT/step_ab_r04_vs_final.txt 2>&1
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 python bench.py --arch slim --no-cpu > $OUT/bench_slim.json 2>> $OUT/bench.err
 for b in 1250 10000; do python bench.py --mode train --batch $b --steps 50 --warmup 5 >> $OUT/bench_train.jsonl 2>> $OUT/bench.err; done
