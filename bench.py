@@ -877,9 +877,10 @@ def main():
     # at N = 1 also at 1 250, one rank's share of that batch on 8 GPUs; at N > 1 also at 10 000 PER rank.
     if not args.no_extras and args.arch == "full" and args.variant is None:
         t_extra = time.perf_counter()
-        sres, sm, _sp, _sb = run_infer("slim", args.batch, 16, 2, rank, ws, dev, batches=batches[:16])
+        sres, sm, _sp, _sb = run_infer("slim", args.batch, 32, 4, rank, ws, dev, batches=batches[:16])
         sm.close()
-        line["slim"] = {"value": sres["value"], "unit": "candidates/s", "ms_per_step": sres["ms_per_step"], "steps": 16,
+        line["slim"] = {"value": sres["value"], "unit": "candidates/s", "ms_per_step": sres["ms_per_step"], "steps": 32,
+                        "kernels": [{"kernel_name": k["kernel_name"], "avg_ms": k["avg_ms"]} for k in sres["kernels"]],
                         "workload": "v3 slim inference, batch %d per GPU (BASELINE.json configs[4])" % args.batch,
                         "roofline": {k: sres["roofline"][k] for k in ("kernel", "frac", "achieved", "peak", "unit",
                                                                       "whole_path_frac", "traffic")}}

@@ -149,6 +149,7 @@ struct cv_model {
     //   128 tiny batches: the side streams chained before the ONE wait of the main stream at the end of the step
     //   256 (off by default) tiny batches: fc4's weight gradient launched at conv3's marker (a marker less on the main stream)
     //   512 conv1's weight gradient on the main stream at EVERY batch size (the chain's tail: -11 us at 5 000, -12 us at 10 000)
+    //   1024 (off unless measured to pay) batches above the tiny range: fc5 + heads + losses + head gradients as one kernel
     int sched;
     int profile;
     void *prof;          // cv_prof*, owned
@@ -217,6 +218,8 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
                       float *part = nullptr, const cv_train_dropout *drop = nullptr, bool *drop_done = nullptr);
 int cv_tile_train_tail(cv_model *m, const float *p3_tm, float *h4_tm, float *h5_tm, const float *y, int64_t n, int want_grad,
                        float *g16, float *g5pre_tm, float *part, const cv_train_dropout *drop, hipStream_t st, bool *done);
+int cv_tile_train_fc5_heads(cv_model *m, float *d4_tm, float *h5_tm, const float *y, int64_t n, int want_grad, float *g16,
+                            float *g5pre_tm, hipStream_t st, bool *done);
 int cv_tile_fc5_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st, const float *g16 = nullptr,
                       const float *mask_tm = nullptr, const float *act_tm = nullptr);
 // act_below (layers without pooling, slim): the layer-below output; the result is then times selu' = its pre-activation gradient

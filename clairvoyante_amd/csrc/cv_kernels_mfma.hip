@@ -2545,8 +2545,10 @@ __global__ __launch_bounds__(256) void heads_train_tm(const f4 *__restrict__ d4,
 // Arithmetic and order per value are those of the three kernels (same bits); the loss sums leave as ONE ROW PER GROUP
 // (heads_train_tm: one per four groups), which t_loss_header adds in its fixed order.
 // ---------------------------------------------------------------------------
-template <int NB4, int NB5>
-__global__ __launch_bounds__(512) void train_tail_tm(const f4 *__restrict__ part, int KS, int G, const float *__restrict__ bias4,
+// NWV waves per workgroup; PART: the fc4 output arrives as k-range partial sums (tiny batches) -- else (larger batches,
+// train_sched bit 10) fc4's own kernel has stored the dropped-out output (dr.d4) and step 1 only brings it into LDS.
+template <int NB4, int NB5, int NWV, bool PART>
+__global__ __launch_bounds__(NWV * 64) void train_tail_tm(const f4 *__restrict__ part, int KS, int G, const float *__restrict__ bias4,
                                                       int nout4, f4 *__restrict__ h4_out, cv_dropout_args dr,
                                                       const f4 *__restrict__ w5s, const float *__restrict__ bias5, int nout5,
                                                       f4 *__restrict__ h5_out, const f4 *__restrict__ wp0,
@@ -2580,14 +2582,20 @@ __global__ __launch_bounds__(512) void train_tail_tm(const f4 *__restrict__ part
     // ---- 1. fc4: k ranges added in ascending order, + bias, SELU, alpha-dropout (dense_ksum).  Eight waves: at most
     // three fragments each, the partial sums of all of them in flight at once (the step is a latency chain: 79 workgroups
     // on 256 CUs)
-    constexpr int NW = 8, MAXF = (NB4 + NW - 1) / NW;
+    constexpr int NW = NWV, MAXF = (NB4 + NW - 1) / NW;
     const int64_t per = (int64_t)G * NB4 * 64;
     // (sixteen ranges instead of eight were measured: the k-range kernel in front takes the same 40 us -- it is not bound by
     // its number of barrier steps -- and the step does not move: profiles/r05/step_ab_session7_join_latefc4_kranges.txt)
-    constexpr int KSF = CV_DENSE_KSPLIT;
+    constexpr int KSF = PART ? CV_DENSE_KSPLIT : 1;
     f4 pz[MAXF][KSF];
-    const bool fast = KS == KSF;
-    if (fast) {
+    const bool fast = !PART || KS == KSF;
+    if constexpr (!PART) {
+#pragma unroll
+        for (int i = 0; i < MAXF; i++) {
+            const int ob = wave + NW * i;
+            if (ob < NB4) pz[i][0] = reinterpret_cast<const f4 *>(dr.d4)[((int64_t)g * NB4 + ob) * 64 + lane];
+        }
+    } else if (fast) {
 #pragma unroll
         for (int i = 0; i < MAXF; i++) {
             const int ob = wave + NW * i;
@@ -2625,6 +2633,7 @@ __global__ __launch_bounds__(512) void train_tail_tm(const f4 *__restrict__ part
         const int ob = wave + NW * i;
         if (ob >= NB4) break;
         const int64_t t = ((int64_t)g * NB4 + ob) * 64 + lane;
+        if constexpr (!PART) { sd4[ob][lane] = pz[i][0]; continue; }
         f4 v;
         if (fast) {
             v = pz[i][0];
@@ -4210,10 +4219,36 @@ int cv_tile_train_tail(cv_model *m, const float *p3_tm, float *h4_tm, float *h5_
     cv_dropout_args dr = cv_dropout_args();
     dr.d4 = drop->d4; dr.amask = drop->amask; dr.nunits = a.fc4; dr.rate = drop->rate; dr.seed = drop->seed;
     dr.step = drop->step; dr.cand0 = drop->cand0;
-    train_tail_tm<21, 11><<<G, 512, 0, st>>>((const f4 *)part, KR, G, P + o[7], a.fc4, (f4 *)h4_tm, dr, (const f4 *)m->wps3_fc5,
+    train_tail_tm<21, 11, 8, true><<<G, 512, 0, st>>>((const f4 *)part, KR, G, P + o[7], a.fc4, (f4 *)h4_tm, dr, (const f4 *)m->wps3_fc5,
                                              P + o[9], a.fc5, (f4 *)h5_tm, (const f4 *)m->wp_heads0, (const f4 *)m->wp_heads1, P + o[11],
                                              P + o[13], P + o[15], P + o[17], P + o[12], P + o[14], P + o[16], y, n, want_grad, g16,
                                              (f4 *)g5pre_tm, rows, m->wp_heads12);
+    CV_HIP(hipGetLastError());
+    *done = true;
+    return 0;
+}
+
+// Larger batches of the full topology (up to 2 048 groups; train_sched bit 10): fc5, the heads, losses, head gradients and
+// the fc5-side data gradient in one kernel behind fc4's own (which has stored the dropped-out output d4_tm) -- the same
+// kernel as the tiny-batch tail without its first step, four waves per group.  *done = false: not this regime.
+int cv_tile_train_fc5_heads(cv_model *m, float *d4_tm, float *h5_tm, const float *y, int64_t n, int want_grad, float *g16,
+                            float *g5pre_tm, hipStream_t st, bool *done)
+{
+    *done = false;
+    const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
+    const float *P = m->params; const int64_t *o = m->poff;
+    const int G = (int)((n + 15) / 16);
+    if (G <= 0 || !is_full(a) || !(m->sched & 1024) || fc5_train_layout(m, G) != CVL_FC5S3 || s.nb4 != 21 || s.nb5 != 11) return 0;
+    if (cv_layout_current(m, CVL_FC5S3 | CVL_HEADS, "training forward fc5 + heads")) return 1;
+    if (m->loss_rows_used + G > m->loss_rows_cap) { cv_set_error("train_tail_tm: loss row buffer too small (internal)"); return 1; }
+    double *rows = m->loss_rows + (size_t)m->loss_rows_used * 4;
+    m->loss_rows_used += G;
+    cv_dropout_args dr = cv_dropout_args();
+    dr.d4 = d4_tm;
+    train_tail_tm<21, 11, 4, false><<<G, 256, 0, st>>>(nullptr, 1, G, P + o[7], a.fc4, nullptr, dr, (const f4 *)m->wps3_fc5,
+                                                       P + o[9], a.fc5, (f4 *)h5_tm, (const f4 *)m->wp_heads0, (const f4 *)m->wp_heads1,
+                                                       P + o[11], P + o[13], P + o[15], P + o[17], P + o[12], P + o[14], P + o[16], y, n,
+                                                       want_grad, g16, (f4 *)g5pre_tm, rows, m->wp_heads12);
     CV_HIP(hipGetLastError());
     *done = true;
     return 0;

@@ -774,9 +774,13 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
         bool drop_done = false;
         if (cv_tile_dense_fwd(m, 4, tp[2], th4, n, st, m->train_ksplit ? kpart : nullptr, &drop, &drop_done)) return 1;
         if (!drop_done && cv_dropout_tm(m, th4, td4, tmask, n, drop.rate, seed, step, cand0, st)) return 1;
-        if (cv_tile_dense_fwd(m, 5, td4, th5, n, st)) return 1;
-        // heads: products, losses, head gradients and the fc5-side data gradient (times selu'(h5)) in one launch
-        if (cv_tile_heads_train(m, td4, th5, y, n, backward ? 1 : 0, ghpre, tg5pre, st)) return 1;
+        bool fused_fc5 = false;
+        if (Gn > m->tiny_g && cv_tile_train_fc5_heads(m, td4, th5, y, n, backward ? 1 : 0, ghpre, tg5pre, st, &fused_fc5)) return 1;
+        if (!fused_fc5) {
+            if (cv_tile_dense_fwd(m, 5, td4, th5, n, st)) return 1;
+            // heads: products, losses, head gradients and the fc5-side data gradient (times selu'(h5)) in one launch
+            if (cv_tile_heads_train(m, td4, th5, y, n, backward ? 1 : 0, ghpre, tg5pre, st)) return 1;
+        }
     }
     m->last_tr_d4 = td4; m->last_tr_mask = tmask; m->last_tr_n = n; m->last_tr_tile = 1;
     CV_HIP(hipGetLastError());
@@ -979,8 +983,8 @@ static int train_workspace(cv_model *m, int64_t n, int64_t *slice_out)
         m->t_bytes = need;
     }
     // block rows of the heads kernel: 4 groups per block, slice after slice
-    // (heads_train_tm: one row per four groups; train_tail_tm, tiny batches: one per group)
-    const int64_t rows_need = nslice * ((slice / 16 + 3) / 4 + 1) + 160;
+    // (heads_train_tm: one row per four groups; train_tail_tm: one per group)
+    const int64_t rows_need = nslice * (slice / 16 + 4);
     if (m->loss_rows_cap < rows_need) {
         CV_HIP(hipDeviceSynchronize());
         if (m->loss_rows) CV_HIP(hipFree(m->loss_rows));

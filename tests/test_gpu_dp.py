@@ -241,9 +241,14 @@ def test_backward_kernel_variants_give_the_same_bits(oracle, arch, n):
                 {"dbg2": 4}, {"train_sched": 0}, {"train_sched": 254}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 223}, {"train_sched": 191}, {"train_sched": 127}, {"train_sched": 511}, {"train_sched": 255}, {"train_sched": 1023}, {"dbg4": 4}, {"dbg2": 1}, {"dbg2": 2}) if arch == "full" else \
                ({"dbg4": 3}, {"train_side_streams": 1}, {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7},
                 {"dbg5": 1, "dbg4": 3, "train_overlap": 0}, {"train_sched": 0}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 223}, {"train_sched": 191}, {"train_sched": 127}, {"train_sched": 255})
+    if arch == "full" and n > 2560:       # fc5 + heads + losses + head gradients as one kernel behind fc4's (train_sched bit 10)
+        variants = variants + ({"train_sched": 767 + 1024},)
     for opts in variants:
         got = run(opts)
-        assert ref[0] == got[0], opts
+        if opts.get("train_sched", 0) & 1024:     # its loss sums leave as one row per group instead of one per four: last bits
+            assert np.allclose(ref[0], got[0], rtol=1e-12, atol=0), opts
+        else:
+            assert ref[0] == got[0], opts
         assert np.array_equal(ref[1].view(np.uint32), got[1].view(np.uint32)), opts
         assert np.array_equal(ref[2].view(np.uint32), got[2].view(np.uint32)), opts
 
