@@ -1,6 +1,7 @@
 // cv_internal.hpp -- model object and data layouts shared by the kernels and the C ABI.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <functional>
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/clairvoyante_amd.h"
@@ -149,6 +150,8 @@ struct cv_model {
     //   128 tiny batches: the side streams chained before the ONE wait of the main stream at the end of the step
     //   256 (off by default) tiny batches: fc4's weight gradient launched at conv3's marker (a marker less on the main stream)
     //   512 conv1's weight gradient on the main stream at EVERY batch size (the chain's tail: -11 us at 5 000, -12 us at 10 000)
+    //   2048 (off unless measured to pay) the side stream's L2 term and weight packing start BEHIND conv1's forward kernel
+    //      instead of beside it (conv1 is HBM-bound and 17 us slower with them on the chip at 625 groups)
     //   1024 batches above the tiny range (up to 2 048 groups): fc5 + heads + losses + head gradients as one kernel (-12 us at
     //      5 000, -10 us at 10 000)
     int sched;
@@ -207,9 +210,9 @@ bool cv_tile_supported(const cv_model *m);
 int cv_pack_train_weights(cv_model *m, hipStream_t st);
 // what a training pass over G groups will read and is stale; sw_ordered: sw already runs behind st (the caller forked)
 int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward, int G, hipStream_t sw = nullptr, hipEvent_t fork = nullptr,
-                         hipEvent_t done = nullptr, bool *wait_before_dense = nullptr, bool sw_ordered = false);
+                         hipEvent_t done = nullptr, bool *wait_before_dense = nullptr, bool sw_ordered = false, int phase = 0);
 int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float *a1, float *p2, float *a2,
-                        float *p3, float *a3, hipStream_t st);
+                        float *p3, float *a3, hipStream_t st, const std::function<int()> *after_conv1 = nullptr);
 #define CV_DENSE_KSPLIT 8      // k ranges of the fc4 training forward at tiny batches (cv_tile_dense_fwd)
 // part: scratch of CV_DENSE_KSPLIT * groups * nb4 fragments, or NULL = always the single ascending-k chain
 // drop / drop_done (fc4 of a training pass): where the kernel set allows it the alpha-dropout is applied by the layer's

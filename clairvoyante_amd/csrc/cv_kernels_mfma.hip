@@ -21,6 +21,7 @@
 #include "cv_math.hpp"
 #include "cv_unpool.hpp"
 #include <type_traits>
+#include <functional>
 #include <atomic>
 #include <string.h>
 
@@ -3138,8 +3139,9 @@ static unsigned fc5_train_layout(const cv_model *m, int G)
 // inference pass that follows packs what it reads).  One launch on `st`; or, with a side stream, the convolution
 // fragments on `st` (the first kernels need them) and the dense / data-gradient fragments on `sw` next to the
 // convolution forward pass -- *wait_before_dense is then the event `st` has to wait for before the first dense layer.
+// phase 0: all of it; 1: only the convolution fragments on st; 2: only the rest on sw (the caller has ordered sw)
 int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward, int G, hipStream_t sw, hipEvent_t fork, hipEvent_t done,
-                         bool *wait_before_dense, bool sw_ordered)
+                         bool *wait_before_dense, bool sw_ordered, int phase)
 {
     if (wait_before_dense) *wait_before_dense = false;
     unsigned need = CVL_CONV | CVL_HEADS | fc4_train_layout(m, G) | fc5_train_layout(m, G);
@@ -3148,11 +3150,12 @@ int cv_pack_for_training(cv_model *m, hipStream_t st, bool backward, int G, hipS
     const unsigned todo = need & ~m->packed_valid;
     if (!todo) return 0;
     if (sw == st || !sw || !wait_before_dense) return pack_launch(m, st, todo);
-    if (!sw_ordered) {
+    if (!sw_ordered && phase != 1) {
         CV_HIP(hipEventRecord(fork, st));              // behind the optimizer update of the previous step
         CV_HIP(hipStreamWaitEvent(sw, fork, 0));
     }
-    if (pack_launch(m, st, todo & CVL_CONV)) return 1;
+    if (phase != 2 && pack_launch(m, st, todo & CVL_CONV)) return 1;
+    if (phase == 1) return 0;
     if (todo & ~CVL_CONV) {
         if (pack_launch(m, sw, todo & ~CVL_CONV)) return 1;
         CV_HIP(hipEventRecord(done, sw));
@@ -4078,7 +4081,7 @@ int cv_pack_train_weights(cv_model *m, hipStream_t st)
 
 // conv1..conv3 (+pools) with the pre-pool activations kept; buffers are TM
 int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float *a1, float *p2, float *a2,
-                        float *p3, float *a3, hipStream_t st)
+                        float *p3, float *a3, hipStream_t st, const std::function<int()> *after_conv1)
 {
     const cv_arch &a = m->arch;
     const float *P = m->params;
@@ -4091,6 +4094,7 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
     // (group, tile).
     if (is_full(a) && m->dbg[1] > 0 && m->dbg[1] < 7) {          // development: forced number of position parts
         conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (u32x2 *)a1);
+        if (after_conv1 && (*after_conv1)()) return 1;       // (side-stream work that should not share the chip with conv1)
         rc |= launch_conv_parts<2, 1, 2, 4, 29, 1>(m->dbg[1], p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
         rc |= launch_conv_parts<3, 2, 3, 3, 26, 1>(m->dbg[1], p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
         CV_HIP(hipGetLastError());
@@ -4098,6 +4102,7 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
     }
     if (is_full(a)) {
         conv1_tm<5, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (u32x2 *)a1);
+        if (after_conv1 && (*after_conv1)()) return 1;       // (side-stream work that should not share the chip with conv1)
         // conv2 stays on position parts (measured at train.py's batch on one box: flat ranges -- dbg1 = 8 -- make the
         // kernel 4 us shorter on its own and the step 40 us longer: its 3 waves per SIMD then hold every slot to the
         // end and the weight packing on the side stream waits)
@@ -4112,6 +4117,7 @@ int cv_tile_train_convs(cv_model *m, const float *x, int64_t n, float *p1, float
             rc |= launch_conv_parts<3, 2, 3, 3, 26, 1>(hs3, p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
     } else {
         conv1_tm<1, true><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, m->wp_conv1, P + o[1], a.cout[0], (f4 *)p1, G, (u32x2 *)a1);
+        if (after_conv1 && (*after_conv1)()) return 1;       // (side-stream work that should not share the chip with conv1)
         rc |= launch_conv_parts<3, 1, 1, 1, 33, 1, 2>(conv_parts(m, m->dbg[1], G, 1, 33, 0, 4), p1, x, n, m->wp_conv[1], P + o[3], a.cout[1], p2, G, st, a2);
         rc |= launch_conv_parts<5, 1, 2, 1, 33, 1>(conv_parts(m, m->dbg[1], G, 2, 33, 0, 4), p2, x, n, m->wp_conv[2], P + o[5], a.cout[2], p3, G, st, a3);
     }

@@ -723,6 +723,10 @@ struct tr_fork {
 
 // the fixed-order loss sums + the bucket's loss header (t_loss_header, below) launched from inside a slice
 struct tr_header { double lambda; bool l2; };
+// train_sched bit 11: the side stream's work ahead of the backward pass (L2 term, the dense / data-gradient weight packing)
+// is forked behind conv1's forward kernel (first slice of a step) instead of at the head of the step
+struct tr_defer { bool on; float lambda; bool tile_path; };
+static int launch_l2(cv_model *m, hipStream_t sw, bool tile_path);
 
 // forward (+ optional backward) of one slice of the batch on the tile kernels; every
 // intermediate stays tile-major, the only natural-layout tensors are X, Y and the 16 head
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(256) void t_loss_header(double *__restrict__ loss, 
 // backward pass -- instead of at the tail of the step on st (8 us + a launch off the critical path).
 static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t n, int64_t cand0, bool backward,
                             float drop4, uint64_t seed, uint64_t step, hipStream_t st, hipStream_t sw,
-                            hipEvent_t dense_ready, bool sw_ordered, const tr_header *hdr_now)
+                            hipEvent_t dense_ready, bool sw_ordered, const tr_header *hdr_now, const tr_defer *defer)
 {
     const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
     const float *P = m->params; const int64_t *o = m->poff;
@@ -760,8 +764,20 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     if (!ghpre || !kpart) { cv_set_error("training workspace too small"); return 1; }
     // ---- forward
     bool pack_wait = false;       // dbg5 = 1: all packing in one launch on st, as before
-    if (cv_pack_for_training(m, st, backward, (int)Gn, m->dbg[5] == 1 ? st : sw, m->tr_pack_fork, m->tr_pack_done, &pack_wait, sw_ordered)) return 1;
-    if (cv_tile_train_convs(m, x, n, tp[0], ta[0], tp[1], ta[1], tp[2], ta[2], st)) return 1;
+    if (defer && defer->on && sw != st && m->dbg[5] != 1) {
+        // convolution fragments now; the marker, the L2 term and the rest of the packing behind conv1's kernel
+        if (cv_pack_for_training(m, st, backward, (int)Gn, sw, m->tr_pack_fork, m->tr_pack_done, &pack_wait, false, 1)) return 1;
+        const std::function<int()> hook = [&]() -> int {
+            CV_HIP(hipEventRecord(m->tr_ev[CV_TR_EVENTS - 1], st));
+            CV_HIP(hipStreamWaitEvent(sw, m->tr_ev[CV_TR_EVENTS - 1], 0));
+            if (defer->lambda != 0.0f && launch_l2(m, sw, defer->tile_path)) return 1;
+            return cv_pack_for_training(m, st, backward, (int)Gn, sw, m->tr_pack_fork, m->tr_pack_done, &pack_wait, true, 2);
+        };
+        if (cv_tile_train_convs(m, x, n, tp[0], ta[0], tp[1], ta[1], tp[2], ta[2], st, &hook)) return 1;
+    } else {
+        if (cv_pack_for_training(m, st, backward, (int)Gn, m->dbg[5] == 1 ? st : sw, m->tr_pack_fork, m->tr_pack_done, &pack_wait, sw_ordered)) return 1;
+        if (cv_tile_train_convs(m, x, n, tp[0], ta[0], tp[1], ta[1], tp[2], ta[2], st)) return 1;
+    }
     if (pack_wait) CV_HIP(hipStreamWaitEvent(st, m->tr_pack_done, 0));
     const cv_train_dropout drop{td4, tmask, backward ? drop4 : 0.0f, seed, step, cand0};
     float *tg5pre = backward ? sb.take(np * f5u) : nullptr;
@@ -902,10 +918,10 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
 
 static int train_slice(cv_model *m, const float *x, const float *y, int64_t n, int64_t cand0, bool backward,
                        float drop4, uint64_t seed, uint64_t step, hipStream_t st, hipStream_t sw, hipEvent_t dense_ready,
-                       bool sw_ordered, const tr_header *hdr_now)
+                       bool sw_ordered, const tr_header *hdr_now, const tr_defer *defer)
 {
     if (m->impl == 1 && cv_tile_supported(m))
-        return train_slice_tile(m, x, y, n, cand0, backward, drop4, seed, step, st, sw, dense_ready, sw_ordered, hdr_now);
+        return train_slice_tile(m, x, y, n, cand0, backward, drop4, seed, step, st, sw, dense_ready, sw_ordered, hdr_now, defer);
     if (train_slice_plain(m, x, y, n, cand0, backward, drop4, seed, step, st)) return 1;
     if (dense_ready) CV_HIP(hipEventRecord(dense_ready, st));
     return 0;
@@ -965,6 +981,15 @@ __global__ void t_loss_accumulate(const float *__restrict__ hdr, double *__restr
     if (t < 4) acc[t] += (double)hdr[2 * t] + (double)hdr[2 * t + 1];
     else if (t == 4) acc[4] += ((double)hdr[8] + (double)hdr[9]) / (double)(hdr[10] > 0.5f ? hdr[10] : 1.0f);
     else if (t == 6) acc[6] += 1.0;
+}
+
+static int launch_l2(cv_model *m, hipStream_t sw, bool tile_path)
+{
+    l2_args la;
+    for (int p = 0; p < CV_NUM_PARAMS; p += 2) { la.w[p / 2] = m->params + m->poff[p]; la.count[p / 2] = m->psize[p]; }
+    t_l2<<<dim3(256, CV_NUM_PARAMS / 2), 256, 0, sw>>>(la, m->loss_dev + 4, tile_path ? m->l2_rows : nullptr);
+    CV_HIP(hipGetLastError());
+    return 0;
 }
 
 static int train_workspace(cv_model *m, int64_t n, int64_t *slice_out)
@@ -1045,8 +1070,9 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
     // both depend on the weights alone, i.e. on the optimizer update of the previous step (cv_pack_for_training is
     // told that sw is ordered already)
     const bool one_marker = (m->sched & 4) != 0;
+    const tr_defer defer{(m->sched & 2048) != 0 && one_marker && tile_path && sw != st && n > 0 && m->dbg[5] != 1, lambda, tile_path};
     const bool sw_ordered = sw != st && n > 0 && (one_marker || lambda != 0.0f);
-    if (sw_ordered) {
+    if (sw_ordered && !defer.on) {
         CV_HIP(hipEventRecord(m->tr_ev[CV_TR_EVENTS - 1], st));
         CV_HIP(hipStreamWaitEvent(sw, m->tr_ev[CV_TR_EVENTS - 1], 0));
     }
@@ -1054,9 +1080,7 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
     // before they return), instead of at the tail of the step
     bool l2_done = false;
     if (lambda != 0.0f && sw_ordered) {
-        l2_args la;
-        for (int p = 0; p < CV_NUM_PARAMS; p += 2) { la.w[p / 2] = m->params + m->poff[p]; la.count[p / 2] = m->psize[p]; }
-        t_l2<<<dim3(256, CV_NUM_PARAMS / 2), 256, 0, sw>>>(la, m->loss_dev + 4, tile_path ? m->l2_rows : nullptr);
+        if (!defer.on && launch_l2(m, sw, tile_path)) return 1;       // (deferred: the first slice launches it behind conv1)
         l2_done = true;
     }
     // single-slice step on the tile path with side streams: the loss header rides behind the heads kernel on the side stream
@@ -1085,7 +1109,7 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
         // gradients final", so the side streams are not gathered for it)
         hipEvent_t ev = (backward && last && comm) ? m->tr_dense_ready : nullptr;
         if (train_slice(m, x + (size_t)off * (CV_INPUT_H * 16), y + (size_t)off * 16, cn, off, backward, drop4,
-                        seed, step, st, sw, ev, sw_ordered && one_marker, early ? &hdr_early : nullptr))
+                        seed, step, st, sw, ev, sw_ordered && one_marker, early ? &hdr_early : nullptr, off == 0 ? &defer : nullptr))
             return 1;
         recorded = recorded || ev != nullptr;
         m->tr_accumulate = 1;                     // the slices behind the first one add
