@@ -121,7 +121,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     m->train_sides = 3;
     m->train_ksplit = 1;
     m->tiny_g = 160;
-    m->sched = 1791;
+    m->sched = 3839;
     alloc(&m->wp_conv1, 4 * 64);
     for (int l = 1; l < 3; l++) alloc(&m->wp_conv[l], (size_t)s.ntile[l] * arch->kh[l] * 4 * s.cinb[l] * 256);
     alloc(&m->wp_fc4, (size_t)s.kb4 * ((s.nb4 + 3) / 4 * 4) * 256);   // fragments padded to the wave count

@@ -136,7 +136,7 @@ struct cv_model {
     //   dbg5 = 1: all weight packing in one launch in stream order      dbg6 = n: row parts of dense_dgrad_unpool (few groups)
     //   dbg7 = 1: training-forward conv3 on conv_tm instead of conv3_rot
     int dbg[8];
-    // option "train_sched": the round-5 re-cut of the step's schedule, one bit per change (default 1791 = all but bit 8; A/B runs and
+    // option "train_sched": the round-5 re-cut of the step's schedule, one bit per change (default 3839 = all but bit 8; A/B runs and
     // the variant tests switch them off one by one -- same arithmetic either way):
     //   1  loss header behind the heads kernel on the side stream (tiny batches only) instead of at the tail of the step
     //   2  conv1's weight gradient on the main stream at tiny batches instead of a side stream
@@ -150,8 +150,8 @@ struct cv_model {
     //   128 tiny batches: the side streams chained before the ONE wait of the main stream at the end of the step
     //   256 (off by default) tiny batches: fc4's weight gradient launched at conv3's marker (a marker less on the main stream)
     //   512 conv1's weight gradient on the main stream at EVERY batch size (the chain's tail: -11 us at 5 000, -12 us at 10 000)
-    //   2048 (off unless measured to pay) the side stream's L2 term and weight packing start BEHIND conv1's forward kernel
-    //      instead of beside it (conv1 is HBM-bound and 17 us slower with them on the chip at 625 groups)
+    //   2048 up to 512 groups: the side stream's L2 term and weight packing start BEHIND conv1's forward kernel instead of
+    //      beside it (-20 us at 79 groups, -5 at 313; +8 at 625, hence the bound)
     //   1024 batches above the tiny range (up to 2 048 groups): fc5 + heads + losses + head gradients as one kernel (-12 us at
     //      5 000, -10 us at 10 000)
     int sched;
