@@ -169,6 +169,7 @@ extern "C" int cv_destroy(cv_model *m)
         for (int i = 0; i < 2; i++) if (m->tr_side_more[i]) { (void)hipStreamSynchronize(m->tr_side_more[i]); (void)hipStreamDestroy(m->tr_side_more[i]); }
         for (int i = 0; i < CV_TR_EVENTS; i++) (void)hipEventDestroy(m->tr_ev[i]);
         (void)hipEventDestroy(m->tr_dense_ready);
+        (void)hipEventDestroy(m->tr_l2_done);
         (void)hipEventDestroy(m->tr_pack_fork); (void)hipEventDestroy(m->tr_pack_done);
     }
     cv_prof_free(m);

@@ -112,6 +112,7 @@ struct cv_model {
     int train_sides;     // option "train_side_streams": side streams of the weight gradients at tiny batches, 1..3 (default 3)
     hipEvent_t tr_ev[16];
     hipEvent_t tr_dense_ready;
+    hipEvent_t tr_l2_done;         // recorded on the side stream behind the L2 kernel of a step
     hipEvent_t tr_pack_fork, tr_pack_done;   // weight packing on the side stream (cv_pack_for_training)
     int train_overlap;   // option: weight gradients on the side stream (default 1)
     int train_ksplit;    // option: k-split fc4 forward at tiny batches (default 1)
@@ -138,7 +139,8 @@ struct cv_model {
     int dbg[8];
     // option "train_sched": the round-5 re-cut of the step's schedule, one bit per change (default 3839 = all but bit 8; A/B runs and
     // the variant tests switch them off one by one -- same arithmetic either way):
-    //   1  loss header behind the heads kernel on the side stream (tiny batches only) instead of at the tail of the step
+    //   1  loss header behind the heads kernel on a side stream (tiny batches: the first, larger ones: the second, idle one)
+    //      instead of at the tail of the step
     //   2  conv1's weight gradient on the main stream at tiny batches instead of a side stream
     //   4  ONE marker on the main stream for the L2 term and the weight packing instead of one each
     //   8  launch sites at the same point of the main stream share a marker (not for the full topology above 512 groups:

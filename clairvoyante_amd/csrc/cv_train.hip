@@ -743,7 +743,8 @@ __global__ __launch_bounds__(256) void t_loss_header(double *__restrict__ loss, 
 // backward pass -- instead of at the tail of the step on st (8 us + a launch off the critical path).
 static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t n, int64_t cand0, bool backward,
                             float drop4, uint64_t seed, uint64_t step, hipStream_t st, hipStream_t sw,
-                            hipEvent_t dense_ready, bool sw_ordered, const tr_header *hdr_now, const tr_defer *defer)
+                            hipEvent_t dense_ready, bool sw_ordered, const tr_header *hdr_now, const tr_defer *defer,
+                            bool *hdr_launched)
 {
     const cv_shapes &s = m->sh; const cv_arch &a = m->arch;
     const float *P = m->params; const int64_t *o = m->poff;
@@ -831,9 +832,25 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     // heads: weight gradients on the matrix cores (inputs tile-major, the 16 gradients as they lie), data
     // gradients written to TM, times selu'(h5)
     if (f.to_side(0, &sx)) return 1;
-    if (hdr_now && f.nside > 0 && sx == sw)        // (sw carries the L2 kernel of this step: stream order covers it)
-        t_loss_header<<<1, 256, 0, sx>>>(m->loss_dev, hdr_now->lambda, m->grads - CV_GRAD_HEADER, m->loss_rows, m->loss_rows_used,
-                                         hdr_now->l2 ? m->l2_rows : nullptr, CV_NUM_PARAMS / 2, 1);
+    if (hdr_now && f.nside > 0) {
+        // tiny batches: on sw, behind the heads' marker (sw carries the L2 kernel of this step: stream order covers it).
+        // Larger batches: sw's weight-gradient chain is as long as the main one (a header at its head cost the step 33 us),
+        // but the SECOND side stream idles until conv2's weight gradient: the header goes there, behind the same marker
+        // and behind the event recorded after the L2 kernel
+        hipStream_t hs = nullptr;
+        if (Gn <= m->tiny_g && sx == sw) hs = sx;
+        else if (Gn > m->tiny_g && f.nside > 1 && f.mark) {
+            hs = f.side[1];
+            CV_HIP(hipStreamWaitEvent(hs, f.mark, 0));
+            CV_HIP(hipStreamWaitEvent(hs, m->tr_l2_done, 0));
+            f.used[1] = true;
+        }
+        if (hs) {
+            t_loss_header<<<1, 256, 0, hs>>>(m->loss_dev, hdr_now->lambda, m->grads - CV_GRAD_HEADER, m->loss_rows, m->loss_rows_used,
+                                             hdr_now->l2 ? m->l2_rows : nullptr, CV_NUM_PARAMS / 2, 1);
+            *hdr_launched = true;
+        }
+    }
     if (cv_tile_heads_wgrad(m, td4, th5, ghpre, n, sx)) return 1;
     // fc5 (its pre-activation gradient came out of the heads kernel: the same point of st as the heads' launch site)
     if (f.to_side(1, &sx, true)) return 1;
@@ -918,10 +935,10 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
 
 static int train_slice(cv_model *m, const float *x, const float *y, int64_t n, int64_t cand0, bool backward,
                        float drop4, uint64_t seed, uint64_t step, hipStream_t st, hipStream_t sw, hipEvent_t dense_ready,
-                       bool sw_ordered, const tr_header *hdr_now, const tr_defer *defer)
+                       bool sw_ordered, const tr_header *hdr_now, const tr_defer *defer, bool *hdr_launched)
 {
     if (m->impl == 1 && cv_tile_supported(m))
-        return train_slice_tile(m, x, y, n, cand0, backward, drop4, seed, step, st, sw, dense_ready, sw_ordered, hdr_now, defer);
+        return train_slice_tile(m, x, y, n, cand0, backward, drop4, seed, step, st, sw, dense_ready, sw_ordered, hdr_now, defer, hdr_launched);
     if (train_slice_plain(m, x, y, n, cand0, backward, drop4, seed, step, st)) return 1;
     if (dense_ready) CV_HIP(hipEventRecord(dense_ready, st));
     return 0;
@@ -989,6 +1006,7 @@ static int launch_l2(cv_model *m, hipStream_t sw, bool tile_path)
     for (int p = 0; p < CV_NUM_PARAMS; p += 2) { la.w[p / 2] = m->params + m->poff[p]; la.count[p / 2] = m->psize[p]; }
     t_l2<<<dim3(256, CV_NUM_PARAMS / 2), 256, 0, sw>>>(la, m->loss_dev + 4, tile_path ? m->l2_rows : nullptr);
     CV_HIP(hipGetLastError());
+    CV_HIP(hipEventRecord(m->tr_l2_done, sw));       // (a loss header on another side stream waits for it)
     return 0;
 }
 
@@ -1026,6 +1044,8 @@ static int train_workspace(cv_model *m, int64_t n, int64_t *slice_out)
         // 2.249 ms at 10 000, no difference at 1 250 -- every large kernel fills the chip either way)
         for (int i = 0; i < CV_TR_EVENTS; i++) CV_HIP(hipEventCreateWithFlags(&m->tr_ev[i], hipEventDisableTiming));
         CV_HIP(hipEventCreateWithFlags(&m->tr_dense_ready, hipEventDisableTiming));
+        CV_HIP(hipEventCreateWithFlags(&m->tr_l2_done, hipEventDisableTiming));
+        CV_HIP(hipEventRecord(m->tr_l2_done, m->tr_side));       // (recorded once, so that a wait before any L2 kernel passes)
         CV_HIP(hipEventCreateWithFlags(&m->tr_pack_fork, hipEventDisableTiming));
         CV_HIP(hipEventCreateWithFlags(&m->tr_pack_done, hipEventDisableTiming));
     }
@@ -1087,10 +1107,10 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
     }
     // single-slice step on the tile path with side streams: the loss header rides behind the heads kernel on the side stream
     const tr_header hdr_early{(double)lambda, lambda != 0.0f};
-    // (tiny batches only: at train.py's batch the side stream is as long as the main chain, and 14 us of header at its head
-    // made the step 33 us longer -- profiles/r05/step_ab_session3.txt)
-    const bool early = backward && tile_path && sw_ordered && n <= slice && (l2_done || lambda == 0.0f) && (m->sched & 1) &&
-                       (n + 15) / 16 <= m->tiny_g;
+    // (tiny batches: behind the heads kernel on sw; larger ones: on the second side stream -- at train.py's batch sw is as
+    // long as the main chain, and 14 us of header at its head made the step 33 us longer, profiles/r05/step_ab_session3.txt)
+    const bool early = backward && tile_path && sw_ordered && n <= slice && (l2_done || lambda == 0.0f) && (m->sched & 1);
+    bool hdr_launched = false;
     // option keep_activations and several slices: the dropout maps of every slice are kept (cv_get_activation 6 / 7 then
     // covers the whole batch, and the oracle tests can feed a multi-slice step's own keep mask back); one slice: in place
     const size_t keep_per = tile_path ? (size_t)m->sh.nb4 * 16 : (size_t)m->arch.fc4;       // floats per candidate of a map
@@ -1111,7 +1131,8 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
         // gradients final", so the side streams are not gathered for it)
         hipEvent_t ev = (backward && last && comm) ? m->tr_dense_ready : nullptr;
         if (train_slice(m, x + (size_t)off * (CV_INPUT_H * 16), y + (size_t)off * 16, cn, off, backward, drop4,
-                        seed, step, st, sw, ev, sw_ordered && one_marker, early ? &hdr_early : nullptr, off == 0 ? &defer : nullptr))
+                        seed, step, st, sw, ev, sw_ordered && one_marker, early ? &hdr_early : nullptr, off == 0 ? &defer : nullptr,
+                        &hdr_launched))
             return 1;
         recorded = recorded || ev != nullptr;
         m->tr_accumulate = 1;                     // the slices behind the first one add
@@ -1132,7 +1153,7 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
         t_l2<<<dim3(256, CV_NUM_PARAMS / 2), 256, 0, st>>>(la, m->loss_dev + 4, tile_path ? m->l2_rows : nullptr);
     }
     // the fixed-order loss sums (and, for a training step, the header of the gradient bucket) -- unless the slice launched them
-    if (!early)
+    if (!hdr_launched)
         t_loss_header<<<1, 256, 0, st>>>(m->loss_dev, (double)lambda, backward ? m->grads - CV_GRAD_HEADER : nullptr, m->loss_rows,
                                          m->loss_rows_used, (lambda != 0.0f && tile_path) ? m->l2_rows : nullptr, CV_NUM_PARAMS / 2,
                                          tile_path ? 1 : 0);
