@@ -152,8 +152,8 @@ struct cv_model {
     //   128 tiny batches: the side streams chained before the ONE wait of the main stream at the end of the step
     //   256 (off by default) tiny batches: fc4's weight gradient launched at conv3's marker (a marker less on the main stream)
     //   512 conv1's weight gradient on the main stream at EVERY batch size (the chain's tail: -11 us at 5 000, -12 us at 10 000)
-    //   2048 up to 512 groups: the side stream's L2 term and weight packing start BEHIND conv1's forward kernel instead of
-    //      beside it (-20 us at 79 groups, -5 at 313; +8 at 625, hence the bound)
+    //   2048 full topology up to 512 groups: the side stream's L2 term and weight packing start BEHIND conv1's forward kernel
+    //      instead of beside it (-20 us at 79 groups, -5 at 313; +8 at 625 and +25 us for slim at 79, hence the bounds)
     //   1024 batches above the tiny range (up to 2 048 groups): fc5 + heads + losses + head gradients as one kernel (-12 us at
     //      5 000, -10 us at 10 000)
     int sched;

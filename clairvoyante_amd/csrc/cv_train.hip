@@ -1090,9 +1090,10 @@ static int train_enqueue(cv_model *m, const float *x, const float *y, int64_t n,
     // both depend on the weights alone, i.e. on the optimizer update of the previous step (cv_pack_for_training is
     // told that sw is ordered already)
     const bool one_marker = (m->sched & 4) != 0;
-    // (up to 512 groups: -20 us at 79 groups, -5 at 313, +8 at 625 -- profiles/r05/step_ab_session11_side_work_behind_conv1.txt)
+    // (full topology up to 512 groups: -20 us at 79 groups, -5 at 313, +8 at 625 -- profiles/r05/step_ab_session11_side_work_behind_conv1.txt;
+    // slim, whose first layer is a quarter of the work and whose fc4 needs its weights sooner: +25 us at 79 groups, so not there)
     const tr_defer defer{(m->sched & 2048) != 0 && one_marker && tile_path && sw != st && n > 0 && m->dbg[5] != 1 &&
-                         (n < slice ? n : slice) <= 512 * 16, lambda, tile_path};
+                         m->wpr_fc4 != nullptr && (n < slice ? n : slice) <= 512 * 16, lambda, tile_path};
     const bool sw_ordered = sw != st && n > 0 && (one_marker || lambda != 0.0f);
     if (sw_ordered && !defer.on) {
         CV_HIP(hipEventRecord(m->tr_ev[CV_TR_EVENTS - 1], st));
