@@ -3477,35 +3477,37 @@ struct cm_stage {
 };
 
 // dense layer: dW[k][j] += sum_cand X[cand][k] G[cand][j], db[j] += sum_cand G[cand][j].
-// Workgroup = 8 waves = 16 input fragments (two per wave) x all NJB output fragments.  Per group the
-// workgroup stages the NJB gradient fragments (shared) and every wave its two input fragments, double
+// Workgroup = 8 waves = 8 XF input fragments (XF per wave) x all NJB output fragments.  Per group the
+// workgroup stages the NJB gradient fragments (shared) and every wave its XF input fragments, double
 // buffered: the pieces of group g+1 are in flight while group g is multiplied; one barrier per group.
-// grid = (ceil(KB/16), group splits); dynamic LDS = 2 * (NJB + 16) KiB.
+// grid = (ceil(KB / (8 XF)), group splits); dynamic LDS = 2 * (NJB + 8 XF) KiB.
+// XF = 1 (few groups): twice the workgroups along k, so half the candidate ranges fill the same CUs -- and the
+// per-range tiles, which the second pass has to read back, are half as many bytes.
 // GNAT (heads, NJB == 1): the gradient is the natural [n][16] array of the 16 head pre-activation gradients.
-template <int NJB, bool GNAT = false>
+template <int NJB, bool GNAT = false, int XF = 2>
 __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_tm, int KB,
                                                        const f4 *__restrict__ g_tm, int G, int64_t n,
                                                        f4 *__restrict__ part)
 {
     static_assert(!GNAT || NJB == 1, "natural gradients: one fragment per group");
     extern __shared__ __attribute__((aligned(16))) float wg_lds[];
-    constexpr int NSLOT = NJB + 16;                  // per buffer: NJB gradient fragments, then 2 per wave
+    constexpr int NSLOT = NJB + 8 * XF;              // per buffer: NJB gradient fragments, then XF per wave
     constexpr int PERG = (NJB + 7) / 8;              // gradient fragments each wave fetches (clamped: duplicates
                                                      // of the last one land on identical bytes)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     CV_STAMP_BEGIN
     const cm_stage S(wg_lds, lane);
-    const int kb0 = blockIdx.x * 16 + wid * 2;
+    const int kb0 = blockIdx.x * (8 * XF) + wid * XF;
     const int per = (G + gridDim.y - 1) / gridDim.y;
     const int g0 = blockIdx.y * per, g1 = g0 + per < G ? g0 + per : G;
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
-    f4 acc[2][NJB];
+    f4 acc[XF][NJB];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < XF; a++)
 #pragma unroll
         for (int jb = 0; jb < NJB; jb++) acc[a][jb] = zero;
-    const bool v0 = kb0 < KB, v1 = kb0 + 1 < KB;
+    const bool v0 = kb0 < KB, v1 = XF > 1 && kb0 + 1 < KB;
     const int kc0 = v0 ? kb0 : KB - 1, kc1 = v1 ? kb0 + 1 : KB - 1;       // clamped: fetched, never multiplied
     constexpr int NBS = (NJB + 7) / 8;               // bias: wave w of column 0 sums fragments w, w+8, ..
     f4 bs[NBS];
@@ -3513,7 +3515,7 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
     for (int i = 0; i < NBS; i++) bs[i] = zero;
     const bool do_bias = blockIdx.x == 0;
     // this wave's DMA pieces of group g: i < PERG gradient fragments, then its two input fragments
-    constexpr int NP = PERG + 2;
+    constexpr int NP = PERG + XF;
     auto piece = [&](int g, int buf, int i) {
         if (i < PERG) {
             if constexpr (GNAT) {
@@ -3524,7 +3526,7 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
             }
         } else {
             const int a = i - PERG;
-            S.fetch_s(x_tm + ((size_t)g * KB + (a ? kc1 : kc0)) * 64, buf * NSLOT + NJB + 2 * wid + a);
+            S.fetch_s(x_tm + ((size_t)g * KB + (a ? kc1 : kc0)) * 64, buf * NSLOT + NJB + XF * wid + a);
         }
     };
     // In the loop the pieces of group g+1 go out one at a time between the multiplications of group g (every
@@ -3548,7 +3550,8 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
 #pragma unroll
             for (int i = 0; i < NP; i++) piece(gn, buf ^ 1, i);
         }
-        f4 X0 = S.read(buf * NSLOT + NJB + 2 * wid), X1 = S.read(buf * NSLOT + NJB + 2 * wid + 1);
+        f4 X0 = S.read(buf * NSLOT + NJB + XF * wid), X1 = zero;
+        if constexpr (XF > 1) X1 = S.read(buf * NSLOT + NJB + XF * wid + 1);
         if (!v0) X0 = zero;
         if (!v1) X1 = zero;
         f4 Bnext = zero;                     // gradient fragment jb + 1, read while fragment jb is multiplied
@@ -3570,7 +3573,7 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 acc[0][jb] = mfma4(X0[t], B[t], acc[0][jb]);
-                acc[1][jb] = mfma4(X1[t], B[t], acc[1][jb]);
+                if constexpr (XF > 1) acc[1][jb] = mfma4(X1[t], B[t], acc[1][jb]);
             }
             if (do_bias && (jb & 7) == wid) bs[jb >> 3] += B;
             if (SPREAD && jb % PSTEP == 0 && jb / PSTEP < NP) piece(gn, buf ^ 1, jb / PSTEP);
@@ -3593,7 +3596,7 @@ __global__ __launch_bounds__(512) void wgrad_dense_cm(const f4 *__restrict__ x_t
         }
     }
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
+    for (int a = 0; a < XF; a++) {
         const int kb = kb0 + a;
         if (kb >= KB) continue;
         f4 *pp = part + (((size_t)blockIdx.y * KB + kb) * NJB) * 64 + lane;
@@ -4477,24 +4480,45 @@ int cv_wgrad_scratch_reserve(cv_model *m)
     return 0;
 }
 
-template <int NJB>
+// ranges: candidate ranges (0 = enough for one workgroup per CU with two input fragments per wave)
+template <int NJB, int XF = 2>
 static int dense_wgrad_launch(cv_model *m, int region, const float *x_tm, int KB, const float *g_tm, int G, int K, int N, float *dw,
-                              float *db, hipStream_t st)
+                              float *db, hipStream_t st, int ranges = 0)
 {
     float *scratch = nullptr;
-    const int kblocks = (KB + 15) / 16;
-    int splits = 256 / kblocks;
+    const int kblocks = (KB + 8 * XF - 1) / (8 * XF);
+    int splits = ranges > 0 ? ranges : 256 / ((KB + 15) / 16);
     if (splits > G) splits = G;
     if (splits < 1) splits = 1;
     if (wg_region(m, region, (size_t)splits * (KB * NJB * 256 + NJB * 16) * sizeof(float), &scratch)) return 1;
-    const size_t lds = (size_t)2 * (NJB + 16) * 1024;
-    if (set_lds(wgrad_dense_cm<NJB>, lds)) return 1;
-    wgrad_dense_cm<NJB><<<dim3(kblocks, splits), 512, lds, st>>>((const f4 *)x_tm, KB, (const f4 *)g_tm, G, 0,
-                                                                 (f4 *)scratch);
+    const size_t lds = (size_t)2 * (NJB + 8 * XF) * 1024;
+    if (set_lds(wgrad_dense_cm<NJB, false, XF>, lds)) return 1;
+    wgrad_dense_cm<NJB, false, XF><<<dim3(kblocks, splits), 512, lds, st>>>((const f4 *)x_tm, KB, (const f4 *)g_tm, G, 0,
+                                                                            (f4 *)scratch);
     const int64_t per = (int64_t)KB * NJB * 64;
     wgrad_dense_reduce<<<nblk(per + NJB * 16, 256), 256, 0, st>>>((const f4 *)scratch, splits, KB, NJB, K, N, dw, db, m->tr_accumulate);
     CV_HIP(hipGetLastError());
     return 0;
+}
+
+// fc4 of the full topology (6.2 MB of weights, 18 blocks of 16 input fragments): how many candidate ranges, and how the
+// input fragments are dealt.  Above 256 groups: 14 ranges x 18 blocks, one workgroup per CU.  Below, the kernel runs on a
+// side stream next to the data-gradient chain and what it costs the step is the CUs and the HBM bytes it takes from that
+// chain -- the per-range tiles are 6.2 MB each, written here and read back by the second pass: 7 ranges (5 at 79 groups:
+// at least 16 groups each) leave half the CUs to the main stream and halve those bytes; between 140 and 256 groups the
+// same 7 ranges over 36 blocks of 8 fragments (one per wave) fill the CUs at that size.  Same-box sweep over ten batch
+// sizes, profiles/r05/step_ab_session13_fc4_ranges.txt: -10 .. -38 us of a step from 960 to 4 000 candidates, nothing lost
+// elsewhere.  (Development: dbg5 >= 16 sets the ranges, bit 3 deals one fragment per wave, bit 2 two.)
+static void fc4_wgrad_shape(const cv_model *m, int G, int *ranges, int *xf)
+{
+    int r = 14, x = 2;
+    if (G <= 140) { r = (G + 15) / 16; r = r < 4 ? 4 : r > 7 ? 7 : r; }
+    else if (G <= 256) { r = 7; x = 1; }
+    if (m->dbg[5] >= 16) r = m->dbg[5] >> 4;
+    if (r > 14) r = 14;                                  // the scratch region holds 15
+    if (m->dbg[5] & 8) x = 1;
+    if (m->dbg[5] & 4) x = 2;
+    *ranges = r; *xf = x;
 }
 
 int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_tm, const float *g_tm, int64_t n, hipStream_t st)
@@ -4503,7 +4527,12 @@ int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_tm, const float *
     const int G = (int)((n + 15) / 16);
     float *Gd = m->grads; const int64_t *o = m->poff;
     if (layer == 4) {
-        if (is_full(a)) return dense_wgrad_launch<21>(m, 2, x_tm, s.kb4, g_tm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7], st);
+        if (is_full(a)) {
+            int ranges, xf;
+            fc4_wgrad_shape(m, G, &ranges, &xf);
+            if (xf == 1) return dense_wgrad_launch<21, 1>(m, 2, x_tm, s.kb4, g_tm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7], st, ranges);
+            return dense_wgrad_launch<21>(m, 2, x_tm, s.kb4, g_tm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7], st, ranges);
+        }
         return dense_wgrad_launch<3>(m, 2, x_tm, s.kb4, g_tm, G, s.flat, a.fc4, Gd + o[6], Gd + o[7], st);
     }
     if (is_full(a)) return dense_wgrad_launch<11>(m, 1, x_tm, s.nb4, g_tm, G, a.fc4, a.fc5, Gd + o[8], Gd + o[9], st);
