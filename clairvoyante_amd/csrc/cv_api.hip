@@ -120,7 +120,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     m->train_overlap = 1;
     m->train_sides = 3;
     m->train_ksplit = 1;
-    m->tiny_g = 160;
+    m->tiny_g = 400;
     m->sched = 3839;
     alloc(&m->wp_conv1, 4 * 64);
     for (int l = 1; l < 3; l++) alloc(&m->wp_conv[l], (size_t)s.ntile[l] * arch->kh[l] * 4 * s.cinb[l] * 256);
@@ -250,9 +250,9 @@ extern "C" int cv_set_option(cv_model *m, const char *key, int64_t value)
     if (!strcmp(key, "train_overlap")) { m->train_overlap = value ? 1 : 0; return 0; }
     if (!strcmp(key, "train_ksplit")) { m->train_ksplit = value ? 1 : 0; return 0; }
     if (!strcmp(key, "train_side_streams")) { m->train_sides = value < 1 ? 1 : (value > 3 ? 3 : (int)value); return 0; }
-    if (!strcmp(key, "train_tiny_groups")) { m->tiny_g = value < 0 ? 0 : (value > 160 ? 160 : (int)value); return 0; }
+    if (!strcmp(key, "train_tiny_groups")) { m->tiny_g = value < 0 ? 0 : (value > 4096 ? 4096 : (int)value); return 0; }
     if (!strcmp(key, "variant")) { m->variant = (int)value; return 0; }
-    if (!strcmp(key, "train_sched")) { m->sched = (int)value & 4095; return 0; }
+    if (!strcmp(key, "train_sched")) { m->sched = (int)value & 8191; return 0; }
     if (!strncmp(key, "dbg", 3) && key[3] >= '0' && key[3] <= '7' && !key[4]) { m->dbg[key[3] - '0'] = (int)value; cv_layouts_stale(m, CVL_BACKWARD); return 0; }
     if (!strcmp(key, "chunk")) {
         if (value < 16 || value > (1 << 22)) { cv_set_error("chunk must be in [16, 4194304]"); return 1; }

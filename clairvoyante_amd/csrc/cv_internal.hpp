@@ -44,6 +44,10 @@ struct cv_shapes {
     int nb4, nb5; // fc4 / fc5 output fragments
 };
 
+// up to this many groups the convolutions of a training step run as position parts of whole groups and the side
+// streams are chained before the main stream's one wait (the rest of the small-batch kernel set goes by cv_model::tiny_g)
+constexpr int CV_TINY_PARTS_MAX_G = 160;
+
 struct cv_model {
     cv_arch arch;
     cv_shapes sh;
@@ -117,7 +121,7 @@ struct cv_model {
     int train_overlap;   // option: weight gradients on the side stream (default 1)
     int train_ksplit;    // option: k-split fc4 forward at tiny batches (default 1)
     int tiny_g;          // option "train_tiny_groups": batches of up to this many groups take the latency-oriented
-                         // kernel variants of the training step (default 160; 0 = never)
+                         // kernel variants of the training step (default 400; 0 = never)
     // fc4 dropout output / keep mask (a*keep) of the LAST training slice, for cv_get_activation 6 / 7
     const float *last_tr_d4, *last_tr_mask;
     int64_t last_tr_n;

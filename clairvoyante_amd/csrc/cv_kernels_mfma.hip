@@ -2806,9 +2806,11 @@ __global__ __launch_bounds__(NWV * 64) void train_tail_tm(const f4 *__restrict__
 // up to this many groups (16 candidates each) fc4 runs as 3 output slabs per group block: 8-wave workgroups
 // x 3 slabs fill the 256 CUs from ~700 groups on; above the threshold one workgroup keeps all 21 tiles
 constexpr int CV_FC4_SLAB_MAX_G = 2048;
-// "tiny" batches of the training step (cv_model::tiny_g, option "train_tiny_groups", default 160 groups = 2 560
+// "tiny" batches of the training step (cv_model::tiny_g, option "train_tiny_groups", default 400 groups = 6 400
 // candidates): the step is a chain of latency-bound kernels on a fraction of the chip; the layers then split their
-// serial loops over more waves
+// serial loops over more waves.  (Rounds 2-4 drew the line at 160 groups, tuned at 79; a sweep over eight batch sizes
+// with the line lifted, profiles/r05/step_ab_session14_small_batch_regime.txt: at 161 groups 0.951 -> 0.735 ms, at 313
+// groups 1.260 -> 1.215, break-even near 400, +7 % at 625.)
 
 inline unsigned nblk(int64_t total, int bs) { return (unsigned)((total + bs - 1) / bs); }
 
@@ -2884,7 +2886,10 @@ static int pick_hsplit(int G, int NT, int rows, int overlap, int max_parts)
 static int conv_parts(const cv_model *m, int dbg, int G, int NT, int rows, int overlap, int max_parts)
 {
     if (m->tiny_g <= 0) return 1;
-    if ((G > m->tiny_g && dbg != 9) || dbg == 7) return 0;      // (dbg 7: flat ranges for a small batch too)
+    // (the position parts stop at CV_TINY_PARTS_MAX_G groups whatever the option says: from 161 to 400 groups the rest of
+    // the small-batch kernel set still pays, the parts no longer do -- 0.992 against 1.008 ms at 250 groups)
+    const int parts_g = m->tiny_g < CV_TINY_PARTS_MAX_G ? m->tiny_g : CV_TINY_PARTS_MAX_G;
+    if ((G > parts_g && dbg != 9) || dbg == 7) return 0;      // (dbg 7: flat ranges for a small batch too)
     return pick_hsplit(G, NT, rows, overlap, max_parts);
 }
 

@@ -824,7 +824,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
         // data-gradient chain (the last 100 us of the step had two small kernels on the chip).  Full topology: conv2 and
         // conv1 (with conv3 as well 2.13 -> 2.17 ms: its kernel fills the chip next to fc4's); slim: conv3, conv2, conv1
         // (1.233 / 1.176 / 1.167 ms with one stream / two layers / three layers on the second; profiles/r03).
-        const int want = Gn <= m->tiny_g ? m->train_sides : (m->train_sides >= 2 ? 2 : 1);
+        const int want = (Gn <= m->tiny_g || (m->sched & 4096)) ? m->train_sides : (m->train_sides >= 2 ? 2 : 1);      // (bit 12: development)
         for (int i = 0; i < 2 && f.nside < want; i++) f.side[f.nside++] = m->tr_side_more[i];
         f.used[0] = true;                    // sw already carries the L2 term / the weight packing of this step
     }
@@ -903,7 +903,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
         const bool have_gpre = (l == 2 && fused3) || (l < 2 && fusedc) || nopool_fused;
         // the first layer's unpool rides inside its weight-gradient kernel (its gradient map has no other reader)
         const bool conv1_fused = l == 0 && !have_gpre && a.pool[0] == 5 && s.ntile[0] == 1 && m->dbg[4] != 4;
-        if (!have_gpre && !conv1_fused && launch_unpool(tgin[l], tp[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st, m->dbg[2] == 1 ? (1 << 30) : (m->dbg[2] == 2 ? 0 : m->tiny_g), m->dbg[2] == 1 || m->dbg[2] == 4)) return 1;
+        if (!have_gpre && !conv1_fused && launch_unpool(tgin[l], tp[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st, (m->dbg[2] == 1 || m->dbg[2] == 6) ? (1 << 30) : (m->dbg[2] == 2 ? 0 : m->tiny_g), m->dbg[2] == 1 || m->dbg[2] == 4)) return 1;
         f.st_moved();
         // The first layer's weight gradient is the LAST work of the backward pass: nothing of st is left to run beside it.
         // At tiny batches it stays on st (a marker, the hand-over to the side stream and the wait for it back cost ~25 us
@@ -928,7 +928,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
             else if (cv_tile_conv_dgrad(m, l, tgpre[l], tgin[l - 1], n, st)) return 1;
         }
     }
-    if ((Gn <= m->tiny_g && (m->sched & 2) && (m->sched & 128)) ? f.join_chained() : f.join()) return 1;
+    if ((Gn <= m->tiny_g && Gn <= CV_TINY_PARTS_MAX_G && (m->sched & 2) && (m->sched & 128)) ? f.join_chained() : f.join()) return 1;
     CV_HIP(hipGetLastError());
     return 0;
 }

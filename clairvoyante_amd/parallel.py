@@ -110,7 +110,8 @@ def _broadcast(t, src):
 
 
 # A rank's share of the batch at or below which the step exchanges its bucket in ONE collective (see plan_exchange):
-# 160 groups of 16 candidates, the same bound as the library's tiny-batch kernel choices (cv_model::tiny_g).
+# 160 groups of 16 candidates (its own bound, from the exchange's fixed cost against the time there is to hide the first
+# piece under -- not the library's small-batch kernel threshold, cv_model::tiny_g, which is 400 groups).
 TINY_SHARE = 2560
 
 

@@ -132,8 +132,9 @@ int cv_selu_sweep(int device, uint32_t lo_bits, uint32_t hi_bits, uint64_t *viol
  * which then only cv_get_activation layers 4 / 5 read; off, those layers report an error after such a pass and the
  * kernel writes a third of the bytes), "train_overlap" (0/1: weight
  * gradients of the training step on a side stream next to the data-gradient chain; default 1, same bits),
- * "train_tiny_groups" (0..160, default 160: training batches of up to that many groups of 16 candidates split the
- * serial loops of their layers over more waves -- same bits), "train_ksplit" (0/1, default 1: at such batches
+ * "train_tiny_groups" (0..4096, default 400: training batches of up to that many groups of 16 candidates split the
+ * serial loops of their layers over more waves -- same bits; the position parts of the convolutions stop at 160 groups
+ * whatever the value), "train_ksplit" (0/1, default 1: at such batches
  * the fc4 forward of the TRAINING pass adds eight partial sums over k ranges instead of one ascending-k chain; fixed
  * order, reproducible run to run, within the gradient tolerance of the single chain, 4 % faster at 1 250 candidates;
  * the slim topology's fc4 -- 396 dependent k steps -- does so at every batch; never used by cv_forward) and

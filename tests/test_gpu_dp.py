@@ -162,7 +162,8 @@ def test_side_stream_weight_gradients_give_the_same_bits(oracle, arch, n):
     assert np.isfinite(a[1]).all()
 
 
-@pytest.mark.parametrize("arch,n", [("full", 1250), ("slim", 1250), ("full", 83), ("full", 2560), ("slim", 2560), ("full", 17)])
+@pytest.mark.parametrize("arch,n", [("full", 1250), ("slim", 1250), ("full", 83), ("full", 2560), ("slim", 2560), ("full", 17),
+                                    ("full", 5000), ("slim", 5000), ("full", 6400)])
 def test_tiny_batch_kernel_variants_give_the_same_bits(oracle, arch, n):
     """batches of few groups (a rank's share of train.py's batch) split the serial loops of the training step over
     more waves: position ranges in the convolutions (pooled layers recompute the window overlap), one thread per
@@ -171,9 +172,10 @@ def test_tiny_batch_kernel_variants_give_the_same_bits(oracle, arch, n):
     pre-activations are eight partial sums added in order and the step stays within rounding of it"""
     import torch
     from clairvoyante_amd import synth
-    # only sizes where the switch changes the path: above 160 groups both settings run the regular kernels (those sizes
-    # are compared with the oracle in tests/test_gpu_train_parity.py)
-    assert (n + 15) // 16 <= 160
+    # only sizes where the switch changes the path: above 400 groups both settings run the regular kernels (those sizes
+    # are compared with the oracle in tests/test_gpu_train_parity.py).  Up to 160 groups the whole small-batch set runs;
+    # from 161 to 400 everything but the position parts of the convolutions and the chained join.
+    assert (n + 15) // 16 <= 400
     xt, cls, rf, alt, il = synth.make_candidates(n, seed=43, device="cuda", return_class=True)
     y = synth.make_labels(cls, rf, alt, il)
     P = common.bench_params(oracle, arch)
@@ -189,11 +191,11 @@ def test_tiny_batch_kernel_variants_give_the_same_bits(oracle, arch, n):
         m.close()
         return out
     regular = run(0, 0)
-    tiny = run(160, 0)
+    tiny = run(400, 0)
     assert regular[0] == tiny[0] and regular[3] == tiny[3]
     assert np.array_equal(regular[1].view(np.uint32), tiny[1].view(np.uint32))
     assert np.array_equal(regular[2].view(np.uint32), tiny[2].view(np.uint32))
-    ks = run(160, 1)
+    ks = run(400, 1)
     assert np.allclose(regular[0], ks[0], rtol=1e-6, atol=0)
     gmax = np.abs(regular[2]).max()
     assert np.abs(regular[2] - ks[2]).max() <= 1e-4 * gmax
@@ -201,7 +203,7 @@ def test_tiny_batch_kernel_variants_give_the_same_bits(oracle, arch, n):
     # full topology: everything behind fc4's k ranges as ONE kernel (train_tail_tm) or as three (dbg2 = 5): the same
     # arithmetic per value -- weights and gradients bit for bit; the loss sums leave as one row per group instead of one
     # per four groups, so the reported loss may differ in its last bits
-    three = run(160, 1, dbg2=5)
+    three = run(400, 1, dbg2=5)
     assert np.array_equal(ks[1].view(np.uint32), three[1].view(np.uint32))
     assert np.array_equal(ks[2].view(np.uint32), three[2].view(np.uint32))
     assert np.allclose(ks[0], three[0], rtol=1e-12, atol=0) and abs(ks[3] - three[3]) <= 1e-12 * abs(three[3])

@@ -1,7 +1,7 @@
 """The training step against the ORACLE at the sizes it is used and benchmarked at (SURVEY 8 a9, a10, a12;
 clairvoyante_v3.py:140-152, 174, 183-227 at param.trainBatchSize = 10 000, train.py:95-102).
 
-Above 160 groups of 16 candidates the library chooses kernels and schedules by SIZE that the small oracle tests
+Above 160 (and again above 400) groups of 16 candidates the library chooses kernels and schedules by SIZE that the small oracle tests
 (tests/test_gpu_dp.py n <= 1 000, tests/test_gpu_pipeline.py n <= 83) never reach: flat (group, row) ranges, the
 two-group fc4 data gradient fused with conv3's unpool, the three-slab fc4 forward with the dropout on its store,
 the tile unpool kernels, the second side stream, the two-groups-per-wave fc4 forward above 2 048 groups, several
@@ -59,8 +59,8 @@ def compare_step(oracle, arch, n, rate, lam, lr=1e-3, seed=9, options=None, kspl
     m = _model(arch); m.setParameters(P)
     for k, v in (options or {}).items():
         m.setOption(k, v)
-    if ksplit is None:          # full: only in the tiny-batch regime (<= 160 groups); slim: at every size
-        ksplit = arch == "slim" or (n + 15) // 16 <= 160
+    if ksplit is None:          # full: only in the small-batch regime (<= 400 groups); slim: at every size
+        ksplit = arch == "slim" or (n + 15) // 16 <= 400
     m.dropoutRateFC4Val = rate; m.setL2RegularizationLambda(lam); m.setLearningRate(lr)
     m._dropout_seed = 4242
     # getLoss first (v3.py:207-216: phase False, dropout 0, lambda 0); it must not disturb the step that follows
@@ -122,10 +122,12 @@ def compare_step(oracle, arch, n, rate, lam, lr=1e-3, seed=9, options=None, kspl
 
 
 @pytest.mark.parametrize("arch", ["full", "slim"])
-@pytest.mark.parametrize("n", [1250, 2561, 10000, 20000, 40010])
+@pytest.mark.parametrize("n", [1250, 2561, 5000, 6401, 10000, 20000, 40010])
 def test_training_step_matches_oracle_at_training_sizes(oracle, arch, n):
     """1 250 = a rank's share of train.py's batch on 8 GPUs (BASELINE config 4 as it runs: 79 groups, the tiny-batch
-    kernel set); 2 561 = the first size past the tiny-batch regime (161 groups, ragged last group); 10 000 = train.py's
+    kernel set); 2 561 = the first size past the position parts of the convolutions (161 groups, ragged last group: the
+    rest of the small-batch kernel set on flat convolution ranges); 5 000 = a rank's share on 2 GPUs; 6 401 = the first size
+    past the small-batch regime (401 groups, ragged); 10 000 = train.py's
     batch (the benchmarked step); 20 000 = two ranks' worth; 40 010 = 2 501 groups (> 2 048: the fc4 forward changes
     kernel), ragged.  The reference's training defaults: dropout 0.5 on fc4, lambda from param.py."""
     from clairvoyante_amd import param
