@@ -431,9 +431,11 @@ def test_data_parallel_step_equals_the_single_process_step(oracle, arch, n, ws, 
         sz = P[name].size
         sl = slice(off, off + sz); off += sz
         # the sum of the shard gradients against the full-batch gradient at the SAME weights: summation order only
-        # (eight shards of 1 250 run the tiny-batch step, whose fc4 forward is eight k ranges added in order: 1e-4, the
-        # bound test_alpha_dropout_* uses for that variant)
-        assert np.abs(r0["g1"][sl] - g1[sl]).max() <= (2e-5 if ws < 8 else 1e-4) * np.abs(g1[sl]).max() + 1e-7, name
+        # (shards of up to 400 groups -- 1 250 on 8 ranks, 5 000 on 2 -- run the small-batch step, whose fc4 forward is
+        # eight k ranges added in order, against ONE ascending-k chain for the whole batch: 1e-4, the bound
+        # test_alpha_dropout_* uses for that variant; measured 2.9e-5 on fc4/kernel with two shards of 5 000)
+        ksplit_shard = arch == "full" and ((n + ws - 1) // ws + 15) // 16 <= 400 < (n + 15) // 16
+        assert np.abs(r0["g1"][sl] - g1[sl]).max() <= (1e-4 if ksplit_shard else 2e-5) * np.abs(g1[sl]).max() + 1e-7, name
         # after three updates the weights differ in their last bits (Adam divides by sqrt(v)): looser
         assert np.abs(r0["g"][sl] - g[sl]).max() <= 1e-3 * np.abs(g[sl]).max() + 1e-6, name
         assert np.abs(r0["am"][sl] - am[sl]).max() <= 1e-3 * np.abs(am[sl]).max() + 1e-9, name
