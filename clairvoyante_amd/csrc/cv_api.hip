@@ -121,6 +121,9 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     m->train_sides = 3;
     m->train_ksplit = 1;
     m->tiny_g = 400;
+    // (rounds 1-4: 160 / 256 / 2 048, set where each kernel was first tuned; a ladder of batch sizes showed steps of 75 us,
+    // 105 us and 840 us in the time of a call one group past each line: profiles/r05/infer_size_sweep.txt)
+    m->inf_small_g = 256; m->inf_fc4_small_g = 288; m->inf_slab_g = 3400;
     m->sched = 3839;
     alloc(&m->wp_conv1, 4 * 64);
     for (int l = 1; l < 3; l++) alloc(&m->wp_conv[l], (size_t)s.ntile[l] * arch->kh[l] * 4 * s.cinb[l] * 256);
@@ -250,6 +253,9 @@ extern "C" int cv_set_option(cv_model *m, const char *key, int64_t value)
     if (!strcmp(key, "train_overlap")) { m->train_overlap = value ? 1 : 0; return 0; }
     if (!strcmp(key, "train_ksplit")) { m->train_ksplit = value ? 1 : 0; return 0; }
     if (!strcmp(key, "train_side_streams")) { m->train_sides = value < 1 ? 1 : (value > 3 ? 3 : (int)value); return 0; }
+    if (!strcmp(key, "infer_small_groups")) { m->inf_small_g = value < 0 ? 0 : (int)(value > 65536 ? 65536 : value); return 0; }
+    if (!strcmp(key, "infer_fc4_small_groups")) { m->inf_fc4_small_g = value < 0 ? 0 : (int)(value > 65536 ? 65536 : value); return 0; }
+    if (!strcmp(key, "infer_slab_groups")) { m->inf_slab_g = value < 0 ? 0 : (int)(value > 65536 ? 65536 : value); return 0; }
     if (!strcmp(key, "train_tiny_groups")) { m->tiny_g = value < 0 ? 0 : (value > 4096 ? 4096 : (int)value); return 0; }
     if (!strcmp(key, "variant")) { m->variant = (int)value; return 0; }
     if (!strcmp(key, "train_sched")) { m->sched = (int)value & 8191; return 0; }
@@ -273,6 +279,9 @@ extern "C" int cv_get_option(const cv_model *m, const char *key, int64_t *value)
     if (!strcmp(key, "train_overlap")) { *value = m->train_overlap; return 0; }
     if (!strcmp(key, "train_ksplit")) { *value = m->train_ksplit; return 0; }
     if (!strcmp(key, "train_side_streams")) { *value = m->train_sides; return 0; }
+    if (!strcmp(key, "infer_small_groups")) { *value = m->inf_small_g; return 0; }
+    if (!strcmp(key, "infer_fc4_small_groups")) { *value = m->inf_fc4_small_g; return 0; }
+    if (!strcmp(key, "infer_slab_groups")) { *value = m->inf_slab_g; return 0; }
     if (!strcmp(key, "train_tiny_groups")) { *value = m->tiny_g; return 0; }
     if (!strcmp(key, "variant")) { *value = m->variant; return 0; }
     if (!strncmp(key, "dbg", 3) && key[3] >= '0' && key[3] <= '7' && !key[4]) { *value = m->dbg[key[3] - '0']; return 0; }

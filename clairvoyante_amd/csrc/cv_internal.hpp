@@ -45,8 +45,9 @@ struct cv_shapes {
 };
 
 // up to this many groups the convolutions of a training step run as position parts of whole groups and the side
-// streams are chained before the main stream's one wait (the rest of the small-batch kernel set goes by cv_model::tiny_g)
-constexpr int CV_TINY_PARTS_MAX_G = 160;
+// streams are chained before the main stream's one wait (the rest of the small-batch kernel set goes by cv_model::tiny_g).
+// 160 in rounds 2-4; swept in round 5 (profiles/r05/step_ab_session14_small_batch_regime.txt)
+constexpr int CV_TINY_PARTS_MAX_G = 80;
 
 struct cv_model {
     cv_arch arch;
@@ -120,6 +121,10 @@ struct cv_model {
     hipEvent_t tr_pack_fork, tr_pack_done;   // weight packing on the side stream (cv_pack_for_training)
     int train_overlap;   // option: weight gradients on the side stream (default 1)
     int train_ksplit;    // option: k-split fc4 forward at tiny batches (default 1)
+    // cv_forward picks kernels by the number of groups (options "infer_small_groups", "infer_fc4_small_groups",
+    // "infer_slab_groups"): up to inf_small_g the convolutions unfused with their positions over four waves, up to
+    // inf_fc4_small_g fc4 / fc5 as one wave per (group, slab), up to inf_slab_g fc4 as three output slabs per group block
+    int inf_small_g, inf_fc4_small_g, inf_slab_g;
     int tiny_g;          // option "train_tiny_groups": batches of up to this many groups take the latency-oriented
                          // kernel variants of the training step (default 400; 0 = never)
     // fc4 dropout output / keep mask (a*keep) of the LAST training slice, for cv_get_activation 6 / 7

@@ -2886,8 +2886,9 @@ static int pick_hsplit(int G, int NT, int rows, int overlap, int max_parts)
 static int conv_parts(const cv_model *m, int dbg, int G, int NT, int rows, int overlap, int max_parts)
 {
     if (m->tiny_g <= 0) return 1;
-    // (the position parts stop at CV_TINY_PARTS_MAX_G groups whatever the option says: from 161 to 400 groups the rest of
-    // the small-batch kernel set still pays, the parts no longer do -- 0.992 against 1.008 ms at 250 groups)
+    // (the position parts stop at CV_TINY_PARTS_MAX_G groups whatever the option says: they win from 60 to 79 groups
+    // -- 23 us of the step at 79, a rank's share on 8 GPUs -- and lose 25 us from 88 groups on, slim 29 us at 157;
+    // the rest of the small-batch kernel set pays up to 400 groups)
     const int parts_g = m->tiny_g < CV_TINY_PARTS_MAX_G ? m->tiny_g : CV_TINY_PARTS_MAX_G;
     if ((G > parts_g && dbg != 9) || dbg == 7) return 0;      // (dbg 7: flat ranges for a small batch too)
     return pick_hsplit(G, NT, rows, overlap, max_parts);
@@ -2969,10 +2970,7 @@ int launch_dense_small(const float *in, int KB, const float *wp, const float *bi
     return 0;
 }
 
-// up to this many groups fc4 runs on dense_small (one wave per group and slab of 3 output fragments, no barriers)
-constexpr int CV_FC4_SMALL_MAX_G = 256;
-// up to this many groups the convolutions of an inference pass split their positions over four waves
-constexpr int CV_CONV_SMALL_MAX_G = 160;
+// (the size lines of an inference pass are cv_model::inf_small_g / inf_fc4_small_g / inf_slab_g: cv_api.hip)
 
 bool arch_is(const cv_arch &a, int k0, int k1, int k2, int c0, int c1, int c2, int p0, int p1, int p2,
              int f4_, int f5_)
@@ -3238,7 +3236,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         // very small passes (a predict() call of the reference's batch of 1 000 is 63 groups) are latency-bound by the
         // serial position loop of one (group, tile): the layers are launched unfused with their positions split over
         // four waves (pooled layers recompute the window overlap) -- the same values row for row
-        const bool small_pass = (m->variant & 128) && G <= CV_CONV_SMALL_MAX_G;
+        const bool small_pass = (m->variant & 128) && G <= m->inf_small_g;
         if (small_pass) {
             cv_prof_begin(m, 0, st);
             m->stage_kernel[0] = "conv1_tm<5, false>";
@@ -3280,8 +3278,8 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         else { m->stage_kernel[2] = "conv_tm<3, 2, 3, 3, 26, 0, 0, 1>"; rc |= launch_conv<3, 2, 3, 3, 26, 0>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st); }
         cv_prof_end(m, 2, st);
         cv_prof_begin(m, 3, st);
-        if (G <= CV_FC4_SMALL_MAX_G && (m->variant & 128)) { m->stage_kernel[3] = "dense_small<3, 8, 0>"; rc |= launch_dense_small<3, 8>(m->tm_p3, s.kb4, m->wps7_fc4, P + o[7], a.fc4, m->tm_h4, G, 7, st); }
-        else if (G <= CV_FC4_SLAB_MAX_G) { m->stage_kernel[3] = "dense_tm<7, 8, 0, 1>"; rc |= launch_dense<7, 8>(m->tm_p3, s.kb4, m->wps_fc4, P + o[7], a.fc4, m->tm_h4, G, st, 3); }
+        if (G <= m->inf_fc4_small_g && (m->variant & 128)) { m->stage_kernel[3] = "dense_small<3, 8, 0>"; rc |= launch_dense_small<3, 8>(m->tm_p3, s.kb4, m->wps7_fc4, P + o[7], a.fc4, m->tm_h4, G, 7, st); }
+        else if (G <= m->inf_slab_g) { m->stage_kernel[3] = "dense_tm<7, 8, 0, 1>"; rc |= launch_dense<7, 8>(m->tm_p3, s.kb4, m->wps_fc4, P + o[7], a.fc4, m->tm_h4, G, st, 3); }
         else if ((m->variant & 1024) && (m->variant & 32) && m->wp5p_fc5) {      // fc4 + fc5 + heads as one kernel
             m->stage_kernel[3] = "dense_tm<21, 8, 3, 2>";
             heads_args h3 = hd;
@@ -3305,7 +3303,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             return 0;
         }
         cv_prof_begin(m, 4, st);
-        if (G <= CV_FC4_SMALL_MAX_G && (m->variant & 128)) {
+        if (G <= m->inf_fc4_small_g && (m->variant & 128)) {
             m->stage_kernel[4] = "dense_small<4, 7, 0>";
             rc |= launch_dense_small<4, 7>(m->tm_h4, s.nb4, m->wps3_fc5, P + o[9], a.fc5, m->tm_h5, G, 3, st, s.nb5);
         } else if (m->variant & 512) {      // fc5 + heads as one kernel

@@ -132,6 +132,10 @@ int cv_selu_sweep(int device, uint32_t lo_bits, uint32_t hi_bits, uint64_t *viol
  * which then only cv_get_activation layers 4 / 5 read; off, those layers report an error after such a pass and the
  * kernel writes a third of the bytes), "train_overlap" (0/1: weight
  * gradients of the training step on a side stream next to the data-gradient chain; default 1, same bits),
+ * "infer_small_groups" / "infer_fc4_small_groups" / "infer_slab_groups" (defaults 256 / 288 / 3400: cv_forward picks its
+ * kernels by the number of groups of 16 candidates in the pass -- up to the first the convolutions unfused with their
+ * positions over four waves, up to the second fc4 / fc5 as one wave per (group, slab), up to the third fc4 as three
+ * output slabs per group block, beyond it fc4 + fc5 + heads as one kernel; the same bits whichever runs),
  * "train_tiny_groups" (0..4096, default 400: training batches of up to that many groups of 16 candidates split the
  * serial loops of their layers over more waves -- same bits; the position parts of the convolutions stop at 160 groups
  * whatever the value), "train_ksplit" (0/1, default 1: at such batches

@@ -102,12 +102,12 @@ def test_plain_and_tile_kernels_agree_bitwise(setup):
 
 
 def test_large_pass_kernels_equal_small_pass_kernels(setup):
-    """A pass of more than 2 048 groups runs fc4 with all 21 output tiles per workgroup, smaller passes in
+    """A pass of more than 3 400 groups runs fc4 with all 21 output tiles per workgroup, smaller passes in
     three output slabs: both must give the same bits (the small-pass bits are the oracle's, see above)."""
     import torch
     from clairvoyante_amd import synth
     arch, P, m, x, ref = setup
-    n = 40010                                # 2 501 groups: odd, so one wave of the two-groups-per-wave fc4 is half empty
+    n = 60010                                # 3 751 groups: odd, so one wave of the two-groups-per-wave fc4 is half empty
     xd = synth.make_candidates(n, seed=77, device="cuda")
     m.setOption("impl", 1)
     m.setOption("chunk", 8192)
@@ -129,6 +129,30 @@ def test_large_pass_kernels_equal_small_pass_kernels(setup):
     assert np.array_equal(np.concatenate(head, axis=1), small[:256])
 
 
+def test_passes_either_side_of_every_size_line_give_the_same_bits(setup):
+    """cv_forward picks its kernels by the number of groups of the pass (options infer_small_groups 256,
+    infer_fc4_small_groups 288, infer_slab_groups 3 400): a pass one group either side of each line must give the bits of
+    the same candidates run in chunks of 2 048 (128 groups: the small-pass kernels throughout, the oracle's bits)"""
+    import torch
+    from clairvoyante_amd import synth
+    arch, P, m, x, ref = setup
+    m.setOption("impl", 1); m.setOption("variant", common.DEFAULT_VARIANT)
+    xd = synth.make_candidates(54417, seed=79, device="cuda")
+    m.setOption("chunk", 2048)
+    want = m.predict_device(xd).cpu().numpy()
+    m.setOption("chunk", 65536)
+    for n in (2560, 2577, 4096, 4113, 4608, 4625, 32768, 32785, 54400, 54417):
+        got = m.predict_device(xd[:n].contiguous()).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want[:n].view(np.uint32)), n
+    for key, value in (("infer_small_groups", 160), ("infer_fc4_small_groups", 256), ("infer_slab_groups", 2048)):
+        m.setOption(key, value)                  # the lines of rounds 1-4
+    for n in (2577, 4113, 32785):
+        got = m.predict_device(xd[:n].contiguous()).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want[:n].view(np.uint32)), n
+    for key, value in (("infer_small_groups", 256), ("infer_fc4_small_groups", 288), ("infer_slab_groups", 3400)):
+        m.setOption(key, value)
+
+
 def test_fused_tail_back_to_back_calls_with_changing_outputs(setup):
     """fc5 + heads ride on the tail of the large-pass fc4 kernel (variant bit 10) and take the number of candidates and the
     output pointer per call: several large passes enqueued back to back, each with its own output tensor and size, no
@@ -137,7 +161,7 @@ def test_fused_tail_back_to_back_calls_with_changing_outputs(setup):
     from clairvoyante_amd import synth
     arch, P, m, x, ref = setup
     m.setOption("impl", 1); m.setOption("chunk", 65536)
-    sizes = (40010, 33000, 65536, 40010)
+    sizes = (60010, 55000, 65536, 60010)
     xs = [synth.make_candidates(n, seed=90 + i, device="cuda") for i, n in enumerate(sizes)]
     m.setOption("variant", 495)
     want = [m.predict_device(xd).cpu().numpy() for xd in xs]
@@ -228,7 +252,7 @@ def test_fused_tail_writes_no_maps_unless_asked(oracle, arch):
     bits either way"""
     import torch
     from clairvoyante_amd import _lib, synth
-    n = 40010
+    n = 60010
     xd = synth.make_candidates(n, seed=78, device="cuda")
     m = _model(arch); m.setParameters(common.bench_params(oracle, arch))
     try:
