@@ -140,7 +140,7 @@ struct cv_model {
     //   dbg0 = n: position parts of the convolution data gradients      dbg1 = n: ... of the training-forward convolutions
     //        (n = 9: the batch-dependent number of parts instead of flat row ranges; n = 7: flat ranges for a small batch too;
     //         dbg1 = 8: conv2 forward on flat ranges too)
-    //   dbg2 = 1 / 2: unpool always thread-per-row / always streaming, 3: fc4's alpha-dropout as its own pass, 4: thread-per-row at tiny batches (default there: row segments), 5: the tail of the tiny-batch forward as three kernels
+    //   dbg2 = 1 / 2: unpool always thread-per-row / always streaming, 3: fc4's alpha-dropout as its own pass, 4: thread-per-row at tiny batches (default there: row segments), 5: the tail of the tiny-batch forward as three kernels, 6: row segments at every size
     //   dbg3 = 1: fc4 data gradient and conv3 unpool as two kernels
     //   dbg4 = 2: conv data gradients fused with the unpool below (conv_dgrad_unpool), 3: slim selu' as its own pass, 4: conv1's unpool and weight gradient as two kernels
     //   dbg5 = 1: all weight packing in one launch in stream order (>= 16: dbg5 >> 4 candidate ranges of fc4's weight gradient, bit 3 / bit 2: one / two input fragments per wave there)      dbg6 = n: row parts of dense_dgrad_unpool (few groups)

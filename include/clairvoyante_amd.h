@@ -153,8 +153,8 @@ int cv_selu_sweep(int device, uint32_t lo_bits, uint32_t hi_bits, uint64_t *viol
  * its first slice store instead of adding), 128 tiny batches: the side streams chained before the one wait of the main stream, 256 (off) tiny batches: fc4's
  * weight gradient launched at conv3's marker, 512 the first layer's weight gradient on the main stream at every batch
  * size, 1024 fc5 + heads + losses + head gradients of a training pass above the tiny range as one kernel, 2048 up to 512
- * groups the side stream's L2 term and packing start behind conv1's forward kernel; same bits with any value -- the
- * reported loss to its last bits),
+ * groups the side stream's L2 term and packing start behind conv1's forward kernel, 4096 (off, development) three side
+ * streams at every batch size; same bits with any value -- the reported loss to its last bits),
  * "dbg0".."dbg7" (development A/B switches of the training step, 0 = shipped path; see cv_internal.hpp),
  * "variant" (bit 0: first layer fused into the conv2 kernel, bit 1: MFMA heads kernel,
  * bit 2: 8-wave fc4 workgroups, bit 3: rotating-window conv3 kernel, bit 5: fc4 with two groups of
