@@ -283,6 +283,7 @@ extern "C" int cv_get_option(const cv_model *m, const char *key, int64_t *value)
     if (!strcmp(key, "infer_fc4_small_groups")) { *value = m->inf_fc4_small_g; return 0; }
     if (!strcmp(key, "infer_slab_groups")) { *value = m->inf_slab_g; return 0; }
     if (!strcmp(key, "train_tiny_groups")) { *value = m->tiny_g; return 0; }
+    if (!strcmp(key, "train_sched")) { *value = m->sched; return 0; }
     if (!strcmp(key, "variant")) { *value = m->variant; return 0; }
     if (!strncmp(key, "dbg", 3) && key[3] >= '0' && key[3] <= '7' && !key[4]) { *value = m->dbg[key[3] - '0']; return 0; }
     cv_set_error("unknown option '%s'", key);

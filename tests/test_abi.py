@@ -36,6 +36,22 @@ def test_library_exports_every_declared_symbol():
     _lib.load()
 
 
+def test_every_option_key_is_documented_in_the_header():
+    """cv_set_option / cv_get_option take string keys: every key the library accepts is described in the header's option
+    list (the dbg0..dbg7 development switches are named there as a family), and both functions know the same keys"""
+    api = open(os.path.join(ROOT, "clairvoyante_amd", "csrc", "cv_api.hip")).read()
+    header = open(os.path.join(ROOT, "include", "clairvoyante_amd.h")).read()
+    setter = api[api.index('extern "C" int cv_set_option'):api.index('extern "C" int cv_get_option')]
+    getter = api[api.index('extern "C" int cv_get_option'):]
+    getter = getter[:getter.index("\n}\n")]
+    set_keys = set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', setter))
+    get_keys = set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', getter))
+    assert len(set_keys) >= 10 and set_keys <= get_keys, sorted(set_keys - get_keys)
+    for k in sorted(set_keys):
+        assert '"%s"' % k in header, "option %s is not described in include/clairvoyante_amd.h" % k
+    assert '"dbg0".."dbg7"' in header
+
+
 def test_error_reporting_without_gpu():
     """bad arguments fail with a message instead of crashing"""
     from clairvoyante_amd import _lib
