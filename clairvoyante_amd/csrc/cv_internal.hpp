@@ -125,6 +125,14 @@ struct cv_model {
     // "infer_slab_groups"): up to inf_small_g the convolutions unfused with their positions over four waves, up to
     // inf_fc4_small_g fc4 / fc5 as one wave per (group, slab), up to inf_slab_g fc4 as three output slabs per group block
     int inf_small_g, inf_fc4_small_g, inf_slab_g;
+    // option "dense_rag": fc4's three-slab form on ragged waves (dense_rag, round 6): 0 = shape by formula (default), 4..14 = that many
+    // tile-units per SIMD and workgroup (A/B, calibration), -1 = the round-5 kernel (one group x 7 tiles per wave)
+    int inf_rag_s;
+    // option "infer_flat": the per-group convolution kernels of an inference pass on flat (group, row) ranges when the model says a
+    // whole-group launch would take longer (1, default); 0 = always whole groups (rounds 1-5), 2 = always flat ranges (tests)
+    int inf_flat;
+    // option "slim_waves": groups per workgroup of the slim topology's conv3 + fc4 kernel: 0 = from the number of groups (default), 2 / 4 / 8
+    int inf_slim_waves;
     int tiny_g;          // option "train_tiny_groups": batches of up to this many groups take the latency-oriented
                          // kernel variants of the training step (default 400; 0 = never)
     // fc4 dropout output / keep mask (a*keep) of the LAST training slice, for cv_get_activation 6 / 7

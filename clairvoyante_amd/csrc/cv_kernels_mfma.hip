@@ -880,28 +880,39 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
 // those of conv_tm: bit-identical.  LDS: 16 KB conv2 weights + 2 groups x CH x 4 KB rows (CH = 6: 64 KB, two
 // workgroups per CU).
 // ---------------------------------------------------------------------------
-template <int CH>
-__global__ __launch_bounds__(256, 2) void front2_tm(const float *__restrict__ x, int64_t n,
+// FLAT (round 6): a workgroup is ONE pair of waves and owns the pooled conv2 rows [r0, r1) of the flat (group, row)
+// sequence -- rows_per of them, whatever the group boundaries -- so that a launch whose groups do not fill the chip's
+// workgroup slots evenly still gives every SIMD the same work.  The rows of each group in the range are one segment:
+// pooled rows [oa, ob) need the conv2 rows [oa, ob + 3) and those the first-layer rows [oa, ob + 3] (a whole group: 26,
+// 29 and 29 rows -- a segment pays 3 conv2 rows and 4 first-layer rows for its first window).  Same values row for row.
+template <int CH, bool FLAT = false>
+__global__ __launch_bounds__(FLAT ? 128 : 256, 2) void front2_tm(const float *__restrict__ x, int64_t n,
                                                      const float *__restrict__ wp1, const float *__restrict__ bias1,
                                                      int cout1, const f4 *__restrict__ wp,
                                                      const float *__restrict__ bias, int cout,
-                                                     f4 *__restrict__ out_tm, int G)
+                                                     f4 *__restrict__ out_tm, int G, int rows_per = 0)
 {
     constexpr int P1 = 5, H1 = CV_INPUT_H - P1 + 1;      // 29 pooled first-layer rows
     constexpr int NT = 2, P2 = 4, H2 = H1 - P2 + 1;      // conv2: 29 rows -> 26 pooled rows
     constexpr int NW = NT * 2 * 4 * 64;                  // f4 of packed conv2 weights [nt][kh][kw][64]
     extern __shared__ __attribute__((aligned(16))) f4 lds[];
     f4 *rows = lds + NW;                                 // [group in workgroup][CH][w][64]
-    for (int i = threadIdx.x; i < NW; i += 256) lds[i] = wp[i];
+    for (int i = threadIdx.x; i < NW; i += (FLAT ? 128 : 256)) lds[i] = wp[i];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int gl = wid >> 1, nt = wid & 1;
-    const int gq = blockIdx.x * 2 + gl;
-    const bool live = gq < G;                            // a spare half workgroup still takes part in the barriers
-    const int g = live ? gq : G - 1;
+    const int gl = FLAT ? 0 : wid >> 1, nt = wid & 1;
+    int gF, gL, r0 = 0, r1 = 0;
+    bool live = true;
+    if constexpr (FLAT) {
+        r0 = (int)blockIdx.x * rows_per;
+        r1 = r0 + rows_per < G * H2 ? r0 + rows_per : G * H2;
+        if (r0 >= r1) return;                            // (the whole workgroup: both waves own the same range)
+        gF = r0 / H2; gL = (r1 - 1) / H2;
+    } else {
+        const int gq = blockIdx.x * 2 + gl;
+        live = gq < G;                                   // a spare half workgroup still takes part in the barriers
+        gF = gL = live ? gq : G - 1;
+    }
     const int q = lane >> 4;
-    int64_t cand = (int64_t)g * 16 + (lane & 15);
-    if (cand >= n) cand = n - 1;
-    const float *xp = x + (size_t)cand * (CV_INPUT_H * 16) + q;      // lane (c, ci = q)
     float A1[4];
 #pragma unroll
     for (int kw = 0; kw < 4; kw++) A1[kw] = wp1[kw * 64 + lane];
@@ -909,13 +920,28 @@ __global__ __launch_bounds__(256, 2) void front2_tm(const float *__restrict__ x,
     const f4 b2 = load_bias4(bias, nt, q, cout);
     const f4 *wl = lds + (size_t)nt * (2 * 4 * 64) + lane;
     f4 *myrows = rows + (size_t)gl * (CH * 4 * 64) + lane;
-    f4 *op = out_tm + (size_t)g * (H2 * 4 * NT * 64) + (size_t)nt * 64 + lane;
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
     f4 prev[4], m1[4], m2[4], m3[4];
 #pragma unroll
     for (int w = 0; w < 4; w++) { prev[w] = zero; m1[w] = zero; m2[w] = zero; m3[w] = zero; }
+    __syncthreads();                                     // conv2 weights are in LDS
+    CV_PHASE_BEGIN
+#pragma unroll 1
+    for (int g = gF; g <= gL; g++) {
+    // this segment: pooled conv2 rows [oa, ob) of group g (a whole group: 0, H2)
+    int oa = 0, ob = H2;
+    if constexpr (FLAT) {
+        oa = r0 - g * H2 > 0 ? r0 - g * H2 : 0;
+        ob = r1 - g * H2 < H2 ? r1 - g * H2 : H2;
+    }
+    const int pend = ob + P2 < H1 ? ob + P2 : H1;        // first-layer rows [oa, pend)
+    int64_t cand = (int64_t)g * 16 + (lane & 15);
+    if (cand >= n) cand = n - 1;
+    const float *xp = x + (size_t)cand * (CV_INPUT_H * 16) + q;      // lane (c, ci = q)
+    f4 *op = out_tm + (size_t)g * (H2 * 4 * NT * 64) + (size_t)nt * 64 + lane;
 
     // conv2 output row h from input rows h (prev) and h + 1 (cur; absent below the last row), pooled over 4 rows
+    // (the running maxima of a segment's first three rows hold values of the segment before: they are never stored)
     auto out_row = [&](int h, const f4 (&cur)[4], bool has_cur) {
         f4 acc[4];
 #pragma unroll
@@ -953,15 +979,13 @@ __global__ __launch_bounds__(256, 2) void front2_tm(const float *__restrict__ x,
             m3[w] = max4(m2[w], t);
             m2[w] = max4(m1[w], t);
             m1[w] = t;
-            if (h >= P2 - 1 && live) op[(size_t)((h - (P2 - 1)) * 4 + w) * (NT * 64)] = selu4(o);
+            if (h - oa >= P2 - 1 && live) op[(size_t)((h - (P2 - 1)) * 4 + w) * (NT * 64)] = selu4(o);
         }
     };
 
-    __syncthreads();                                     // conv2 weights are in LDS
-    CV_PHASE_BEGIN
 #pragma unroll 1
-    for (int c0 = 0; c0 < H1; c0 += CH) {
-        const int cn = H1 - c0 < CH ? H1 - c0 : CH;
+    for (int c0 = oa; c0 < pend; c0 += CH) {
+        const int cn = pend - c0 < CH ? pend - c0 : CH;
         // ---- phase A: this wave's half of the chunk's first-layer rows
         const int half = (cn + 1) >> 1;
         const int a0 = c0 + nt * half;
@@ -1019,7 +1043,7 @@ __global__ __launch_bounds__(256, 2) void front2_tm(const float *__restrict__ x,
             f4 cur[4];
 #pragma unroll
             for (int w = 0; w < 4; w++) cur[w] = myrows[(size_t)((p - c0) * 4 + w) * 64];
-            if (p > 0) out_row(p - 1, cur, true);
+            if (p > oa) out_row(p - 1, cur, true);
 #pragma unroll
             for (int w = 0; w < 4; w++) prev[w] = cur[w];
         }
@@ -1027,7 +1051,8 @@ __global__ __launch_bounds__(256, 2) void front2_tm(const float *__restrict__ x,
         __syncthreads();
         CV_PHASE(2);
     }
-    out_row(H1 - 1, prev, false);                        // the row below the last one is SAME padding
+    if (ob == H2) out_row(H1 - 1, prev, false);          // the row below the last one is SAME padding
+    }                                                    // segments (groups) of this pair of waves
     CV_PHASE(1);
     CV_PHASE_END(true, wid);
 }
@@ -1058,25 +1083,25 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
     __syncthreads();
     const int lane = threadIdx.x & 63;
     int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
-    int gX = -1;
-    if (!(SAVE && rows_per > 0) && gridDim.x >= 16) {
-        // XCD-aware mapping (workgroup b runs on XCD b % 8, each XCD has its own L2): the NT waves of a group read the
-        // same input map, and with WAVES = 4, NT = 3 every other group has its waves in two consecutive workgroups =
-        // two XCDs, which then both fetch the map from HBM (measured: 1.44 x the input per launch).  Here XCD x owns
-        // the groups g = x (mod 8): the waves of the workgroups b = x, x + 8, x + 16, ... are numbered in that order,
-        // so a group's waves sit in workgroups of ONE XCD.  A speed-only assumption: the values do not depend on it.
+    // rows_per == 0: one wave per (group, tile), all HIN positions.  rows_per > 0 (round 6: also the inference pass, when a
+    // whole-group launch would leave part of the chip idle or need a round more -- launch_conv3_rot): the wave owns the
+    // POOLED rows [r0, r1) of the flat (group, row) sequence of its tile, so that a launch is one round of equal waves
+    // (conv_tm HSPLIT == 0); the rows of each group in the range are one segment of the loop below -- positions
+    // [hbeg, hend) = its pooled rows and the POOL - 1 behind them; same values row for row.
+    const bool flat = rows_per > 0;
+    if (!(SAVE && flat) && gridDim.x >= 16) {
+        // XCD-aware mapping (workgroup b runs on XCD b % 8, each XCD has its own L2): the NT waves of a group (of a range)
+        // read the same input rows, and with WAVES = 4, NT = 3 every other one has its waves in two consecutive workgroups
+        // = two XCDs, which then both fetch the map from HBM (measured: 1.44 x the input per launch).  Here XCD x owns the
+        // units u = x (mod 8): the waves of the workgroups b = x, x + 8, x + 16, ... are numbered in that order, so a
+        // unit's waves sit in workgroups of ONE XCD.  A speed-only assumption: the values do not depend on it.
         const int x = blockIdx.x & 7;
         const int lw = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * WAVES + (threadIdx.x >> 6));
-        gX = (lw / NT) * 8 + x;
-        wv = gX * NT + lw % NT;
+        wv = ((lw / NT) * 8 + x) * NT + lw % NT;
     }
     const int nt = wv % NT;
-    // rows_per == 0: one wave per (group, tile), all HIN positions.  rows_per > 0 (training forward, larger batches):
-    // the wave owns the POOLED rows [r0, r1) of the flat (group, row) sequence of its tile, so that a launch is one round
-    // of equal waves (conv_tm HSPLIT == 0); the rows of each group in the range are one segment of the loop below --
-    // positions [hbeg, hend) = its pooled rows and the POOL - 1 behind them; same values row for row.
     int gF = wv / NT, gL = gF, r0 = 0, r1 = 0;
-    if (SAVE && rows_per > 0) {
+    if (flat) {
         r0 = (wv / NT) * rows_per;
         r1 = r0 + rows_per < G * HOUT ? r0 + rows_per : G * HOUT;
         if (r0 >= r1) return;
@@ -1091,7 +1116,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
 #pragma unroll 1
     for (int g = gF; g <= gL; g++) {
     int hbeg = 0, hend = HIN;
-    if (SAVE && rows_per > 0) {
+    if (flat) {
         hbeg = r0 - g * HOUT > 0 ? r0 - g * HOUT : 0;
         hend = (r1 - g * HOUT < HOUT ? r1 - g * HOUT : HOUT) + POOL - 1;
     }
@@ -1367,7 +1392,11 @@ struct heads_args {
 // position (~600 MFMAs apart).  Same ascending-k chain per output value as conv_tm + dense_tm: bit-identical.
 // LDS: 40 KB conv3 weights + 3 x 24 KB.  All VMEM from inline asm with one counted wait per position (dense_tm).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void conv3fc4_slim(const f4 *__restrict__ in_tm, const f4 *__restrict__ wp3,
+// WAVES (round 6) = groups per workgroup, 8 or 4: the 112 KB of LDS allow one workgroup per CU whatever its size, so a pass
+// of up to 2 048 groups took the time of 2 048 (8 groups on each of G / 8 CUs, the other CUs idle); with fewer waves per
+// workgroup the same groups spread over more CUs (each wave then stages 8 / WAVES of a position's k fragments).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void conv3fc4_slim(const f4 *__restrict__ in_tm, const f4 *__restrict__ wp3,
                                                         const float *__restrict__ bias3, int cout3,
                                                         const f4 *__restrict__ wp4, const float *__restrict__ bias4,
                                                         int nout4, f4 *__restrict__ out_h4, int G,
@@ -1376,7 +1405,9 @@ __global__ __launch_bounds__(512, 2) void conv3fc4_slim(const f4 *__restrict__ i
 {
     // tail != nullptr (variant bit 10): fc5 (36 -> 18: 3 k fragments x 2 tiles) and the four heads follow on the same
     // wave from the fc4 fragments in its registers -- 44 MFMAs instead of two more launches; weights straight from L2
-    constexpr int KH = 5, PADT = 2, HIN = CV_INPUT_H, NT = 2, NB4 = 3, NBP4 = 4, WAVES = 8;
+    constexpr int KH = 5, PADT = 2, HIN = CV_INPUT_H, NT = 2, NB4 = 3, NBP4 = 4;
+    static_assert(WAVES == 8 || WAVES == 4, "a wave stages 8 / WAVES k fragments of a position");
+    constexpr int KPW = 8 / WAVES;                        // k fragments of a position's fc4 slab each wave stages
     constexpr int NW3 = NT * KH * 4 * 64;                 // f4 of packed conv3 weights [nt][kh][kw][64]
     constexpr int SLOT = 8 * NB4 * 64;                    // f4 per ring slot: 8 k fragments x 3 output fragments
     extern __shared__ __attribute__((aligned(16))) f4 lds[];
@@ -1392,13 +1423,15 @@ __global__ __launch_bounds__(512, 2) void conv3fc4_slim(const f4 *__restrict__ i
     const f4 *inp = in_tm + (size_t)g * (HIN * 4 * 64) + lane;
     const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
     const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) f4 *)ring;
-    // this wave's share of the fc4 slab of position h: k fragment (h*8 + wid), its 3 real output fragments
+    // this wave's share of the fc4 slab of position h: k fragments (h*8 + wid*KPW ..), their 3 real output fragments
     auto stage_async = [&](int h, int slot) {
         const int hc = h < HIN ? h : HIN - 1;              // surplus stages of the last positions re-read valid data
 #pragma unroll
+        for (int kf = 0; kf < KPW; kf++)
+#pragma unroll
         for (int ob = 0; ob < NB4; ob++) {
-            const f4 *gp = wp4 + ((size_t)(hc * 8 + wid) * NBP4 + ob) * 64 + lane;
-            const unsigned ldst = ring_base + (unsigned)(((slot * 8 + wid) * NB4 + ob) * 1024);
+            const f4 *gp = wp4 + ((size_t)(hc * 8 + wid * KPW + kf) * NBP4 + ob) * 64 + lane;
+            const unsigned ldst = ring_base + (unsigned)(((slot * 8 + wid * KPW + kf) * NB4 + ob) * 1024);
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                          "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -1493,7 +1526,8 @@ __global__ __launch_bounds__(512, 2) void conv3fc4_slim(const f4 *__restrict__ i
         __builtin_amdgcn_sched_barrier(0);
         // counted wait: this position's 3 DMA pieces (slab h + 2) stay in flight; the row loads issued before them
         // and the pieces of slab h + 1 (issued one position ago) have landed; the barrier publishes slab h + 1
-        asm volatile("s_waitcnt vmcnt(3)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
+        if constexpr (KPW == 1) asm volatile("s_waitcnt vmcnt(3)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
         __syncthreads();
 #pragma unroll
         for (int j = 0; j + 1 < KH; j++)
@@ -1902,6 +1936,162 @@ __global__ __launch_bounds__(WAVES * 64, (GR == 2 ? 2 : WAVES / 2)) void dense_t
 }
 
 
+
+// ---------------------------------------------------------------------------
+// dense layer in output slabs with RAGGED waves (round 6): time proportional to the work at every batch size.
+//
+// dense_tm<7, 8> in three slabs hands every wave ONE group x the 7 output tiles of its slab, 8 waves to a workgroup: a
+// workgroup is 14 tile-units of matrix work per SIMD (one tile-unit = one 16 x 16 output tile over all k = 288 x 4 MFMAs,
+// 18 us of a SIMD) whatever the batch, so a launch costs ceil(workgroups / CUs) x 254 us: 768 groups (288 workgroups on
+// 256 CUs) take the time of 1 365.  Here the (group, tile) pairs of a slab form ONE flat sequence u = group * NBS + tile,
+// cut into equal pieces: the first four waves of a workgroup take `ca` consecutive pairs each, the last four `cb`
+// (ca - cb <= 1; waves w and w + 4 share a SIMD, so every SIMD of the workgroup gets s = ca + cb tile-units, any s from 2 to
+// 2 NBS).  The launcher picks s so that ceil(workgroups / CUs) x s is as close to 21 G / 1024 as it gets
+// (dense_rag_shape).  A piece of c <= NBS pairs touches at most two groups: its first n0 tiles are tiles t0 .. of group
+// g0, the rest tiles 0 .. of g0 + 1.  The accumulators are indexed by the POSITION in the piece (static registers), the
+// LDS offset of a position's weight fragment is a wave-uniform scalar, and which group's activation fragment a position
+// multiplies is decided at COMPILE time: the k loop exists once per (c, n0) -- a wave jumps to its copy before the loop
+// (branches around single MFMA blocks cost the compiler's accumulator copies and 40 % of the kernel: first version of this
+// kernel, profiles/r06/dense_rag_first_version.txt).  Weights through the same 3-slot LDS-DMA ring as dense_tm (one
+// fragment per wave and k step), one barrier per k step.  Per output value the chain is dense_tm's: ascending k, + bias,
+// SELU -- the same bits whatever the shape.  drop.d4 != NULL: the alpha-dropout of the value follows on the store (fc4 of
+// a training pass, as dense_tm<7, 8>'s three-slab form does).
+// ---------------------------------------------------------------------------
+template <int NBS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 2) void dense_rag(const f4 *__restrict__ in_tm, int KB,
+                                                                   const f4 *__restrict__ wp_all,
+                                                                   const float *__restrict__ bias, int nout,
+                                                                   f4 *__restrict__ out_tm, int G, int NBT, int ca, int cb,
+                                                                   cv_dropout_args drop)
+{
+    static_assert(WAVES == 8 && NBS == 7, "one padded stage of WAVES fragments per k step, one DMA piece per wave; the dispatch below names 7 tiles");
+    extern __shared__ __attribute__((aligned(16))) f4 ring[];
+    constexpr int STAGE = WAVES * 64;            // f4 per stage (NBS real fragments + zero pad)
+    constexpr int HW = WAVES / 2;
+    const f4 *wp = wp_all + (size_t)blockIdx.y * KB * STAGE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // this wave's piece of the slab's (group, tile) sequence
+    const int u0 = (int)blockIdx.x * HW * (ca + cb) + (wid < HW ? wid * ca : HW * ca + (wid - HW) * cb);
+    const int g0 = u0 / NBS, t0 = u0 - g0 * NBS;
+    int c = wid < HW ? ca : cb;
+    int n0 = c < NBS - t0 ? c : NBS - t0;
+    if (g0 + 1 >= G) c = n0;                     // the piece ends with the batch
+    if (g0 >= G) { c = 0; n0 = 0; }              // a spare wave: it still stages its fragment and takes part in the barriers
+    c = __builtin_amdgcn_readfirstlane(c); n0 = __builtin_amdgcn_readfirstlane(n0);
+    int tj[NBS];                                 // tile of position i (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < NBS; i++) tj[i] = __builtin_amdgcn_readfirstlane(i < n0 ? t0 + i : (i < c ? i - n0 : 0));
+    const int ga = g0 < G ? g0 : G - 1, gb = g0 + 1 < G ? g0 + 1 : G - 1;
+    const unsigned bo0 = (unsigned)((((size_t)ga * KB) * 64 + lane) * sizeof(f4));
+    const unsigned bo1 = (unsigned)((((size_t)gb * KB) * 64 + lane) * sizeof(f4));
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 acc[NBS];
+#pragma unroll
+    for (int j = 0; j < NBS; j++) acc[j] = zero;
+    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) f4 *)ring;
+    auto stage_async = [&](int kb, int slot) {       // one 1 KiB fragment per wave (see dense_tm)
+        const f4 *gp = wp + ((size_t)kb * WAVES + wid) * 64 + lane;
+        const unsigned ldst = ring_base + (unsigned)((slot * WAVES + wid) * 1024);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gp), "s"(ldst) : "memory");
+    };
+    auto load_frag_off = [&](unsigned byte_off) {
+        f4 v;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(in_tm) : "memory");
+        return v;
+    };
+    // the k loop for a piece of CC positions of which the first N0 belong to the first group (both compile-time).
+    // Unrolled by three so that the ring slot and the activation registers of a step are static: the activation fragments
+    // are fetched TWO steps ahead into three rotating register sets (a step of a short piece is ~0.25 us of MFMAs, less
+    // than the L2 round trip of a fragment requested at its start), no copies, no address arithmetic in the loop.
+    auto run = [&](auto CCc, auto N0c) {
+        constexpr int CC = decltype(CCc)::value, N0 = decltype(N0c)::value;
+        constexpr bool TWO = N0 < CC;
+        const int K1 = KB - 1;
+        stage_async(0, 0);
+        stage_async(K1 < 1 ? K1 : 1, 1);
+        f4 B0[3], B1[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) { B0[r] = zero; B1[r] = zero; }
+        B0[0] = load_frag_off(bo0);
+        if constexpr (TWO) B1[0] = load_frag_off(bo1);
+        B0[1] = load_frag_off(bo0 + (unsigned)(K1 < 1 ? K1 : 1) * 1024u);
+        if constexpr (TWO) B1[1] = load_frag_off(bo1 + (unsigned)(K1 < 1 ? K1 : 1) * 1024u);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(B0[0]), "+v"(B1[0]), "+v"(B0[1]), "+v"(B1[1]) : : "memory");
+        __syncthreads();
+        const f4 *wl = ring + lane;
+        auto step = [&](auto Rc, int kb) {
+            constexpr int R = decltype(Rc)::value, RN = (R + 2) % 3;
+            const int k2 = kb + 2 < KB ? kb + 2 : K1;           // (clamped: the surplus loads of the last steps re-read valid data)
+            B0[RN] = load_frag_off(bo0 + (unsigned)k2 * 1024u);
+            if constexpr (TWO) B1[RN] = load_frag_off(bo1 + (unsigned)k2 * 1024u);
+            stage_async(k2, RN);                 // slot (kb + 2) % 3 was last read in step kb - 1 (barrier passed)
+            constexpr int AB = 3;                // weight fragments read ahead of their MFMAs
+#pragma unroll
+            for (int i = 0; i < CC; i += AB) {
+                f4 A[AB];
+#pragma unroll
+                for (int j = 0; j < AB; j++)
+                    if (i + j < CC) A[j] = wl[R * STAGE + tj[i + j] * 64];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+                    for (int j = 0; j < AB; j++)
+                        if (i + j < CC) acc[i + j] = mfma4(A[j][s4], (i + j < N0 ? B0[R] : B1[R])[s4], acc[i + j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the MFMAs above the wait
+            // counted wait: this step's loads (1 or 2 fragments + the DMA piece: stage and fragments kb + 2) stay in flight;
+            // what the previous step issued -- stage kb + 1, which the barrier publishes, and fragments kb + 1 -- has landed
+            constexpr int R1 = (R + 1) % 3;
+            if constexpr (TWO) asm volatile("s_waitcnt vmcnt(3)" : "+v"(B0[R1]), "+v"(B1[R1]) : : "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" : "+v"(B0[R1]) : : "memory");
+            __syncthreads();
+        };
+#pragma unroll 1
+        for (int kb = 0; kb < KB; kb += 3) {
+            step(std::integral_constant<int, 0>{}, kb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 1 < KB) step(std::integral_constant<int, 1>{}, kb + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 2 < KB) step(std::integral_constant<int, 2>{}, kb + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the surplus loads of the last steps
+    };
+#define CV_RAG_N0(CCV, N0V) case N0V: if constexpr (N0V <= CCV) run(std::integral_constant<int, CCV>{}, std::integral_constant<int, N0V>{}); break;
+#define CV_RAG_C(CCV) case CCV: switch (n0) { CV_RAG_N0(CCV, 1) CV_RAG_N0(CCV, 2) CV_RAG_N0(CCV, 3) CV_RAG_N0(CCV, 4) CV_RAG_N0(CCV, 5) CV_RAG_N0(CCV, 6) CV_RAG_N0(CCV, 7) default: break; } break;
+    switch (c) {
+    CV_RAG_C(1) CV_RAG_C(2) CV_RAG_C(3) CV_RAG_C(4) CV_RAG_C(5) CV_RAG_C(6) CV_RAG_C(7)
+    default: run(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); break;
+    }
+#undef CV_RAG_C
+#undef CV_RAG_N0
+    const int q = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < NBS; i++) {
+        if (i >= c) break;
+        const int g = i < n0 ? g0 : g0 + 1;
+        const int ob = (int)blockIdx.y * NBS + tj[i];
+        const size_t t = ((size_t)g * NBT + ob) * 64 + lane;
+        const f4 h = selu4(acc[i] + load_bias4(bias, ob, q, nout));
+        out_tm[t] = h;
+        if (drop.d4) {
+            f4 d, mk;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                float x = h[s4], k;
+                dropout_value(x, k, 16 * ob + 4 * s4 + q, drop.nunits, drop.cand0 + (int64_t)g * 16 + (lane & 15), drop.rate,
+                              drop.seed, drop.step);
+                d[s4] = x; mk[s4] = k;
+            }
+            reinterpret_cast<f4 *>(drop.d4)[t] = d;
+            reinterpret_cast<f4 *>(drop.amask)[t] = mk;
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------
 // conv data gradient FUSED with the max-pool backward + SELU' of the layer below (training step, pooled layers).
@@ -2912,22 +3102,62 @@ int launch_conv_parts(int hs, const float *in, const float *x, int64_t n, const 
 #undef CV_PARTS
 }
 
+// flat_slots > 0 (training forward): flat ranges sized for that many resident waves.  flat_slots < 0 (inference, round 6):
+// whole groups or flat ranges, whichever the model says is shorter.  One wave alone on a SIMD already takes 93 % of its
+// matrix pipe (26 positions: 131 us alone, 245 us for two waves side by side), so what a launch costs is the number of
+// wave-positions its busiest SIMD has to run:
+//   whole groups: ceil(G NT / SIMDs) waves of HIN positions (768 groups: 2 304 waves = 3 on some SIMDs, 2 on others);
+//   flat ranges:  two equal waves per SIMD, each rows_per = ceil(G HOUT / (slots / NT)) pooled rows + the POOL - 1 rows
+//                 every one of its ~ rows_per / HOUT + 1 segments computes for its first window
+// (+ 0.7 of a position per segment / group for the prologue of its window; a single wave per SIMD pays 7 % for the idle
+// issue slots).  Measured against this model at 13 sizes: profiles/r06/conv3_flat_ab.txt.
+// *chose_flat (optional): which one ran (development probes).
 template <int CINB, int NT, int HIN, int WAVES, int MINW, bool SAVE = false>
 int launch_conv3_rot(const float *in, const float *wp, const float *bias, int cout, float *out, int G, hipStream_t st,
-                     float *codes = nullptr, int flat_slots = 0)
+                     float *codes = nullptr, int flat_slots = 0, bool *chose_flat = nullptr)
 {
     auto k = conv3_rot<CINB, NT, HIN, WAVES, MINW, SAVE>;
     size_t lds = (size_t)NT * 3 * 4 * CINB * 1024;
     if (set_lds(k, lds)) return 1;
+    constexpr int HOUT = HIN - 2;
     unsigned grid = nblk((int64_t)G * NT, WAVES);
     if (grid >= 16) grid = 8 * nblk((int64_t)((G + 7) / 8) * NT, WAVES);      // per-XCD wave numbering (see the kernel)
     int rows_per = 0;
+    if (chose_flat) *chose_flat = false;
     if (SAVE && flat_slots > 0) {            // training forward: one round of equal waves (see launch_conv)
-        const int64_t rows = (int64_t)G * (HIN - 2);
+        const int64_t rows = (int64_t)G * HOUT;
         const int per_tile = flat_slots / NT;
         rows_per = (int)((rows + per_tile - 1) / per_tile);
         if (rows_per < 4) rows_per = 4;
         grid = nblk((rows + rows_per - 1) / rows_per * NT, WAVES);
+    } else if (!SAVE && flat_slots < 0) {
+        static std::atomic<int> slots_by_dev[64];
+        int dev = 0;
+        CV_HIP(hipGetDevice(&dev));
+        int slots = slots_by_dev[dev & 63].load(std::memory_order_relaxed);
+        if (slots == 0) {
+            int nb = 0, cus = 0;
+            CV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), WAVES * 64, lds));
+            CV_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            slots = (nb > 0 ? nb : 2) * WAVES * (cus > 0 ? cus : 256);
+            slots_by_dev[dev & 63].store(slots, std::memory_order_relaxed);
+        }
+        const int64_t rows = (int64_t)G * HOUT;
+        const int per_tile = slots / NT / 8 * 8;       // (a multiple of 8: the per-XCD numbering pads the units to one)
+        int rp = (int)((rows + per_tile - 1) / per_tile);
+        if (rp < 4) rp = 4;
+        const double seg = 0.7 + 2.0;
+        const int simds = slots / 2;                    // (the kernel runs two waves per SIMD)
+        const int64_t per_simd = ((int64_t)G * NT + simds - 1) / simds;
+        const double cost_flat = 2.0 * (rp + seg * ((double)rp / HOUT + 1.0));
+        const double cost_whole = (double)per_simd * (HIN + 0.7) * (per_simd == 1 ? 1.07 : 1.0);
+        if (flat_slots == -2 || (flat_slots == -1 && cost_flat < 0.98 * cost_whole)) {
+            rows_per = rp;
+            const int64_t units = (rows + rp - 1) / rp;
+            grid = nblk(units * NT, WAVES);
+            if (grid >= 16) grid = 8 * nblk((units + 7) / 8 * NT, WAVES);
+            if (chose_flat) *chose_flat = true;
+        }
     }
     k<<<grid, WAVES * 64, lds, st>>>((const f4 *)in, (const f4 *)wp, bias, cout, (f4 *)out, G, (u32x2 *)codes, rows_per);
     CV_HIP(hipGetLastError());
@@ -2970,7 +3200,64 @@ int launch_dense_small(const float *in, int KB, const float *wp, const float *bi
     return 0;
 }
 
-// (the size lines of an inference pass are cv_model::inf_small_g / inf_fc4_small_g / inf_slab_g: cv_api.hip)
+// Shape of a dense_rag launch over G groups: s = tile-units per SIMD and workgroup (ca + cb), from the model
+//   time ~ ceil(workgroups / CUs) x (s + OV + ODD [s odd]) x UNIT        workgroups = nslab x ceil(NBS G / (4 s))
+// UNIT = 15.5 us: a tile-unit (288 x 4 MFMAs) on a SIMD at the clock the chip holds under this load; OV = 2: what a
+// round costs besides its MFMAs; ODD = 0.5: odd shapes (ca = cb + 1) run a little over the trend.  Calibrated on the
+// (G, s) table of tools/gpu_dense_rag_probe.py (profiles/r06/dense_rag_calibration.txt): the shape the model picks is
+// within 2.2 % of the best measured one at all 17 sizes from 289 to 4 096 groups.  Ties go to the larger s (fewer
+// workgroups stream the weight slab from L2).  force > 0: that s (development A/B).
+struct rag_shape { int s, ca, cb, wgs; double us; };
+constexpr double CV_RAG_UNIT_US = 15.5;
+static rag_shape dense_rag_shape(int G, int NBS, int nslab, int cus, int force)
+{
+    const double OV = 2.0, ODD = 0.5;
+    int best = 2 * NBS;
+    double best_cost = -1.0;
+    for (int s = 2 * NBS; s >= 4; s--) {
+        if (force >= 4 && force <= 2 * NBS && s != force) continue;
+        const long wg = (long)nslab * (((long)NBS * G + 4 * s - 1) / (4 * s));
+        const double cost = (double)((wg + cus - 1) / cus) * (s + OV + ((s & 1) ? ODD : 0.0));
+        if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    rag_shape r;
+    r.s = best; r.ca = (best + 1) / 2; r.cb = best / 2;
+    r.wgs = (int)(((long)NBS * G + 4 * best - 1) / (4 * best));
+    r.us = best_cost * CV_RAG_UNIT_US;
+    return r;
+}
+
+static int device_cus(int *out)
+{
+    static std::atomic<int> cus_by_dev[64];
+    int dev = 0;
+    CV_HIP(hipGetDevice(&dev));
+    int cus = cus_by_dev[dev & 63].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        CV_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (cus <= 0) cus = 256;
+        cus_by_dev[dev & 63].store(cus, std::memory_order_relaxed);
+    }
+    *out = cus;
+    return 0;
+}
+
+// fc4 of the full topology (3 slabs of 7 output tiles, cv_model::wps_fc4) on ragged waves
+static int launch_dense_rag(const float *in, int KB, const float *wps, const float *bias, int nout, float *out, int G, int nbt,
+                            int force_s, hipStream_t st, cv_dropout_args dr = cv_dropout_args())
+{
+    auto k = dense_rag<7, 8>;
+    const size_t lds = (size_t)3 * 8 * 1024;
+    if (set_lds(k, lds)) return 1;
+    int cus = 256;
+    if (device_cus(&cus)) return 1;
+    const rag_shape sh = dense_rag_shape(G, 7, 3, cus, force_s);
+    k<<<dim3(sh.wgs, 3), 512, lds, st>>>((const f4 *)in, KB, (const f4 *)wps, bias, nout, (f4 *)out, G, nbt, sh.ca, sh.cb, dr);
+    CV_HIP(hipGetLastError());
+    return 0;
+}
+
+// (the size options of an inference pass are cv_model::inf_small_g / inf_fc4_small_g / inf_slab_g: cv_api.hip, cv_mfma_forward)
 
 bool arch_is(const cv_arch &a, int k0, int k1, int k2, int c0, int c1, int c2, int p0, int p1, int p2,
              int f4_, int f5_)
@@ -3248,13 +3535,30 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             cv_prof_end(m, 1, st);
         } else if (fuse_front && (m->variant & 64)) {
             cv_prof_begin(m, 1, st);
-            m->stage_kernel[1] = "front2_tm<6>";
-            {
+            // whole groups (a workgroup = 2 groups x 2 tiles, two workgroups per CU: ceil(G / 512) waves per SIMD of 29 + 29
+            // rows; 91 us alone, 156 us for two side by side) or flat ranges (FLAT: one pair of waves per workgroup, 1 024
+            // resident, a segment pays ~4 rows for its first windows) -- whichever the model says is shorter
+            int cusf = 256;
+            if (device_cus(&cusf)) return 1;
+            const int per_simd = (G + 2 * cusf - 1) / (2 * cusf);
+            const int rpf = (int)(((int64_t)G * 26 + 4 * cusf - 1) / (4 * cusf));
+            const double cost_whole = per_simd * 30.0 * (per_simd == 1 ? 1.17 : 1.0);
+            const double cost_flat = 2.12 * (rpf + 4.0 * (rpf / 26.0 + 1.0));      // (2.12: the two-wave workgroups run 6 % under the four-wave ones on a full chip)
+            if (m->inf_flat == 2 || (m->inf_flat == 1 && rpf >= 6 && cost_flat < 0.98 * cost_whole)) {
+                m->stage_kernel[1] = "front2_tm<6, true>";
+                auto k = front2_tm<6, true>;
+                const size_t lds = (size_t)(16 + 6 * 4) * 1024;
+                if (set_lds(k, lds)) return 1;
+                const int rp = rpf < 6 ? 6 : rpf;
+                k<<<nblk((int64_t)G * 26, rp), 128, lds, st>>>(x, n, W1, B1, a.cout[0], (const f4 *)m->wp_conv[1], P + o[3], a.cout[1],
+                                                               (f4 *)m->tm_p2, G, rp);
+            } else {
+                m->stage_kernel[1] = "front2_tm<6>";
                 auto k = front2_tm<6>;
                 const size_t lds = (size_t)(16 + 2 * 6 * 4) * 1024;
                 if (set_lds(k, lds)) return 1;
                 k<<<nblk(G, 2), 256, lds, st>>>(x, n, W1, B1, a.cout[0], (const f4 *)m->wp_conv[1], P + o[3], a.cout[1],
-                                                (f4 *)m->tm_p2, G);
+                                                (f4 *)m->tm_p2, G, 0);
             }
             cv_prof_end(m, 1, st);
         } else if (fuse_front) {
@@ -3274,13 +3578,36 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         }
         cv_prof_begin(m, 2, st);
         if (small_pass) { m->stage_kernel[2] = "conv_tm<3, 2, 3, 3, 26, 0, 0, 4>"; rc |= launch_conv<3, 2, 3, 3, 26, 0, 0, 4>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st); }
-        else if (m->variant & 8) { m->stage_kernel[2] = "conv3_rot<2, 3, 26, 4, 2, false>"; rc |= launch_conv3_rot<2, 3, 26, 4, 2>(m->tm_p2, m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st); }
+        else if (m->variant & 8) { m->stage_kernel[2] = "conv3_rot<2, 3, 26, 4, 2, false>"; rc |= launch_conv3_rot<2, 3, 26, 4, 2>(m->tm_p2, m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st, nullptr, m->inf_flat == 0 ? 0 : (m->inf_flat == 2 ? -2 : -1)); }
         else { m->stage_kernel[2] = "conv_tm<3, 2, 3, 3, 26, 0, 0, 1>"; rc |= launch_conv<3, 2, 3, 3, 26, 0>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st); }
         cv_prof_end(m, 2, st);
         cv_prof_begin(m, 3, st);
-        if (G <= m->inf_fc4_small_g && (m->variant & 128)) { m->stage_kernel[3] = "dense_small<3, 8, 0>"; rc |= launch_dense_small<3, 8>(m->tm_p3, s.kb4, m->wps7_fc4, P + o[7], a.fc4, m->tm_h4, G, 7, st); }
-        else if (G <= m->inf_slab_g) { m->stage_kernel[3] = "dense_tm<7, 8, 0, 1>"; rc |= launch_dense<7, 8>(m->tm_p3, s.kb4, m->wps_fc4, P + o[7], a.fc4, m->tm_h4, G, st, 3); }
-        else if ((m->variant & 1024) && (m->variant & 32) && m->wp5p_fc5) {      // fc4 + fc5 + heads as one kernel
+        // fc4: which kernel form runs is an ESTIMATE of each form's time at this number of groups (round 6; rounds 1-5 drew
+        // fixed lines at 288 / 3 400 groups) -- the same bits whichever runs:
+        //   dense_small (one wave per group and slab of 3 tiles, weights from L2): 83 us per round of 1 024 waves;
+        //   dense_rag (three slabs on ragged waves): its shape model, + fc5 and the heads as kernels of their own;
+        //   dense_tm<21, 8, 3, 2> (fc4 + fc5 + heads, 16 groups per workgroup, one workgroup per CU): 1 525 us per round.
+        // Options: infer_fc4_small_groups = the size up to which dense_small is considered at all (288: beyond it the weight
+        // matrix is read from L2 7 x G times), infer_slab_groups >= 0 = a fixed line between dense_rag and the fused kernel
+        // instead of the estimate (A/B, tests), dense_rag -1 = the round-5 three-slab kernel in dense_rag's place.
+        int cus = 256;
+        if (device_cus(&cus)) return 1;
+        const bool can_small = G <= m->inf_fc4_small_g && (m->variant & 128) && m->wps7_fc4;
+        const bool can_fused = (m->variant & 1024) && (m->variant & 32) && m->wp5p_fc5;
+        const bool can_rag = m->wps_fc4 != nullptr;
+        const rag_shape rsh = dense_rag_shape(G, 7, 3, cus, m->inf_rag_s);
+        const double us_rag = rsh.us + 20.0 + 0.0165 * G;                         // + dense_tm<11, 4> and heads_tm
+        const double us_small = 83.0 * (double)(((long)7 * G + 4 * cus - 1) / (4 * cus)) + 12.0;
+        const double us_wide = 1525.0 * (double)(((G + 15) / 16 + cus - 1) / cus) + (can_fused ? -17.0 : 85.0);   // (the launches the fused tail saves the pass / fc5 + heads on their own)
+        int form;                                                                  // 0 small, 1 three slabs, 2 all 21 tiles per wave (fused with fc5 + heads by variant bit 10)
+        if (can_small && (!can_rag || us_small <= us_rag + 12.0)) form = 0;       // (fc5 follows on dense_small too: 12 us less)
+        else if (!can_rag) form = 2;
+        else if (m->inf_slab_g >= 0) form = G <= m->inf_slab_g ? 1 : 2;
+        else form = us_wide < us_rag ? 2 : 1;
+        if (form == 0) { m->stage_kernel[3] = "dense_small<3, 8, 0>"; rc |= launch_dense_small<3, 8>(m->tm_p3, s.kb4, m->wps7_fc4, P + o[7], a.fc4, m->tm_h4, G, 7, st); }
+        else if (form == 1 && m->inf_rag_s >= 0) { m->stage_kernel[3] = "dense_rag<7, 8>"; rc |= launch_dense_rag(m->tm_p3, s.kb4, m->wps_fc4, P + o[7], a.fc4, m->tm_h4, G, s.nb4, m->inf_rag_s, st); }
+        else if (form == 1) { m->stage_kernel[3] = "dense_tm<7, 8, 0, 1>"; rc |= launch_dense<7, 8>(m->tm_p3, s.kb4, m->wps_fc4, P + o[7], a.fc4, m->tm_h4, G, st, 3); }
+        else if (can_fused) {      // fc4 + fc5 + heads as one kernel
             m->stage_kernel[3] = "dense_tm<21, 8, 3, 2>";
             heads_args h3 = hd;
             h3.wp5p = (const f4 *)m->wp5p_fc5; h3.bias5 = P + o[9]; h3.nout5 = a.fc5; h3.h5_out = (f4 *)m->tm_h5;
@@ -3333,10 +3660,19 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         }
         if (m->variant & 256) {
             cv_prof_begin(m, 2, st);
-            m->stage_kernel[2] = "conv3fc4_slim";
             {
                 const size_t lds = (size_t)(40 + 3 * 24) * 1024;
-                if (set_lds(conv3fc4_slim, lds)) return 1;
+                // groups per workgroup by the estimate rounds of CUs x time per position of a workgroup alone on its CU: 18.4 us
+                // with two waves per SIMD (8 groups), 10.2 us with one (4 groups; 2 groups: the same 10.2 -- not built).
+                // Measured at 14 sizes: profiles/r06/slim_waves_ab.txt (8 192 candidates: 0.69 -> 0.42 ms per pass)
+                int cuss = 256;
+                if (device_cus(&cuss)) return 1;
+                int wv = 8;
+                if (m->inf_slim_waves == 4 || m->inf_slim_waves == 8) wv = m->inf_slim_waves;
+                else {
+                    const double t8 = (double)(((G + 7) / 8 + cuss - 1) / cuss) * 18.4, t4 = (double)(((G + 3) / 4 + cuss - 1) / cuss) * 10.2;
+                    wv = t4 < 0.97 * t8 ? 4 : 8;
+                }
                 const heads_args *tail = nullptr;
                 if (m->variant & 1024) {            // fc5 + heads on the kernel's tail: arguments through a device copy
                     heads_args h3 = hd;
@@ -3345,8 +3681,12 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
                     if (tail_args_refresh(m, h3, st, &tail)) return 1;
                     tail_done = true;
                 }
-                conv3fc4_slim<<<nblk(G, 8), 512, lds, st>>>((const f4 *)m->tm_p2, (const f4 *)m->wp_conv[2], P + o[5], a.cout[2],
-                                                          (const f4 *)m->wp_fc4, P + o[7], a.fc4, (f4 *)m->tm_h4, G, tail, n, out16);
+#define CV_SLIM_LAUNCH(W) do { if (set_lds(conv3fc4_slim<W>, lds)) return 1; \
+                    conv3fc4_slim<W><<<nblk(G, W), W * 64, lds, st>>>((const f4 *)m->tm_p2, (const f4 *)m->wp_conv[2], P + o[5], a.cout[2], \
+                                                          (const f4 *)m->wp_fc4, P + o[7], a.fc4, (f4 *)m->tm_h4, G, tail, n, out16); } while (0)
+                if (wv == 8) { m->stage_kernel[2] = "conv3fc4_slim<8>"; CV_SLIM_LAUNCH(8); }
+                else { m->stage_kernel[2] = "conv3fc4_slim<4>"; CV_SLIM_LAUNCH(4); }
+#undef CV_SLIM_LAUNCH
             }
             cv_prof_end(m, 2, st);
             if (tail_done) {
@@ -4147,7 +4487,9 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
             if (cv_layout_current(m, lay, "fc4 forward (training pass)")) return 1;
             // tiny batches: 288 dependent k steps at ~0.9 us each are the longest kernel of the step; eight k ranges
             // (CV_DENSE_KSPLIT) run side by side instead and a second pass adds them up in order
-            if (lay == CVL_FC4S3 && G <= m->tiny_g) {
+            // (option train_ksplit 0 with variant bit 7 cleared also reads the 3-slab layout at these sizes: that is the
+            // single-chain three-slab kernel below, not this branch)
+            if (lay == CVL_FC4S3 && G <= m->tiny_g && m->train_ksplit) {
                 if (!part) { cv_set_error("k-split fc4 forward without its scratch (internal)"); return 1; }
                 cv_dropout_args dr = cv_dropout_args();
                 if (drop && drop_done) {            // the alpha-dropout of fc4 rides on the second pass of the k-split
@@ -4171,6 +4513,7 @@ int cv_tile_dense_fwd(cv_model *m, int layer, const float *in_tm, float *out_tm,
                     hd.drop.seed = drop->seed; hd.drop.step = drop->step; hd.drop.cand0 = drop->cand0;
                     *drop_done = true;
                 }
+                if (m->inf_rag_s >= 0) return launch_dense_rag(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, s.nb4, m->inf_rag_s, st, hd.drop);
                 return launch_dense<7, 8>(in_tm, s.kb4, m->wps_fc4, P + o[7], a.fc4, out_tm, G, st, 3, 1, nullptr, hd);
             }
             return launch_dense<21, 8, 0, 2>(in_tm, s.kb4, m->wp_fc4, P + o[7], a.fc4, out_tm, G, st);      // slices of more than 2 048 groups: the inference kernel

@@ -137,8 +137,13 @@ def plan_exchange(model, global_batch):
 
 
 def exchange_mode(model):
-    """the plan of plan_exchange; a model nobody planned for exchanges in two pieces (correct at any size)"""
-    return getattr(model, "_exchange_mode", None) or os.environ.get("CV_EXCHANGE") or "split"
+    """the plan of plan_exchange; a model nobody planned for exchanges in two pieces (correct at any size -- and not
+    re-planned here from the batch a step is handed: a rank only sees its own share, shares differ by one candidate
+    between ranks, and ranks that chose differently around the line would issue different collectives)"""
+    mode = getattr(model, "_exchange_mode", None) or os.environ.get("CV_EXCHANGE") or "split"
+    if mode not in ("one", "split"):
+        raise ValueError("CV_EXCHANGE must be 'one' or 'split', not %r" % (mode,))
+    return mode
 
 
 def comm_stream(model):

@@ -927,7 +927,8 @@ class _PinnedPool(object):
         import threading
         self.free = {}
         self.enabled = None
-        self.lock = threading.Lock()      # GetTensorFiles takes buffers from up to 8 reader threads; finalizers give them back
+        self.lock = threading.RLock()     # (re-entrant: a finalizer may run inside _give when its allocation triggers a collection)
+                                           # GetTensorFiles takes buffers from up to 8 reader threads; finalizers give them back
 
     def _give(self, cls, t):
         with self.lock:

@@ -132,12 +132,20 @@ int cv_selu_sweep(int device, uint32_t lo_bits, uint32_t hi_bits, uint64_t *viol
  * which then only cv_get_activation layers 4 / 5 read; off, those layers report an error after such a pass and the
  * kernel writes a third of the bytes), "train_overlap" (0/1: weight
  * gradients of the training step on a side stream next to the data-gradient chain; default 1, same bits),
- * "infer_small_groups" / "infer_fc4_small_groups" / "infer_slab_groups" (defaults 256 / 288 / 3400: cv_forward picks its
+ * "infer_small_groups" / "infer_fc4_small_groups" / "infer_slab_groups" (defaults 256 / 288 / -1: cv_forward picks its
  * kernels by the number of groups of 16 candidates in the pass -- up to the first the convolutions unfused with their
- * positions over four waves, up to the second fc4 / fc5 as one wave per (group, slab), up to the third fc4 as three
- * output slabs per group block, beyond it fc4 + fc5 + heads as one kernel; the same bits whichever runs),
+ * positions over four waves; up to the second fc4 / fc5 may run as one wave per (group, slab); fc4 otherwise as three
+ * output slabs on ragged waves (dense_rag) or, with fc5 and the heads on its tail, all 21 tiles per wave: -1 = whichever an
+ * estimate of the launch's time says is shorter at this size, >= 0 = the slab form up to that many groups; the same bits
+ * whichever runs), "dense_rag" (0 default: the shape of the three-slab fc4 launch -- tile-units per SIMD and workgroup --
+ * from the number of groups, so that the time of a pass is proportional to its size; 4..14 = that shape, -1 = the round-5
+ * kernel with one group x 7 tiles per wave; A/B and calibration, same bits), "infer_flat" (1 default: the per-group
+ * convolution kernel of an inference pass runs on equal ranges of the flat (group, row) sequence when a whole-group launch
+ * would leave SIMDs with a wave more than others; 0 = always whole groups, 2 = always flat ranges; same bits),
+ * "slim_waves" (0 default: groups per workgroup of the slim topology's conv3 + fc4 kernel -- 8 or 4 -- from the number of
+ * groups, so that a small pass spreads over all CUs; 4 / 8 = that many; same bits),
  * "train_tiny_groups" (0..4096, default 400: training batches of up to that many groups of 16 candidates split the
- * serial loops of their layers over more waves -- same bits; the position parts of the convolutions stop at 160 groups
+ * serial loops of their layers over more waves -- same bits; the position parts of the convolutions stop at 80 groups
  * whatever the value), "train_ksplit" (0/1, default 1: at such batches
  * the fc4 forward of the TRAINING pass adds eight partial sums over k ranges instead of one ascending-k chain; fixed
  * order, reproducible run to run, within the gradient tolerance of the single chain, 4 % faster at 1 250 candidates;

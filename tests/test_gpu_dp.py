@@ -173,7 +173,7 @@ def test_tiny_batch_kernel_variants_give_the_same_bits(oracle, arch, n):
     import torch
     from clairvoyante_amd import synth
     # only sizes where the switch changes the path: above 400 groups both settings run the regular kernels (those sizes
-    # are compared with the oracle in tests/test_gpu_train_parity.py).  Up to 160 groups the whole small-batch set runs;
+    # are compared with the oracle in tests/test_gpu_train_parity.py).  Up to 80 groups the whole small-batch set runs;
     # from 161 to 400 everything but the position parts of the convolutions and the chained join.
     assert (n + 15) // 16 <= 400
     xt, cls, rf, alt, il = synth.make_candidates(n, seed=43, device="cuda", return_class=True)

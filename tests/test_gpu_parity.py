@@ -149,8 +149,57 @@ def test_passes_either_side_of_every_size_line_give_the_same_bits(setup):
     for n in (2577, 4113, 32785):
         got = m.predict_device(xd[:n].contiguous()).cpu().numpy()
         assert np.array_equal(got.view(np.uint32), want[:n].view(np.uint32)), n
-    for key, value in (("infer_small_groups", 256), ("infer_fc4_small_groups", 288), ("infer_slab_groups", 3400)):
+    for key, value in (("infer_small_groups", 256), ("infer_fc4_small_groups", 288), ("infer_slab_groups", -1)):
         m.setOption(key, value)
+
+
+LADDER = (1000, 1600, 2000, 2560, 2576, 3200, 4096, 4112, 5120, 6400, 8192, 10000, 12288, 16384, 24576, 32768, 32784,
+          40000, 49152, 54417)
+
+
+def test_every_size_of_the_ladder_gives_the_bits_of_small_chunks(setup):
+    """Round 6: the launch shape of every per-group kernel is a function of the pass size (ragged fc4 slabs, flat
+    (group, row) ranges of the convolutions, 4- or 8-wave slim workgroups, the fused tail by estimate).  Every size of
+    the size-sweep ladder (tools/gpu_infer_stage_ladder.py) must give, bit for bit, what the same candidates give in
+    chunks of 2 048 (the small-pass kernels throughout = the oracle's bits, tests above)."""
+    from clairvoyante_amd import synth
+    arch, P, m, x, ref = setup
+    m.setOption("impl", 1); m.setOption("variant", common.DEFAULT_VARIANT)
+    xd = synth.make_candidates(54417, seed=79, device="cuda")
+    m.setOption("chunk", 2048)
+    want = m.predict_device(xd).cpu().numpy()
+    m.setOption("chunk", 65536)
+    for n in LADDER:
+        got = m.predict_device(xd[:n].contiguous()).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want[:n].view(np.uint32)), n
+
+
+@pytest.mark.parametrize("n", [4107, 12283, 32779])
+def test_forced_launch_shapes_give_the_same_bits(setup, n):
+    """the shapes the estimates choose between, each forced at sizes where it is NOT the default (ragged last group):
+    every fc4 slab shape s = 4 .. 14 and the round-5 slab kernel (option dense_rag), whole groups / flat ranges for the
+    convolutions (infer_flat 0 / 2), 4- / 8-wave slim workgroups (slim_waves), the slab form / the fused tail by a fixed
+    line (infer_slab_groups)"""
+    from clairvoyante_amd import synth
+    arch, P, m, x, ref = setup
+    m.setOption("impl", 1); m.setOption("variant", common.DEFAULT_VARIANT); m.setOption("chunk", 65536)
+    xd = synth.make_candidates(n, seed=83, device="cuda")
+    want = m.predict_device(xd).cpu().numpy()
+    settings = [{"infer_flat": 0}, {"infer_flat": 2}, {"slim_waves": 4}, {"slim_waves": 8}, {"infer_slab_groups": 0},
+                {"infer_slab_groups": 65536}, {"dense_rag": -1, "infer_slab_groups": 65536}]
+    settings += [{"dense_rag": s, "infer_slab_groups": 65536, "infer_flat": 2 if s % 2 else 0} for s in range(4, 15)]
+    defaults = {"infer_flat": 1, "slim_waves": 0, "infer_slab_groups": -1, "dense_rag": 0}
+    try:
+        for st in settings:
+            for k, v in defaults.items():
+                m.setOption(k, v)
+            for k, v in st.items():
+                m.setOption(k, v)
+            got = m.predict_device(xd).cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), st
+    finally:
+        for k, v in defaults.items():
+            m.setOption(k, v)
 
 
 def test_fused_tail_back_to_back_calls_with_changing_outputs(setup):

@@ -24,6 +24,24 @@ def test_shard_ranges_cover_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_a_mistyped_exchange_plan_is_refused_everywhere(monkeypatch):
+    """CV_EXCHANGE is read by plan_exchange AND, for a model nobody planned, by exchange_mode: a typo must not fall
+    through to the two-piece exchange silently on either path"""
+    from clairvoyante_amd import parallel
+
+    class Stub(object):
+        device = torch.device("cpu")
+    monkeypatch.setenv("CV_EXCHANGE", "onee")
+    with pytest.raises(ValueError):
+        parallel.exchange_mode(Stub())
+    with pytest.raises(ValueError):
+        parallel.plan_exchange(Stub(), 10000)
+    monkeypatch.setenv("CV_EXCHANGE", "one")
+    assert parallel.exchange_mode(Stub()) == "one"
+    monkeypatch.delenv("CV_EXCHANGE")
+    assert parallel.exchange_mode(Stub()) == "split"
+
+
 def _worker(rank, ws, port, tmp, n):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws),
