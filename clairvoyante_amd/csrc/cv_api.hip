@@ -140,7 +140,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     alloc(&m->wp_heads0, (size_t)s.nb4 * 256);
     alloc(&m->wp_heads1, (size_t)s.nb5 * 256);
     alloc(&m->wp_heads12, (size_t)s.nb5 * 16 * 12 + 16);
-    m->variant = 1519;
+    m->variant = 2031;
     if (e == hipSuccess) e = hipMalloc(&m->loss_acc, sizeof(double) * 8);
     if (e == hipSuccess) e = hipMemset(m->loss_acc, 0, sizeof(double) * 8);
     if (e != hipSuccess) {

@@ -3596,7 +3596,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         const bool can_fused = (m->variant & 1024) && (m->variant & 32) && m->wp5p_fc5;
         const bool can_rag = m->wps_fc4 != nullptr;
         const rag_shape rsh = dense_rag_shape(G, 7, 3, cus, m->inf_rag_s);
-        const double us_rag = rsh.us + 20.0 + 0.0165 * G;                         // + dense_tm<11, 4> and heads_tm
+        const double us_rag = rsh.us + 22.0 + 0.019 * G;                          // + fc5 with the heads on its tail (dense_tm<11, 4, 2>)
         const double us_small = 83.0 * (double)(((long)7 * G + 4 * cus - 1) / (4 * cus)) + 12.0;
         const double us_wide = 1525.0 * (double)(((G + 15) / 16 + cus - 1) / cus) + (can_fused ? -17.0 : 85.0);   // (the launches the fused tail saves the pass / fc5 + heads on their own)
         int form;                                                                  // 0 small, 1 three slabs, 2 all 21 tiles per wave (fused with fc5 + heads by variant bit 10)

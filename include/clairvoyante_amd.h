@@ -170,9 +170,10 @@ int cv_selu_sweep(int device, uint32_t lo_bits, uint32_t hi_bits, uint64_t *viol
  * LDS (full topology), bit 7: fc4 of passes of up to 256 groups on a kernel without barriers (one wave per group
  * and slab of 3 output fragments, operands prefetched from L2 through a register ring), bit 8: slim topology, conv3
  * and fc4 as one kernel (the conv3 map stays in registers), bit 9: the four heads ride on the fc5 kernel (passes of
- * more than 256 groups; measured neutral: 0.108 vs 0.107 ms, off by default), bit 10: fc5 and the four heads on the TAIL
+ * more than 256 groups whose fc5 is a kernel of its own: 12-16 us of a pass between 5 000 and 50 000 candidates, on by
+ * default since round 6), bit 10: fc5 and the four heads on the TAIL
  * of the large-pass fc4 kernel (passes of more than 2 048 groups, full topology: the fc4 output never leaves the
- * registers it was accumulated in; 1.533 -> 1.516 ms for the three layers); default 1519; the alternatives give bit-identical results and exist for A/B
+ * registers it was accumulated in; 1.533 -> 1.516 ms for the three layers); default 2031; the alternatives give bit-identical results and exist for A/B
  * timing).                                                                                          */
 int cv_set_option(cv_model *m, const char *key, int64_t value);
 int cv_get_option(const cv_model *m, const char *key, int64_t *value);

@@ -2,7 +2,7 @@
 import numpy as np
 
 HEADS = ((0, 4), (4, 6), (6, 10), (10, 16))
-DEFAULT_VARIANT = 1519     # cv_create's default kernel selection (include/clairvoyante_amd.h, option "variant")
+DEFAULT_VARIANT = 2031     # cv_create's default kernel selection (include/clairvoyante_amd.h, option "variant")
 
 
 def bench_params(oracle, arch, seed=1):
