@@ -190,12 +190,70 @@ class Clairvoyante(object):
                                         ctypes.c_void_p(out16.data_ptr()), self._stream()))
         return out16
 
+    # predict(numpy): batches of at least PIPE_MIN candidates go to the device in parts, part k + 1's host-to-device copy on
+    # a copy stream under part k's kernels (round 5: one synchronous copy, the pass, one copy back -- nothing overlapped --
+    # gave a host caller 8.7 M candidates/s of the device's 18.7).  The copy moves 26 candidates/us, the kernels take 19:
+    # a part may be up to ~1.4 x the one before without the pass waiting for its input, and the first one is small (its copy
+    # is the only one nothing hides): a tenth of the batch, then x 1.6, at most PIPE_PART_MAX.  The 16 outputs go back per
+    # part on a third stream, enqueued AFTER the last input copy (a device-to-host copy in flight stalls the runtime's
+    # staged pageable copy: 6.7 against 4.6 ms for 65 536 candidates, profiles/r06/host_copy_probe.txt).
+    PIPE_MIN, PIPE_FIRST_MIN, PIPE_GROW, PIPE_PART_MAX = 24576, 4096, 1.6, 65536
+
+    @classmethod
+    def _pipe_cuts(cls, n):
+        """[0, c1, c2, ..., n]: part boundaries (multiples of 16) of a host batch of n candidates"""
+        cuts, size = [0], max(cls.PIPE_FIRST_MIN, n // 10)
+        while cuts[-1] < n:
+            step = min(int(size), cls.PIPE_PART_MAX) // 16 * 16
+            nxt = cuts[-1] + step
+            if n - nxt < step // 2:          # a short tail joins the last part
+                nxt = n
+            cuts.append(min(nxt, n))
+            size *= cls.PIPE_GROW
+        return cuts
+
+    def _host_streams(self):
+        st = getattr(self, "_hstreams", None)
+        if st is None:
+            st = self._hstreams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+        return st
+
     def _predict_host(self, XArray):
         with torch.cuda.device(self.device):
-            x = self._to_dev(XArray, (33, 4, 4))
-            out = self.predict_device(x).cpu().numpy()
-        return (np.ascontiguousarray(out[:, 0:4]), np.ascontiguousarray(out[:, 4:6]),
-                np.ascontiguousarray(out[:, 6:10]), np.ascontiguousarray(out[:, 10:16]))
+            if torch.is_tensor(XArray):
+                out = self.predict_device(self._to_dev(XArray, (33, 4, 4))).cpu().numpy()
+            else:
+                x = np.ascontiguousarray(XArray, dtype=np.float32).reshape((-1, 33, 4, 4))
+                n = x.shape[0]
+                if n < self.PIPE_MIN:
+                    out = self.predict_device(torch.from_numpy(x).to(self.device)).cpu().numpy()
+                else:
+                    out = self._predict_host_parts(x, n)
+        # (views of ONE fresh [n,16] array: the four heads side by side, as the kernels store them)
+        return out[:, 0:4], out[:, 4:6], out[:, 6:10], out[:, 10:16]
+
+    def _predict_host_parts(self, x, n):
+        cut = self._pipe_cuts(n)
+        main = torch.cuda.current_stream(self.device)
+        cs, ds = self._host_streams()
+        dev = torch.empty((n, 33, 4, 4), dtype=torch.float32, device=self.device)
+        out = torch.empty((n, _lib.NUM_OUT), dtype=torch.float32, device=self.device)
+        host = torch.empty((n, _lib.NUM_OUT), dtype=torch.float32, pin_memory=True)
+        cs.wait_stream(main)                  # the fresh buffers may still be in use by work queued on the caller's stream
+        done = []
+        for lo, hi in zip(cut[:-1], cut[1:]):
+            with torch.cuda.stream(cs):
+                dev[lo:hi].copy_(torch.from_numpy(x[lo:hi]))       # (host-synchronous: the runtime stages pageable memory)
+                ev = torch.cuda.Event(); ev.record(cs)
+            main.wait_event(ev)
+            self.predict_device(dev[lo:hi], out[lo:hi])
+            d = torch.cuda.Event(); d.record(main); done.append(d)
+        with torch.cuda.stream(ds):
+            for (lo, hi), d in zip(zip(cut[:-1], cut[1:]), done):
+                ds.wait_event(d)
+                host[lo:hi].copy_(out[lo:hi], non_blocking=True)
+        ds.synchronize()                      # everything above is complete: the buffers may go back to their pools
+        return host.numpy()
 
     def predict(self, XArray):
         """v3.py:257-267 -> (base [n,4], zygosity [n,2], varType [n,4], indelLength [n,6])"""

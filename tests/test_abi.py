@@ -92,3 +92,17 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b|from\s+\.\.?\s*oracle|cv_oracle|cvo_", text, re.M):
                     bad.append(f)
     assert bad == []
+
+
+def test_host_batch_parts_cover_the_batch():
+    """model._pipe_cuts: the parts predict(numpy) sends a large host batch to the device in -- contiguous, complete,
+    boundaries on whole groups of 16 candidates, the first part the smallest (its copy is the one nothing hides), no part
+    more than ~1.6 x the one before except the last (which takes a short tail)"""
+    from clairvoyante_amd.model import Clairvoyante as C
+    for n in (24576, 24577, 30000, 40003, 65536, 70001, 140000, 1000003):
+        c = C._pipe_cuts(n)
+        assert c[0] == 0 and c[-1] == n and all(b > a for a, b in zip(c[:-1], c[1:]))
+        assert all(v % 16 == 0 for v in c[:-1])
+        sizes = [b - a for a, b in zip(c[:-1], c[1:])]
+        assert sizes[0] == min(sizes[:-1] or sizes) and len(sizes) >= 2
+        assert all(b <= 1.61 * a + 16 for a, b in zip(sizes[:-2], sizes[1:-1]))

@@ -202,6 +202,30 @@ def test_forced_launch_shapes_give_the_same_bits(setup, n):
             m.setOption(k, v)
 
 
+@pytest.mark.parametrize("n", [24576, 40003, 70001, 140000])
+def test_predict_of_a_large_host_batch_in_overlapped_parts_gives_the_same_bits(setup, n):
+    """predict(numpy) sends batches of >= 24 576 candidates to the device in parts (copy of part k + 1 under the kernels of
+    part k, outputs back per part: model._predict_host_parts); the four arrays must be what one pass over the
+    device-resident batch gives, bit for bit -- also when called twice in a row and from a worker thread (predictNoRT,
+    callVar.py:197-204)"""
+    import threading
+    import torch
+    from clairvoyante_amd import synth
+    arch, P, m, x, ref = setup
+    m.setOption("impl", 1); m.setOption("variant", common.DEFAULT_VARIANT); m.setOption("chunk", 65536)
+    xd = synth.make_candidates(n, seed=91, device="cuda")
+    want = m.predict_device(xd).cpu().numpy()
+    xh = xd.cpu().numpy()
+    for _ in range(2):
+        got = np.concatenate(m.predict(xh), axis=1)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    t = threading.Thread(target=m.predictNoRT, args=(xh,))
+    t.start(); t.join()
+    got = np.concatenate([m.predictBaseRTVal, m.predictZygosityRTVal, m.predictVarTypeRTVal, m.predictIndelLengthRTVal], axis=1)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert not xh.flags.writeable or np.array_equal(xh, xd.cpu().numpy())       # the caller's array is never written
+
+
 def test_fused_tail_back_to_back_calls_with_changing_outputs(setup):
     """fc5 + heads ride on the tail of the large-pass fc4 kernel (variant bit 10) and take the number of candidates and the
     output pointer per call: several large passes enqueued back to back, each with its own output tensor and size, no
