@@ -746,6 +746,109 @@ def run_infer(arch, batch, steps, warmup, rank, ws, dev, variant=None, batches=N
     return res, m, P, batches
 
 
+def host_legs(dev, rows=1000000, train_items=600000):
+    """The reference's own API and loops at the CURRENT tree, outside every timed region of the headline (rank 0, N = 1):
+    SURVEY 8 a11 (`predict` on caller-owned numpy batches, v3.py:257-267: 65 536 candidates and the reference's
+    predictBatchSize of 1 000), a14 + a16 + a17 (`callVar.Run` over a text-tensor file of `rows` synthetic rows written to
+    /dev/shm: GetTensor -> predict -> Output -> VCF, callVar.py:180-216), a15 + a18 (`train.TrainAll` over a synthetic
+    .bin of `train_items` candidates, blosc blocks -> DecompressArray -> training step, train.py:63-160; the second epoch).
+    Each leg names its workload; a leg that fails reports its error instead of taking the line down."""
+    import logging
+    import pickle
+    import shutil
+    import tempfile
+    import types
+    import numpy as np
+    import torch
+    from clairvoyante_amd import callVar, clairvoyante_v3, param, synth, train, utils_v2
+    from clairvoyante_amd.pileup import format_rows
+    out = {}
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="cv_bench_host_", dir=base)
+    try:
+        m = clairvoyante_v3.Clairvoyante(); m.setParameters(synth.bench_params("full"))
+        # ---- predict(numpy)
+        pn = {}
+        for n in (65536, 1000):
+            x = synth.make_candidates(n, seed=synth.BASE_SEED + 7, device=dev).cpu().numpy()
+            for _ in range(3):
+                m.predict(x)
+            reps = 10 if n > 4096 else 200
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    m.predict(x)
+                best = min(best, (time.perf_counter() - t0) / reps)
+            pn[str(n)] = {"candidates_per_s": n / best, "ms_per_call": best * 1e3}
+        out["predict_numpy"] = dict(pn, workload="model.predict(x) on a caller-owned pageable numpy batch [n,33,4,4] -> four numpy arrays "
+                                                 "(host-to-device copy, pass, copy back inside the call)")
+        chk = os.path.join(tmp, "model-000001"); m.saveParameters(chk); m.close()
+        # ---- callVar over a text-tensor file
+        try:
+            nsrc = min(rows, 200000)
+            x = synth.make_candidates(nsrc, seed=synth.BASE_SEED + 9, device=dev).cpu().numpy()
+            x[..., 1:] += x[..., 0:1]; x = np.maximum(x, 0)          # back to raw counts: the reader subtracts matrix 0 again
+            txt = os.path.join(tmp, "t.txt")
+            refseq = b"N" * 83 + b"ACGT" * ((rows + 200) // 4 + 8)
+            with open(txt, "wb") as fh:
+                for s0 in range(0, rows, nsrc):
+                    k = min(nsrc, rows - s0)
+                    fh.write(b"\n".join(format_rows("chr1", np.arange(100 + s0, 100 + s0 + k), refseq, 0, x[:k])) + b"\n")
+            a = types.SimpleNamespace(tensor_fn=txt, chkpnt_fn=chk, call_fn=os.path.join(tmp, "out.vcf"), qual=None, sampleName="S",
+                                      ref_fn=None, threads=None, showRef=False, v3=True, v2=False, slim=False)
+            best = 1e9
+            for _ in range(2):                                    # (the second pass finds the file in the page cache)
+                t0 = time.perf_counter(); callVar.Run(a); best = min(best, time.perf_counter() - t0)
+            nrec = sum(1 for l in open(a.call_fn) if not l.startswith("#"))
+            out["callvar_text"] = {"rows_per_s": rows / best, "seconds": best, "rows": rows, "vcf_records": nrec,
+                                   "file_MB": os.path.getsize(txt) / 1e6,
+                                   "workload": "callVar.Run on an uncompressed text-tensor file in %s (model load + GetTensor + "
+                                               "predict + Output + VCF), %d rows" % (base or "the temp dir", rows)}
+            os.unlink(txt)
+        except BaseException as e:
+            out["callvar_text"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # ---- train.TrainAll over a .bin
+        try:
+            xt, cls, rf, alt, il = synth.make_candidates(train_items, seed=synth.BASE_SEED + 11, device=dev, return_class=True)
+            X = xt.cpu().numpy(); Y = synth.make_labels(cls, rf, alt, il).cpu().numpy().astype(np.float64)
+            XC = [utils_v2.pack_array(X[s0:s0 + 500]) for s0 in range(0, train_items + 1, 500)]
+            YC = [utils_v2.pack_array(Y[s0:s0 + 500]) for s0 in range(0, train_items + 1, 500)]
+            fn = os.path.join(tmp, "t.bin")
+            with open(fn, "wb") as fh:
+                pickle.dump(train_items, fh); pickle.dump(XC, fh); pickle.dump(YC, fh); pickle.dump([], fh)
+            del X, Y, XC, YC
+            times = []
+
+            class H(logging.Handler):
+                def emit(self, rec):
+                    msg = rec.getMessage()
+                    if msg.startswith("Epoch time elapsed"):
+                        times.append(float(msg.split(":")[1].split()[0]))
+            h = H(); lg = logging.getLogger(); lvl = lg.level
+            lg.addHandler(h); lg.setLevel(logging.INFO)
+            old_epochs = param.maxEpoch
+            param.maxEpoch = 4                                    # three epochs
+            try:
+                m2 = clairvoyante_v3.Clairvoyante(); m2.init()
+                a = types.SimpleNamespace(bin_fn=fn, tensor_fn=None, var_fn=None, bed_fn=None, chkpnt_fn=None, learning_rate=1e-3,
+                                          lambd=1e-3, ochk_prefix=None, olog_dir=None, v2=False, v3=True, slim=False)
+                train.TrainAll(a, m2, utils_v2)
+                m2.close()
+            finally:
+                param.maxEpoch = old_epochs; lg.removeHandler(h); lg.setLevel(lvl)
+            ep = min(times[1:]) if len(times) > 1 else times[0]
+            out["trainall"] = {"candidates_per_s": train_items / ep, "epoch_seconds": ep, "epochs_timed": len(times), "items": train_items,
+                               "workload": "train.TrainAll on a synthetic .bin (blosc blocks of 500, 90 %% trained in batches of %d, "
+                                           "10 %% validated), best epoch after the first (the log prints hundredths of a second)"
+                                           % param.trainBatchSize}
+        except BaseException as e:
+            out["trainall"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def float64_outputs(arch, P, xs, dev=None, chunk=16384):
     """The independent float64 torch formulation (tests/torch_ref.py; no oracle/ in the loop) over xs, with stock torch
     ops on `dev` (the GPU: 262 144 candidates take a second or two) or, when the device refuses a float64 op, on the
@@ -820,6 +923,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="infer mode: skip the slim / training legs (configs 4, 5)")
+    ap.add_argument("--no-host", action="store_true", help="infer mode: skip the host legs (predict(numpy), callVar over a text file, TrainAll over a .bin)")
     ap.add_argument("--dry", action="store_true", help="start the ranks, count them, print the skeleton; no GPU work")
     ap.add_argument("--sync-loss", action="store_true", help="train mode: read the losses back after every step (m.train)")
     ap.add_argument("--variant", type=int, default=None, help="infer mode: option variant (kernel selection, A/B)")
@@ -897,6 +1001,13 @@ def main():
                 tr["parity"] = train_parity("full", gb, dev)
             except Exception as e:      # the checker must not take the line down
                 tr["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0 and ws == 1 and not args.no_host:
+            t_host = time.perf_counter()
+            try:
+                line["host"] = host_legs(dev)
+            except BaseException as e:
+                line["host"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            line["host"]["seconds"] = time.perf_counter() - t_host
 
     if rank == 0:
         if not args.no_cpu and ws == 1:          # the CPU leg (and the parity block it feeds) runs at N = 1 only
