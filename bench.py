@@ -222,7 +222,39 @@ def init_ranks(args):
                   "n_gpus differs from the request" % (args.gpus, ws), file=sys.stderr)
         finish_ranks()
         sys.exit(2)
+    verify_ranks(args, rank, ws, local)
     return rank, ws, local
+
+
+_RANK_CHECK = {}
+
+
+def verify_ranks(args, rank, ws, local):
+    """BEFORE anything is timed: the ranks count themselves with one all-reduce (must be --gpus) and compare the devices they
+    sit on -- N ranks on fewer than N devices is not an N-GPU measurement (exit 2) unless CV_SHARE_DEVICES says the run is
+    the functional rehearsal on one GPU.  What was found travels in the line (rank_info: counted_ranks, distinct_devices)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        _RANK_CHECK.update(counted_ranks=1, distinct_devices=1)
+        return
+    on_gpu = torch.cuda.is_available() and not args.dry
+    dev = "cuda:%d" % local if dist.get_backend() == "nccl" else "cpu"
+    t = torch.ones(1, dtype=torch.int64, device=dev)
+    dist.all_reduce(t)
+    counted = int(t.item())
+    ident = "%s/%s" % (os.uname().nodename, (getattr(torch.cuda.get_device_properties(local), "uuid", None) or local) if on_gpu else "cpu%d" % rank)
+    idents = [None] * ws
+    dist.all_gather_object(idents, ident)
+    distinct = len(set(idents))
+    _RANK_CHECK.update(counted_ranks=counted, distinct_devices=distinct)
+    bad = counted != args.gpus or (on_gpu and distinct != ws and not os.environ.get("CV_SHARE_DEVICES"))
+    if bad:
+        if rank == 0:
+            print("bench.py: --gpus %d: %d rank(s) answered the all-reduce on %d distinct device(s) %s; refusing to time it"
+                  % (args.gpus, counted, distinct, sorted(set(idents))), file=sys.stderr)
+        finish_ranks()
+        sys.exit(2)
 
 
 def rank_info(ws):
@@ -230,6 +262,9 @@ def rank_info(ws):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         info = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
+        info.update(_RANK_CHECK)
+        if os.environ.get("CV_SHARE_DEVICES"):
+            info["shared_devices"] = True         # a functional rehearsal: the ranks share GPUs, no number of this line is an N-GPU number
         if dist.get_backend() == "nccl":
             info["rccl_log"] = rccl_summary()
         return info
@@ -460,9 +495,16 @@ def exchange_timing(m, step, x, y, steps, step_ms, dev):
         comp_ms = timed(lambda: step(x, y), steps)
     m.readLosses()
     hidden = 1.0 - (step_ms - comp_ms) / ex_ms if ex_ms > 0 else None
+    nbytes = int(m._bucket.numel()) * 4
+    ws = dist.get_world_size()
+    algbw = nbytes / (ex_ms * 1e-3) / 1e9 if ex_ms > 0 else None
     res = {"exchange_ms": ex_ms, "compute_ms_per_step": comp_ms,
            "exchange_hidden_frac": None if hidden is None else max(0.0, min(1.0, hidden)),
-           "exchange_bytes": int(m._bucket.numel()) * 4}
+           "exchange_bytes": nbytes,
+           # the step's own exchange as a bandwidth: bytes of the bucket / exchange_ms, and the bus bandwidth a ring moves
+           # for it (x 2 (N - 1) / N: what --mode exchange prints per piece; one xGMI link is ~153 GB/s)
+           "exchange_algbw_GBps": algbw,
+           "exchange_busbw_GBps": None if algbw is None else algbw * 2.0 * (ws - 1) / max(ws, 1)}
     # the same steps under the OTHER plan (one collective behind the step <-> the dense part under the backward pass), so
     # that the first run on real links says which one the batch wants; the model's plan is restored afterwards
     if not os.environ.get("CV_EXCHANGE"):
@@ -629,7 +671,8 @@ def train_main(args):
                            "dbg": args.dbg + (" sides=%d" % args.sides if args.sides is not None else "") +
                                   (" ksplit=%d" % args.ksplit if args.ksplit is not None else "")},
                 "roofline": r["roofline"], "final_loss": r["final_loss"]}
-        for k in ("exchange_ms", "compute_ms_per_step", "exchange_hidden_frac", "exchange_bytes", "exchange_plan", "other_plan"):
+        for k in ("exchange_ms", "compute_ms_per_step", "exchange_hidden_frac", "exchange_bytes", "exchange_algbw_GBps", "exchange_busbw_GBps",
+                  "exchange_plan", "other_plan"):
             if k in r:
                 line[k] = r[k]
         line.update(rank_info(ws))

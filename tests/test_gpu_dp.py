@@ -726,6 +726,11 @@ def test_bench_line_under_eight_ranks_sharing_the_gpu(mode):
         assert b["config"]["global_batch"] == 10000 and b["scaling"] == "strong"
         assert b["exchange_ms"] > 0 and b["compute_ms_per_step"] > 0 and 0.0 <= b["exchange_hidden_frac"] <= 1.0
         assert b["exchange_bytes"] == 4 * (1631496 + 16) and np.isfinite(b["final_loss"])
+        # the step's own exchange as bandwidths (what the first run on real links is read by), and the rank check that ran
+        # before anything was timed: eight ranks counted, here on ONE device, flagged as shared
+        assert abs(b["exchange_algbw_GBps"] - b["exchange_bytes"] / (b["exchange_ms"] * 1e-3) / 1e9) <= 1e-6 * b["exchange_algbw_GBps"]
+        assert abs(b["exchange_busbw_GBps"] - b["exchange_algbw_GBps"] * 2 * 7 / 8) <= 1e-9 * max(1.0, b["exchange_busbw_GBps"])
+        assert b["counted_ranks"] == 8 and b["distinct_devices"] == 1 and b["shared_devices"] is True
         assert b["exchange_plan"] == "one"          # 1 250 candidates per rank: one collective per step
         assert b["other_plan"]["plan"] == "split" and b["other_plan"]["ms_per_step"] > 0      # ... and the same steps under the other plan
     else:
