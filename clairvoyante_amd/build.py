@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libclairvoyante_hip.so")
-SOURCES = ["cv_api.hip", "cv_kernels_ref.hip", "cv_kernels_mfma.hip", "cv_post.hip", "cv_train.hip", "cv_pileup.hip", "cv_hostio.cpp", "cv_bam.cpp", "cv_inflate.cpp"]
+SOURCES = ["cv_api.hip", "cv_kernels_ref.hip", "cv_kernels_mfma.hip", "cv_kernels_wgrad.hip", "cv_post.hip", "cv_train.hip", "cv_pileup.hip", "cv_hostio.cpp", "cv_bam.cpp", "cv_inflate.cpp"]
 # -ffp-contract=off: the canonical arithmetic fuses only where fmaf()/MFMA say so
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value"]
 

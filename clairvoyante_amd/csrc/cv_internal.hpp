@@ -150,7 +150,7 @@ struct cv_model {
     //         dbg1 = 8: conv2 forward on flat ranges too)
     //   dbg2 = 1 / 2: unpool always thread-per-row / always streaming, 3: fc4's alpha-dropout as its own pass, 4: thread-per-row at tiny batches (default there: row segments), 5: the tail of the tiny-batch forward as three kernels, 6: row segments at every size
     //   dbg3 = 1: fc4 data gradient and conv3 unpool as two kernels
-    //   dbg4 = 2: conv data gradients fused with the unpool below (conv_dgrad_unpool), 3: slim selu' as its own pass, 4: conv1's unpool and weight gradient as two kernels
+    //   dbg4 = 3: slim selu' as its own pass, 4: conv1's unpool and weight gradient as two kernels
     //   dbg5 = 1: all weight packing in one launch in stream order (>= 16: dbg5 >> 4 candidate ranges of fc4's weight gradient, bit 3 / bit 2: one / two input fragments per wave there)      dbg6 = n: row parts of dense_dgrad_unpool (few groups)
     //   dbg7 = 1: training-forward conv3 on conv_tm instead of conv3_rot
     int dbg[8];
@@ -167,7 +167,6 @@ struct cv_model {
     //      instead of a pass of their own
     //   64 no memset of the gradient at the head of a step: the second passes of the first slice store instead of adding
     //   128 tiny batches: the side streams chained before the ONE wait of the main stream at the end of the step
-    //   256 (off by default) tiny batches: fc4's weight gradient launched at conv3's marker (a marker less on the main stream)
     //   512 conv1's weight gradient on the main stream at EVERY batch size (the chain's tail: -11 us at 5 000, -12 us at 10 000)
     //   2048 full topology up to 512 groups: the side stream's L2 term and weight packing start BEHIND conv1's forward kernel
     //      instead of beside it (-20 us at 79 groups, -5 at 313; +8 at 625 and +25 us for slim at 79, hence the bounds)
@@ -251,8 +250,6 @@ int cv_tile_fc4_dgrad_unpool(cv_model *m, const float *g_tm, const float *pooled
                              hipStream_t st);
 int cv_tile_conv_dgrad(cv_model *m, int layer, const float *g_tm, float *gin_tm, int64_t n, hipStream_t st,
                        const float *act_below = nullptr);
-int cv_tile_conv_dgrad_unpool(cv_model *m, int layer, const float *g_tm, const float *pooled, const float *codes, float *gpre,
-                              int64_t n, hipStream_t st);
 int cv_tile_dense_wgrad(cv_model *m, int layer, const float *x_tm, const float *g_tm, int64_t n, hipStream_t st);
 int cv_tile_conv_wgrad(cv_model *m, int layer, const float *in_tm, const float *g_tm, int64_t n, hipStream_t st);
 int cv_tile_conv1_wgrad(cv_model *m, const float *x, const float *g_tm, int64_t n, hipStream_t st);

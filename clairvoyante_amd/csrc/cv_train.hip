@@ -824,7 +824,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
         // data-gradient chain (the last 100 us of the step had two small kernels on the chip).  Full topology: conv2 and
         // conv1 (with conv3 as well 2.13 -> 2.17 ms: its kernel fills the chip next to fc4's); slim: conv3, conv2, conv1
         // (1.233 / 1.176 / 1.167 ms with one stream / two layers / three layers on the second; profiles/r03).
-        const int want = (Gn <= m->tiny_g || (m->sched & 4096)) ? m->train_sides : (m->train_sides >= 2 ? 2 : 1);      // (bit 12: development)
+        const int want = Gn <= m->tiny_g ? m->train_sides : (m->train_sides >= 2 ? 2 : 1);
         for (int i = 0; i < 2 && f.nside < want; i++) f.side[f.nside++] = m->tr_side_more[i];
         f.used[0] = true;                    // sw already carries the L2 term / the weight packing of this step
     }
@@ -868,12 +868,9 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     f.st_moved();
     // fc4's data gradient; full topology: fused with conv3's max-pool backward + SELU' (dbg3 = 1: as two kernels)
     const bool fused3 = m->wpr_fc4 != nullptr && m->dbg[3] != 1;
-    // fc4's weight gradient.  train_sched bit 8 (OFF by default): at tiny batches launched one kernel LATER, at the marker of
-    // conv3's weight gradient -- a marker less on the main stream.  Measured with the chained join (one box, alternating,
-    // profiles/r05/step_ab_session6_sched_bit7.txt): 14 us SLOWER at 79 groups (the weight gradient fills the chip and then
-    // meets conv3's two gradient kernels instead of the fused fc4 data gradient, which leaves half the CUs free), 14 us
-    // faster at 157.  Here by default.
-    const bool fc4_late = fused3 && Gn <= m->tiny_g && (m->sched & 256) && !dense_ready && f.nside > 1;
+    // fc4's weight gradient.  (Launched one kernel later at tiny batches, at the marker of conv3's weight gradient -- a marker
+    // less on the main stream -- it was 14 us slower at 79 groups and 14 us faster at 157: profiles/r05/
+    // step_ab_session6_sched_bit7.txt; the schedule bit was removed in round 6.)
     auto fc4_wgrad = [&](bool same_point) -> int {
         if (f.to_side(2, &sx, same_point)) return 1;
         if (cv_tile_dense_wgrad(m, 4, tp[2], tg4pre, n, sx)) return 1;
@@ -883,7 +880,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
         }
         return 0;
     };
-    if (!fc4_late && fc4_wgrad(false)) return 1;
+    if (fc4_wgrad(false)) return 1;
     // layers without pooling (slim): the selu' factor of the layer below rides on the data-gradient kernel's store
     // (dbg4 = 3: as a separate element-wise pass)
     const bool nopool_fused = a.pool[0] == 1 && a.pool[1] == 1 && a.pool[2] == 1 && m->dbg[4] != 3;
@@ -891,16 +888,12 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     if (fused3) { if (cv_tile_fc4_dgrad_unpool(m, tg4pre, tp[2], ta[2], tgpre[2], n, st)) return 1; }
     else if (nopool_fused) { if (cv_tile_fc4_dgrad(m, tg4pre, tgpre[2], n, st, tp[2])) return 1; }
     else if (cv_tile_fc4_dgrad(m, tg4pre, tgin[2], n, st)) return 1;
-    // conv stack.  Pooled layers of the full topology: the data gradient of layer l writes the pre-activation gradient of
-    // layer l - 1 directly (conv_dgrad_unpool; dbg4 = 1: data gradient and unpool as two kernels)
-    // Measured (profiles/r03): the fused kernel loses at every batch -- at train.py's 625 groups one wave per (group,
-    // tile) is 1 250 waves for 1 024 SIMDs and position parts recompute P - 1 windows each (385 us against 254 + 79
-    // for conv3); at 79 groups (a rank's share under data parallelism) 114 + 78 us against 60 + 25 + 17 + 24 once the
-    // weight gradients run on their own streams (0.698 against 0.672 ms per step).  Kept as a tested variant: dbg4 = 2.
-    const bool fusedc = m->wpr_fc4 != nullptr && m->dbg[4] == 2;
+    // conv stack.  (A convolution data gradient fused with the unpool below it -- the pre-activation gradient of layer l - 1
+    // written directly -- was built in round 3 and lost at every batch: 385 us against 254 + 79 for conv3 at 625 groups,
+    // 0.698 against 0.672 ms per step at 79; removed in round 6, profiles/HISTORY.md.)
     for (int l = 2; l >= 0; l--) {
         const int H = s.hc[l], NT = s.ntile[l];
-        const bool have_gpre = (l == 2 && fused3) || (l < 2 && fusedc) || nopool_fused;
+        const bool have_gpre = (l == 2 && fused3) || nopool_fused;
         // the first layer's unpool rides inside its weight-gradient kernel (its gradient map has no other reader)
         const bool conv1_fused = l == 0 && !have_gpre && a.pool[0] == 5 && s.ntile[0] == 1 && m->dbg[4] != 4;
         if (!have_gpre && !conv1_fused && launch_unpool(tgin[l], tp[l], ta[l], tgpre[l], Gn, H, NT, a.pool[l], st, (m->dbg[2] == 1 || m->dbg[2] == 6) ? (1 << 30) : (m->dbg[2] == 2 ? 0 : m->tiny_g), m->dbg[2] == 1 || m->dbg[2] == 4)) return 1;
@@ -911,11 +904,6 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
         if (l == 0 && ((Gn <= m->tiny_g && (m->sched & 2)) || (m->sched & 512))) sx = st;
         else {
             if (f.to_side(5 - l, &sx)) return 1;
-            if (l == 2 && fc4_late) {            // the same marker serves fc4's weight gradient (another side stream)
-                hipStream_t s3 = sx;
-                if (fc4_wgrad(true)) return 1;
-                sx = s3;
-            }
         }
         if (l == 0) {        // first layer: X viewed as [33][16] fragments, read in place
             bool done1 = false;
@@ -923,8 +911,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
             if (!done1 && cv_tile_conv1_wgrad(m, x, tgpre[0], n, sx)) return 1;
         } else {
             if (cv_tile_conv_wgrad(m, l, tp[l - 1], tgpre[l], n, sx)) return 1;
-            if (fusedc) { if (cv_tile_conv_dgrad_unpool(m, l, tgpre[l], tp[l - 1], ta[l - 1], tgpre[l - 1], n, st)) return 1; }
-            else if (nopool_fused) { if (cv_tile_conv_dgrad(m, l, tgpre[l], tgpre[l - 1], n, st, tp[l - 1])) return 1; }
+            if (nopool_fused) { if (cv_tile_conv_dgrad(m, l, tgpre[l], tgpre[l - 1], n, st, tp[l - 1])) return 1; }
             else if (cv_tile_conv_dgrad(m, l, tgpre[l], tgin[l - 1], n, st)) return 1;
         }
     }

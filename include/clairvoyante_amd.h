@@ -158,11 +158,11 @@ int cv_selu_sweep(int device, uint32_t lo_bits, uint32_t hi_bits, uint64_t *viol
  * marker for L2 term + weight packing, 8 launch sites at one point of the main stream share a marker, 16 a pass packs
  * only the weight layouts its kernels read, 32 the base head's data gradient + dropout / selu' factor on the store of
  * fc5's data-gradient kernel, 64 no memset of the gradient at the head of a step (the weight-gradient second passes of
- * its first slice store instead of adding), 128 tiny batches: the side streams chained before the one wait of the main stream, 256 (off) tiny batches: fc4's
- * weight gradient launched at conv3's marker, 512 the first layer's weight gradient on the main stream at every batch
- * size, 1024 fc5 + heads + losses + head gradients of a training pass above the tiny range as one kernel, 2048 up to 512
- * groups the side stream's L2 term and packing start behind conv1's forward kernel, 4096 (off, development) three side
- * streams at every batch size; same bits with any value -- the reported loss to its last bits),
+ * its first slice store instead of adding), 128 tiny batches: the side streams chained before the one wait of the main
+ * stream, 512 the first layer's weight gradient on the main stream at every batch size, 1024 fc5 + heads + losses + head
+ * gradients of a training pass above the tiny range as one kernel, 2048 up to 512 groups the side stream's L2 term and
+ * packing start behind conv1's forward kernel (bits 256 and 4096 named two schedules that lost their A/B runs in round 5
+ * and are gone); same bits with any value -- the reported loss to its last bits),
  * "dbg0".."dbg7" (development A/B switches of the training step, 0 = shipped path; see cv_internal.hpp),
  * "variant" (bit 0: first layer fused into the conv2 kernel, bit 1: MFMA heads kernel,
  * bit 2: 8-wave fc4 workgroups, bit 3: rotating-window conv3 kernel, bit 5: fc4 with two groups of
