@@ -657,7 +657,8 @@ def train_main(args):
     r = run_train(args.arch, gb, steps, args.warmup, rank, ws, dev, sync_loss=args.sync_loss,
                   options=dict({"train_overlap": args.overlap, "train_tiny_groups": args.tiny, "train_ksplit": args.ksplit,
                                 "train_side_streams": args.sides, "train_sched": args.sched},
-                               **{"dbg" + kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.dbg.split(",") if kv}))
+                               **{"dbg" + kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.dbg.split(",") if kv},
+                               **{kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.opt.split(",") if kv}))
     if rank == 0:
         line = {"metric": "training candidate tensors/sec", "value": r["value"], "unit": "candidates/s",
                 "n_gpus": ws, "steps": steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
@@ -975,6 +976,7 @@ def main():
     ap.add_argument("--ksplit", type=int, default=None, help="train mode: option train_ksplit (A/B)")
     ap.add_argument("--sides", type=int, default=None, help="train mode: option train_side_streams (A/B)")
     ap.add_argument("--dbg", default="", help="train mode: development switches, e.g. 0=3,2=1 sets options dbg0=3, dbg2=1")
+    ap.add_argument("--opt", default="", help="train mode: any library option, e.g. dense_rag=13,infer_flat=0 (A/B)")
     ap.add_argument("--sched", type=int, default=None, help="train mode: option train_sched (bits of the re-cut step schedule, A/B)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "pileup", "exchange"],
                     help="infer (default, the headline metric) or train: Adam steps on the reference's global "

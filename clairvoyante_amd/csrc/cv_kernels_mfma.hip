@@ -912,7 +912,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void conv3_rot(const f4 *__restri
     // (conv_tm HSPLIT == 0); the rows of each group in the range are one segment of the loop below -- positions
     // [hbeg, hend) = its pooled rows and the POOL - 1 behind them; same values row for row.
     const bool flat = rows_per > 0;
-    if (!(SAVE && flat) && gridDim.x >= 16) {
+    if (gridDim.x >= 16) {
         // XCD-aware mapping (workgroup b runs on XCD b % 8, each XCD has its own L2): the NT waves of a group (of a range)
         // read the same input rows, and with WAVES = 4, NT = 3 every other one has its waves in two consecutive workgroups
         // = two XCDs, which then both fetch the map from HBM (measured: 1.44 x the input per launch).  Here XCD x owns the
@@ -1785,17 +1785,25 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 2) void dense_rag(const f4 *__r
                                                                    const f4 *__restrict__ wp_all,
                                                                    const float *__restrict__ bias, int nout,
                                                                    f4 *__restrict__ out_tm, int G, int NBT, int ca, int cb,
-                                                                   cv_dropout_args drop)
+                                                                   int wgs, int nslab, cv_dropout_args drop)
 {
     static_assert(WAVES == 8 && NBS == 7, "one padded stage of WAVES fragments per k step, one DMA piece per wave; the dispatch below names 7 tiles");
     extern __shared__ __attribute__((aligned(16))) f4 ring[];
     constexpr int STAGE = WAVES * 64;            // f4 per stage (NBS real fragments + zero pad)
     constexpr int HW = WAVES / 2;
-    const f4 *wp = wp_all + (size_t)blockIdx.y * KB * STAGE;
+    // XCD-aware numbering of a one-dimensional grid (workgroup b runs on XCD b % 8, each XCD has its own L2): the nslab
+    // workgroups that multiply the SAME activation fragments -- one per output slab -- are b = 8 (nslab t + y) + x % 8, i.e.
+    // on one XCD and dispatched together, so that two of three reads of the layer's input hit that L2 (as a (pieces, slabs)
+    // grid they ran whole launches apart: the 184 MB pool3 map of a 10 000-candidate pass came in from outside the L2 three
+    // times).  A speed-only assumption: the values do not depend on it.
+    const int xcd = blockIdx.x & 7, tq = blockIdx.x >> 3;
+    const int slab = tq % nslab, bx = (tq / nslab) * 8 + xcd;
+    if (bx >= wgs) return;                       // (padding of the grid to whole XCD rows: the whole workgroup leaves)
+    const f4 *wp = wp_all + (size_t)slab * KB * STAGE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     // this wave's piece of the slab's (group, tile) sequence
-    const int u0 = (int)blockIdx.x * HW * (ca + cb) + (wid < HW ? wid * ca : HW * ca + (wid - HW) * cb);
+    const int u0 = bx * HW * (ca + cb) + (wid < HW ? wid * ca : HW * ca + (wid - HW) * cb);
     const int g0 = u0 / NBS, t0 = u0 - g0 * NBS;
     int c = wid < HW ? ca : cb;
     int n0 = c < NBS - t0 ? c : NBS - t0;
@@ -1871,7 +1879,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 2) void dense_rag(const f4 *__r
             constexpr int R1 = (R + 1) % 3;
             if constexpr (TWO) asm volatile("s_waitcnt vmcnt(3)" : "+v"(B0[R1]), "+v"(B1[R1]) : : "memory");
             else asm volatile("s_waitcnt vmcnt(2)" : "+v"(B0[R1]) : : "memory");
-            __syncthreads();
+            __syncthreads();      // (without it -- wrong results, a timing ceiling -- the kernel is 2-3 % shorter: the step is MFMA-bound)
         };
 #pragma unroll 1
         for (int kb = 0; kb < KB; kb += 3) {
@@ -1897,7 +1905,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 2) void dense_rag(const f4 *__r
     for (int i = 0; i < NBS; i++) {
         if (i >= c) break;
         const int g = i < n0 ? g0 : g0 + 1;
-        const int ob = (int)blockIdx.y * NBS + tj[i];
+        const int ob = slab * NBS + tj[i];
         const size_t t = ((size_t)g * NBT + ob) * 64 + lane;
         const f4 h = selu4(acc[i] + load_bias4(bias, ob, q, nout));
         out_tm[t] = h;
@@ -2825,10 +2833,12 @@ int launch_conv3_rot(const float *in, const float *wp, const float *bias, int co
     if (chose_flat) *chose_flat = false;
     if (SAVE && flat_slots > 0) {            // training forward: one round of equal waves (see launch_conv)
         const int64_t rows = (int64_t)G * HOUT;
-        const int per_tile = flat_slots / NT;
+        const int per_tile = flat_slots / NT / 8 * 8;      // (a multiple of 8: the per-XCD numbering pads the units to one)
         rows_per = (int)((rows + per_tile - 1) / per_tile);
         if (rows_per < 4) rows_per = 4;
-        grid = nblk((rows + rows_per - 1) / rows_per * NT, WAVES);
+        const int64_t units = (rows + rows_per - 1) / rows_per;
+        grid = nblk(units * NT, WAVES);
+        if (grid >= 16) grid = 8 * nblk((units + 7) / 8 * NT, WAVES);
     } else if (!SAVE && flat_slots < 0) {
         static std::atomic<int> slots_by_dev[64];
         int dev = 0;
@@ -2900,7 +2910,7 @@ int launch_dense_small(const float *in, int KB, const float *wp, const float *bi
 }
 
 // Shape of a dense_rag launch over G groups: s = tile-units per SIMD and workgroup (ca + cb), from the model
-//   time ~ ceil(workgroups / CUs) x (s + OV + ODD [s odd]) x UNIT        workgroups = nslab x ceil(NBS G / (4 s))
+//   time ~ ceil(workgroups per XCD / CUs per XCD) x (s + OV + ODD [s odd]) x UNIT    workgroups per XCD = nslab x ceil(ceil(NBS G / (4 s)) / 8)
 // UNIT = 15.5 us: a tile-unit (288 x 4 MFMAs) on a SIMD at the clock the chip holds under this load; OV = 2: what a
 // round costs besides its MFMAs; ODD = 0.5: odd shapes (ca = cb + 1) run a little over the trend.  Calibrated on the
 // (G, s) table of tools/gpu_dense_rag_probe.py (profiles/r06/dense_rag_calibration.txt): the shape the model picks is
@@ -2915,8 +2925,11 @@ static rag_shape dense_rag_shape(int G, int NBS, int nslab, int cus, int force)
     double best_cost = -1.0;
     for (int s = 2 * NBS; s >= 4; s--) {
         if (force >= 4 && force <= 2 * NBS && s != force) continue;
-        const long wg = (long)nslab * (((long)NBS * G + 4 * s - 1) / (4 * s));
-        const double cost = (double)((wg + cus - 1) / cus) * (s + OV + ((s & 1) ? ODD : 0.0));
+        // (workgroups per XCD: the kernel numbers its grid so that the nslab workgroups of a piece share an XCD -- 8 pieces to
+        // a row of the grid -- and an XCD runs cus / 8 workgroups of a round)
+        const long wg = (long)nslab * ((((long)NBS * G + 4 * s - 1) / (4 * s) + 7) / 8);
+        const long per_xcd = cus / 8 > 0 ? cus / 8 : 1;
+        const double cost = (double)((wg + per_xcd - 1) / per_xcd) * (s + OV + ((s & 1) ? ODD : 0.0));
         if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = s; }
     }
     rag_shape r;
@@ -2936,7 +2949,7 @@ static int launch_dense_rag(const float *in, int KB, const float *wps, const flo
     int cus = 256;
     if (device_cus(&cus)) return 1;
     const rag_shape sh = dense_rag_shape(G, 7, 3, cus, force_s);
-    k<<<dim3(sh.wgs, 3), 512, lds, st>>>((const f4 *)in, KB, (const f4 *)wps, bias, nout, (f4 *)out, G, nbt, sh.ca, sh.cb, dr);
+    k<<<8 * 3 * ((sh.wgs + 7) / 8), 512, lds, st>>>((const f4 *)in, KB, (const f4 *)wps, bias, nout, (f4 *)out, G, nbt, sh.ca, sh.cb, sh.wgs, 3, dr);
     CV_HIP(hipGetLastError());
     return 0;
 }
