@@ -3633,7 +3633,11 @@ int cv_tile_fc4_dgrad_unpool(cv_model *m, const float *g_tm, const float *pooled
     if (cv_layout_current(m, CVL_DFC4, "fc4 data gradient")) return 1;
     const size_t lds = (size_t)3 * 24 * 1024;
     const int HO = s.hp[2], NT = s.ntile[2];
-    // (workgroup shape measured at 625 groups: 8 waves x 2 groups 298 us, 4 waves x 2 groups 298 us, 8 waves x 1 group 292 us)
+    // (workgroup shape measured at 625 groups: 8 waves x 2 groups 298 us, 4 waves x 2 groups 298 us, 8 waves x 1 group 292 us;
+    // round 6: the twelve column workgroups of a block of groups numbered onto one XCD so that they share the block's gradient
+    // fragments in its L2 -- what halved fc4's forward traffic -- RAISES this kernel's traffic, 520 -> 541 MB per step, and the
+    // step by 40 us: twelve columns then stream twelve different 576 KB weight slabs through one 4 MB L2 at a time, where the
+    // (blocks, columns) grid runs one column's workgroups together.  Not kept.)
     if (G > 512) {
         auto k = dense_dgrad_unpool<21, 3, 8, 2>;
         if (set_lds(k, lds)) return 1;
