@@ -151,7 +151,7 @@ struct cv_model {
     //   dbg2 = 1 / 2: unpool always thread-per-row / always streaming, 3: fc4's alpha-dropout as its own pass, 4: thread-per-row at tiny batches (default there: row segments), 5: the tail of the tiny-batch forward as three kernels, 6: row segments at every size
     //   dbg3 = 1: fc4 data gradient and conv3 unpool as two kernels
     //   dbg4 = 3: slim selu' as its own pass, 4: conv1's unpool and weight gradient as two kernels
-    //   dbg5 = 1: all weight packing in one launch in stream order (>= 16: dbg5 >> 4 candidate ranges of fc4's weight gradient, bit 3 / bit 2: one / two input fragments per wave there)      dbg6 = n: row parts of dense_dgrad_unpool (few groups)
+    //   dbg5 = 1: all weight packing in one launch in stream order (>= 16: dbg5 >> 4 candidate ranges of fc4's weight gradient, bit 3 / bit 2: one / two input fragments per wave there)      dbg6 = n: row parts of dense_dgrad_unpool (few groups; + 100: 4-wave workgroups; 0 = chosen by the number of groups)
     //   dbg7 = 1: training-forward conv3 on conv_tm instead of conv3_rot
     int dbg[8];
     // option "train_sched": the round-5 re-cut of the step's schedule, one bit per change (default 3839 = all but bit 8; A/B runs and

@@ -3644,16 +3644,28 @@ int cv_tile_fc4_dgrad_unpool(cv_model *m, const float *g_tm, const float *pooled
         k<<<dim3(nblk(G, 16), 4 * NT), 512, lds, st>>>((const f4 *)g_tm, (const f4 *)m->wpr_fc4, (const f4 *)pooled,
                                                        (const u32x2 *)codes, (f4 *)gpre, G, HO, NT);
     } else {
-        // few groups: row parts (gridDim.z; each recomputes the two windows in front of its rows) would shorten the
-        // 24-row walk of a workgroup -- measured at 79 groups: 0.672 / 0.690 / 0.688 / 0.719 ms per step with 1 / 2 / 3 / 4
-        // parts, so one; dbg6 = parts for A/B.  (4-wave workgroups -- 240 instead of 120 CUs busy at 79 groups -- change
-        // nothing either, 0.620 against 0.615 ms: the weight gradients on the side streams use the other CUs meanwhile)
-        int parts = m->dbg[6] > 0 ? m->dbg[6] : 1;
+        // few groups: row parts (gridDim.z; each recomputes the two windows in front of its rows) shorten the 24-row walk of a
+        // workgroup, 4-wave workgroups put one wave on each SIMD of twice as many CUs.  Same values row for row.  Same-box
+        // steps (profiles/r06/dgrad_unpool_parts_ab.txt; 8 waves x 1 part / the form kept):  20 groups 0.424 / 0.379 ms
+        // (4 waves x 4 parts), 40 groups 0.449 / 0.403 (4 waves x 2 parts), 60 groups 0.465 / 0.451 and 79 groups 0.498 /
+        // 0.485 (8 waves x 2 parts); from 100 groups one part is the fastest again (0.587 / 0.597): the weight gradients on the
+        // side streams use the other CUs meanwhile.  dbg6 = parts (+ 100: 4-wave workgroups) for A/B.
+        int parts = G <= 24 ? 4 : G <= 80 ? 2 : 1;
+        bool four = G <= 48;
+        if (m->dbg[6] > 0) { parts = m->dbg[6] % 100; four = m->dbg[6] >= 100; }
         if (parts > 6) parts = 6;
-        auto k = dense_dgrad_unpool<21, 3, 8, 1>;
-        if (set_lds(k, lds)) return 1;
-        k<<<dim3(nblk(G, 8), 4 * NT, parts), 512, lds, st>>>((const f4 *)g_tm, (const f4 *)m->wpr_fc4, (const f4 *)pooled,
-                                                             (const u32x2 *)codes, (f4 *)gpre, G, HO, NT);
+        if (parts < 1) parts = 1;
+        if (four) {
+            auto k4 = dense_dgrad_unpool<21, 3, 4, 1>;
+            if (set_lds(k4, lds)) return 1;
+            k4<<<dim3(nblk(G, 4), 4 * NT, parts), 256, lds, st>>>((const f4 *)g_tm, (const f4 *)m->wpr_fc4, (const f4 *)pooled,
+                                                                  (const u32x2 *)codes, (f4 *)gpre, G, HO, NT);
+        } else {
+            auto k = dense_dgrad_unpool<21, 3, 8, 1>;
+            if (set_lds(k, lds)) return 1;
+            k<<<dim3(nblk(G, 8), 4 * NT, parts), 512, lds, st>>>((const f4 *)g_tm, (const f4 *)m->wpr_fc4, (const f4 *)pooled,
+                                                                 (const u32x2 *)codes, (f4 *)gpre, G, HO, NT);
+        }
     }
     CV_HIP(hipGetLastError());
     return 0;

@@ -209,7 +209,7 @@ def test_tiny_batch_kernel_variants_give_the_same_bits(oracle, arch, n):
     assert np.allclose(ks[0], three[0], rtol=1e-12, atol=0) and abs(ks[3] - three[3]) <= 1e-12 * abs(three[3])
 
 
-@pytest.mark.parametrize("arch,n", [("full", 1250), ("full", 83), ("full", 10000), ("slim", 1250), ("slim", 10000)])
+@pytest.mark.parametrize("arch,n", [("full", 1250), ("full", 83), ("full", 640), ("full", 10000), ("slim", 1250), ("slim", 10000)])
 def test_backward_kernel_variants_give_the_same_bits(oracle, arch, n):
     """development switches of the backward pass (full topology): fc4's data gradient fused with conv3's unpool or as
     two kernels (dbg3), one or three side streams for the weight gradients, weight packing on
@@ -238,7 +238,9 @@ def test_backward_kernel_variants_give_the_same_bits(oracle, arch, n):
     # (round 5: dbg2 = 4 the thread-per-row unpool at tiny batches instead of row segments; option train_sched: the bits of
     # the re-cut schedule -- early loss header, conv1's weight gradient on the main stream, one fork marker, shared launch-site
     # markers, per-layout packing -- switched off in groups)
-    variants = ({"dbg3": 1}, {"train_side_streams": 1}, {"dbg5": 1}, {"dbg6": 3}, {"dbg7": 1},
+    # (round 6: dbg6 = row parts of fc4's data gradient + unpool, + 100 = 4-wave workgroups; the default picks them by the
+    # number of groups -- 83 candidates: 4 waves x 4 parts, 640: 4 waves x 2, 1 250: 8 waves x 2, larger: 8 waves x 1)
+    variants = ({"dbg3": 1}, {"train_side_streams": 1}, {"dbg5": 1}, {"dbg6": 3}, {"dbg6": 1}, {"dbg6": 104}, {"dbg6": 102}, {"dbg7": 1},
                 {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7}, {"dbg1": 8}, {"dbg2": 3}, {"dbg3": 1, "train_overlap": 0},
                 {"dbg2": 4}, {"train_sched": 0}, {"train_sched": 254}, {"train_sched": 21}, {"train_sched": 42}, {"train_sched": 223}, {"train_sched": 191}, {"train_sched": 127}, {"train_sched": 511}, {"train_sched": 255}, {"train_sched": 1023}, {"train_sched": 1791}, {"dbg4": 4}, {"dbg2": 1}, {"dbg2": 2}, {"dbg5": 8}, {"dbg5": 4}) if arch == "full" else \
                ({"dbg4": 3}, {"train_side_streams": 1}, {"dbg0": 9, "dbg1": 9}, {"dbg0": 7, "dbg1": 7},
