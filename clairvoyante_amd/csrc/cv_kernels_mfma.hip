@@ -433,6 +433,8 @@ struct front_source {
 // (pooled) positions -- more waves in flight when a batch has few groups.
 // KS4: MFMA steps per 16-channel input fragment (4 channels each); a layer whose last fragment holds fewer than 16
 // real channels (slim conv2: 8) skips the steps that would multiply the zero padding -- they add an exact +0.
+// (waves per group that do not make whole 4-wave workgroups, or more than one: see the XCD-aware numbering in the kernel)
+#define CV_CONV_XCD_UNITS(W) ((W) != 1 && (W) != 2 && (W) != 4)
 template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT, int MODE, int HSPLIT = 1, int KS4 = 4>
 __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, const float *__restrict__ x,
                                                    int64_t n, const float *__restrict__ wp1,
@@ -453,7 +455,19 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
     for (int i = threadIdx.x; i < NFRAG * 64; i += 256) ldsw[i] = wp[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if constexpr (HSPLIT >= 1 && CV_CONV_XCD_UNITS(NT * HSPLIT)) {
+        // XCD-aware numbering (workgroup b runs on XCD b % 8, each XCD has its own L2): the NT x HSPLIT waves of a group read
+        // the same input rows (tiles) or overlapping ones (parts); when they do not fill whole workgroups they sit in
+        // consecutive workgroups = different XCDs, and the group's rows come in from HBM once per XCD (conv2's training
+        // forward at 625 groups, 2 tiles x 3 parts: 318 MB per launch for a 74 MB input and 150 MB of output).  Here XCD x
+        // owns the groups g = x (mod 8), as in conv3_rot; launch_conv pads the grid to whole XCD rows.  Speed only.
+        if (gridDim.x >= 16) {
+            const int x = blockIdx.x & 7;
+            const int lw = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4 + (threadIdx.x >> 6));
+            wv = ((lw / (NT * HSPLIT)) * 8 + x) * (NT * HSPLIT) + lw % (NT * HSPLIT);
+        }
+    }
     // HSPLIT >= 1: a wave owns part hs of the positions of ONE (group, tile).
     // HSPLIT == 0 (training, larger batches): a wave owns the output rows [r0, r1) of the flat (group, row) sequence
     // of its tile -- rows_per of them, whatever the group boundaries -- so that a launch is ONE round of equal waves
@@ -2728,6 +2742,8 @@ int launch_conv(const float *in, const float *x, int64_t n, const float *wp1, co
     size_t lds = (size_t)NT * KH * 4 * CINB * 1024;
     if (set_lds(k, lds)) return 1;
     unsigned grid = nblk((int64_t)G * NT * HSPLIT, 4);
+    if constexpr (HSPLIT >= 1 && CV_CONV_XCD_UNITS(NT * HSPLIT))
+        if (grid >= 16) grid = 8 * nblk((int64_t)((G + 7) / 8) * NT * HSPLIT, 4);       // per-XCD group numbering (see the kernel)
     int rows_per = 0;
     if constexpr (HSPLIT == 0) {
         // flat ranges: one round of equal waves.  slots = resident waves of this kernel (4-wave workgroups per CU by its
