@@ -133,6 +133,7 @@ struct cv_model {
     int inf_flat;
     // option "slim_waves": groups per workgroup of the slim topology's conv3 + fc4 kernel: 0 = from the number of groups (default), 2 / 4 / 8
     int inf_slim_waves;
+    int inf_slim_small_g;      // slim: passes of up to this many groups run the small-pass kernel set (cv_mfma_forward)
     int tiny_g;          // option "train_tiny_groups": batches of up to this many groups take the latency-oriented
                          // kernel variants of the training step (default 400; 0 = never)
     // fc4 dropout output / keep mask (a*keep) of the LAST training slice, for cv_get_activation 6 / 7

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
     static_assert(FRONT == 0 || CINB == 1, "the fused first layer feeds one 16-channel fragment");
     static_assert(MODE != 2 || (POOL == 1 && FRONT == 0), "the data-gradient pass has no pooling / first layer");
     static_assert(HSPLIT == 1 || FRONT == 0, "position ranges read their rows from a TM buffer");
-    static_assert(HSPLIT != 0 || (FRONT == 0 && MODE != 0), "flat ranges: training kernels");
+    static_assert(HSPLIT != 0 || (FRONT == 0 && (MODE != 0 || POOL == 1)), "flat ranges: training kernels, and inference layers without pooling (slim small passes)");
     extern __shared__ __attribute__((aligned(16))) f4 ldsw[];
     constexpr int PADT = MODE == 2 ? KH - 1 - (KH - 1) / 2 : (KH - 1) / 2;
     constexpr int PADL = MODE == 2 ? 2 : 1;
@@ -2825,6 +2825,41 @@ int launch_conv_parts(int hs, const float *in, const float *x, int64_t n, const 
 #undef CV_PARTS
 }
 
+// inference pass of a layer WITHOUT pooling over position parts (slim, small passes): 1, 2, 4 or 8 waves per (group, tile)
+template <int KH, int CINB, int NT, int HIN, int KS4 = 4>
+int launch_conv_parts_infer(int hs, const float *in, int64_t n, const float *wp, const float *bias, int cout, float *out, int G,
+                            hipStream_t st)
+{
+#define CV_PARTS(H) return launch_conv<KH, CINB, NT, 1, HIN, 0, 0, H, KS4>(in, nullptr, n, nullptr, nullptr, 0, wp, bias, cout, out, G, st)
+    switch (hs) {
+    case 0: CV_PARTS(0);          // equal ranges of the flat (group, row) sequence
+    case 2: CV_PARTS(2);
+    case 4: CV_PARTS(4);
+    case 8: CV_PARTS(8);
+    default: CV_PARTS(1);
+    }
+#undef CV_PARTS
+}
+// ... and how many: a launch costs (waves per slot, rounded up) x (positions per wave + what a wave pays before its first
+// position: the workgroup's weight fragments into LDS, its first window).  slots = the chip's SIMDs for a layer whose wave
+// keeps the matrix pipe of its SIMD busy on its own (slim conv3: 240 MFMAs per position, two waves on a SIMD take twice
+// the time of one), twice that for a layer whose positions are mostly activation arithmetic (slim conv2: 72 MFMAs).
+static int infer_parts(int G, int NT, int rows, int slots)
+{
+    // enough rows for equal ranges of at least 4 (launch_conv's flat form, two waves per SIMD): time proportional to the
+    // pass whatever the number of groups -- whole parts step where G NT hs passes a multiple of the chip (257 groups:
+    // 219 us against 143 at 256)
+    if ((long)G * rows * NT >= 4L * 2048) return 0;
+    int best = 1;
+    double best_cost = -1.0;
+    for (int hs = 1; hs <= 8; hs *= 2) {
+        const long waves = (long)G * NT * hs;
+        const double cost = (double)((waves + slots - 1) / slots) * ((rows + hs - 1) / hs + 3.0);
+        if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = hs; }
+    }
+    return best;
+}
+
 // flat_slots > 0 (training forward): flat ranges sized for that many resident waves.  flat_slots < 0 (inference, round 6):
 // whole groups or flat ranges, whichever the model says is shorter.  One wave alone on a SIMD already takes 93 % of its
 // matrix pipe (26 positions: 131 us alone, 245 us for two waves side by side), so what a launch costs is the number of
@@ -3061,8 +3096,10 @@ static int pack_launch(cv_model *m, hipStream_t st, unsigned mask)
         J.i[0] = a.fc4; J.i[1] = a.fc5; J.i[2] = s.nb4; J.i[3] = 4; J.i[4] = 4; J.i[5] = 3;
     }
     if ((mask & CVL_FC4S7) && m->wps7_fc4) {     // ... and in 7 slabs of 3 fragments for the one-wave-per-slab kernel of very small batches
-        pack_job &J = pb.add(3, (int64_t)7 * s.kb4 * 3 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wps7_fc4;
-        J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = 3; J.i[4] = 3; J.i[5] = 7;
+        // (slim, 3 output fragments: 3 slabs of one)
+        const int per = s.nb4 == 21 ? 3 : 1, nsl = s.nb4 == 21 ? 7 : s.nb4;
+        pack_job &J = pb.add(3, (int64_t)nsl * s.kb4 * per * 256); J.src[0] = P + o[6]; J.dst[0] = m->wps7_fc4;
+        J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = per; J.i[4] = per; J.i[5] = nsl;
     }
     if (mask & CVL_HEADS) {
         pack_job &J = pb.add(6, (int64_t)(s.nb4 + s.nb5) * 256 + (int64_t)s.nb5 * 16 * 12);
@@ -3196,6 +3233,12 @@ static int tail_args_refresh(cv_model *m, heads_args h, hipStream_t st, const he
 }
 
 // one chunk (n <= chunk) through the tile kernels
+// slim topology: does a pass over G groups run the small-pass kernel set?  (option "slim_small_groups")
+static bool slim_small_pass(const cv_model *m, int G)
+{
+    return is_slim(m->arch) && (m->variant & 128) && m->wps7_fc4 != nullptr && G <= m->inf_slim_small_g;
+}
+
 int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStream_t st)
 {
     if (n <= 0) return 0;
@@ -3344,6 +3387,45 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         } else {                            // (two groups per wave, as for fc4, measured: 79.5 -> 75.3 us; not worth a variant)
             m->stage_kernel[4] = "dense_tm<11, 4, 0, 1>";
             rc |= launch_dense<11, 4>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st);
+        }
+        cv_prof_end(m, 4, st);
+    } else if (slim_small_pass(m, G)) {
+        // Small passes of the slim topology (round 6).  The fused kernels walk the 33 positions of a group in ONE wave: the
+        // first two layers take 82 us and conv3 + fc4 330 us whether a pass has 63 groups or 1 024 (one 112 KB workgroup per
+        // CU) -- a predict() call of the reference's batch of 1 000 took 400 us, twice the full topology's.  Here, as in the
+        // full topology's small pass, the layers run unfused with their positions split over up to 8 waves (no pooling in
+        // this topology: nothing is recomputed), fc4 as one wave per (group, output fragment) straight from L2; fc5 and the
+        // heads as in larger passes.  Same values row for row.
+        int cusm = 256;
+        if (device_cus(&cusm)) return 1;
+        cv_prof_begin(m, 0, st);
+        m->stage_kernel[0] = "conv1_tm<1, false>";
+        conv1_tm<1><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, W1, B1, a.cout[0], (f4 *)m->tm_p1, G);
+        cv_prof_end(m, 0, st);
+        cv_prof_begin(m, 1, st);
+        static const char *const n2[5] = {"conv_tm<3, 1, 1, 1, 33, 0, 0, 0, 2>", "conv_tm<3, 1, 1, 1, 33, 0, 0, 1, 2>", "conv_tm<3, 1, 1, 1, 33, 0, 0, 2, 2>", "conv_tm<3, 1, 1, 1, 33, 0, 0, 4, 2>", "conv_tm<3, 1, 1, 1, 33, 0, 0, 8, 2>"};
+        static const char *const n3[5] = {"conv_tm<5, 1, 2, 1, 33, 0, 0, 0, 4>", "conv_tm<5, 1, 2, 1, 33, 0, 0, 1, 4>", "conv_tm<5, 1, 2, 1, 33, 0, 0, 2, 4>", "conv_tm<5, 1, 2, 1, 33, 0, 0, 4, 4>", "conv_tm<5, 1, 2, 1, 33, 0, 0, 8, 4>"};
+        auto slot_of = [](int hs) { return hs == 8 ? 4 : hs == 4 ? 3 : hs == 2 ? 2 : hs == 1 ? 1 : 0; };
+        const int hs2 = infer_parts(G, 1, 33, 8 * cusm), hs3 = infer_parts(G, 2, 33, 4 * cusm);
+        m->stage_kernel[1] = n2[slot_of(hs2)];
+        rc |= launch_conv_parts_infer<3, 1, 1, 33, 2>(hs2, m->tm_p1, n, m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
+        cv_prof_end(m, 1, st);
+        cv_prof_begin(m, 2, st);
+        m->stage_kernel[2] = n3[slot_of(hs3)];
+        rc |= launch_conv_parts_infer<5, 1, 2, 33>(hs3, m->tm_p2, n, m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st);
+        cv_prof_end(m, 2, st);
+        cv_prof_begin(m, 3, st);
+        m->stage_kernel[3] = "dense_small<1, 8, 0>";
+        rc |= launch_dense_small<1, 8>(m->tm_p3, s.kb4, m->wps7_fc4, P + o[7], a.fc4, m->tm_h4, G, s.nb4, st);
+        cv_prof_end(m, 3, st);
+        cv_prof_begin(m, 4, st);
+        if (m->variant & 512) {
+            m->stage_kernel[4] = "dense_tm<2, 4, 2, 1>";
+            rc |= launch_dense<2, 4, 2>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st, 1, 1, nullptr, hd);
+            heads_done = true;
+        } else {
+            m->stage_kernel[4] = "dense_tm<2, 4, 0, 1>";
+            rc |= launch_dense<2, 4>(m->tm_h4, s.nb4, m->wp_fc5, P + o[9], a.fc5, m->tm_h5, G, st);
         }
         cv_prof_end(m, 4, st);
     } else {

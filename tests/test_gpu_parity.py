@@ -178,17 +178,18 @@ def test_every_size_of_the_ladder_gives_the_bits_of_small_chunks(setup):
 def test_forced_launch_shapes_give_the_same_bits(setup, n):
     """the shapes the estimates choose between, each forced at sizes where it is NOT the default (ragged last group):
     every fc4 slab shape s = 4 .. 14 and the round-5 slab kernel (option dense_rag), whole groups / flat ranges for the
-    convolutions (infer_flat 0 / 2), 4- / 8-wave slim workgroups (slim_waves), the slab form / the fused tail by a fixed
-    line (infer_slab_groups)"""
+    convolutions (infer_flat 0 / 2), 4- / 8-wave slim workgroups (slim_waves), the slim topology's small-pass kernel set at
+    every size / never (slim_small_groups), the slab form / the fused tail by a fixed line (infer_slab_groups)"""
     from clairvoyante_amd import synth
     arch, P, m, x, ref = setup
     m.setOption("impl", 1); m.setOption("variant", common.DEFAULT_VARIANT); m.setOption("chunk", 65536)
     xd = synth.make_candidates(n, seed=83, device="cuda")
     want = m.predict_device(xd).cpu().numpy()
-    settings = [{"infer_flat": 0}, {"infer_flat": 2}, {"slim_waves": 4}, {"slim_waves": 8}, {"infer_slab_groups": 0},
+    settings = [{"infer_flat": 0}, {"infer_flat": 2}, {"slim_waves": 4}, {"slim_waves": 8}, {"slim_small_groups": 65536},
+                {"slim_small_groups": 0}, {"infer_slab_groups": 0},
                 {"infer_slab_groups": 65536}, {"dense_rag": -1, "infer_slab_groups": 65536}]
     settings += [{"dense_rag": s, "infer_slab_groups": 65536, "infer_flat": 2 if s % 2 else 0} for s in range(4, 15)]
-    defaults = {"infer_flat": 1, "slim_waves": 0, "infer_slab_groups": -1, "dense_rag": 0}
+    defaults = {"infer_flat": 1, "slim_waves": 0, "slim_small_groups": 640, "infer_slab_groups": -1, "dense_rag": 0}
     try:
         for st in settings:
             for k, v in defaults.items():
