@@ -123,7 +123,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     m->tiny_g = 400;
     // (rounds 1-4: 160 / 256 / 2 048, set where each kernel was first tuned; a ladder of batch sizes showed steps of 75 us,
     // 105 us and 840 us in the time of a call one group past each line: profiles/r05/infer_size_sweep.txt)
-    m->inf_small_g = 256; m->inf_fc4_small_g = 288; m->inf_slab_g = -1; m->inf_flat = 1; m->inf_slim_small_g = 640;      // (-1: fc4's kernel form by estimate, cv_mfma_forward)
+    m->inf_small_g = 256; m->inf_fc4_small_g = 288; m->inf_slab_g = -1; m->inf_flat = 1; m->inf_slim_small_g = -1;      // (-1: fc4's kernel form by estimate, cv_mfma_forward)
     m->sched = 3839;
     alloc(&m->wp_conv1, 4 * 64);
     for (int l = 1; l < 3; l++) alloc(&m->wp_conv[l], (size_t)s.ntile[l] * arch->kh[l] * 4 * s.cinb[l] * 256);
@@ -259,7 +259,7 @@ extern "C" int cv_set_option(cv_model *m, const char *key, int64_t value)
     if (!strcmp(key, "infer_slab_groups")) { m->inf_slab_g = value < 0 ? -1 : (int)(value > 65536 ? 65536 : value); return 0; }
     if (!strcmp(key, "infer_flat")) { m->inf_flat = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return 0; }
     if (!strcmp(key, "slim_waves")) { m->inf_slim_waves = (value == 4 || value == 8) ? (int)value : 0; return 0; }
-    if (!strcmp(key, "slim_small_groups")) { m->inf_slim_small_g = value < 0 ? 0 : (int)(value > 65536 ? 65536 : value); return 0; }
+    if (!strcmp(key, "slim_small_groups")) { m->inf_slim_small_g = value < 0 ? -1 : (int)(value > 65536 ? 65536 : value); return 0; }
     if (!strcmp(key, "dense_rag")) { m->inf_rag_s = value < 0 ? -1 : (value > 14 ? 14 : (int)value); return 0; }
     if (!strcmp(key, "train_tiny_groups")) { m->tiny_g = value < 0 ? 0 : (value > 4096 ? 4096 : (int)value); return 0; }
     if (!strcmp(key, "variant")) { m->variant = (int)value; return 0; }

@@ -3234,9 +3234,20 @@ static int tail_args_refresh(cv_model *m, heads_args h, hipStream_t st, const he
 
 // one chunk (n <= chunk) through the tile kernels
 // slim topology: does a pass over G groups run the small-pass kernel set?  (option "slim_small_groups")
+// Default (-1): whichever an estimate says is shorter.  The unfused set runs on equal flat ranges, its time is linear in the
+// pass, 0.46 us per group + 25; the fused pair is a staircase -- the front kernel 65 us per started 1 024 groups + 20, conv3 +
+// fc4 one 112 KB workgroup per CU, 337 us per round of 4-group workgroups or 614 us per round of 8-group ones.  The fused
+// pair wins where a round is nearly full (1 024, 2 048, 3 072, 4 096 groups and the few hundred below each), the unfused
+// set everywhere else up to ~3 100 groups (profiles/r06/slim_small_pass.txt).
 static bool slim_small_pass(const cv_model *m, int G)
 {
-    return is_slim(m->arch) && (m->variant & 128) && m->wps7_fc4 != nullptr && G <= m->inf_slim_small_g;
+    if (!is_slim(m->arch) || !(m->variant & 128) || m->wps7_fc4 == nullptr) return false;
+    if (m->inf_slim_small_g >= 0) return G <= m->inf_slim_small_g;
+    const double unfused = 0.46 * G + 25.0;
+    const long r8 = ((G + 7) / 8 + 255) / 256, r4 = ((G + 3) / 4 + 255) / 256;
+    const double k8 = 614.0 * r8, k4 = 337.0 * r4;
+    const double fused = 65.0 * ((G + 1023) / 1024) + 20.0 + (k8 < k4 ? k8 : k4);
+    return unfused < 0.97 * fused;
 }
 
 int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStream_t st)

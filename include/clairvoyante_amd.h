@@ -143,10 +143,11 @@ int cv_selu_sweep(int device, uint32_t lo_bits, uint32_t hi_bits, uint64_t *viol
  * convolution kernel of an inference pass runs on equal ranges of the flat (group, row) sequence when a whole-group launch
  * would leave SIMDs with a wave more than others; 0 = always whole groups, 2 = always flat ranges; same bits),
  * "slim_waves" (0 default: groups per workgroup of the slim topology's conv3 + fc4 kernel -- 8 or 4 -- from the number of
- * groups, so that a small pass spreads over all CUs; 4 / 8 = that many; same bits), "slim_small_groups" (0..65536, default
- * 640: passes of the slim topology of up to that many groups run their layers unfused, positions split over several waves
- * or equal ranges of the flat (group, row) sequence, fc4 as one wave per (group, output fragment) -- a predict() call of
- * 1 000 candidates takes 84 us instead of 400; same bits),
+ * groups, so that a small pass spreads over all CUs; 4 / 8 = that many; same bits), "slim_small_groups" (-1 default: a pass
+ * of the slim topology runs its layers unfused -- positions split over several waves or equal ranges of the flat (group,
+ * row) sequence, fc4 as one wave per (group, output fragment); time linear in the pass -- wherever an estimate says the
+ * fused kernels' rounds of workgroups would take longer: a predict() call of 1 000 candidates takes 84 us instead of 400,
+ * 32 784 candidates 0.98 ms instead of 1.18; 0..65536 = up to that many groups, fused beyond; same bits),
  * "train_tiny_groups" (0..4096, default 400: training batches of up to that many groups of 16 candidates split the
  * serial loops of their layers over more waves -- same bits; the position parts of the convolutions stop at 80 groups
  * whatever the value), "train_ksplit" (0/1, default 1: at such batches

@@ -189,7 +189,7 @@ def test_forced_launch_shapes_give_the_same_bits(setup, n):
                 {"slim_small_groups": 0}, {"infer_slab_groups": 0},
                 {"infer_slab_groups": 65536}, {"dense_rag": -1, "infer_slab_groups": 65536}]
     settings += [{"dense_rag": s, "infer_slab_groups": 65536, "infer_flat": 2 if s % 2 else 0} for s in range(4, 15)]
-    defaults = {"infer_flat": 1, "slim_waves": 0, "slim_small_groups": 640, "infer_slab_groups": -1, "dense_rag": 0}
+    defaults = {"infer_flat": 1, "slim_waves": 0, "slim_small_groups": -1, "infer_slab_groups": -1, "dense_rag": 0}
     try:
         for st in settings:
             for k, v in defaults.items():
