@@ -123,7 +123,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     m->tiny_g = 400;
     // (rounds 1-4: 160 / 256 / 2 048, set where each kernel was first tuned; a ladder of batch sizes showed steps of 75 us,
     // 105 us and 840 us in the time of a call one group past each line: profiles/r05/infer_size_sweep.txt)
-    m->inf_small_g = 256; m->inf_fc4_small_g = 288; m->inf_slab_g = -1; m->inf_flat = 1; m->inf_slim_small_g = -1;      // (-1: fc4's kernel form by estimate, cv_mfma_forward)
+    m->inf_small_g = 256; m->inf_fc4_small_g = 288; m->inf_slab_g = -1; m->inf_flat = 1; m->inf_slim_small_g = -1; m->inf_fc4_one_g = 80;      // (-1: fc4's kernel form by estimate, cv_mfma_forward)
     m->sched = 3839;
     alloc(&m->wp_conv1, 4 * 64);
     for (int l = 1; l < 3; l++) alloc(&m->wp_conv[l], (size_t)s.ntile[l] * arch->kh[l] * 4 * s.cinb[l] * 256);
@@ -135,6 +135,7 @@ extern "C" int cv_create(const cv_arch *arch, int device, cv_model **out)
     if (s.nb4 == 21 && s.ntile[2] == 3 && arch->pool[2] == 3) alloc(&m->wpr_fc4, (size_t)4 * s.ntile[2] * s.hp[2] * 24 * 256);
     if (s.nb4 == 21) alloc(&m->wps_fc4, (size_t)3 * s.kb4 * 8 * 256);
     if (s.nb4 == 21) alloc(&m->wps7_fc4, (size_t)7 * s.kb4 * 3 * 256);
+    if (s.nb4 == 21) alloc(&m->wps21_fc4, (size_t)21 * s.kb4 * 256);
     else if (s.nb4 == 3) alloc(&m->wps7_fc4, (size_t)3 * s.kb4 * 256);          // slim: 3 slabs of one fragment
     if (s.nb4 == 21 && s.nb5 == 11) alloc(&m->wps3_fc5, (size_t)3 * s.nb4 * 4 * 256);
     if (s.nb4 == 21 && s.nb5 == 11) alloc(&m->wp5p_fc5, (size_t)((s.nb4 + 3) / 4) * 48 * 256);
@@ -159,7 +160,7 @@ extern "C" int cv_destroy(cv_model *m)
     if (!m) return 0;
     hipSetDevice(m->device);
     float *bufs[] = {m->params, m->grads_own, m->adam_m, m->adam_v, m->wp_conv1, m->wp_conv[1], m->wp_conv[2],
-                     m->wp_fc4, m->wp_fc5, m->wp_heads0, m->wp_heads1, m->wp_heads12, m->wpd_conv[1], m->wpd_conv[2], m->wpd_fc4, m->wpr_fc4, m->wpd_fc5, m->wps_fc4, m->wps7_fc4, m->wps3_fc5, m->wp5p_fc5, m->wg_part, m->tm_p1, m->tm_p2, m->tm_p3, m->tm_h4, m->tm_h5, m->r_a[0],
+                     m->wp_fc4, m->wp_fc5, m->wp_heads0, m->wp_heads1, m->wp_heads12, m->wpd_conv[1], m->wpd_conv[2], m->wpd_fc4, m->wpr_fc4, m->wpd_fc5, m->wps_fc4, m->wps7_fc4, m->wps21_fc4, m->wps3_fc5, m->wp5p_fc5, m->wg_part, m->tm_p1, m->tm_p2, m->tm_p3, m->tm_h4, m->tm_h5, m->r_a[0],
                      m->r_a[1], m->r_a[2], m->r_p[0], m->r_p[1], m->r_p[2], m->r_h4, m->r_h5, m->t_buf, m->tr_keep};
     for (float *b : bufs)
         if (b) hipFree(b);
@@ -256,6 +257,7 @@ extern "C" int cv_set_option(cv_model *m, const char *key, int64_t value)
     if (!strcmp(key, "train_side_streams")) { m->train_sides = value < 1 ? 1 : (value > 3 ? 3 : (int)value); return 0; }
     if (!strcmp(key, "infer_small_groups")) { m->inf_small_g = value < 0 ? 0 : (int)(value > 65536 ? 65536 : value); return 0; }
     if (!strcmp(key, "infer_fc4_small_groups")) { m->inf_fc4_small_g = value < 0 ? 0 : (int)(value > 65536 ? 65536 : value); return 0; }
+    if (!strcmp(key, "infer_fc4_one_groups")) { m->inf_fc4_one_g = value < 0 ? 0 : (int)(value > 65536 ? 65536 : value); return 0; }
     if (!strcmp(key, "infer_slab_groups")) { m->inf_slab_g = value < 0 ? -1 : (int)(value > 65536 ? 65536 : value); return 0; }
     if (!strcmp(key, "infer_flat")) { m->inf_flat = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return 0; }
     if (!strcmp(key, "slim_waves")) { m->inf_slim_waves = (value == 4 || value == 8) ? (int)value : 0; return 0; }
@@ -286,6 +288,7 @@ extern "C" int cv_get_option(const cv_model *m, const char *key, int64_t *value)
     if (!strcmp(key, "train_side_streams")) { *value = m->train_sides; return 0; }
     if (!strcmp(key, "infer_small_groups")) { *value = m->inf_small_g; return 0; }
     if (!strcmp(key, "infer_fc4_small_groups")) { *value = m->inf_fc4_small_g; return 0; }
+    if (!strcmp(key, "infer_fc4_one_groups")) { *value = m->inf_fc4_one_g; return 0; }
     if (!strcmp(key, "infer_slab_groups")) { *value = m->inf_slab_g; return 0; }
     if (!strcmp(key, "infer_flat")) { *value = m->inf_flat; return 0; }
     if (!strcmp(key, "slim_waves")) { *value = m->inf_slim_waves; return 0; }

@@ -73,7 +73,8 @@ struct cv_model {
     size_t wg_part_bytes;
     size_t wg_off[6], wg_size[6];   // regions of wg_part in floats (CV_WG_REGIONS), one per weight-gradient launch site
     float *wps_fc4;      // forward weights of fc4 in 3 slabs [slab][kb][8][64][4] (full topology, small batches)
-    float *wps7_fc4;     // ... and in 7 slabs [slab][kb][3][64][4] (dense_small: one wave per group and slab)
+    float *wps7_fc4;     // ... and in 7 slabs [slab][kb][3][64][4] (dense_small: one wave per group and slab; slim: 3 slabs of one)
+    float *wps21_fc4;    // full topology: 21 slabs of one fragment [slab][kb][1][64][4] (dense_small, the smallest inference passes)
     float *wps3_fc5;     // fc5 in 3 slabs [slab][kb][4][64][4] (dense_small)
     void *tail_dev;      // device copy of the tail arguments of the fused fc4 + fc5 + heads kernel (dense_tm EPI 3)
     unsigned char tail_host[256];   // what tail_dev holds
@@ -125,6 +126,7 @@ struct cv_model {
     // "infer_slab_groups"): up to inf_small_g the convolutions unfused with their positions over four waves, up to
     // inf_fc4_small_g fc4 / fc5 as one wave per (group, slab), up to inf_slab_g fc4 as three output slabs per group block
     int inf_small_g, inf_fc4_small_g, inf_slab_g;
+    int inf_fc4_one_g;         // ... up to this many groups fc4 as one wave per (group, fragment) (21 slabs)
     // option "dense_rag": fc4's three-slab form on ragged waves (dense_rag, round 6): 0 = shape by formula (default), 4..14 = that many
     // tile-units per SIMD and workgroup (A/B, calibration), -1 = the round-5 kernel (one group x 7 tiles per wave)
     int inf_rag_s;
@@ -199,7 +201,8 @@ enum : unsigned {
     CVL_DCONV = 256u,   // wpd_conv[1..2]
     CVL_DFC4 = 512u,    // wpr_fc4 or wpd_fc4 (by dbg3)
     CVL_DFC5 = 1024u,   // wpd_fc5
-    CVL_FORWARD = CVL_CONV | CVL_FC4 | CVL_FC5 | CVL_FC5P | CVL_FC4S3 | CVL_FC5S3 | CVL_FC4S7 | CVL_HEADS,
+    CVL_FC4S21 = 2048u, // wps21_fc4
+    CVL_FORWARD = CVL_CONV | CVL_FC4 | CVL_FC5 | CVL_FC5P | CVL_FC4S3 | CVL_FC5S3 | CVL_FC4S7 | CVL_FC4S21 | CVL_HEADS,
     CVL_BACKWARD = CVL_DCONV | CVL_DFC4 | CVL_DFC5,
 };
 inline void cv_layouts_stale(cv_model *m, unsigned which = ~0u) { m->packed_valid &= ~which; }

@@ -2825,6 +2825,33 @@ int launch_conv_parts(int hs, const float *in, const float *x, int64_t n, const 
 #undef CV_PARTS
 }
 
+// inference pass of a POOLED layer over 2, 4 or 8 position parts (full topology, small passes; parts recompute the window overlap)
+template <int KH, int CINB, int NT, int POOL, int HIN>
+int launch_conv_parts_pooled(int hs, const float *in, int64_t n, const float *wp, const float *bias, int cout, float *out, int G,
+                             hipStream_t st)
+{
+#define CV_PARTS(H) return launch_conv<KH, CINB, NT, POOL, HIN, 0, 0, H>(in, nullptr, n, nullptr, nullptr, 0, wp, bias, cout, out, G, st)
+    switch (hs) {
+    case 2: CV_PARTS(2);
+    case 8: CV_PARTS(8);
+    default: CV_PARTS(4);
+    }
+#undef CV_PARTS
+}
+static int pooled_parts(int G, int NT, int rows, int overlap)
+{
+    int best = 4;
+    long best_cost = -1;
+    for (int hs = 2; hs <= 8; hs *= 2) {
+        const long waves = (long)G * NT * hs;
+        // (per SIMD, not per wave slot: measured at 63 groups, conv3 in 8 parts = 1 512 waves 57.8 us against 50.5 in 4 = 756 waves;
+        // conv2 in 8 parts = 1 008 waves 21.7 us against 27.7 -- two of these waves on a SIMD take twice the time of one)
+        const long cost = ((waves + 1023) / 1024) * ((rows + hs - 1) / hs + overlap + 1);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = hs; }
+    }
+    return best;
+}
+
 // inference pass of a layer WITHOUT pooling over position parts (slim, small passes): 1, 2, 4 or 8 waves per (group, tile)
 template <int KH, int CINB, int NT, int HIN, int KS4 = 4>
 int launch_conv_parts_infer(int hs, const float *in, int64_t n, const float *wp, const float *bias, int cout, float *out, int G,
@@ -3101,6 +3128,10 @@ static int pack_launch(cv_model *m, hipStream_t st, unsigned mask)
         pack_job &J = pb.add(3, (int64_t)nsl * s.kb4 * per * 256); J.src[0] = P + o[6]; J.dst[0] = m->wps7_fc4;
         J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = per; J.i[4] = per; J.i[5] = nsl;
     }
+    if ((mask & CVL_FC4S21) && m->wps21_fc4) {   // ... and in 21 slabs of one (inference passes of up to ~100 groups)
+        pack_job &J = pb.add(3, (int64_t)21 * s.kb4 * 256); J.src[0] = P + o[6]; J.dst[0] = m->wps21_fc4;
+        J.i[0] = s.flat; J.i[1] = a.fc4; J.i[2] = s.kb4; J.i[3] = 1; J.i[4] = 1; J.i[5] = 21;
+    }
     if (mask & CVL_HEADS) {
         pack_job &J = pb.add(6, (int64_t)(s.nb4 + s.nb5) * 256 + (int64_t)s.nb5 * 16 * 12);
         J.src[0] = P + o[10]; J.src[1] = P + o[12]; J.src[2] = P + o[14]; J.src[3] = P + o[16];
@@ -3288,8 +3319,10 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             conv1_tm<5><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, W1, B1, a.cout[0], (f4 *)m->tm_p1, G);
             cv_prof_end(m, 0, st);
             cv_prof_begin(m, 1, st);
-            m->stage_kernel[1] = "conv_tm<2, 1, 2, 4, 29, 0, 0, 4>";
-            rc |= launch_conv<2, 1, 2, 4, 29, 0, 0, 4>(m->tm_p1, x, n, W1, B1, a.cout[0], m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
+            // (round 6: 2, 4 or 8 parts by the number of groups -- 63 groups: 8 parts of 4 + 3 rows instead of 4 of 7 + 3)
+            const int hs2 = m->dbg[0] == 4 ? 4 : pooled_parts(G, 2, 26, 3);
+            m->stage_kernel[1] = hs2 == 8 ? "conv_tm<2, 1, 2, 4, 29, 0, 0, 8>" : hs2 == 2 ? "conv_tm<2, 1, 2, 4, 29, 0, 0, 2>" : "conv_tm<2, 1, 2, 4, 29, 0, 0, 4>";
+            rc |= launch_conv_parts_pooled<2, 1, 2, 4, 29>(hs2, m->tm_p1, n, m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st);
             cv_prof_end(m, 1, st);
         } else if (fuse_front && (m->variant & 64)) {
             cv_prof_begin(m, 1, st);
@@ -3335,7 +3368,11 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             cv_prof_end(m, 1, st);
         }
         cv_prof_begin(m, 2, st);
-        if (small_pass) { m->stage_kernel[2] = "conv_tm<3, 2, 3, 3, 26, 0, 0, 4>"; rc |= launch_conv<3, 2, 3, 3, 26, 0, 0, 4>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st); }
+        if (small_pass) {
+            const int hs3 = m->dbg[0] == 4 ? 4 : pooled_parts(G, 3, 24, 2);
+            m->stage_kernel[2] = hs3 == 8 ? "conv_tm<3, 2, 3, 3, 26, 0, 0, 8>" : hs3 == 2 ? "conv_tm<3, 2, 3, 3, 26, 0, 0, 2>" : "conv_tm<3, 2, 3, 3, 26, 0, 0, 4>";
+            rc |= launch_conv_parts_pooled<3, 2, 3, 3, 26>(hs3, m->tm_p2, n, m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st);
+        }
         else if (m->variant & 8) { m->stage_kernel[2] = "conv3_rot<2, 3, 26, 4, 2, false>"; rc |= launch_conv3_rot<2, 3, 26, 4, 2>(m->tm_p2, m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st, nullptr, m->inf_flat == 0 ? 0 : (m->inf_flat == 2 ? -2 : -1)); }
         else { m->stage_kernel[2] = "conv_tm<3, 2, 3, 3, 26, 0, 0, 1>"; rc |= launch_conv<3, 2, 3, 3, 26, 0>(m->tm_p2, x, n, W1, B1, a.cout[0], m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st); }
         cv_prof_end(m, 2, st);
@@ -3362,7 +3399,14 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         else if (!can_rag) form = 2;
         else if (m->inf_slab_g >= 0) form = G <= m->inf_slab_g ? 1 : 2;
         else form = us_wide < us_rag ? 2 : 1;
-        if (form == 0) { m->stage_kernel[3] = "dense_small<3, 8, 0>"; rc |= launch_dense_small<3, 8>(m->tm_p3, s.kb4, m->wps7_fc4, P + o[7], a.fc4, m->tm_h4, G, 7, st); }
+        if (form == 0 && m->wps21_fc4 && G <= m->inf_fc4_one_g) {
+            // the smallest passes: one wave per (group, output fragment) -- a wave's chain is 288 x 4 MFMAs instead of 288 x 12
+            // (16 groups 31.7 us against 79.5, 63 groups 63.6 against 82.1, 100 groups 97.7 against 83.5: option
+            // infer_fc4_one_groups, 80)
+            m->stage_kernel[3] = "dense_small<1, 8, 0>";
+            rc |= launch_dense_small<1, 8>(m->tm_p3, s.kb4, m->wps21_fc4, P + o[7], a.fc4, m->tm_h4, G, 21, st);
+        }
+        else if (form == 0) { m->stage_kernel[3] = "dense_small<3, 8, 0>"; rc |= launch_dense_small<3, 8>(m->tm_p3, s.kb4, m->wps7_fc4, P + o[7], a.fc4, m->tm_h4, G, 7, st); }
         else if (form == 1 && m->inf_rag_s >= 0) { m->stage_kernel[3] = "dense_rag<7, 8>"; rc |= launch_dense_rag(m->tm_p3, s.kb4, m->wps_fc4, P + o[7], a.fc4, m->tm_h4, G, s.nb4, m->inf_rag_s, st); }
         else if (form == 1) { m->stage_kernel[3] = "dense_tm<7, 8, 0, 1>"; rc |= launch_dense<7, 8>(m->tm_p3, s.kb4, m->wps_fc4, P + o[7], a.fc4, m->tm_h4, G, st, 3); }
         else if (can_fused) {      // fc4 + fc5 + heads as one kernel

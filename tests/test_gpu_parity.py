@@ -141,7 +141,9 @@ def test_passes_either_side_of_every_size_line_give_the_same_bits(setup):
     m.setOption("chunk", 2048)
     want = m.predict_device(xd).cpu().numpy()
     m.setOption("chunk", 65536)
-    for n in (2560, 2577, 4096, 4113, 4608, 4625, 32768, 32785, 54400, 54417):
+    # (round 6: up to 80 groups fc4 runs as one wave per (group, output fragment) -- option infer_fc4_one_groups; the position
+    # parts of the small-pass convolutions are 8 / 4 / 2 by the number of groups; slim: the small-pass set by estimate)
+    for n in (250, 1000, 1280, 1297, 1600, 2560, 2577, 4096, 4113, 4608, 4625, 32768, 32785, 54400, 54417):
         got = m.predict_device(xd[:n].contiguous()).cpu().numpy()
         assert np.array_equal(got.view(np.uint32), want[:n].view(np.uint32)), n
     for key, value in (("infer_small_groups", 160), ("infer_fc4_small_groups", 256), ("infer_slab_groups", 2048)):
@@ -185,11 +187,11 @@ def test_forced_launch_shapes_give_the_same_bits(setup, n):
     m.setOption("impl", 1); m.setOption("variant", common.DEFAULT_VARIANT); m.setOption("chunk", 65536)
     xd = synth.make_candidates(n, seed=83, device="cuda")
     want = m.predict_device(xd).cpu().numpy()
-    settings = [{"infer_flat": 0}, {"infer_flat": 2}, {"slim_waves": 4}, {"slim_waves": 8}, {"slim_small_groups": 65536},
+    settings = [{"infer_flat": 0}, {"infer_flat": 2}, {"infer_fc4_one_groups": 65536}, {"infer_fc4_one_groups": 0}, {"slim_waves": 4}, {"slim_waves": 8}, {"slim_small_groups": 65536},
                 {"slim_small_groups": 0}, {"infer_slab_groups": 0},
                 {"infer_slab_groups": 65536}, {"dense_rag": -1, "infer_slab_groups": 65536}]
     settings += [{"dense_rag": s, "infer_slab_groups": 65536, "infer_flat": 2 if s % 2 else 0} for s in range(4, 15)]
-    defaults = {"infer_flat": 1, "slim_waves": 0, "slim_small_groups": -1, "infer_slab_groups": -1, "dense_rag": 0}
+    defaults = {"infer_flat": 1, "infer_fc4_one_groups": 80, "slim_waves": 0, "slim_small_groups": -1, "infer_slab_groups": -1, "dense_rag": 0}
     try:
         for st in settings:
             for k, v in defaults.items():
