@@ -1,5 +1,5 @@
 #!/bin/bash
-# Training-step A/B on ONE box, alternating (box-to-box differences are as large as the effects measured): the round-4
+# Training-step A/B on ONE box, alternating (box-to-box differences are as large as the effects measured): the base
 # library (csrc/libclairvoyante_hip_base.so, built from that commit with clairvoyante_amd/build.py's flags) against the
 # in-tree build, plus any number of in-tree settings given as "label|bench flags".  How profiles/r05/step_ab_*.txt were made.
 #   bash tools/gpu_step_ab.sh TAG "1250 10000" 3 "sched 255|--sched 255" "two kernels for conv1|--dbg 4=4"
@@ -19,10 +19,10 @@ r=json.loads(sys.stdin.read()); print('%s batch %5d %-52s %.3f ms' % (r['config'
 }
 for round in $(seq $R); do
   for b in $BATCHES; do
-    [ -f $A ] && run "round-4 library" $b $A
+    [ -f $A ] && run "base library" $b $A
     run "in-tree" $b ""
     for spec in "$@"; do run "in-tree, ${spec%%|*}" $b "" ${spec#*|}; done
-    [ -f $A ] && run "round-4 library" $b $A --arch slim
+    [ -f $A ] && run "base library" $b $A --arch slim
     run "in-tree" $b "" --arch slim
   done
 done

@@ -17,8 +17,14 @@ cp $OUT/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null     # the bench b
 bash tools/gpu_pmc_train.sh $(basename $OUT)_t $HEAD > $OUT/pmc_train.log 2>&1
 cp gpurun_out/$(basename $OUT)_t/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
-# round 4's library against the in-tree one on this box (only if the base library was built and shipped)
-[ -f clairvoyante_amd/csrc/libclairvoyante_hip_base.so ] && bash tools/gpu_step_ab.sh $(basename $OUT)_ab "1250 10000" 2 > $OUT/step_ab_r04_vs_final.txt 2>&1
+# the previous round's library (clairvoyante_amd/csrc/libclairvoyante_hip_base.so, built from that commit with its own flags)
+# against the in-tree one on this box, alternating (only if the base library was built and shipped)
+[ -f clairvoyante_amd/csrc/libclairvoyante_hip_base.so ] && bash tools/gpu_step_ab.sh $(basename $OUT)_ab "320 1250 5000 10000" 2 > $OUT/step_ab_base_vs_final.txt 2>&1
+# cv_forward over the ladder of pass sizes (full, slim), per stage
+python tools/gpu_infer_stage_ladder.py full > $OUT/infer_stage_ladder_full.txt 2>> $OUT/bench.err
+python tools/gpu_infer_stage_ladder.py slim > $OUT/infer_stage_ladder_slim.txt 2>> $OUT/bench.err
+SIZES="320 640 1250 2500 5000 8000 10000 12288 16384 32768" STEPS=30 bash tools/gpu_step_size_sweep.sh $(basename $OUT)_steps > /dev/null 2>&1
+cp gpurun_out/$(basename $OUT)_steps/step_sizes.txt $OUT/step_size_ladder.txt 2>/dev/null
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 python bench.py --arch slim --no-cpu > $OUT/bench_slim.json 2>> $OUT/bench.err
 for b in 1250 10000; do python bench.py --mode train --batch $b --steps 50 --warmup 5 >> $OUT/bench_train.jsonl 2>> $OUT/bench.err; done
