@@ -3344,7 +3344,7 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
                 k<<<nblk((int64_t)G * 26, rp), 128, lds, st>>>(x, n, W1, B1, a.cout[0], (const f4 *)m->wp_conv[1], P + o[3], a.cout[1],
                                                                (f4 *)m->tm_p2, G, rp);
             } else {
-                m->stage_kernel[1] = "front2_tm<6>";
+                m->stage_kernel[1] = "front2_tm<6, false>";
                 auto k = front2_tm<6>;
                 const size_t lds = (size_t)(16 + 2 * 6 * 4) * 1024;
                 if (set_lds(k, lds)) return 1;
