@@ -1036,9 +1036,11 @@ def main():
         gb = param.trainBatchSize
         tr = {}
         sizes = [(str(gb), gb)] + ([("1250", gb // 8)] if ws == 1 else [("%d_per_rank" % gb, gb * ws)])
+        # (50 steps behind 5 warm-up steps, as `--mode train` in the validation script: with 20 behind 3 the 10 000 leg read
+        # 2.084 ms where its own line on the same box reads 2.046 -- a 40 ms timed region still carries first-use costs)
         for key, g in sizes:
-            tr[key] = run_train("full", g, 20, 3, rank, ws, dev)
-        tr["slim_%d" % gb] = run_train("slim", gb, 20, 3, rank, ws, dev)
+            tr[key] = run_train("full", g, 50, 5, rank, ws, dev)
+        tr["slim_%d" % gb] = run_train("slim", gb, 50, 5, rank, ws, dev)
         line["train"] = tr
         line["extras_seconds"] = time.perf_counter() - t_extra
         if rank == 0 and ws == 1 and not args.no_cpu:
