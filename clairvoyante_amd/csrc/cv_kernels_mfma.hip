@@ -2724,6 +2724,123 @@ __global__ __launch_bounds__(NWV * 64) void train_tail_tm(const f4 *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------
+// Small inference passes of the full topology (round 6): fc5 and the four heads in ONE launch, a workgroup of four
+// waves per group -- train_tail_tm's steps 2 and 3 without the losses.  As two launches (dense_small<4, 7> + heads_tm)
+// they were 12.6 + 17.6 us of a six-kernel chain at 63 groups, each a latency chain of its own: heads_tm re-reads from
+// L2 what dense_small has just stored.  Here the group's 21 fc4 fragments go to LDS once; waves 0..2 run one slab of 4
+// fc5 tiles each (dense_small's loop: weights from L2 through a register ring), wave 3 the base head's product over
+// the same fragments; the fc5 outputs meet in LDS and wave 0 finishes the heads (heads_finish).  Per value the chains
+// are dense_small's and heads_tm's: the same bits.
+// ---------------------------------------------------------------------------
+template <int NB4, int NB5>
+__global__ __launch_bounds__(256) void infer_tail_tm(const f4 *__restrict__ h4, const f4 *__restrict__ w5s,
+                                                    const float *__restrict__ bias5, int nout5, f4 *__restrict__ h5_out,
+                                                    const f4 *__restrict__ wp0, const f4 *__restrict__ wp1,
+                                                    const float *__restrict__ bb, const float *__restrict__ bz,
+                                                    const float *__restrict__ bt, const float *__restrict__ bl, int64_t n,
+                                                    float *__restrict__ out16)
+{
+    constexpr int NBW = 4, D = 7;
+    static_assert(NB4 % D == 0 && NB5 <= 3 * NBW && NB4 <= D * NBW, "three slabs of four fc5 tiles, 21 k fragments in rings of 7");
+    __shared__ __attribute__((aligned(16))) f4 sd4[NB4][64];
+    __shared__ __attribute__((aligned(16))) f4 sh5[NB5][64];
+    __shared__ __attribute__((aligned(16))) f4 sa0[64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = blockIdx.x;
+    const int q = lane >> 4;
+    // the group's fc4 fragments: wave w brings w, w + 4, ...; the operands that depend on nothing computed here are
+    // requested right behind them (the first ring of fc5 weights / all of the base head's, ONE register array for both roles)
+    constexpr int MAXF = (NB4 + 3) / 4;
+    f4 pz[MAXF];
+#pragma unroll
+    for (int i = 0; i < MAXF; i++) {
+        const int ob = wave + 4 * i;
+        if (ob < NB4) pz[i] = h4[((size_t)g * NB4 + ob) * 64 + lane];
+    }
+    const f4 *wp5 = w5s + (size_t)(wave < 3 ? wave : 0) * NB4 * (NBW * 64) + lane;
+    f4 A[D][NBW];
+    {
+        const f4 *src = wave == 3 ? wp0 + lane : wp5;
+#pragma unroll
+        for (int d = 0; d < D; d++)
+#pragma unroll
+            for (int j = 0; j < NBW; j++) {
+                const int f = d * NBW + j;
+                if (wave < 3 || f < NB4) A[d][j] = src[(size_t)f * 64];      // (wave-uniform)
+            }
+    }
+    f4 W1[NB5];
+    if (wave == 0) {
+#pragma unroll
+        for (int kb = 0; kb < NB5; kb++) W1[kb] = wp1[(size_t)kb * 64 + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXF; i++) {
+        const int ob = wave + 4 * i;
+        if (ob < NB4) sd4[ob][lane] = pz[i];
+    }
+    __syncthreads();
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    if (wave < 3) {
+        const int slab = wave;
+        const f4 *wp = wp5;
+        f4 acc[NBW];
+#pragma unroll
+        for (int j = 0; j < NBW; j++) acc[j] = zero;
+        auto fetch = [&](const f4 *pw, int d) {
+#pragma unroll
+            for (int j = 0; j < NBW; j++) A[d][j] = pw[((size_t)d * NBW + j) * 64];
+        };
+        auto step = [&](int kb, int d) {
+            const f4 B = sd4[kb][lane];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+                for (int j = 0; j < NBW; j++) acc[j] = mfma4(A[d][j][s4], B[s4], acc[j]);
+        };
+#pragma unroll 1
+        for (int kb0 = D; kb0 < NB4; kb0 += D) {
+            wp += (size_t)D * NBW * 64;
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                step(kb0 - D + d, d);
+                fetch(wp, d);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; d++) step(NB4 - D + d, d);
+#pragma unroll
+        for (int j = 0; j < NBW; j++) {
+            const int ob = slab * NBW + j;
+            if (ob >= NB5) break;
+            const f4 h = selu4(acc[j] + load_bias4(bias5, ob, q, nout5));
+            h5_out[((size_t)g * NB5 + ob) * 64 + lane] = h;      // (kept: cv_get_activation layer 5)
+            sh5[ob][lane] = h;
+        }
+    } else {
+        f4 a0 = zero;
+#pragma unroll
+        for (int kb = 0; kb < NB4; kb++) {
+            const f4 B = sd4[kb][lane];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) a0 = mfma4(A[kb / NBW][kb % NBW][s4], B[s4], a0);
+        }
+        sa0[lane] = a0;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    f4 a1 = zero;
+#pragma unroll
+    for (int kb = 0; kb < NB5; kb++) {
+        const f4 B = sh5[kb][lane];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) a1 = mfma4(W1[kb][s4], B[s4], a1);
+    }
+    heads_finish(sa0[lane], a1, bb, bz, bt, bl, n, out16, g, lane);
+}
+
 // up to this many groups (16 candidates each) fc4 runs as 3 output slabs per group block: 8-wave workgroups
 // x 3 slabs fill the 256 CUs from ~700 groups on; above the threshold one workgroup keeps all 21 tiles
 constexpr int CV_FC4_SLAB_MAX_G = 2048;
@@ -3432,7 +3549,14 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             return 0;
         }
         cv_prof_begin(m, 4, st);
-        if (G <= m->inf_fc4_small_g && (m->variant & 128)) {
+        if (G <= m->inf_fc4_small_g && (m->variant & 128) && (m->variant & 512) && (m->variant & 2) && m->wps3_fc5 && s.nb4 == 21 && s.nb5 == 11) {
+            // fc5 + the heads of a small pass as one launch of four-wave workgroups (was dense_small<4, 7> + heads_tm)
+            m->stage_kernel[4] = "infer_tail_tm<21, 11>";
+            infer_tail_tm<21, 11><<<G, 256, 0, st>>>((const f4 *)m->tm_h4, (const f4 *)m->wps3_fc5, P + o[9], a.fc5, (f4 *)m->tm_h5,
+                                                     (const f4 *)m->wp_heads0, (const f4 *)m->wp_heads1, P + o[11], P + o[13],
+                                                     P + o[15], P + o[17], n, out16);
+            heads_done = true;
+        } else if (G <= m->inf_fc4_small_g && (m->variant & 128)) {
             m->stage_kernel[4] = "dense_small<4, 7, 0>";
             rc |= launch_dense_small<4, 7>(m->tm_h4, s.nb4, m->wps3_fc5, P + o[9], a.fc5, m->tm_h5, G, 3, st, s.nb5);
         } else if (m->variant & 512) {      // fc5 + heads as one kernel
