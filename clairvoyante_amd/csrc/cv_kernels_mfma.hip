@@ -3520,8 +3520,12 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             // the smallest passes: one wave per (group, output fragment) -- a wave's chain is 288 x 4 MFMAs instead of 288 x 12
             // (16 groups 31.7 us against 79.5, 63 groups 63.6 against 82.1, 100 groups 97.7 against 83.5: option
             // infer_fc4_one_groups, 80)
-            m->stage_kernel[3] = "dense_small<1, 8, 0>";
-            rc |= launch_dense_small<1, 8>(m->tm_p3, s.kb4, m->wps21_fc4, P + o[7], a.fc4, m->tm_h4, G, 21, st);
+            // operand ring depth by the number of groups (same-box ladder, 16 / 40 / 63 / 80 groups, us: depth 4: 41 / 39 / 55 / 56,
+            // 8: 32 / 31 / 63 / 64, 12: 27 / 28 / 71 / 71, 16: 29 / 30 / 68 / 69): up to 48 groups (1 008 waves: one per SIMD) a wave
+            // is alone with its load latency and a deeper ring hides more of it; beyond, two waves share a SIMD and a CU's
+            // 64 B per clock of vector loads, and the shallow ring's smaller register set lets them overlap
+            if (G <= 48) { m->stage_kernel[3] = "dense_small<1, 12, 0>"; rc |= launch_dense_small<1, 12>(m->tm_p3, s.kb4, m->wps21_fc4, P + o[7], a.fc4, m->tm_h4, G, 21, st); }
+            else { m->stage_kernel[3] = "dense_small<1, 4, 0>"; rc |= launch_dense_small<1, 4>(m->tm_p3, s.kb4, m->wps21_fc4, P + o[7], a.fc4, m->tm_h4, G, 21, st); }
         }
         else if (form == 0) { m->stage_kernel[3] = "dense_small<3, 8, 0>"; rc |= launch_dense_small<3, 8>(m->tm_p3, s.kb4, m->wps7_fc4, P + o[7], a.fc4, m->tm_h4, G, 7, st); }
         else if (form == 1 && m->inf_rag_s >= 0) { m->stage_kernel[3] = "dense_rag<7, 8>"; rc |= launch_dense_rag(m->tm_p3, s.kb4, m->wps_fc4, P + o[7], a.fc4, m->tm_h4, G, s.nb4, m->inf_rag_s, st); }
@@ -3594,8 +3598,9 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         rc |= launch_conv_parts_infer<5, 1, 2, 33>(hs3, m->tm_p2, n, m->wp_conv[2], P + o[5], a.cout[2], m->tm_p3, G, st);
         cv_prof_end(m, 2, st);
         cv_prof_begin(m, 3, st);
-        m->stage_kernel[3] = "dense_small<1, 8, 0>";
-        rc |= launch_dense_small<1, 8>(m->tm_p3, s.kb4, m->wps7_fc4, P + o[7], a.fc4, m->tm_h4, G, s.nb4, st);
+        // (operand ring depth as for the full topology's smallest passes: 12 while every wave has a SIMD to itself, 4 beyond)
+        if ((long)G * s.nb4 <= 4L * cusm) { m->stage_kernel[3] = "dense_small<1, 12, 0>"; rc |= launch_dense_small<1, 12>(m->tm_p3, s.kb4, m->wps7_fc4, P + o[7], a.fc4, m->tm_h4, G, s.nb4, st); }
+        else { m->stage_kernel[3] = "dense_small<1, 4, 0>"; rc |= launch_dense_small<1, 4>(m->tm_p3, s.kb4, m->wps7_fc4, P + o[7], a.fc4, m->tm_h4, G, s.nb4, st); }
         cv_prof_end(m, 3, st);
         cv_prof_begin(m, 4, st);
         if (m->variant & 512) {

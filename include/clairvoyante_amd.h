@@ -135,7 +135,7 @@ int cv_selu_sweep(int device, uint32_t lo_bits, uint32_t hi_bits, uint64_t *viol
  * "infer_small_groups" / "infer_fc4_small_groups" / "infer_slab_groups" (defaults 256 / 288 / -1: cv_forward picks its
  * kernels by the number of groups of 16 candidates in the pass -- up to the first the convolutions unfused with their
  * positions over 8, 4 or 2 waves; up to the second fc4 / fc5 may run as one wave per (group, slab) -- up to
- * "infer_fc4_one_groups" (default 80) fc4 as one wave per (group, output fragment): 1 000 candidates 194 -> 167 us --; fc4 otherwise as three
+ * "infer_fc4_one_groups" (default 80) fc4 as one wave per (group, output fragment): 1 000 candidates 194 -> 148 us with fc5 + the heads as one launch --; fc4 otherwise as three
  * output slabs on ragged waves (dense_rag) or, with fc5 and the heads on its tail, all 21 tiles per wave: -1 = whichever an
  * estimate of the launch's time says is shorter at this size, >= 0 = the slab form up to that many groups; the same bits
  * whichever runs), "dense_rag" (0 default: the shape of the three-slab fc4 launch -- tile-units per SIMD and workgroup --
