@@ -376,16 +376,17 @@ struct front_source {
         hx++;
         load_x(xn, hx + 1);
     }
+    // h0: the first pooled row next() will be asked for (a position part of the layer above starts there)
     __device__ __forceinline__ void init(const float *x, int64_t cand, int q, const float *wp1,
-                                         const float *bias1, int cout1, int lane)
+                                         const float *bias1, int cout1, int lane, int h0 = 0)
     {
         xp = x + (size_t)cand * (CV_INPUT_H * 16) + q;
 #pragma unroll
         for (int kw = 0; kw < 4; kw++) A[kw] = wp1[kw * 64 + lane];
         b4 = load_bias4(bias1, 0, q, cout1);
-        hx = 0;
-        load_x(xc, 0);
-        load_x(xn, 1);
+        hx = h0;
+        load_x(xc, h0);
+        load_x(xn, h0 + 1);
         if constexpr (FRONT > 1) {
             // cw[j] = running maximum of the last j+1 pre-activation rows
 #pragma unroll
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
 {
     static_assert(FRONT == 0 || CINB == 1, "the fused first layer feeds one 16-channel fragment");
     static_assert(MODE != 2 || (POOL == 1 && FRONT == 0), "the data-gradient pass has no pooling / first layer");
-    static_assert(HSPLIT == 1 || FRONT == 0, "position ranges read their rows from a TM buffer");
+    static_assert(HSPLIT >= 1 || FRONT == 0, "flat ranges read their rows from a TM buffer (position parts may make them: front_source::init h0)");
     static_assert(HSPLIT != 0 || (FRONT == 0 && (MODE != 0 || POOL == 1)), "flat ranges: training kernels, and inference layers without pooling (slim small passes)");
     extern __shared__ __attribute__((aligned(16))) f4 ldsw[];
     constexpr int PADT = MODE == 2 ? KH - 1 - (KH - 1) / 2 : (KH - 1) / 2;
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void conv_tm(const f4 *__restrict__ in_tm, 
     if constexpr (FRONT > 0) {
         int64_t cand = (int64_t)g * 16 + (lane & 15);
         if (cand >= n) cand = n - 1;
-        fs.init(x, cand, q, wp1, bias1, cout1, lane);
+        fs.init(x, cand, q, wp1, bias1, cout1, lane, hbeg - PADT > 0 ? hbeg - PADT : 0);
     }
     auto fetch_row = [&](int hr, f4 (&row)[4][CINB]) {     // rows are requested in ascending order
         if constexpr (FRONT > 0) {
@@ -2943,11 +2944,13 @@ int launch_conv_parts(int hs, const float *in, const float *x, int64_t n, const 
 }
 
 // inference pass of a POOLED layer over 2, 4 or 8 position parts (full topology, small passes; parts recompute the window overlap)
-template <int KH, int CINB, int NT, int POOL, int HIN>
+// (FRONT > 0: the first layer fused in -- every part makes the pooled first-layer rows it needs from the raw X: x, wp1, bias1)
+template <int KH, int CINB, int NT, int POOL, int HIN, int FRONT = 0>
 int launch_conv_parts_pooled(int hs, const float *in, int64_t n, const float *wp, const float *bias, int cout, float *out, int G,
-                             hipStream_t st)
+                             hipStream_t st, const float *x = nullptr, const float *wp1 = nullptr, const float *bias1 = nullptr,
+                             int cout1 = 0)
 {
-#define CV_PARTS(H) return launch_conv<KH, CINB, NT, POOL, HIN, 0, 0, H>(in, nullptr, n, nullptr, nullptr, 0, wp, bias, cout, out, G, st)
+#define CV_PARTS(H) return launch_conv<KH, CINB, NT, POOL, HIN, FRONT, 0, H>(in, x, n, wp1, bias1, cout1, wp, bias, cout, out, G, st)
     switch (hs) {
     case 2: CV_PARTS(2);
     case 8: CV_PARTS(8);
@@ -3430,7 +3433,18 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
         // serial position loop of one (group, tile): the layers are launched unfused with their positions split over
         // four waves (pooled layers recompute the window overlap) -- the same values row for row
         const bool small_pass = (m->variant & 128) && G <= m->inf_small_g;
-        if (small_pass) {
+        if (small_pass && fuse_front && m->dbg[0] != 5 && (G <= 96 || m->dbg[0] == 6)) {
+            // conv1 + pool1 inside conv2's position parts (round 6): each part makes the pooled first-layer rows it needs from
+            // the raw X in registers (front_source from its first row: 4 + 1 more conv1 rows than conv2 input rows) -- a launch
+            // and the 7.4 KB-per-candidate pool1 map less: 63 groups 30.6 us against 16.0 + 21.4, a pass of 1 000 candidates
+            // 148 -> 144 us; from 160 groups on the recomputed rows cost more than the launch (59.4 against 16.4 + 40.6):
+            // up to 96 groups.  dbg0 = 5: as two kernels, 6: fused at every small-pass size
+            cv_prof_begin(m, 1, st);
+            const int hs2 = pooled_parts(G, 2, 26, 3 + 2);
+            m->stage_kernel[1] = hs2 == 8 ? "conv_tm<2, 1, 2, 4, 29, 5, 0, 8>" : hs2 == 2 ? "conv_tm<2, 1, 2, 4, 29, 5, 0, 2>" : "conv_tm<2, 1, 2, 4, 29, 5, 0, 4>";
+            rc |= launch_conv_parts_pooled<2, 1, 2, 4, 29, 5>(hs2, nullptr, n, m->wp_conv[1], P + o[3], a.cout[1], m->tm_p2, G, st, x, W1, B1, a.cout[0]);
+            cv_prof_end(m, 1, st);
+        } else if (small_pass) {
             cv_prof_begin(m, 0, st);
             m->stage_kernel[0] = "conv1_tm<5, false>";
             conv1_tm<5><<<nblk((int64_t)G * 4, 4), 256, 0, st>>>(x, n, W1, B1, a.cout[0], (f4 *)m->tm_p1, G);

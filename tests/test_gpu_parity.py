@@ -45,7 +45,7 @@ def test_outputs_match_oracle(setup, impl):
     assert common.argmax_match(got, ref["out"]) == [1.0, 1.0, 1.0, 1.0]
 
 
-@pytest.mark.parametrize("impl,variant", [(1, 1007), (1, 495), (1, 239), (1, 111), (1, 47), (1, 6), (1, 0), (0, 47)])
+@pytest.mark.parametrize("impl,variant", [(1, 1007), (1, 1006), (1, 495), (1, 239), (1, 111), (1, 47), (1, 6), (1, 0), (0, 47)])
 def test_intermediates_match_oracle(setup, impl, variant):
     import torch
     arch, P, m, x, ref = setup
@@ -55,9 +55,10 @@ def test_intermediates_match_oracle(setup, impl, variant):
     m.predict_device(torch.from_numpy(x).cuda())
     m.setOption("variant", common.DEFAULT_VARIANT)
     for layer, name in ((1, "pool1"), (2, "pool2"), (3, "pool3"), (4, "fc4"), (5, "fc5")):
-        if layer == 1 and impl == 1 and (variant & 1) and not ((variant & 128) and arch == "full"):
-            continue      # with the first layer fused into the conv2 kernel pool1 never reaches HBM (small passes of the
-                          # full topology run unfused under variant bit 7)
+        if layer == 1 and impl == 1 and (variant & 1):
+            continue      # with the first layer fused into the conv2 kernel pool1 never reaches HBM (round 6: also in the
+                          # small passes of the full topology, where conv2's position parts make their own first-layer rows;
+                          # variant 1006 = the small-pass set with the first layer as its own kernel)
         if layer == 3 and impl == 1 and (variant & 256) and arch == "slim":
             continue      # slim conv3 + fc4 as one kernel: the conv3 map never exists in memory
         a = m.getActivation(layer, n).cpu().numpy().reshape(n, -1)
@@ -194,6 +195,32 @@ def test_forced_launch_shapes_give_the_same_bits(setup, n):
     defaults = {"infer_flat": 1, "infer_fc4_one_groups": 80, "slim_waves": 0, "slim_small_groups": -1, "infer_slab_groups": -1, "dense_rag": 0}
     try:
         for st in settings:
+            for k, v in defaults.items():
+                m.setOption(k, v)
+            for k, v in st.items():
+                m.setOption(k, v)
+            got = m.predict_device(xd).cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), st
+    finally:
+        for k, v in defaults.items():
+            m.setOption(k, v)
+
+
+@pytest.mark.parametrize("n", [100, 1000, 1530, 4000])
+def test_small_pass_shapes_give_the_same_bits(setup, n):
+    """the small-pass kernel sets (round 6), each choice forced the other way at sizes either side of its line: the first
+    layer inside conv2's position parts or as its own kernel (dbg0 6 / 5; default: fused up to 96 groups), fc4 as one wave
+    per (group, fragment) or per (group, slab of 3) (infer_fc4_one_groups; default up to 80 groups), the slim topology's
+    unfused set or its fused pair (slim_small_groups) -- same bits as the default"""
+    from clairvoyante_amd import synth
+    arch, P, m, x, ref = setup
+    m.setOption("impl", 1); m.setOption("variant", common.DEFAULT_VARIANT); m.setOption("chunk", 65536)
+    xd = synth.make_candidates(n, seed=89, device="cuda")
+    want = m.predict_device(xd).cpu().numpy()
+    defaults = {"dbg0": 0, "infer_fc4_one_groups": 80, "slim_small_groups": -1}
+    try:
+        for st in ({"dbg0": 5}, {"dbg0": 6}, {"infer_fc4_one_groups": 0}, {"infer_fc4_one_groups": 65536},
+                   {"slim_small_groups": 0}, {"slim_small_groups": 65536}):
             for k, v in defaults.items():
                 m.setOption(k, v)
             for k, v in st.items():
