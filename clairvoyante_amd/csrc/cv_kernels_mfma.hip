@@ -3567,8 +3567,10 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             return 0;
         }
         cv_prof_begin(m, 4, st);
-        if (G <= m->inf_fc4_small_g && (m->variant & 128) && (m->variant & 512) && (m->variant & 2) && m->wps3_fc5 && s.nb4 == 21 && s.nb5 == 11) {
-            // fc5 + the heads of a small pass as one launch of four-wave workgroups (was dense_small<4, 7> + heads_tm)
+        if (G <= (m->inf_fc4_small_g > 560 ? m->inf_fc4_small_g : 560) && (m->variant & 128) && (m->variant & 512) && (m->variant & 2) && m->wps3_fc5 && s.nb4 == 21 && s.nb5 == 11) {
+            // fc5 + the heads as one launch of four-wave workgroups, one per group (was dense_small<4, 7> + heads_tm in small
+            // passes: 30 -> 18 us).  Up to 560 groups it also beats the ring kernel with the heads on its tail (dense_tm<11, 4, 2>:
+            // 257 / 320 / 512 groups 23 / 24 / 25 us against 31 / 31 / 33; from 625 on 34 against 32 and growing with the pass)
             m->stage_kernel[4] = "infer_tail_tm<21, 11>";
             infer_tail_tm<21, 11><<<G, 256, 0, st>>>((const f4 *)m->tm_h4, (const f4 *)m->wps3_fc5, P + o[9], a.fc5, (f4 *)m->tm_h5,
                                                      (const f4 *)m->wp_heads0, (const f4 *)m->wp_heads1, P + o[11], P + o[13],

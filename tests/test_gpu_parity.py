@@ -144,7 +144,7 @@ def test_passes_either_side_of_every_size_line_give_the_same_bits(setup):
     m.setOption("chunk", 65536)
     # (round 6: up to 80 groups fc4 runs as one wave per (group, output fragment) -- option infer_fc4_one_groups; the position
     # parts of the small-pass convolutions are 8 / 4 / 2 by the number of groups; slim: the small-pass set by estimate)
-    for n in (1, 17, 100, 250, 770, 1000, 1280, 1297, 1600, 2560, 2577, 4096, 4113, 4608, 4625, 32768, 32785, 54400, 54417):
+    for n in (1, 17, 100, 250, 770, 1000, 1280, 1297, 1600, 2560, 2577, 4096, 4113, 4608, 4625, 8960, 8977, 32768, 32785, 54400, 54417):
         got = m.predict_device(xd[:n].contiguous()).cpu().numpy()
         assert np.array_equal(got.view(np.uint32), want[:n].view(np.uint32)), n
     for key, value in (("infer_small_groups", 160), ("infer_fc4_small_groups", 256), ("infer_slab_groups", 2048)):
