@@ -2470,8 +2470,11 @@ __global__ __launch_bounds__(256) void heads_train_tm(const f4 *__restrict__ d4,
 // ---------------------------------------------------------------------------
 // NWV waves per workgroup; PART: the fc4 output arrives as k-range partial sums (tiny batches) -- else (larger batches,
 // train_sched bit 10) fc4's own kernel has stored the dropped-out output (dr.d4) and step 1 only brings it into LDS.
+// (four-wave form: three workgroups per CU -- 168 registers, 40 dwords of them spilled -- so that the 625 workgroups of
+// train.py's batch are ONE round on 256 CUs instead of two: 52.7 -> 40.6 us, the step 2.060 -> 2.054 ms, 12 288: 2.574 ->
+// 2.559; profiles/r06/train_tail_occupancy_ab.txt)
 template <int NB4, int NB5, int NWV, bool PART>
-__global__ __launch_bounds__(NWV * 64) void train_tail_tm(const f4 *__restrict__ part, int KS, int G, const float *__restrict__ bias4,
+__global__ __launch_bounds__(NWV * 64, (PART ? 1 : 3)) void train_tail_tm(const f4 *__restrict__ part, int KS, int G, const float *__restrict__ bias4,
                                                       int nout4, f4 *__restrict__ h4_out, cv_dropout_args dr,
                                                       const f4 *__restrict__ w5s, const float *__restrict__ bias5, int nout5,
                                                       f4 *__restrict__ h5_out, const f4 *__restrict__ wp0,
