@@ -1306,6 +1306,13 @@ int cv_tile_fc4_dgrad(cv_model *m, const float *g_tm, float *gin_tm, int64_t n, 
     heads_args hd;
     hd.dact = (const f4 *)act_below;        // not null: the result is already the pre-activation gradient of conv3 (no pooling)
     if (cv_layout_current(m, CVL_DFC4, "fc4 data gradient")) return 1;
+    // (slim: 11 slabs of 24 output fragments over 3 k fragments -- a streaming kernel: it reads and writes the 16.9 KB-per-
+    // candidate conv3 map once each.  Up to 128 groups four-wave workgroups, twice as many of them: the slim step at 320 / 640 /
+    // 1 250 / 2 000 candidates 0.331 / 0.344 / 0.352 / 0.395 -> 0.322 / 0.327 / 0.340 / 0.385 ms; from 157 groups on the
+    // eight-wave form is as good or better (two groups per wave: -20 us at 4 000 and 5 000 only, +10 .. +25 us at 2 500 and
+    // 3 200: not used) -- profiles/r06/slim_fc4_dgrad_shapes_ab.txt; dbg4 = 9: eight waves at every size)
+    if (G <= 128 && m->dbg[4] != 9)
+        return launch_dense<24, 4, 1>(g_tm, s.nb4, m->wpd_fc4, nullptr, 0, gin_tm, G, st, s.kb4 / 24, 1, nullptr, hd);
     return launch_dense<24, 8, 1>(g_tm, s.nb4, m->wpd_fc4, nullptr, 0, gin_tm, G, st, s.kb4 / 24, 1, nullptr, hd);
 }
 
