@@ -1181,6 +1181,58 @@ __global__ __launch_bounds__(256) void dense_small(const f4 *__restrict__ in_tm,
     }
 }
 
+// dense_small<1, D> with TWO groups per wave: the weight fragment of a step multiplies both groups' activation fragments
+// -- 3 KB of loads per 8 MFMAs instead of 4 KB, half as many waves.  For passes where dense_small's waves are two to a SIMD
+// and share a CU's 64 B per clock of vector loads (49 .. 80 groups of the full topology's fc4).  Same chain per value.
+template <int D>
+__global__ __launch_bounds__(256) void dense_small2(const f4 *__restrict__ in_tm, int KB, const f4 *__restrict__ wp_all,
+                                                     const float *__restrict__ bias, int nout, f4 *__restrict__ out_tm,
+                                                     int G, int NSLAB, int NBT)
+{
+    const int lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int GP = (G + 1) / 2;
+    if (unit >= GP * NSLAB) return;
+    const int g0 = 2 * (unit / NSLAB), slab = unit % NSLAB;
+    const bool two = g0 + 1 < G;
+    const f4 *bp0 = in_tm + (size_t)g0 * KB * 64 + lane;
+    const f4 *bp1 = in_tm + (size_t)(two ? g0 + 1 : g0) * KB * 64 + lane;
+    const f4 *wp = wp_all + (size_t)slab * KB * 64 + lane;
+    const f4 zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 acc0 = zero, acc1 = zero;
+    f4 A[D], B0[D], B1[D];
+    auto fetch = [&](int d) {
+        B0[d] = bp0[(size_t)d * 64];
+        B1[d] = bp1[(size_t)d * 64];
+        A[d] = wp[(size_t)d * 64];
+    };
+    auto step = [&](int d) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            acc0 = mfma4(A[d][s4], B0[d][s4], acc0);
+            acc1 = mfma4(A[d][s4], B1[d][s4], acc1);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < D; d++) fetch(d);
+#pragma unroll 1
+    for (int kb0 = D; kb0 < KB; kb0 += D) {
+        bp0 += (size_t)D * 64; bp1 += (size_t)D * 64; wp += (size_t)D * 64;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            step(d);
+            fetch(d);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) step(d);
+    if (slab >= NBT) return;
+    const int q = lane >> 4;
+    const f4 b4 = load_bias4(bias, slab, q, nout);
+    out_tm[((size_t)g0 * NBT + slab) * 64 + lane] = selu4(acc0 + b4);
+    if (two) out_tm[((size_t)(g0 + 1) * NBT + slab) * 64 + lane] = selu4(acc1 + b4);
+}
+
 // second pass of a k-split dense layer: out = selu(sum_z part[z] + bias), ranges added in ascending z; with dr.d4 set
 // (fc4 of a training pass) the alpha-dropout of the value follows in the same thread -- dropout_tm's arithmetic, one launch less
 __global__ void dense_ksum(const f4 *__restrict__ part, int KS, int G, int NBT, const float *__restrict__ bias, int nout,

@@ -868,6 +868,14 @@ int cv_mfma_forward(cv_model *m, const float *x, int64_t n, float *out16, hipStr
             // is alone with its load latency and a deeper ring hides more of it; beyond, two waves share a SIMD and a CU's
             // 64 B per clock of vector loads, and the shallow ring's smaller register set lets them overlap
             if (G <= 48) { m->stage_kernel[3] = "dense_small<1, 12, 0>"; rc |= launch_dense_small<1, 12>(m->tm_p3, s.kb4, m->wps21_fc4, P + o[7], a.fc4, m->tm_h4, G, 21, st); }
+            else if (m->dbg[1] != 4) {
+                // two groups per wave (dense_small2): 3 KB of loads per 8 MFMAs instead of 4 KB -- 63 groups 55.2 -> 48.7 us, a
+                // pass of 1 000 candidates 143.8 -> 137.3 us (ring depth 8; 4 / 6 / 12: 148.2 / 142.5 / 139.6); at 100 groups
+                // it loses to the slab form (120.6 against 83.6 us).  dbg1 = 4: one group per wave, ring depth 4
+                m->stage_kernel[3] = "dense_small2<8>";
+                dense_small2<8><<<nblk((int64_t)((G + 1) / 2) * 21, 4), 256, 0, st>>>((const f4 *)m->tm_p3, s.kb4, (const f4 *)m->wps21_fc4,
+                                                                                      P + o[7], a.fc4, (f4 *)m->tm_h4, G, 21, 21);
+            }
             else { m->stage_kernel[3] = "dense_small<1, 4, 0>"; rc |= launch_dense_small<1, 4>(m->tm_p3, s.kb4, m->wps21_fc4, P + o[7], a.fc4, m->tm_h4, G, 21, st); }
         }
         else if (form == 0) { m->stage_kernel[3] = "dense_small<3, 8, 0>"; rc |= launch_dense_small<3, 8>(m->tm_p3, s.kb4, m->wps7_fc4, P + o[7], a.fc4, m->tm_h4, G, 7, st); }

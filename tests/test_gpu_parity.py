@@ -206,20 +206,21 @@ def test_forced_launch_shapes_give_the_same_bits(setup, n):
             m.setOption(k, v)
 
 
-@pytest.mark.parametrize("n", [100, 1000, 1530, 4000])
+@pytest.mark.parametrize("n", [100, 777, 1000, 1530, 4000])
 def test_small_pass_shapes_give_the_same_bits(setup, n):
     """the small-pass kernel sets (round 6), each choice forced the other way at sizes either side of its line: the first
     layer inside conv2's position parts or as its own kernel (dbg0 6 / 5; default: fused up to 96 groups), fc4 as one wave
-    per (group, fragment) or per (group, slab of 3) (infer_fc4_one_groups; default up to 80 groups), the slim topology's
+    per (group, fragment) or per (group, slab of 3) (infer_fc4_one_groups; default up to 80 groups; from 49 groups two groups
+    per wave, dbg1 4: one), the slim topology's
     unfused set or its fused pair (slim_small_groups) -- same bits as the default"""
     from clairvoyante_amd import synth
     arch, P, m, x, ref = setup
     m.setOption("impl", 1); m.setOption("variant", common.DEFAULT_VARIANT); m.setOption("chunk", 65536)
     xd = synth.make_candidates(n, seed=89, device="cuda")
     want = m.predict_device(xd).cpu().numpy()
-    defaults = {"dbg0": 0, "infer_fc4_one_groups": 80, "slim_small_groups": -1}
+    defaults = {"dbg0": 0, "dbg1": 0, "infer_fc4_one_groups": 80, "slim_small_groups": -1}
     try:
-        for st in ({"dbg0": 5}, {"dbg0": 6}, {"infer_fc4_one_groups": 0}, {"infer_fc4_one_groups": 65536},
+        for st in ({"dbg0": 5}, {"dbg0": 6}, {"dbg1": 4}, {"infer_fc4_one_groups": 0}, {"infer_fc4_one_groups": 65536},
                    {"slim_small_groups": 0}, {"slim_small_groups": 65536}):
             for k, v in defaults.items():
                 m.setOption(k, v)
