@@ -177,6 +177,27 @@ def test_every_size_of_the_ladder_gives_the_bits_of_small_chunks(setup):
         assert np.array_equal(got.view(np.uint32), want[:n].view(np.uint32)), n
 
 
+def test_random_pass_sizes_give_the_bits_of_small_chunks(setup):
+    """Round 6 made every launch shape a function of the pass size (position parts, flat ranges, ragged slabs, kernel forms
+    and the slim kernel set by estimate): 64 seeded sizes, log-uniform over 1 .. 70 000 candidates -- ragged last groups,
+    sizes next to nothing in particular -- must each give, bit for bit, what the same candidates give in chunks of 2 048
+    (the small-pass kernels throughout = the oracle's bits, tests above), and a second call of the same size the same."""
+    from clairvoyante_amd import synth
+    arch, P, m, x, ref = setup
+    m.setOption("impl", 1); m.setOption("variant", common.DEFAULT_VARIANT)
+    rng = np.random.RandomState(20260)
+    sizes = sorted(set(int(v) for v in np.exp(rng.uniform(0.0, np.log(70000.0), 64)).astype(np.int64)) | {1, 70000})
+    xd = synth.make_candidates(70000, seed=91, device="cuda")
+    m.setOption("chunk", 2048)
+    want = m.predict_device(xd).cpu().numpy()
+    m.setOption("chunk", 65536)
+    for n in sizes:
+        got = m.predict_device(xd[:n].contiguous()).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want[:n].view(np.uint32)), n
+        again = m.predict_device(xd[:n].contiguous()).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), again.view(np.uint32)), n
+
+
 @pytest.mark.parametrize("n", [4107, 12283, 32779])
 def test_forced_launch_shapes_give_the_same_bits(setup, n):
     """the shapes the estimates choose between, each forced at sizes where it is NOT the default (ragged last group):
