@@ -324,7 +324,20 @@ extern "C" int cv_forward(cv_model *m, const float *x_dev, int64_t n, float *out
 extern "C" int cv_get_activation(cv_model *m, int layer, float *dst_dev, int64_t n, void *stream)
 {
     if (!m || !dst_dev) { cv_set_error("cv_get_activation: null argument"); return 1; }
-    if (layer < 1 || layer > 7) { cv_set_error("cv_get_activation: layer %d not in 1..7", layer); return 1; }
+    if ((layer >= 11 && layer <= 13) || (layer >= 21 && layer <= 23)) {   // maps of the last training slice (single-slice steps)
+        const int l = layer % 10 - 1; const bool grad = layer > 20;
+        const float *src = grad ? m->last_tr_gpre[l] : m->last_tr_pool[l];
+        if (n <= 0 || n > m->last_tr_n || !src) {
+            cv_set_error("cv_get_activation: layer %d of the last training slice (%lld candidates) is not there", layer, (long long)m->last_tr_n);
+            return 1;
+        }
+        CV_HIP(hipSetDevice(m->device));
+        const int npos = (grad ? m->sh.hc[l] : m->sh.hp[l]) * 4;
+        if (m->last_tr_tile) return cv_tm_to_natural(src, npos * m->sh.ntile[l], m->sh.ntile[l] * 16, m->arch.cout[l], npos, n, dst_dev, (hipStream_t)stream);
+        CV_HIP(hipMemcpyAsync(dst_dev, src, sizeof(float) * (size_t)npos * m->arch.cout[l] * n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return 0;
+    }
+    if (layer < 1 || layer > 7) { cv_set_error("cv_get_activation: layer %d not in 1..7, 11..13, 21..23", layer); return 1; }
     if (layer >= 6) {        // training-pass tensors: 6 = keep mask scaled by a (0 where dropped), 7 = dropout output
         if (n <= 0 || n > m->last_tr_n || !m->last_tr_d4) {
             cv_set_error("cv_get_activation: n=%lld but the last training slice held %lld candidates", (long long)n,

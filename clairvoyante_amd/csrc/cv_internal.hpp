@@ -140,6 +140,7 @@ struct cv_model {
                          // kernel variants of the training step (default 400; 0 = never)
     // fc4 dropout output / keep mask (a*keep) of the LAST training slice, for cv_get_activation 6 / 7
     const float *last_tr_d4, *last_tr_mask;
+    const float *last_tr_pool[3], *last_tr_gpre[3];   // cv_get_activation 11..13 / 21..23: maps of the last training slice (nullptr: not materialised)
     int64_t last_tr_n;
     int last_tr_tile;    // 1: tile-major buffers, 0: natural [n, fc4]
     // option keep_activations + a step of several slices: the two maps of EVERY slice, copied here slice after slice

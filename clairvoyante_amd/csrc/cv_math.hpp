@@ -56,6 +56,10 @@ constexpr float SELU_SA = (float)(1.0507009873554804934193349852946 * 1.67326324
 // multiply-add with the product constant -- 18 element operations per value where scale*(alpha*(expf_fixed(x)-1))
 // took 21, a little MORE accurate (max |err| 1.2e-7 vs 2.0e-7 over all negative floats) and monotone over every
 // fp32 input (cv_selu_sweep).  The select is `x < 0 ? neg : pos`, which routes NaN (and -0) to pos.
+// The negative branch carries the SIGN of its input even where its value rounds to zero (-2^-25 < x < 0: exp(x) rounds to 1
+// and the result is -0.0, computed as -(SA - SA*y)): the backward pass takes selu' from the layer OUTPUT (cv_unpool.hpp:
+// sign bit set -> y + SA, else SCALE), and an output of +0 there would read as the x >= 0 branch -- one element in ~3e7,
+// a flip of selu' from 1.758 to 1.051 that the reference (selu.py:21-25 through tf.where's gradient) does not have.
 // (Development build flag CV_FAST_SELU: the negative branch through the hardware exponential, v_exp_f32(x * log2 e) and
 // one fma -- 5 element operations instead of 18, ~1 ulp of 2^t instead of the fixed sequence: NOT the canonical
 // arithmetic, no bitwise parity with the CPU checker; measured against the exact path by tools/gpu_fast_selu_ab.sh.)
@@ -82,9 +86,9 @@ __device__ __forceinline__ float selu(float x)
     float y = __builtin_fmaf(p, r2, r);
     y = y + 1.0f;
     y = __builtin_ldexpf(y, (int)z);
-    const float neg = __builtin_fmaf(y, SELU_SA, -SELU_SA);
+    const float mag = __builtin_fmaf(y, -SELU_SA, SELU_SA);      // scale*alpha*(1 - y) >= +0
     const float pos = SELU_SCALE * x;
-    return x < 0.0f ? neg : pos;
+    return x < 0.0f ? -mag : pos;                                // (the negation is a source modifier of the select)
 }
 
 // Two SELUs at once on the packed fp32 pipe (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two IEEE operations per
@@ -121,11 +125,11 @@ __device__ __forceinline__ f2v selu2(f2v x)
     y = y + 1.0f;
     y[0] = __builtin_ldexpf(y[0], (int)z[0]);
     y[1] = __builtin_ldexpf(y[1], (int)z[1]);
-    const f2v neg = __builtin_elementwise_fma(y, (f2v)(SELU_SA), (f2v)(-SELU_SA));
+    const f2v mag = __builtin_elementwise_fma(y, (f2v)(-SELU_SA), (f2v)(SELU_SA));
     const f2v pos = SELU_SCALE * x;
     f2v o;
-    o[0] = x[0] < 0.0f ? neg[0] : pos[0];
-    o[1] = x[1] < 0.0f ? neg[1] : pos[1];
+    o[0] = x[0] < 0.0f ? -mag[0] : pos[0];
+    o[1] = x[1] < 0.0f ? -mag[1] : pos[1];
     return o;
 }
 

@@ -271,14 +271,17 @@ __global__ void b_pool_selu(const float *__restrict__ gpool, const float *__rest
     int64_t i = r / H;
     const float *b = pre + (size_t)i * H * row + e;
     float me = b[(size_t)h * row];
+    // the pooling compares ACTIVATIONS (v3.py:59-67: selu, then max_pooling2d): two pre-activations an ulp apart can share
+    // one activation (selu' < 1 below -0.56), and the window's gradient then goes to the first of them
+    const float me_act = cvm::selu(me);
     float acc = 0.0f;
     for (int ho = h - p + 1; ho <= h; ho++) {
         if (ho < 0 || ho >= Ho) continue;
         bool win = true;
         for (int d = 0; d < p; d++) {
-            float v = b[(size_t)(ho + d) * row];
+            float v = cvm::selu(b[(size_t)(ho + d) * row]);
             int hh = ho + d;
-            if (hh < h ? v >= me : v > me) { win = false; break; }   // first maximum wins
+            if (hh < h ? v >= me_act : v > me_act) { win = false; break; }   // first maximum wins
         }
         if (win) acc += gpool[((size_t)i * Ho + ho) * row + e];
     }
@@ -607,6 +610,7 @@ static int train_slice_plain(cv_model *m, const float *x, const float *y, int64_
     t_fc4_act<<<nblk(n * a.fc4, 256), 256, 0, st>>>(fc4pre, d4, amask, n, a.fc4, backward ? drop4 : 0.0f, seed,
                                                     step, cand0);
     m->last_tr_d4 = d4; m->last_tr_mask = amask; m->last_tr_n = n; m->last_tr_tile = 0;
+    for (int l = 0; l < 3; l++) { m->last_tr_pool[l] = pool[l]; m->last_tr_gpre[l] = backward ? gpre[l] : nullptr; }
     t_dense_pre<<<nblk(n * a.fc5, 256), 256, 0, st>>>(d4, P + o[8], P + o[9], fc5pre, n, a.fc4, a.fc5);
     t_selu_act<<<nblk(n * a.fc5, 256), 256, 0, st>>>(fc5pre, h5, n * a.fc5);
     t_heads<<<nblk(n, 16), 256, 0, st>>>(d4, h5, a.fc4, a.fc5, P + o[10], P + o[11], P + o[12], P + o[13],
@@ -800,6 +804,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
         }
     }
     m->last_tr_d4 = td4; m->last_tr_mask = tmask; m->last_tr_n = n; m->last_tr_tile = 1;
+    for (int l = 0; l < 3; l++) { m->last_tr_pool[l] = tp[l]; m->last_tr_gpre[l] = nullptr; }
     CV_HIP(hipGetLastError());
     if (!backward) return 0;
     // ---- backward buffers (TM gradients; the weight-gradient kernels transpose their operands on the way in)
@@ -807,6 +812,7 @@ static int train_slice_tile(cv_model *m, const float *x, const float *y, int64_t
     float *tgpre[3], *tgin[3];
     for (int l = 0; l < 3; l++) { tgpre[l] = sb.take(np * fa[l]); tgin[l] = sb.take(np * fp[l]); }
     if (!tgin[2]) { cv_set_error("training workspace too small"); return 1; }
+    for (int l = 0; l < 3; l++) m->last_tr_gpre[l] = tgpre[l];
     tr_fork f;
     f.m = m; f.st = st; f.k = 0; f.nside = 0; f.tail_only = Gn > m->tiny_g; f.tail_first = m->wpr_fc4 ? 4 : 3;
     f.mark = nullptr; f.mark_fresh = false;

@@ -16,10 +16,11 @@
 typedef float unp_f4 __attribute__((ext_vector_type(4)));
 
 // d selu / d pre-activation expressed through the layer OUTPUT y = selu(pre):
-//   pre >= 0  <=>  y >= 0 : SCALE ;   pre < 0 : SCALE*ALPHA*exp(pre) = y + SCALE*ALPHA
+//   pre >= 0  <=>  sign bit of y clear : SCALE ;   pre < 0 : SCALE*ALPHA*exp(pre) = y + SCALE*ALPHA
+// (cvm::selu keeps the sign of a negative input on an output that rounds to zero: -0.0 is the x < 0 branch, +0.0 is x = 0.)
 __device__ __forceinline__ float cv_selu_grad_from_out(float y)
 {
-    return y >= 0.0f ? cvm::SELU_SCALE : y + cvm::SELU_SCALE * cvm::SELU_ALPHA;
+    return (int32_t)__builtin_bit_cast(uint32_t, y) >= 0 ? cvm::SELU_SCALE : y + cvm::SELU_SCALE * cvm::SELU_ALPHA;
 }
 
 // one fragment column (fixed base w and tile): the last P window gradients and their 16-bit code groups

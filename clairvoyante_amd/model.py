@@ -274,7 +274,9 @@ class Clairvoyante(object):
         hp.append(hp[0] - (a.pool[1] - 1)); hp.append(hp[1] - (a.pool[2] - 1))
         shp = {1: (n, hp[0], 4, a.cout[0]), 2: (n, hp[1], 4, a.cout[1]), 3: (n, hp[2], 4, a.cout[2]),
                4: (n, a.fc4), 5: (n, a.fc5),
-               6: (n, a.fc4), 7: (n, a.fc4)}[layer]     # last TRAINING slice: a*keep mask of fc4, dropout4 output
+               6: (n, a.fc4), 7: (n, a.fc4),            # last TRAINING slice: a*keep mask of fc4, dropout4 output
+               11: (n, hp[0], 4, a.cout[0]), 12: (n, hp[1], 4, a.cout[1]), 13: (n, hp[2], 4, a.cout[2]),   # its pooled maps
+               21: (n, 33, 4, a.cout[0]), 22: (n, hp[0], 4, a.cout[1]), 23: (n, hp[1], 4, a.cout[2])}[layer]   # its pre-activation gradients
         dst = torch.empty(shp, dtype=torch.float32, device=self.device)
         _lib.check(self._lib.cv_get_activation(self._h, layer, ctypes.c_void_p(dst.data_ptr()), n,
                                                self._stream()))

@@ -114,6 +114,9 @@ int cv_format_vcf(const int32_t *call, const float *qual, int64_t n, const float
  * keep mask of fc4 times its affine factor a (selu.py:53-62; 0 where a unit was
  * dropped, a where kept, 1 everywhere at rate 0), 7 = dropout4, the layer's output
  * [n, fc4] -- what the parity tests feed to / compare with the oracle.
+ * layers 11..13 / 21..23: the pooled maps (slim: conv outputs) and the pre-activation gradients of conv1..conv3 of the
+ * last single-slice training step, natural layout (21 of the full topology is not materialised: the first layer's
+ * unpool rides in its weight-gradient kernel) -- what tools/gpu_train_map_diff.py lays beside the plain kernels'.
  * Layers 4 / 5 of a pass that ran fc5 and the heads on the tail of the fc4 kernel exist only with option
  * "keep_activations" set before the pass (error otherwise).                        */
 int cv_get_activation(cv_model *m, int layer, float *dst_dev, int64_t n, void *stream);

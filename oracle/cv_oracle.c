@@ -135,7 +135,13 @@ static inline float cvo_selu(float x)
     float y = __builtin_fmaf(p, r2, r);
     y = y + 1.0f;
     y = ldexpf(y, (int)z);                                      /* z in [-126, 0], y in [0.70, 1.42): a normal number */
-    return __builtin_fmaf(y, SELU_SA, -SELU_SA);
+    /* scale*alpha*(y - 1) as -(SA - SA*y): the same bits as fma(y, SA, -SA) except where y == 1 (-2^-25 < x < 0), which
+     * gives -0.0 -- the output keeps the sign of a negative input, and the device's backward pass reads selu' off the
+     * output's sign bit (csrc/cv_unpool.hpp).  The sign is set on the bit pattern: a compiler may turn -fma(a, b, c)
+     * into a fused negate-multiply-subtract, whose exact zero is +0. */
+    float mag = __builtin_fmaf(y, -SELU_SA, SELU_SA);           /* >= +0 */
+    uint32_t mb; memcpy(&mb, &mag, 4); mb |= 0x80000000u; memcpy(&mag, &mb, 4);
+    return mag;
 }
 float cvo_selu_scalar(float x) { return cvo_selu(x); }
 

@@ -192,18 +192,20 @@ def test_evaluate_report_on_a_small_bin(oracle, tmp_path, caplog):
 
 @pytest.mark.gpu
 def test_training_reduces_the_loss_and_keeps_predictions_finite():
-    """functional check of the whole step (forward, backward, Adam, dropout): 60 steps on one labelled batch bring
-    the loss far down and the network then predicts the labels of that batch"""
+    """functional check of the whole step (forward, backward, Adam, dropout): 100 steps on one labelled batch bring
+    the loss far down and the network then predicts the labels of that batch (at 60 steps the type head is still on
+    its way -- 0.90 to 0.99 depending on the dropout stream; the stream is seeded here)"""
     import torch
     from clairvoyante_amd import clairvoyante_v3, synth
     m = clairvoyante_v3.Clairvoyante()
     m._seed_rng.seed(7)
     m.init()
     m.setLearningRate(1e-3)
+    m._dropout_seed = 77
     xt, cls, rf, alt, il = synth.make_candidates(2000, seed=11, device="cuda", return_class=True)
     y = synth.make_labels(cls, rf, alt, il)
     first = m.getLoss(xt, y)
-    for _ in range(60):
+    for _ in range(100):
         loss, _ = m.train(xt, y)
     last = m.getLoss(xt, y)
     assert np.isfinite(first) and np.isfinite(last) and last < 0.25 * first
