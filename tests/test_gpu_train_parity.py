@@ -227,3 +227,42 @@ def test_one_in_ten_million_elements_take_the_reference_branch(oracle, arch, n, 
                 err = np.abs(got[off:off + sz] - want[off:off + sz]).max() / (np.abs(want[off:off + sz]).max() + 1e-30)
                 assert err <= 2e-5, (arch, i, impl, name, err)
                 off += sz
+
+
+@pytest.mark.parametrize("arch", ["full", "slim"])
+@pytest.mark.parametrize("n", [37, 1250])
+def test_zero_biases_and_empty_positions_tie_everywhere(oracle, arch, n):
+    """The state train.py starts from (v3.py:54-109: tf.layers' bias_initializer is zeros) on sparse pileups: every bias
+    0, whole position ranges of a candidate empty, a tenth of the candidates entirely empty -- pre-activations of exactly
+    0 (selu' = scale there: x >= 0) and pooling windows whose entries are all equal (the gradient goes to the first).
+    One step with the reference's dropout rate, tile and plain kernels against the oracle under the device's keep mask:
+    loss within 1e-5, every gradient within 2e-5 of the bucket's largest entry."""
+    from clairvoyante_amd import param, synth
+    P = {k: v.copy() for k, v in common.bench_params(oracle, arch).items()}
+    for k in P:
+        if "bias" in k:
+            P[k][...] = 0.0
+    rng = np.random.RandomState(n)
+    xt, cls, rf, alt, il = synth.make_candidates(n, seed=77 + n, return_class=True)
+    x = xt.numpy().copy(); y = synth.make_labels(cls, rf, alt, il).numpy()
+    for i in range(n):
+        lo = rng.randint(0, 33); hi = rng.randint(lo, 34)
+        x[i, lo:hi] = 0.0
+    x[rng.rand(n) < 0.1] = 0.0
+    lam = param.l2RegularizationLambda
+    for impl in (1, 0):
+        m = _model(arch); m.setParameters(P); m.setOption("impl", impl); m.setOption("train_ksplit", 0)
+        m.dropoutRateFC4Val = param.dropoutRateFC4; m.setL2RegularizationLambda(lam); m.setLearningRate(1e-3)
+        m._dropout_seed = 5
+        loss, _ = m.train(x, y)
+        keep = (m.getActivation(6, n).cpu().numpy() != 0).astype(np.float32)
+        got = _flat(m, 1); m.close()
+        l_or, _, g_or = oracle.loss_grad(arch, P, x, y, lam=lam, mask4=keep, rate4=param.dropoutRateFC4)
+        assert abs(float(loss) - l_or) <= 1e-5 * abs(l_or), (impl, loss, l_or)
+        off = 0
+        for name in oracle.PARAM_NAMES:
+            sz = g_or[name].size
+            gref = (g_or[name] - (lam * P[name] if "bias" not in name else 0)).ravel()
+            err = np.abs(got[off:off + sz] - gref).max() / (np.abs(gref).max() + 1e-30)
+            assert err <= 2e-5, (arch, n, impl, name, err)
+            off += sz
