@@ -2,7 +2,7 @@
 reference's dropout rate) through the tile kernels (fc4 forward as a single chain) and through the plain
 one-thread-per-output kernels; every gradient of the bucket within TOL of its tensor's largest entry, the loss within
 1e-6.  Prints the batches that differ (n, seed) -- feed them to tools/gpu_train_bisect.py / gpu_train_map_diff.py.
-usage: gpu_train_fuzz.py full|slim ROUNDS [NMAX] [seed0]"""
+usage: gpu_train_fuzz.py full|slim ROUNDS [NMAX] [seed0] [NMIN]"""
 import sys, os, ctypes, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -16,6 +16,7 @@ def flat(m, which):
     torch.cuda.synchronize(); return t.cpu().numpy().copy()
 arch = sys.argv[1]; rounds = int(sys.argv[2]); nmax = int(sys.argv[3]) if len(sys.argv) > 3 else 12000
 seed0 = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+nmin = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 mod = clairvoyante_v3_slim if arch == "slim" else clairvoyante_v3
 P = common.bench_params(None, arch)
 names = list(P.keys())
@@ -30,7 +31,7 @@ order = list(O.PARAM_NAMES)          # flat order of the bucket
 rng = np.random.RandomState(seed0)
 bad = 0; worst = 0.0; t0 = time.time(); total = 0
 for r in range(rounds):
-    n = int(np.exp(rng.uniform(0.0, np.log(float(nmax))))); seed = int(rng.randint(1, 1 << 30))
+    n = int(np.exp(rng.uniform(np.log(float(nmin)), np.log(float(nmax))))); seed = int(rng.randint(1, 1 << 30))
     xt, cls, rf, alt, il = synth.make_candidates(n, seed=seed, device="cuda", return_class=True)
     y = synth.make_labels(cls, rf, alt, il)
     out = {}
