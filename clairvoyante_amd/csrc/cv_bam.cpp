@@ -216,6 +216,7 @@ int read_header(cv_bam *b)
     const uint8_t *d = b->data.data();
     if (memcmp(d, "BAM\1", 4)) { cv_set_error("bam: %s has no BAM magic", b->path.c_str()); return 1; }
     const int64_t l_text = rd_i32(d + 4);
+    if (l_text < 0) { cv_set_error("bam: corrupt header (l_text %lld)", (long long)l_text); return 1; }
     if (!need(b, (size_t)(12 + l_text), &err)) { if (!err) cv_set_error("bam: truncated header"); return 1; }
     d = b->data.data();
     const int64_t n_ref = rd_i32(d + 8 + l_text);
@@ -223,6 +224,7 @@ int read_header(cv_bam *b)
     for (int64_t i = 0; i < n_ref; i++) {
         if (!need(b, pos + 4 - b->data_pos, &err)) { if (!err) cv_set_error("bam: truncated reference list"); return 1; }
         const int64_t l_name = rd_i32(b->data.data() + pos);
+        if (l_name < 1 || l_name > (1 << 20)) { cv_set_error("bam: corrupt reference list (l_name %lld)", (long long)l_name); return 1; }
         if (!need(b, pos + 8 + (size_t)l_name - b->data_pos, &err)) { if (!err) cv_set_error("bam: truncated reference list"); return 1; }
         const uint8_t *q = b->data.data() + pos + 4;
         ref_t r;
@@ -255,17 +257,20 @@ void load_index(cv_bam *b)
     size_t pos = 8;
     const int64_t n_ref = rd_i32(buf.data() + 4);
     std::vector<std::vector<uint64_t>> lin;
+    // (every count is checked against the bytes that are left before it sizes anything: a damaged index is ignored)
     for (int64_t r = 0; r < n_ref; r++) {
         if (pos + 4 > buf.size()) return;
         const int64_t n_bin = rd_i32(buf.data() + pos); pos += 4;
+        if (n_bin < 0) return;
         for (int64_t k = 0; k < n_bin; k++) {
             if (pos + 8 > buf.size()) return;
             const int64_t n_chunk = rd_i32(buf.data() + pos + 4);
+            if (n_chunk < 0 || (uint64_t)n_chunk > (buf.size() - pos - 8) / 16) return;
             pos += 8 + (size_t)n_chunk * 16;
         }
         if (pos + 4 > buf.size()) return;
         const int64_t n_intv = rd_i32(buf.data() + pos); pos += 4;
-        if (pos + (size_t)n_intv * 8 > buf.size()) return;
+        if (n_intv < 0 || (uint64_t)n_intv > (buf.size() - pos) / 8) return;
         std::vector<uint64_t> v((size_t)n_intv);
         for (int64_t k = 0; k < n_intv; k++) v[(size_t)k] = rd_u64(buf.data() + pos + (size_t)k * 8);
         pos += (size_t)n_intv * 8;
@@ -512,7 +517,8 @@ extern "C" int64_t cv_bam_view_read(cv_bam *b, char *buf, int64_t cap, int *done
         int64_t rn = n_cig;
         if (take && cv_bam_record_cigar(r, &rcig, &rn)) { cv_set_error("bam: placeholder CIGAR without a CG:B,I tag"); return -1; }
         if (take) {
-            const int64_t worst = l_name + 16 + (int64_t)b->refs[(size_t)tid].name.size() * 2 + 12 * 6 + 11 * rn + 2 * l_seq + 16;
+            const int64_t mate_name = ntid >= 0 && (size_t)ntid < b->refs.size() ? (int64_t)b->refs[(size_t)ntid].name.size() : 1;
+            const int64_t worst = l_name + 16 + (int64_t)b->refs[(size_t)tid].name.size() + mate_name + 12 * 6 + 11 * rn + 2 * l_seq + 16;
             if (wend - w < worst) {
                 if (w == buf) { cv_set_error("cv_bam_view_read: buffer of %lld bytes is too small for one record", (long long)cap); return -1; }
                 break;                                  // the caller comes back for this record

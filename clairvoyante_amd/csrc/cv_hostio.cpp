@@ -18,6 +18,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -520,9 +521,12 @@ extern "C" int cv_blosc_decompress(const uint8_t *chunk, int64_t clen, uint8_t *
     if (codec != 1) { cv_set_error("blosc: compressor format %d not supported (the .bin files use lz4hc)", codec); return 1; }
     const bool doshuffle = (flags & 0x1) && typesize > 1;
     const bool dont_split = (flags & 0x10) != 0;
-    const int nblocks = (nbytes + blocksize - 1) / blocksize;
-    if (16 + 4 * (int64_t)nblocks > clen) { cv_set_error("blosc: truncated bstarts"); return 1; }
-    uint8_t *tmp = doshuffle ? (uint8_t *)malloc((size_t)blocksize) : nullptr;
+    const int64_t nblocks64 = ((int64_t)nbytes + blocksize - 1) / blocksize;
+    if (16 + 4 * nblocks64 > clen) { cv_set_error("blosc: truncated bstarts"); return 1; }
+    const int nblocks = (int)nblocks64;
+    const int64_t data0 = 16 + 4 * nblocks64;           // the first byte a block may start at
+    uint8_t *tmp = doshuffle ? (uint8_t *)malloc((size_t)(blocksize < nbytes ? blocksize : nbytes)) : nullptr;
+    if (doshuffle && !tmp) { cv_set_error("blosc: out of memory"); return 1; }
     int rc = 0;
     for (int b = 0; b < nblocks && !rc; b++) {
         int bsize = blocksize;
@@ -532,6 +536,7 @@ extern "C" int cv_blosc_decompress(const uint8_t *chunk, int64_t clen, uint8_t *
         if (!dont_split && typesize <= 16 && blocksize / typesize >= 128 && !leftover) nsplits = typesize;
         const int neblock = bsize / nsplits;
         int64_t ip = rd32(chunk + 16 + 4 * b);
+        if (ip < data0) { rc = 1; break; }             // (a corrupt start offset: negative, or inside the header)
         uint8_t *out = doshuffle ? tmp : dst + (size_t)b * blocksize;
         for (int s = 0; s < nsplits; s++) {
             if (ip + 4 > clen) { rc = 1; break; }
@@ -750,6 +755,12 @@ int vcf_record(const vcf_job &J, int64_t i, std::string &out, int64_t *nrec)
     const int F = CV_INPUT_H / 2;                      // flankingBaseNum = 16
     const int32_t *c = J.call + i * 8;
     int varType = c[0];
+    // (the decisions are cv_call_postproc's argmax indices; a caller's own array is checked before it sizes a copy)
+    if ((unsigned)varType > 3u || (unsigned)c[1] > 1u || (unsigned)c[2] > 5u) {
+        cv_set_error("cv_format_vcf: record %lld: decision (%d, %d, %d) outside varType 0..3 / zygosity 0..1 / length 0..5",
+                     (long long)i, c[0], c[1], c[2]);
+        return 1;
+    }
     if (varType == 0 && !J.show_ref) return 0;
     const float *q = J.qual + i * 4;
     const float dp = q[2];
@@ -869,19 +880,19 @@ extern "C" int cv_format_vcf(const int32_t *call, const float *qual, int64_t n, 
     // the scratch strings are kept between calls (a free list): after the first batches no call allocates or
     // page-faults
     static std::mutex scratch_mu;
-    static std::vector<std::string *> scratch_free;
+    static std::vector<std::unique_ptr<std::string>> scratch_free;      // (owned: released at process exit)
     std::vector<std::string *> part((size_t)T, nullptr);
     {
         std::lock_guard<std::mutex> lk(scratch_mu);
         for (int t = 0; t < T; t++) {
-            if (!scratch_free.empty()) { part[(size_t)t] = scratch_free.back(); scratch_free.pop_back(); }
+            if (!scratch_free.empty()) { part[(size_t)t] = scratch_free.back().release(); scratch_free.pop_back(); }
             else part[(size_t)t] = new std::string();
             part[(size_t)t]->clear();
         }
     }
     struct give_back {
-        std::vector<std::string *> &v; std::mutex &m; std::vector<std::string *> &f;
-        ~give_back() { std::lock_guard<std::mutex> lk(m); for (auto *x : v) f.push_back(x); }
+        std::vector<std::string *> &v; std::mutex &m; std::vector<std::unique_ptr<std::string>> &f;
+        ~give_back() { std::lock_guard<std::mutex> lk(m); for (auto *x : v) f.emplace_back(x); }
     } gb{part, scratch_mu, scratch_free};
     std::vector<int64_t> cnt((size_t)T, 0);
     std::vector<int> bad((size_t)T, 0);

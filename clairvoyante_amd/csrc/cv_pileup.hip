@@ -1126,6 +1126,7 @@ extern "C" int64_t cv_format_tensor_row(const char *ctg, int64_t center, const c
     memcpy(dst + w, seq, (size_t)seqlen);
     w += seqlen;
     for (int64_t k = 0; k < nvals; ++k) {
+        if (w + 16 > cap) return -1;              // (only after values that print longer than the 16 bytes budgeted each)
         dst[w++] = ' ';
         const float v = counts[k];
         if (v >= 0.f && v < 16777216.f && v == (float)(int32_t)v) {   // "%0.1f" of a small whole number
@@ -1136,9 +1137,12 @@ extern "C" int64_t cv_format_tensor_row(const char *ctg, int64_t center, const c
             while (t) dst[w++] = tmp[--t];
             dst[w++] = '.'; dst[w++] = '0';
         } else {
-            w += snprintf(dst + w, (size_t)(cap - w), "%0.1f", (double)v);
+            const int r = snprintf(dst + w, (size_t)(cap - w), "%0.1f", (double)v);
+            if (r < 0 || r >= cap - w) return -1;  // "%0.1f" of 3e38 is 41 characters
+            w += r;
         }
     }
+    if (w >= cap) return -1;
     dst[w] = 0;
     return w;
 }
