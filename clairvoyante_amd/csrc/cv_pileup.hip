@@ -593,7 +593,8 @@ static bool parse_record(const cv_pileup *p, sam_part &out, const char *line, co
     if (f[0][0] == '@') return true;       // header (:142)
     char msg[160];
     if (nf < 10) {
-        snprintf(msg, sizeof(msg), "cv_pileup_add_sam: record with %d fields (need 10): %.60s", nf, line);
+        snprintf(msg, sizeof(msg), "cv_pileup_add_sam: record with %d fields (need 10): %.*s", nf,
+                 (int)(end - line < 60 ? end - line : 60), line);          // (the text is not NUL-terminated)
         out.err = msg;
         return false;
     }
@@ -603,13 +604,20 @@ static bool parse_record(const cv_pileup *p, sam_part &out, const char *line, co
     const char *cg = f[5], *cge = fe[5];
     const int64_t seqlen = fe[9] - f[9];
     // one scan of the CIGAR: query bases it asks for, all run lengths, soft-clipped bases
+    // (a run is at most 2^28 - 1 in BAM; a longer one in SAM text is damage, and it would size the segment list)
+    constexpr int64_t RUN_MAX = (1LL << 28) - 1, NEED_MAX = 1LL << 31;
     int64_t need = 0, total = 0, clipped = 0;
     for (const char *q = cg; q < cge;) {
         if (*q < '0' || *q > '9') { ++q; continue; }
         int64_t v = 0;
-        while (q < cge && *q >= '0' && *q <= '9') v = v * 10 + (*q++ - '0');
+        while (q < cge && *q >= '0' && *q <= '9') { if (v <= RUN_MAX) v = v * 10 + (*q - '0'); ++q; }
         if (q >= cge) break;
         const char op = *q;
+        if (v > RUN_MAX && (op == 'M' || op == 'I' || op == 'D' || op == 'N' || op == 'S' || op == 'H' || op == 'P' || op == '=' || op == 'X')) {
+            snprintf(msg, sizeof(msg), "cv_pileup_add_sam: CIGAR run longer than %lld at POS %lld", (long long)RUN_MAX, (long long)pos + 1);
+            out.err = msg;
+            return false;
+        }
         if (op == 'M' || op == 'I' || op == 'S' || op == '=' || op == 'X') need += v;
         if (op == 'M' || op == 'I' || op == 'D' || op == 'N' || op == 'S' || op == 'H' || op == 'P' || op == '=' ||
             op == 'X') { total += v; if (op == 'S') clipped += v; }
@@ -629,6 +637,11 @@ static bool parse_record(const cv_pileup *p, sam_part &out, const char *line, co
         out.err = msg;
         return false;
     }
+    if (need > NEED_MAX || total > (1LL << 40)) {
+        snprintf(msg, sizeof(msg), "cv_pileup_add_sam: CIGAR at POS %lld asks for %lld query bases", (long long)pos + 1, (long long)need);
+        out.err = msg;
+        return false;
+    }
     const int rf = (ct_ok ? F_CT : 0) | (evc_ok ? F_EVC : 0);
     const uint64_t base = out.seq.size();
     out.seq.insert(out.seq.end(), (const uint8_t *)f[9], (const uint8_t *)fe[9]);
@@ -639,7 +652,7 @@ static bool parse_record(const cv_pileup *p, sam_part &out, const char *line, co
     for (const char *s = cg; s < cge;) {                    // re.finditer(r"(\d+)([MIDNSHP=X])") (:174)
         if (*s < '0' || *s > '9') { ++s; continue; }
         int64_t v = 0;
-        while (s < cge && *s >= '0' && *s <= '9') v = v * 10 + (*s++ - '0');
+        while (s < cge && *s >= '0' && *s <= '9') { if (v <= RUN_MAX) v = v * 10 + (*s - '0'); ++s; }     // (checked above)
         if (s >= cge) break;
         const char op = *s;
         // an insertion / deletion run that opens the read (r == POS) is provisionally "late"; step (2) keeps the
@@ -707,6 +720,12 @@ static bool parse_bam_record(const cv_pileup *p, sam_part &out, const uint8_t *r
     if (pos < -(1LL << 30) || pos > (1LL << 31) - (1 << 24)) {
         char msg[96];
         snprintf(msg, sizeof(msg), "cv_pileup_add_bam: POS %lld out of range", (long long)pos + 1);
+        out.err = msg;
+        return false;
+    }
+    if (need > (1LL << 31) || total > (1LL << 40)) {
+        char msg[112];
+        snprintf(msg, sizeof(msg), "cv_pileup_add_bam: CIGAR at POS %lld asks for %lld query bases", (long long)pos + 1, (long long)need);
         out.err = msg;
         return false;
     }

@@ -169,6 +169,21 @@ def test_bad_inputs_are_reported():
         pl.add_sam(b"r1\t0\tctgA\t5\t60\t4M\t*\t0\t0\tACGT\t*\n")
         pl.finish()                      # no reference / candidates yet
     pl.close()
+    # damaged CIGARs are refused before they size anything: a run beyond BAM's 2^28 - 1, a digit string that would overflow,
+    # more than 2 Gi query bases in one record; a truncated record at the very end of a buffer that is not NUL-terminated
+    for cigar in (b"300000000M", b"99999999999999999999999M", b"268435455M" * 9):
+        pl = Pileup()
+        pl.set_reference("ACGT" * 50, 0)
+        pl.set_candidates([20])
+        with pytest.raises(_lib.CvError, match="CIGAR"):
+            pl.add_sam(b"r1\t0\tctgA\t5\t60\t" + cigar + b"\t*\t0\t0\tACGT\t*\n", final=True)
+        pl.close()
+    pl = Pileup()
+    pl.set_reference("ACGT" * 50, 0)
+    pl.set_candidates([20])
+    with pytest.raises(_lib.CvError, match="fields"):
+        pl.add_sam(bytes(bytearray(b"r1\t0\tctgA\t5")), final=True)
+    pl.close()
 
 
 # ---- candidate extraction (ExtractVariantCandidates.py) -------------------------------------------
